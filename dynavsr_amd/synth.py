@@ -1,0 +1,79 @@
+"""Deterministic synthetic weights and clips (SURVEY.md §8d "Config 1/2").
+
+There are no datasets or checkpoints in the build environment, so benchmarks, parity tests and
+golden vectors all use tensors generated here.  ``numpy.random.RandomState`` (the frozen legacy
+MT19937 stream) is used rather than ``torch.manual_seed`` so that the same seed gives bit-identical
+tensors across torch versions and devices; fixtures therefore store seeds, not 13 MB of weights.
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .spec import edvr_param_spec, mfdn_param_spec
+
+
+def _rs(seed, name):
+    return np.random.RandomState((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31 - 1))
+
+
+def _fan_in(shape):
+    f = 1
+    for d in shape[1:]:
+        f *= d
+    return f
+
+
+def edvr_state_dict(seed=0, offset_std=0.05, dtype=torch.float32, **cfg):
+    """Kaiming-normal weights (x0.1 inside residual blocks, as arch_util.py:46 does), small random
+    biases, and conv_offset_mask ~ N(0, offset_std^2) so that the DCN offsets are non-trivial
+    (the reference zero-initialises them, deform_conv.py:270-272, which would not exercise sampling).
+    """
+    sd = OrderedDict()
+    for name, shape in edvr_param_spec(**cfg).items():
+        r = _rs(seed, name)
+        if "conv_offset_mask" in name:
+            a = r.standard_normal(shape) * offset_std
+        elif name.endswith(".bias"):
+            a = r.standard_normal(shape) * 0.01
+        else:
+            gain = 0.1 if (".conv1." in name or ".conv2." in name) else 1.0
+            a = r.standard_normal(shape) * (gain * np.sqrt(2.0 / _fan_in(shape)))
+        sd[name] = torch.from_numpy(a).to(dtype)
+    return sd
+
+
+def mfdn_state_dict(seed=0, dtype=torch.float32, **cfg):
+    sd = OrderedDict()
+    for name, shape in mfdn_param_spec(**cfg).items():
+        r = _rs(seed + 7919, name)
+        if name.endswith(".bias"):
+            a = r.standard_normal(shape) * 0.01
+        else:
+            a = r.standard_normal(shape) * np.sqrt(2.0 / _fan_in(shape))
+        sd[name] = torch.from_numpy(a).to(dtype)
+    return sd
+
+
+def clip(seed, b, n, h, w, dtype=torch.float32, smooth=True):
+    """A [b, n, 3, h, w] clip in [0,1].  ``smooth`` gives low-frequency content with a global
+    per-frame shift (so alignment has something to align); otherwise i.i.d. U[0,1)."""
+    r = np.random.RandomState(seed)
+    if not smooth:
+        return torch.from_numpy(r.random_sample((b, n, 3, h, w))).to(dtype)
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    out = np.zeros((b, n, 3, h, w))
+    for bi in range(b):
+        comps = [(r.uniform(0.02, 0.6), r.uniform(0.02, 0.6), r.uniform(0, 6.28), r.uniform(0.3, 1))
+                 for _ in range(6)]
+        dx, dy = r.uniform(-1.5, 1.5, 2)
+        for t in range(n):
+            for c in range(3):
+                img = np.zeros((h, w))
+                for fy, fx, ph, amp in comps:
+                    img += amp * np.sin(fy * (yy + dy * t) + fx * (xx + dx * t) + ph + c)
+                out[bi, t, c] = img
+    out = (out - out.min()) / (out.max() - out.min() + 1e-12)
+    out = 0.9 * out + 0.1 * r.random_sample(out.shape)
+    return torch.from_numpy(out).to(dtype)

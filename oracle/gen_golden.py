@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python on CPU in this container.
+
+TEST INFRASTRUCTURE.  Run from the repo root:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+(/root/reference is read-only; it exists only in the build container, never on the GPU box, so
+the vectors are committed).  How the reference is made importable without a GPU:
+  1. an empty module is registered as ``models.archs.dcn.deform_conv_cuda`` (the CUDA extension),
+  2. ``models.archs.dcn.deform_conv.modulated_deform_conv`` is rebound to the C oracle
+     (oracle/dcn.py) -- ModulatedDeformConvPack.forward looks the name up at call time
+     (deform_conv.py:289), so every line of EDVR_arch.py still runs as reference code,
+  3. ``cv2`` and ``torchvision.utils.make_grid`` are stubbed so utils/util.py imports.
+Weights/inputs come from dynavsr_amd.synth (frozen numpy RandomState streams), so fixtures hold
+seeds + expected outputs only.  Every reference result is also asserted against the functional
+oracle here, i.e. generating the goldens IS the pinning of oracle/{edvr,mfdn,inner}.py.
+DCN itself cannot be executed from the reference (CUDA only): dcn_*.npz is produced by the
+independent torch-gather formulation (oracle/dcn.py:gather_reference) in fp64 -> "parity
+unpinned by reference execution", see DESIGN.md.
+"""
+import os
+import sys
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("DYNAVSR_REFERENCE", "/root/reference/codes")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from dynavsr_amd import synth  # noqa: E402
+from oracle import dcn as odcn, edvr as oedvr, mfdn as omfdn, inner as oinner  # noqa: E402
+
+
+def import_reference():
+    sys.modules["models.archs.dcn.deform_conv_cuda"] = types.ModuleType("deform_conv_cuda")
+    cv2 = types.ModuleType("cv2")
+    sys.modules.setdefault("cv2", cv2)
+    tv = types.ModuleType("torchvision")
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.make_grid = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+    tv.utils = tvu
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.utils", tvu)
+    import models.archs.dcn  # noqa: F401
+    sys.modules["models.archs.dcn.deform_conv"].modulated_deform_conv = odcn.modulated_deform_conv
+    import models.archs.EDVR_arch as E
+    import models.archs.LRimg_estimator as L
+    import models
+    import utils.util as U
+    return E, L, models, U
+
+
+def relerr(a, b):
+    a, b = a.detach(), b.detach()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def dcn_cases():
+    """G1: DCN forward + 5 gradients, fp64, gather formulation.  Case B adds hand-placed offsets:
+    exactly-integer positions, -1+eps, H-eps, far outside, and the +-1 boundaries themselves."""
+    for tag, (n, c, dg, h, w, co, seed) in {"a": (2, 16, 4, 7, 9, 12, 11), "b": (1, 32, 8, 10, 12, 32, 12)}.items():
+        r = np.random.RandomState(seed)
+        x = torch.from_numpy(r.standard_normal((n, c, h, w)))
+        off = torch.from_numpy(r.standard_normal((n, dg * 18, h, w)) * 2.0)
+        if tag == "b":
+            o = off.view(n, dg, 9, 2, h, w)
+            o[0, 0, :, :, 0, :] = 0.0                     # integer sampling positions
+            o[0, 1, :, 0, 1, :] = -1.0 + 1e-3              # just inside the top gate at row 1/tap 0
+            o[0, 1, 0, 0, 0, :] = -1e-3                    # h_im = -1 - 1e-3 -> outside
+            o[0, 2, :, 0, h - 1, :] = 1.0 - 1e-3           # h_im = H - 1e-3 at the bottom row, tap 1
+            o[0, 3, :, :, 3, :] = 50.0                     # far outside
+            o[0, 4, :, :, 4, :] = -50.0
+            o[0, 5, 4, 0, 0, :] = -1.0                     # centre tap on row 0 -> h_im == -1 exactly
+            o[0, 5, 4, 1, :, w - 1] = 1.0                  # w_im == W exactly
+        msk = torch.from_numpy(r.random_sample((n, dg * 9, h, w)))
+        wt = torch.from_numpy(r.standard_normal((co, c, 3, 3)) / np.sqrt(c * 9.0))
+        b = torch.from_numpy(r.standard_normal(co) * 0.1)
+        go = torch.from_numpy(r.standard_normal((n, co, h, w)))
+        leaves = [t.clone().requires_grad_(True) for t in (x, off, msk, wt, b)]
+        out = odcn.gather_reference(*leaves, 1, 1, 1, 1, dg)
+        grads = torch.autograd.grad(out, leaves, go)
+        # the C oracle must agree with the independent formulation before anything is written
+        leaves2 = [t.clone().requires_grad_(True) for t in (x, off, msk, wt, b)]
+        out2 = odcn.modulated_deform_conv(*leaves2, 1, 1, 1, 1, dg)
+        grads2 = torch.autograd.grad(out2, leaves2, go)
+        assert relerr(out2, out) < 1e-12, relerr(out2, out)
+        for g2, g1 in zip(grads2, grads):
+            assert relerr(g2, g1) < 1e-11, relerr(g2, g1)
+        save("dcn_" + tag, x=x, offset=off, mask=msk, weight=wt, bias=b, gout=go, out=out,
+             gx=grads[0], goffset=grads[1], gmask=grads[2], gweight=grads[3], gbias=grads[4],
+             dg=dg)
+
+
+def load_sd(module, sd):
+    module.load_state_dict(OrderedDict((k, v.clone()) for k, v in sd.items()), strict=True)
+    return module
+
+
+def pcd_tsa(E):
+    P = synth.edvr_state_dict(3)
+    pcd = E.PCD_Align(nf=64, groups=8)
+    load_sd(pcd, OrderedDict((k[len("pcd_align."):], v) for k, v in P.items() if k.startswith("pcd_align.")))
+    r = np.random.RandomState(21)
+    mk = lambda s: torch.from_numpy(r.standard_normal((1, 64, s, s)).astype(np.float32) * 0.5)
+    nbr, ref = [mk(16), mk(8), mk(4)], [mk(16), mk(8), mk(4)]
+    with torch.no_grad():
+        y = pcd(nbr, ref)
+        yo = oedvr.pcd_align(P, nbr, ref, 8)
+    assert relerr(yo, y) < 1e-6, relerr(yo, y)
+    save("pcd_align", seed=3, nbr0=nbr[0], nbr1=nbr[1], nbr2=nbr[2], ref0=ref[0], ref1=ref[1],
+         ref2=ref[2], out=y)
+    tsa = E.TSA_Fusion(nf=64, nframes=5, center=2)
+    load_sd(tsa, OrderedDict((k[len("tsa_fusion."):], v) for k, v in P.items() if k.startswith("tsa_fusion.")))
+    a = torch.from_numpy(r.standard_normal((1, 5, 64, 16, 16)).astype(np.float32) * 0.3)
+    with torch.no_grad():
+        y = tsa(a.clone())
+        yo = oedvr.tsa_fusion(P, a, 2)
+    assert relerr(yo, y) < 1e-6, relerr(yo, y)
+    save("tsa_fusion", seed=3, aligned=a, out=y)
+
+
+FULL_GRADS = ("conv_first.weight", "pcd_align.L1_dcnpack.conv_offset_mask.bias",
+              "pcd_align.L3_dcnpack.weight", "tsa_fusion.tAtt_1.bias", "conv_last.weight")
+
+
+def edvr_full(E):
+    """G4: EDVR-M x4 forward + d(charbonnier)/d(params) on two sizes (second is non-square)."""
+    P = synth.edvr_state_dict(0)
+    for tag, (h, w, seed) in {"16x16": (16, 16, 1), "32x48": (32, 48, 2)}.items():
+        net = load_sd(E.EDVR(nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, scale=4), P)
+        x = synth.clip(seed, 1, 5, h, w)
+        tgt = synth.clip(seed + 100, 1, 1, 4 * h, 4 * w)[:, 0]
+        y = net(x.clone())
+        loss = oedvr.charbonnier(y, tgt)
+        loss.backward()
+        ref_g = OrderedDict((k, p.grad.detach()) for k, p in net.named_parameters())
+        PO = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in P.items())
+        yo = oedvr.edvr_forward(PO, x)
+        lo = oedvr.charbonnier(yo, tgt)
+        og = torch.autograd.grad(lo, list(PO.values()))
+        assert relerr(yo, y) < 1e-5, relerr(yo, y)
+        worst = max(relerr(a, ref_g[k]) for k, a in zip(PO, og))
+        assert worst < 1e-4, worst
+        save("edvr_" + tag, wseed=0, xseed=seed, tseed=seed + 100, h=h, w=w, out=y, loss=float(loss),
+             grad_norms=np.array([float(g.norm()) for g in ref_g.values()]),
+             **{"grad__" + k.replace(".", "__"): ref_g[k] for k in FULL_GRADS})
+
+
+def mfdn_full(L):
+    """G5: MFDN x4 forward/backward on 1x5x3x32x32 through the reference module."""
+    M = synth.mfdn_state_dict(0)
+    net = load_sd(L.DirectKernelEstimatorVideo(nf=64, in_nc=3, scale=4), M)
+    lq = synth.clip(5, 1, 5, 32, 32)
+    y = net(lq.transpose(1, 2)).transpose(1, 2)
+    go = torch.from_numpy(np.random.RandomState(6).standard_normal(tuple(y.shape)).astype(np.float32))
+    y.backward(go)
+    MO = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in M.items())
+    yo = omfdn.mfdn_forward(MO, lq)
+    og = torch.autograd.grad(yo, list(MO.values()), go)
+    assert relerr(yo, y) < 1e-6
+    for (k, p), g in zip(net.named_parameters(), og):
+        assert relerr(g, p.grad) < 1e-4, (k, relerr(g, p.grad))
+    save("mfdn_32x32", wseed=0, xseed=5, goseed=6, out=y,
+         grad_norms=np.array([float(p.grad.norm()) for p in net.parameters()]),
+         grad__conv6__weight=net.conv6.weight.grad, grad__conv0__bias=net.conv0.bias.grad)
+
+
+def make_opt(optimizer):
+    from options.options import dict_to_nonedict
+    return dict_to_nonedict({
+        "name": "golden", "model": "video_base+lrimgestimator", "scale": 4, "gpu_ids": None,
+        "dist": False, "is_train": False, "distortion": "sr",
+        "datasets": {"train": {"kernel_size": 21, "patch_size": 128, "batch_size": 1},
+                     "val": {"N_frames": 5}},
+        "network_G": {"which_model_G": "EDVR", "nf": 64, "nframes": 5, "groups": 8, "front_RBs": 5,
+                      "back_RBs": 10, "predeblur": False, "HR_in": False, "w_TSA": True},
+        "network_E": {"which_model_E": "MFDN", "mode": "video", "nf": 64, "in_nc": 3},
+        "path": {"strict_load": True},
+        "train": {"pixel_criterion": "cb", "pixel_weight": 1.0, "loss_ftn": "l1", "use_real": False,
+                  "maml": {"optimizer": optimizer, "lr_alpha": 1e-5, "beta1": 0.9, "beta2": 0.99,
+                           "adapt_iter": 1, "use_patch": False}}})
+
+
+TRACK = ("conv_first.weight", "pcd_align.cas_dcnpack.conv_offset_mask.bias",
+         "tsa_fusion.fea_fusion.bias", "recon_trunk.9.conv2.weight", "conv_last.bias")
+TRACK_E = ("conv0.weight", "conv6.bias")
+
+
+def inner_step(models, U):
+    """G6: one inner step exactly as codes/test_dynavsr.py:208-283 drives the reference wrappers
+    (CPU, gpu_ids=None).  LR 64x64 -> SLR 16x16 (BASELINE.json configs[0])."""
+    from copy import deepcopy
+    import torch.nn.functional as F
+    PG, PE, PEF = synth.edvr_state_dict(0), synth.mfdn_state_dict(0), synth.mfdn_state_dict(1)
+    lqs = synth.clip(1, 1, 5, 64, 64)
+    for optimizer in ("SGD", "Adam"):
+        opt = make_opt(optimizer)
+        model, est_model = models.create_model(opt)
+        modelcp, est_modelcp = models.create_model(opt)
+        _, est_fixed = models.create_model(opt)
+        load_sd(model.netG.module, PG); load_sd(est_model.netE.module, PE); load_sd(est_fixed.netE.module, PEF)
+        val_data = {"LQs": lqs}
+        modelcp.netG, est_modelcp.netE = deepcopy(model.netG), deepcopy(est_model.netE)
+        params = [v for _, v in modelcp.netG.named_parameters()] + [v for _, v in est_modelcp.netE.named_parameters()]
+        m = opt["train"]["maml"]
+        io = (torch.optim.Adam(params, lr=m["lr_alpha"], betas=(m["beta1"], m["beta2"]))
+              if optimizer == "Adam" else torch.optim.SGD(params, lr=m["lr_alpha"]))
+        est_modelcp.feed_data(val_data); est_modelcp.forward_without_optim()
+        slr = est_modelcp.fake_L
+        io.zero_grad()
+        modelcp.feed_data({"LQs": slr, "GT": lqs[:, 2]})
+        loss = modelcp.calculate_loss()
+        est_fixed.feed_data(val_data); est_fixed.test()
+        loss = loss + 10 * F.l1_loss(slr, est_fixed.fake_L)
+        loss.backward()
+        gG = OrderedDict((k, p.grad.detach().clone()) for k, p in modelcp.netG.module.named_parameters())
+        gE = OrderedDict((k, p.grad.detach().clone()) for k, p in est_modelcp.netE.module.named_parameters())
+        io.step()
+        modelcp.feed_data({"LQs": lqs}, need_GT=False); modelcp.test()
+        sr = modelcp.fake_H
+        # functional oracle must reproduce it
+        losses, PGa, PEa, sro = oinner.inner_adapt(PG, PE, PEF, lqs, 1, optimizer, 1e-5, (0.9, 0.99))
+        assert abs(losses[0] - float(loss)) < 1e-5 * abs(float(loss)), (losses, float(loss))
+        assert relerr(sro, sr) < 1e-5, relerr(sro, sr)
+        new = dict(modelcp.netG.module.named_parameters()); newE = dict(est_modelcp.netE.module.named_parameters())
+        arrs = {"loss": float(loss), "sr": sr if optimizer == "SGD" else sr[..., 96:160, 96:160], "slr": slr.detach(),
+                "gradG_norms": np.array([float(g.norm()) for g in gG.values()]),
+                "gradE_norms": np.array([float(g.norm()) for g in gE.values()])}
+        for k in TRACK:
+            arrs["dG__" + k.replace(".", "__")] = (new[k].detach().double() - PG[k].double()).float()
+            assert relerr(PGa[k].detach().double() - PG[k].double(), new[k].detach().double() - PG[k].double()) < (1e-3 if optimizer == "SGD" else 5e-2)
+        for k in TRACK_E:
+            arrs["dE__" + k.replace(".", "__")] = (newE[k].detach().double() - PE[k].double()).float()
+        save("inner_step_" + optimizer.lower(), **arrs)
+        if optimizer == "SGD":      # G7: image conversion + PSNR of the adapted output vs LR-upsampled GT proxy
+            gt = synth.clip(9, 1, 1, 256, 256)[0, 0]
+            a, b = U.tensor2img(sr[0], mode="rgb"), U.tensor2img(gt, mode="rgb")
+            assert (a == oinner.tensor2img_rgb(sr[0])).all()
+            p = U.calculate_psnr(a, b)
+            assert abs(p - oinner.psnr_uint8(a, b)) < 1e-12
+            save("psnr", gtseed=9, img=a, psnr=p)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    E, L, models, U = import_reference()
+    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "inner"]
+    if "dcn" in which: dcn_cases()
+    if "pcd" in which: pcd_tsa(E)
+    if "edvr" in which: edvr_full(E)
+    if "mfdn" in which: mfdn_full(L)
+    if "inner" in which: inner_step(models, U)

@@ -1,0 +1,91 @@
+"""CPU: the functional oracle (oracle/edvr.py, mfdn.py, inner.py) against golden vectors produced
+by the imported reference modules/wrappers (oracle/gen_golden.py)."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relerr
+from dynavsr_amd import synth
+from oracle import edvr, inner, mfdn
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_pcd_align_golden():
+    g = load_golden("pcd_align")
+    P = synth.edvr_state_dict(int(g["seed"]))
+    with torch.no_grad():
+        y = edvr.pcd_align(P, [_t(g["nbr0"]), _t(g["nbr1"]), _t(g["nbr2"])],
+                           [_t(g["ref0"]), _t(g["ref1"]), _t(g["ref2"])], 8)
+    assert relerr(y, g["out"]) < 1e-6
+
+
+def test_tsa_fusion_golden():
+    g = load_golden("tsa_fusion")
+    P = synth.edvr_state_dict(int(g["seed"]))
+    with torch.no_grad():
+        y = edvr.tsa_fusion(P, _t(g["aligned"]), 2)
+    assert relerr(y, g["out"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["16x16", "32x48"])
+def test_edvr_forward_backward_golden(tag):
+    g = load_golden("edvr_" + tag)
+    h, w = int(g["h"]), int(g["w"])
+    P = OrderedDict((k, v.requires_grad_(True)) for k, v in synth.edvr_state_dict(int(g["wseed"])).items())
+    x = synth.clip(int(g["xseed"]), 1, 5, h, w)
+    tgt = synth.clip(int(g["tseed"]), 1, 1, 4 * h, 4 * w)[:, 0]
+    y = edvr.edvr_forward(P, x)
+    loss = edvr.charbonnier(y, tgt)
+    assert relerr(y, g["out"]) < 1e-5
+    assert abs(float(loss) - float(g["loss"])) < 1e-6 * abs(float(g["loss"]))
+    grads = torch.autograd.grad(loss, list(P.values()))
+    norms = np.array([float(x.norm()) for x in grads])
+    assert np.allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-9)
+    by_name = dict(zip(P.keys(), grads))
+    for key in g:
+        if key.startswith("grad__"):
+            name = key[len("grad__"):].replace("__", ".")
+            assert relerr(by_name[name], g[key]) < 2e-4, name
+
+
+def test_mfdn_golden():
+    g = load_golden("mfdn_32x32")
+    M = OrderedDict((k, v.requires_grad_(True)) for k, v in synth.mfdn_state_dict(int(g["wseed"])).items())
+    lq = synth.clip(int(g["xseed"]), 1, 5, 32, 32)
+    y = mfdn.mfdn_forward(M, lq)
+    assert relerr(y, g["out"]) < 1e-6
+    go = _t(np.random.RandomState(int(g["goseed"])).standard_normal(tuple(y.shape)).astype(np.float32))
+    grads = torch.autograd.grad(y, list(M.values()), go)
+    assert np.allclose([float(x.norm()) for x in grads], g["grad_norms"], rtol=2e-4)
+
+
+@pytest.mark.parametrize("optimizer", ["SGD", "Adam"])
+def test_inner_step_golden(optimizer):
+    """BASELINE.json configs[0]: EDVR-M x4, LR 64x64 -> SLR 16x16, one inner step."""
+    g = load_golden("inner_step_" + optimizer.lower())
+    PG, PE, PEF = synth.edvr_state_dict(0), synth.mfdn_state_dict(0), synth.mfdn_state_dict(1)
+    lqs = synth.clip(1, 1, 5, 64, 64)
+    losses, PGa, PEa, sr = inner.inner_adapt(PG, PE, PEF, lqs, 1, optimizer, 1e-5, (0.9, 0.99))
+    assert abs(losses[0] - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    ref_sr = g["sr"]
+    if optimizer == "Adam":
+        sr = sr[..., 96:160, 96:160]
+    assert relerr(sr, ref_sr) < 1e-5
+    tol = 1e-3 if optimizer == "SGD" else 5e-2
+    for key in g:
+        if key.startswith("dG__") or key.startswith("dE__"):
+            name = key[4:].replace("__", ".")
+            src, new = (PG, PGa) if key.startswith("dG__") else (PE, PEa)
+            delta = new[name].detach().double() - src[name].double()
+            assert relerr(delta, g[key]) < tol, name
+
+
+def test_psnr_golden():
+    g = load_golden("psnr")
+    gt = synth.clip(int(g["gtseed"]), 1, 1, 256, 256)[0, 0]
+    assert abs(inner.psnr_uint8(g["img"], inner.tensor2img_rgb(gt)) - float(g["psnr"])) < 1e-12
