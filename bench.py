@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Benchmark of the EDVR hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One step = one pass of the hot path over one synthetic clip per GPU:
+EDVR-M x4 forward, 1x5x3x180x320 -> 3x720x1280, fp32 (BASELINE.json configs[1]).  Clips are
+independent work items, so ranks shard clips with no data-path collective:
+"scaling": "weak".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0           # same guide, HBM3E peak
+
+
+def cpu_baseline(cfg, h, w, seed):
+    """The CPU oracle (torch CPU convs + C restatement of the DCN) timed on this box's host cores
+    on ONE clip of the same workload.  A reported baseline, not the target."""
+    from dynavsr_amd import synth
+    from oracle import dcn as odcn, edvr as oedvr
+    odcn.lib()
+    P = synth.edvr_state_dict(seed)
+    x = synth.clip(1, 1, cfg["nframes"], h, w, smooth=False)
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.time()
+        oedvr.edvr_forward(P, x)
+        dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "1 clip forward (EDVR-M x4, 1x5x3x%dx%d), fp32, oracle/edvr.py on %d torch/OpenMP "
+                      "threads of %d host cpus, no warm-up" % (h, w, threads, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--height", type=int, default=180)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)"
+                         % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dynavsr_amd import engine, synth
+    from dynavsr_amd.models.archs.EDVR_arch import EDVR
+
+    cfg = dict(nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, scale=4)
+    h, w = args.height, args.width
+    net = EDVR(**cfg)
+    net.load_state_dict(synth.edvr_state_dict(0, **cfg), strict=True)   # random init, seed-fixed
+    net = net.to(dev)
+    x = synth.clip(1 + rank, 1, cfg["nframes"], h, w, smooth=False).to(dev)   # U[0,1) clip, resident in HBM
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = net(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = net(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    assert torch.isfinite(y).all()
+
+    line = None
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        line = {
+            "metric": "inner-loop frames/sec/GPU (EDVR-M x4, 5x3x180x320)",
+            "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "EDVR-M x4 forward (PCD deformable alignment + TSA fusion + "
+                                   "reconstruction), 1 clip 1x5x3x%dx%d -> 3x%dx%d per GPU per step "
+                                   "(BASELINE.json configs[1])" % (h, w, 4 * h, 4 * w),
+                       "clips_per_step": world, "sharding": "independent clips per rank, no collective"},
+        }
+        # ---- roofline of the dominant kernel: separate pass, hipEvents around every launch
+        plan = engine.get_plan(net._cfg(), 1, h, w)
+        params = [p.detach().contiguous() for p in net.ordered_parameters()]
+        ws = torch.empty(plan.workspace_bytes(False), dtype=torch.uint8, device=dev)
+        out = torch.empty_like(y)
+        info = plan.op_info()
+        acc = {}
+        reps = max(3, min(10, args.steps))
+        for _ in range(reps):
+            for (kind, _name, fl, by), t_ms in zip(info, plan.forward_timed(params, x, out, ws)):
+                a = acc.setdefault(kind, [0.0, 0.0, 0.0, 0])
+                a[0] += t_ms; a[1] += fl; a[2] += by; a[3] += 1
+        dom = max(acc, key=lambda k: acc[k][0])
+        t_ms, fl, by, cnt = acc[dom]
+        total_ms = sum(a[0] for a in acc.values())
+        if fl / max(by, 1) > FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+            ach = fl / (t_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / FP32_MFMA_PEAK_TFLOPS}
+        else:
+            ach = by / (t_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS}
+        roof.update({"traffic": None, "kernel": dom, "launches_per_step": cnt // reps,
+                     "avg_launch_ms": t_ms / cnt, "share_of_step": t_ms / total_ms,
+                     "method": "hipEvent pair around every launch on the launch stream, %d instrumented "
+                               "passes after the timed region" % reps})
+        line["roofline"] = roof
+        line["kernel_breakdown_ms_per_step"] = {k: round(a[0] / reps, 4) for k, a in
+                                                sorted(acc.items(), key=lambda kv: -kv[1][0])}
+        line["end_to_end_tflops"] = sum(a[1] for a in acc.values()) / reps / (ms * 1e-3) / 1e12
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, h, w, 0)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""ctypes binding of libdynavsr_hip.so (the C ABI declared in include/dynavsr_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, a RuntimeError
+carrying dvsr_last_error() is raised.  The product path never routes through torch CPU ops or
+the oracle.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libdynavsr_hip.so")
+_lib = None
+
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+
+
+class Conv2dDesc(Structure):
+    _fields_ = [("x0", c_void_p), ("x1", c_void_p), ("w", c_void_p), ("bias", c_void_p),
+                ("res", c_void_p), ("y", c_void_p),
+                ("N", c_int), ("c0", c_int), ("c1", c_int), ("H", c_int), ("W", c_int),
+                ("Cout", c_int), ("ks", c_int), ("stride", c_int), ("pad", c_int), ("act", c_int),
+                ("pixel_shuffle", c_int), ("x1_bdiv", c_int),
+                ("x0_bstride", c_longlong), ("x1_bstride", c_longlong)]
+
+
+class EdvrConfig(Structure):
+    _fields_ = [(k, c_int) for k in ("nf", "nframes", "groups", "front_RBs", "back_RBs", "scale",
+                                     "center")]
+
+
+def _declare(lib):
+    P, I, F, LL = c_void_p, c_int, c_float, c_longlong
+    sig = {
+        "dvsr_last_error": (c_char_p, []),
+        "dvsr_version": (I, []),
+        "dvsr_mdcn_forward": (I, [P] * 6 + [I] * 13 + [P]),
+        "dvsr_mdcn_pack_forward": (I, [P] * 5 + [I] * 13 + [P]),
+        "dvsr_conv2d_forward": (I, [POINTER(Conv2dDesc), P]),
+        "dvsr_upsample_bilinear_forward": (I, [P, P, LL, I, I, I, F, P]),
+        "dvsr_upsample_bilinear_backward": (I, [P, P, LL, I, I, I, F, I, P]),
+        "dvsr_pool3s2_forward": (I, [P, P, P, LL, I, I, P]),
+        "dvsr_pool3s2_backward": (I, [P, P, P, P, LL, I, I, P]),
+        "dvsr_tsa_gate_forward": (I, [P] * 5 + [I, I, I, LL, P]),
+        "dvsr_tsa_gate_backward": (I, [P] * 8 + [I, I, I, LL, P]),
+        "dvsr_tsa_blend_forward": (I, [P] * 4 + [LL, P]),
+        "dvsr_tsa_blend_backward": (I, [P] * 5 + [LL, P]),
+        "dvsr_edvr_plan_create": (I, [POINTER(EdvrConfig), I, I, I, POINTER(c_void_p)]),
+        "dvsr_edvr_plan_destroy": (None, [P]),
+        "dvsr_edvr_num_params": (I, [P]),
+        "dvsr_edvr_num_launches": (I, [P]),
+        "dvsr_edvr_workspace_bytes": (c_size_t, [P, I]),
+        "dvsr_edvr_forward": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P]),
+        "dvsr_edvr_op_info": (I, [P, I, c_char_p, I, c_char_p, I, POINTER(ctypes.c_double),
+                                  POINTER(ctypes.c_double)]),
+        "dvsr_edvr_forward_timed": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P, POINTER(c_float)]),
+        "dvsr_edvr_tensor_info": (I, [P, c_char_p, POINTER(LL), POINTER(LL)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "libdynavsr_hip.so is missing (%s). Build it with `python -m dynavsr_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no fallback path." % SO_PATH)
+        _lib = ctypes.CDLL(SO_PATH)
+        _lib._signatures = _declare(_lib)
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().dvsr_last_error().decode("utf-8", "replace")
+        raise RuntimeError("libdynavsr_hip %s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a tensor that must already be fp32, contiguous and on a HIP device."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libdynavsr_hip needs a tensor on the GPU, got device %s" % t.device)
+    if t.dtype != torch.float32:
+        raise RuntimeError("libdynavsr_hip computes in fp32, got %s" % t.dtype)
+    if not t.is_contiguous():
+        raise RuntimeError("libdynavsr_hip needs contiguous tensors")  # deform_conv_cuda.cpp:493-494
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

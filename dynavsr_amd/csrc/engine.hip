@@ -1,0 +1,448 @@
+// EDVR execution plan: the whole backbone (EDVR_arch.py:254-313) as a static tape of kernel
+// launches over one caller-provided workspace arena.  Replaces the reference's Python module
+// graph + autograd for this network: one C call enqueues the ~190 forward launches (and one more
+// the backward), so small clips (the 16x-smaller super-LR clip of the inner MAML step) are not
+// bound by host-side framework overhead, and the stream can be captured into a hipGraph.
+//
+// Design notes
+//  * The N frames of a clip are batched through feature extraction AND through PCD alignment
+//    (the reference loops frames in Python, EDVR_arch.py:291-296); the reference frame's features
+//    enter each two-input conv as a broadcast second pointer (x1_bdiv), so no clone/cat/stack
+//    tensor is ever materialised.
+//  * Every activation gets its own slot in the arena (bump allocation); the arena doubles as the
+//    saved-activation store for backward.  288 GB of HBM make the ~3.3 GB of a 180x320 clip a
+//    non-issue and remove all allocator traffic from the hot loop.
+//  * Parameters are addressed by their position in the reference's state-dict order
+//    (dynavsr_amd/spec.py mirrors the walk below).
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace dvsr {
+
+enum { SP_ARENA = 0, SP_INPUT = 1, SP_OUTPUT = 2, SP_NONE = 3 };
+struct T {
+  int space = SP_NONE;
+  size_t off = 0, numel = 0;
+  bool valid() const { return space != SP_NONE; }
+};
+
+enum OpType { OP_CONV, OP_DCN, OP_UP, OP_POOL, OP_GATE, OP_BLEND, OP_ADD };
+
+struct Op {
+  OpType type;
+  const char* name = "";
+  T x0, x1, res, y, y2;  // generic tensor slots (meaning depends on type)
+  int pw = -1, pb = -1;  // parameter indices (weight, bias)
+  // conv / dcn geometry
+  int N = 0, c0 = 0, c1 = 0, H = 0, W = 0, Cout = 0, ks = 3, stride = 1, act = 0, ps = 0;
+  int x1_bdiv = 1, dg = 8;
+  long long x0_bs = 0, x1_bs = 0;
+  // streaming ops
+  int S = 1;
+  float mul = 1.f;
+  size_t planes = 0;
+  int gB = 0, gN = 0, gC = 0;
+  size_t gHW = 0;
+};
+
+}  // namespace dvsr
+
+struct dvsr_edvr_plan {
+  dvsr_edvr_config cfg;
+  int B, H, W;
+  int n_params = 0;
+  size_t arena_floats = 0;
+  std::vector<dvsr::Op> ops;
+  std::vector<std::pair<std::string, dvsr::T>> named;
+};
+
+namespace dvsr {
+
+struct Builder {
+  dvsr_edvr_plan& p;
+  int pcur = 0;  // parameter cursor (state-dict order)
+  explicit Builder(dvsr_edvr_plan& plan) : p(plan) {}
+
+  T alloc(const char* name, size_t numel) {
+    T t;
+    t.space = SP_ARENA;
+    t.off = p.arena_floats;
+    t.numel = numel;
+    p.arena_floats += (numel + 63) & ~(size_t)63;  // 256-byte aligned slots
+    if (name && *name) p.named.emplace_back(name, t);
+    return t;
+  }
+  static T view(const T& base, size_t off, size_t numel) {
+    T t = base;
+    t.off += off;
+    t.numel = numel;
+    return t;
+  }
+  struct CP { int w, b; };
+  CP take() { CP c{pcur, pcur + 1}; pcur += 2; return c; }
+
+  // y = act(conv(cat(x0, x1)) + b) [+ res]   (optionally pixel-shuffled)
+  T conv(const char* name, CP cp, T x0, int c0, T x1, int c1, int N, int H, int W, int Cout, int ks,
+         int stride, int act, T res = T(), int ps = 0, int x1_bdiv = 1, long long x0_bs = 0,
+         long long x1_bs = 0, T y_override = T()) {
+    Op o;
+    o.type = OP_CONV; o.name = name; o.pw = cp.w; o.pb = cp.b;
+    o.x0 = x0; o.x1 = x1; o.res = res;
+    o.N = N; o.c0 = c0; o.c1 = c1; o.H = H; o.W = W; o.Cout = Cout; o.ks = ks; o.stride = stride;
+    o.act = act; o.ps = ps; o.x1_bdiv = x1_bdiv; o.x0_bs = x0_bs; o.x1_bs = x1_bs;
+    const int Ho = (H + 2 * (ks / 2) - ks) / stride + 1, Wo = (W + 2 * (ks / 2) - ks) / stride + 1;
+    o.y = y_override.valid() ? y_override : alloc(name, (size_t)N * Cout * Ho * Wo);
+    p.ops.push_back(o);
+    return o.y;
+  }
+  T dcn(const char* name, int pw, int pb, T x, T om, int N, int C, int H, int W, int dg, int act) {
+    Op o;
+    o.type = OP_DCN; o.name = name; o.pw = pw; o.pb = pb; o.x0 = x; o.x1 = om;
+    o.N = N; o.c0 = C; o.H = H; o.W = W; o.Cout = C; o.dg = dg; o.act = act;
+    o.y = alloc(name, (size_t)N * C * H * W);
+    p.ops.push_back(o);
+    return o.y;
+  }
+  T up(const char* name, T x, size_t planes, int H, int W, int S, float mul) {
+    Op o;
+    o.type = OP_UP; o.name = name; o.x0 = x; o.planes = planes; o.H = H; o.W = W; o.S = S; o.mul = mul;
+    o.y = alloc(name, planes * H * W * S * S);
+    p.ops.push_back(o);
+    return o.y;
+  }
+  void pool(const char* name, T x, size_t planes, int H, int W, T& ymax, T& yavg) {
+    Op o;
+    o.type = OP_POOL; o.name = name; o.x0 = x; o.planes = planes; o.H = H; o.W = W;
+    const size_t n = planes * (size_t)((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+    o.y = ymax = alloc((std::string(name) + "_max").c_str(), n);
+    o.y2 = yavg = alloc((std::string(name) + "_avg").c_str(), n);
+    p.ops.push_back(o);
+  }
+};
+
+// Walks the network in forward order; parameters are consumed in state-dict order, which is
+// NOT forward order inside PCD/TSA, hence the explicit index bookkeeping there.
+static int build_plan(dvsr_edvr_plan& p) {
+  const dvsr_edvr_config& c = p.cfg;
+  const int B = p.B, Nf = c.nframes, C = c.nf, H = p.H, W = p.W, BN = B * Nf, dg = c.groups;
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+  const size_t HW = (size_t)H * W, HW2 = (size_t)H2 * W2, HW4 = (size_t)H4 * W4;
+  Builder b(p);
+  const int L = ACT_LRELU, R = ACT_RELU, NO = ACT_NONE;
+  T none;
+  T xin; xin.space = SP_INPUT; xin.off = 0; xin.numel = (size_t)BN * 3 * HW;
+
+  // ---- feature extraction (EDVR_arch.py:272-279)
+  T f1 = b.conv("conv_first", b.take(), xin, 3, none, 0, BN, H, W, C, 3, 1, L);
+  for (int i = 0; i < c.front_RBs; ++i) {
+    auto p1 = b.take(); auto p2 = b.take();
+    T t = b.conv("fe_rb_a", p1, f1, C, none, 0, BN, H, W, C, 3, 1, R);
+    f1 = b.conv("fe_rb_b", p2, t, C, none, 0, BN, H, W, C, 3, 1, NO, f1);
+  }
+  p.named.emplace_back("L1_fea", f1);
+  T f2 = b.conv("fea_L2_conv1", b.take(), f1, C, none, 0, BN, H, W, C, 3, 2, L);
+  f2 = b.conv("L2_fea", b.take(), f2, C, none, 0, BN, H2, W2, C, 3, 1, L);
+  T f3 = b.conv("fea_L3_conv1", b.take(), f2, C, none, 0, BN, H2, W2, C, 3, 2, L);
+  f3 = b.conv("L3_fea", b.take(), f3, C, none, 0, BN, H4, W4, C, 3, 1, L);
+
+  // ---- PCD alignment, all N frames batched (EDVR_arch.py:95-128, 281-297)
+  // state-dict order inside pcd_align: L3_offset_conv1, L3_offset_conv2, L3_dcnpack{w,b,com.w,com.b},
+  // L2_offset_conv1..3, L2_dcnpack{..}, L2_fea_conv, L1_offset_conv1..3, L1_dcnpack{..}, L1_fea_conv,
+  // cas_offset_conv1, cas_offset_conv2, cas_dcnpack{..}
+  struct DP { int w, b; Builder::CP com; };
+  auto take_dcn = [&]() { DP d; d.w = b.pcur; d.b = b.pcur + 1; b.pcur += 2; d.com = b.take(); return d; };
+  auto L3o1 = b.take(); auto L3o2 = b.take(); DP L3d = take_dcn();
+  auto L2o1 = b.take(); auto L2o2 = b.take(); auto L2o3 = b.take(); DP L2d = take_dcn(); auto L2f = b.take();
+  auto L1o1 = b.take(); auto L1o2 = b.take(); auto L1o3 = b.take(); DP L1d = take_dcn(); auto L1f = b.take();
+  auto cso1 = b.take(); auto cso2 = b.take(); DP csd = take_dcn();
+  const int ctr = c.center;
+  // reference-frame views: batch item b of the "x1" operand is frame (b*Nf + ctr)
+  T ref1 = Builder::view(f1, (size_t)ctr * C * HW, 0), ref2 = Builder::view(f2, (size_t)ctr * C * HW2, 0),
+    ref3 = Builder::view(f3, (size_t)ctr * C * HW4, 0);
+  const long long rs1 = (long long)Nf * C * HW, rs2 = (long long)Nf * C * HW2, rs3 = (long long)Nf * C * HW4;
+  // L3
+  T o3 = b.conv("L3_offset_conv1", L3o1, f3, C, ref3, C, BN, H4, W4, C, 3, 1, L, none, 0, Nf, 0, rs3);
+  o3 = b.conv("L3_offset", L3o2, o3, C, none, 0, BN, H4, W4, C, 3, 1, L);
+  T om3 = b.conv("L3_om", L3d.com, o3, C, none, 0, BN, H4, W4, dg * 27, 3, 1, NO);
+  T fe3 = b.dcn("L3_aligned", L3d.w, L3d.b, f3, om3, BN, C, H4, W4, dg, L);
+  // L2
+  T o2 = b.conv("L2_offset_conv1", L2o1, f2, C, ref2, C, BN, H2, W2, C, 3, 1, L, none, 0, Nf, 0, rs2);
+  T u3 = b.up("L3_offset_up", o3, (size_t)BN * C, H4, W4, 2, 2.f);
+  o2 = b.conv("L2_offset_conv2", L2o2, o2, C, u3, C, BN, H2, W2, C, 3, 1, L);
+  o2 = b.conv("L2_offset", L2o3, o2, C, none, 0, BN, H2, W2, C, 3, 1, L);
+  T om2 = b.conv("L2_om", L2d.com, o2, C, none, 0, BN, H2, W2, dg * 27, 3, 1, NO);
+  T d2 = b.dcn("L2_dcn", L2d.w, L2d.b, f2, om2, BN, C, H2, W2, dg, NO);
+  T uf3 = b.up("L3_aligned_up", fe3, (size_t)BN * C, H4, W4, 2, 1.f);
+  T fe2 = b.conv("L2_aligned", L2f, d2, C, uf3, C, BN, H2, W2, C, 3, 1, L);
+  // L1
+  T o1 = b.conv("L1_offset_conv1", L1o1, f1, C, ref1, C, BN, H, W, C, 3, 1, L, none, 0, Nf, 0, rs1);
+  T u2 = b.up("L2_offset_up", o2, (size_t)BN * C, H2, W2, 2, 2.f);
+  o1 = b.conv("L1_offset_conv2", L1o2, o1, C, u2, C, BN, H, W, C, 3, 1, L);
+  o1 = b.conv("L1_offset", L1o3, o1, C, none, 0, BN, H, W, C, 3, 1, L);
+  T om1 = b.conv("L1_om", L1d.com, o1, C, none, 0, BN, H, W, dg * 27, 3, 1, NO);
+  T d1 = b.dcn("L1_dcn", L1d.w, L1d.b, f1, om1, BN, C, H, W, dg, NO);
+  T uf2 = b.up("L2_aligned_up", fe2, (size_t)BN * C, H2, W2, 2, 1.f);
+  T fe1 = b.conv("L1_aligned", L1f, d1, C, uf2, C, BN, H, W, C, 3, 1, NO);
+  // cascade
+  T oc = b.conv("cas_offset_conv1", cso1, fe1, C, ref1, C, BN, H, W, C, 3, 1, L, none, 0, Nf, 0, rs1);
+  oc = b.conv("cas_offset", cso2, oc, C, none, 0, BN, H, W, C, 3, 1, L);
+  T omc = b.conv("cas_om", csd.com, oc, C, none, 0, BN, H, W, dg * 27, 3, 1, NO);
+  T aligned = b.dcn("aligned", csd.w, csd.b, fe1, omc, BN, C, H, W, dg, L);  // [B][Nf][C][H][W]
+
+  // ---- TSA fusion (EDVR_arch.py:163-203); state-dict order: tAtt_1, tAtt_2, fea_fusion, sAtt_1..5,
+  // sAtt_L1..L3, sAtt_add_1, sAtt_add_2
+  auto tA1 = b.take(); auto tA2 = b.take(); auto ffu = b.take(); auto s1 = b.take(); auto s2 = b.take();
+  auto s3 = b.take(); auto s4 = b.take(); auto s5 = b.take(); auto sL1 = b.take(); auto sL2 = b.take();
+  auto sL3 = b.take(); auto sa1 = b.take(); auto sa2 = b.take();
+  T emb_ref = b.conv("tsa_emb_ref", tA2, Builder::view(aligned, (size_t)ctr * C * HW, 0), C, none, 0, B, H,
+                     W, C, 3, 1, NO, none, 0, 1, (long long)Nf * C * HW);
+  T emb = b.conv("tsa_emb", tA1, aligned, C, none, 0, BN, H, W, C, 3, 1, NO);
+  T cor = b.alloc("tsa_cor", (size_t)BN * HW);
+  T gated = b.alloc("tsa_gated", (size_t)BN * C * HW);
+  {
+    Op o; o.type = OP_GATE; o.name = "tsa_gate"; o.x0 = emb; o.x1 = emb_ref; o.res = aligned;
+    o.y = cor; o.y2 = gated; o.gB = B; o.gN = Nf; o.gC = C; o.gHW = HW;
+    p.ops.push_back(o);
+  }
+  T fea = b.conv("tsa_fea", ffu, gated, Nf * C, none, 0, B, H, W, C, 1, 1, L);
+  T att = b.conv("tsa_att1", s1, gated, Nf * C, none, 0, B, H, W, C, 1, 1, L);
+  T pmx, pav;
+  b.pool("tsa_pool1", att, (size_t)B * C, H, W, pmx, pav);
+  att = b.conv("tsa_att2", s2, pmx, C, pav, C, B, H2, W2, C, 1, 1, L);
+  T attL = b.conv("tsa_attL1", sL1, att, C, none, 0, B, H2, W2, C, 1, 1, L);
+  T qmx, qav;
+  b.pool("tsa_pool2", attL, (size_t)B * C, H2, W2, qmx, qav);
+  attL = b.conv("tsa_attL2", sL2, qmx, C, qav, C, B, H4, W4, C, 3, 1, L);
+  attL = b.conv("tsa_attL3", sL3, attL, C, none, 0, B, H4, W4, C, 3, 1, L);
+  T attLu = b.up("tsa_attL_up", attL, (size_t)B * C, H4, W4, 2, 1.f);
+  T a3 = b.conv("tsa_att3", s3, att, C, none, 0, B, H2, W2, C, 3, 1, L);
+  T att3 = b.alloc("tsa_att3_sum", (size_t)B * C * HW2);
+  {
+    Op o; o.type = OP_ADD; o.name = "tsa_att3_add"; o.x0 = a3; o.x1 = attLu; o.y = att3;
+    p.ops.push_back(o);
+  }
+  T a4 = b.conv("tsa_att4", s4, att3, C, none, 0, B, H2, W2, C, 1, 1, L);
+  T a4u = b.up("tsa_att4_up", a4, (size_t)B * C, H2, W2, 2, 1.f);
+  T a5 = b.conv("tsa_att", s5, a4u, C, none, 0, B, H, W, C, 3, 1, NO);
+  T ad = b.conv("tsa_add1", sa1, a5, C, none, 0, B, H, W, C, 1, 1, L);
+  ad = b.conv("tsa_add2", sa2, ad, C, none, 0, B, H, W, C, 1, 1, NO);
+  T out = b.alloc("tsa_out", (size_t)B * C * HW);
+  {
+    Op o; o.type = OP_BLEND; o.name = "tsa_blend"; o.x0 = fea; o.x1 = a5; o.res = ad; o.y = out;
+    p.ops.push_back(o);
+  }
+
+  // ---- reconstruction (EDVR_arch.py:302-312)
+  for (int i = 0; i < c.back_RBs; ++i) {
+    auto p1 = b.take(); auto p2 = b.take();
+    T t = b.conv("rc_rb_a", p1, out, C, none, 0, B, H, W, C, 3, 1, R);
+    out = b.conv("rc_rb_b", p2, t, C, none, 0, B, H, W, C, 3, 1, NO, out);
+  }
+  p.named.emplace_back("recon", out);
+  int h = H, w = W;
+  if (c.scale == 4) {
+    out = b.conv("upconv1", b.take(), out, C, none, 0, B, h, w, C * 4, 3, 1, L, none, 2);
+    h *= 2; w *= 2;
+    out = b.conv("upconv2", b.take(), out, C, none, 0, B, h, w, 256, 3, 1, L, none, 2);
+  } else {
+    out = b.conv("upconv2", b.take(), out, C, none, 0, B, h, w, 256, 3, 1, L, none, 2);
+  }
+  h *= 2; w *= 2;
+  out = b.conv("HRconv", b.take(), out, 64, none, 0, B, h, w, 64, 3, 1, L);
+  // base = bilinear x scale of the centre LR frame; one plane group per batch item
+  T base = b.alloc("base", (size_t)B * 3 * h * w);
+  for (int bi = 0; bi < B; ++bi) {
+    Op o; o.type = OP_UP; o.name = "base_up";
+    o.x0 = Builder::view(xin, ((size_t)bi * Nf + ctr) * 3 * HW, 3 * HW);
+    o.planes = 3; o.H = H; o.W = W; o.S = c.scale; o.mul = 1.f;
+    o.y = Builder::view(base, (size_t)bi * 3 * h * w, (size_t)3 * h * w);
+    p.ops.push_back(o);
+  }
+  T yout; yout.space = SP_OUTPUT; yout.off = 0; yout.numel = (size_t)B * 3 * h * w;
+  b.conv("conv_last", b.take(), out, 64, none, 0, B, h, w, 3, 3, 1, NO, base, 0, 1, 0, 0, yout);
+  p.n_params = b.pcur;
+  return DVSR_OK;
+}
+
+struct Bases {
+  float* arena; const float* x; float* out;
+  float* at(const T& t) const {
+    if (t.space == SP_ARENA) return arena + t.off;
+    if (t.space == SP_INPUT) return const_cast<float*>(x) + t.off;
+    if (t.space == SP_OUTPUT) return out + t.off;
+    return nullptr;
+  }
+};
+
+static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, hipStream_t st) {
+  switch (o.type) {
+    case OP_CONV: {
+      dvsr_conv2d_desc d;
+      d.x0 = bs.at(o.x0); d.x1 = bs.at(o.x1); d.w = P[o.pw]; d.bias = P[o.pb]; d.res = bs.at(o.res);
+      d.y = bs.at(o.y);
+      d.N = o.N; d.c0 = o.c0; d.c1 = o.c1; d.H = o.H; d.W = o.W; d.Cout = o.Cout; d.ks = o.ks;
+      d.stride = o.stride; d.pad = o.ks / 2; d.act = o.act; d.pixel_shuffle = o.ps;
+      d.x1_bdiv = o.x1_bdiv; d.x0_bstride = o.x0_bs; d.x1_bstride = o.x1_bs;
+      return conv2d_run(d, 0, st);
+    }
+    case OP_DCN: {
+      const float* om = bs.at(o.x1);
+      const long long bstride = (long long)o.dg * 27 * o.H * o.W;
+      return mdcn_forward_run(bs.at(o.x0), om, bstride, om + (size_t)o.dg * 18 * o.H * o.W, bstride, 1,
+                              P[o.pw], P[o.pb], bs.at(o.y), o.N, o.c0, o.H, o.W, o.Cout, 3, 3, 1, 1,
+                              1, 1, o.dg, o.act, st);
+    }
+    case OP_UP:
+      return upsample_bilinear_fwd(bs.at(o.x0), bs.at(o.y), o.planes, o.H, o.W, o.S, o.mul, st);
+    case OP_POOL:
+      return pool3s2_fwd(bs.at(o.x0), bs.at(o.y), bs.at(o.y2), o.planes, o.H, o.W, st);
+    case OP_GATE:
+      return tsa_gate_fwd(bs.at(o.x0), bs.at(o.x1), bs.at(o.res), bs.at(o.y), bs.at(o.y2), o.gB, o.gN,
+                          o.gC, o.gHW, st);
+    case OP_BLEND:
+      return tsa_blend_fwd(bs.at(o.x0), bs.at(o.x1), bs.at(o.res), bs.at(o.y), o.y.numel, st);
+    case OP_ADD: {
+      hipError_t e = hipMemcpyAsync(bs.at(o.y), bs.at(o.x0), o.y.numel * sizeof(float),
+                                    hipMemcpyDeviceToDevice, st);
+      DVSR_REQUIRE(e == hipSuccess, DVSR_ERR_HIP, "add: memcpy failed: %s", hipGetErrorString(e));
+      return add_inplace(bs.at(o.y), bs.at(o.x1), o.y.numel, st);
+    }
+  }
+  return DVSR_ERR_INVALID;
+}
+
+}  // namespace dvsr
+
+using namespace dvsr;
+
+extern "C" int dvsr_edvr_plan_create(const dvsr_edvr_config* cfg, int B, int H, int W,
+                                     dvsr_edvr_plan** out) {
+  DVSR_REQUIRE(cfg && out, DVSR_ERR_INVALID, "edvr_plan_create: null argument");
+  DVSR_REQUIRE(B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, DVSR_ERR_INVALID,
+               "edvr_plan_create: B=%d H=%d W=%d (H, W must be positive multiples of 4)", B, H, W);
+  DVSR_REQUIRE(cfg->nf > 0 && cfg->nf % cfg->groups == 0 && cfg->nframes > 0 && cfg->front_RBs >= 0 &&
+                   cfg->back_RBs >= 0, DVSR_ERR_INVALID, "edvr_plan_create: bad network config");
+  DVSR_REQUIRE(cfg->scale == 4 || cfg->scale == 2, DVSR_ERR_UNSUPPORTED,
+               "edvr_plan_create: scale=%d (2 or 4)", cfg->scale);
+  DVSR_REQUIRE(cfg->center >= 0 && cfg->center < cfg->nframes, DVSR_ERR_INVALID,
+               "edvr_plan_create: center=%d out of range", cfg->center);
+  const int cpg = cfg->nf / cfg->groups;
+  DVSR_REQUIRE(cpg == 4 || cpg == 8 || cpg == 16, DVSR_ERR_UNSUPPORTED,
+               "edvr_plan_create: nf/groups=%d (supported: 4, 8, 16)", cpg);
+  dvsr_edvr_plan* p = new dvsr_edvr_plan();
+  p->cfg = *cfg; p->B = B; p->H = H; p->W = W;
+  int rc = build_plan(*p);
+  if (rc != DVSR_OK) { delete p; return rc; }
+  *out = p;
+  return DVSR_OK;
+}
+
+extern "C" void dvsr_edvr_plan_destroy(dvsr_edvr_plan* p) { delete p; }
+
+extern "C" int dvsr_edvr_num_params(const dvsr_edvr_plan* p) { return p ? p->n_params : -1; }
+
+extern "C" int dvsr_edvr_num_launches(const dvsr_edvr_plan* p) { return p ? (int)p->ops.size() : -1; }
+
+extern "C" size_t dvsr_edvr_workspace_bytes(const dvsr_edvr_plan* p, int need_grad) {
+  (void)need_grad;
+  return p ? p->arena_floats * sizeof(float) : 0;
+}
+
+extern "C" int dvsr_edvr_forward(const dvsr_edvr_plan* p, const float* const* params, const float* x,
+                                 float* out, void* ws, size_t ws_bytes, dvsr_stream_t stream) {
+  DVSR_REQUIRE(p && params && x && out && ws, DVSR_ERR_INVALID, "edvr_forward: null argument");
+  DVSR_REQUIRE(ws_bytes >= p->arena_floats * sizeof(float), DVSR_ERR_WORKSPACE,
+               "edvr_forward: workspace %zu < %zu bytes", ws_bytes, p->arena_floats * sizeof(float));
+  Bases bs{(float*)ws, x, out};
+  for (const Op& o : p->ops) {
+    int rc = run_forward_op(o, params, bs, (hipStream_t)stream);
+    if (rc != DVSR_OK) return rc;
+  }
+  return DVSR_OK;
+}
+
+// Algorithmic work of one launch: FLOPs = 2*MAC of the contraction (+ the bilinear blends for the
+// DCN sampler); bytes = every distinct input read once + every output written once (fp32).
+static void op_work(const Op& o, const char** kind, double* flops, double* bytes) {
+  *flops = 0; *bytes = 0; *kind = "other";
+  switch (o.type) {
+    case OP_CONV: {
+      const int Ho = (o.H + 2 * (o.ks / 2) - o.ks) / o.stride + 1, Wo = (o.W + 2 * (o.ks / 2) - o.ks) / o.stride + 1;
+      const double ctot = o.c0 + o.c1, px = (double)o.N * Ho * Wo;
+      *flops = 2.0 * px * o.Cout * ctot * o.ks * o.ks;
+      *bytes = 4.0 * ((double)o.N * o.c0 * o.H * o.W + (double)(o.N / o.x1_bdiv) * o.c1 * o.H * o.W +
+                      px * o.Cout * (o.res.valid() ? 2 : 1) + (double)o.Cout * ctot * o.ks * o.ks);
+      *kind = o.ks == 1 ? "conv1x1" : (o.stride == 2 ? "conv3x3s2" : "conv3x3s1");
+      break;
+    }
+    case OP_DCN: {
+      const double px = (double)o.N * o.H * o.W;
+      *flops = 2.0 * px * o.Cout * o.c0 * 9 + px * o.c0 * 9 * 8.0;
+      *bytes = 4.0 * (px * o.c0 + px * o.dg * 27 + px * o.Cout + (double)o.Cout * o.c0 * 9);
+      *kind = "mdcn";
+      break;
+    }
+    case OP_UP: *bytes = 4.0 * o.planes * o.H * o.W * (1.0 + o.S * o.S); *kind = "upsample"; break;
+    case OP_POOL: *bytes = 4.0 * o.planes * o.H * o.W * 1.5; *kind = "pool"; break;
+    case OP_GATE: *bytes = 4.0 * ((double)o.gB * o.gN * o.gC * o.gHW * 3 + (double)o.gB * o.gC * o.gHW +
+                                 (double)o.gB * o.gN * o.gHW); *kind = "tsa_gate"; break;
+    case OP_BLEND: *bytes = 4.0 * o.y.numel * 4; *kind = "tsa_blend"; break;
+    case OP_ADD: *bytes = 4.0 * o.y.numel * 3; *kind = "add"; break;
+  }
+}
+
+extern "C" int dvsr_edvr_op_info(const dvsr_edvr_plan* p, int index, char* kind, int kind_cap,
+                                 char* name, int name_cap, double* flops, double* bytes) {
+  DVSR_REQUIRE(p && kind && name && flops && bytes && index >= 0 && index < (int)p->ops.size(),
+               DVSR_ERR_INVALID, "edvr_op_info: bad argument");
+  const char* k;
+  op_work(p->ops[index], &k, flops, bytes);
+  snprintf(kind, kind_cap, "%s", k);
+  snprintf(name, name_cap, "%s", p->ops[index].name);
+  return DVSR_OK;
+}
+
+// Same launches as dvsr_edvr_forward with a hipEvent recorded on `stream` around every launch;
+// synchronises the stream and returns per-launch milliseconds (measurement aid for bench.py).
+extern "C" int dvsr_edvr_forward_timed(const dvsr_edvr_plan* p, const float* const* params,
+                                       const float* x, float* out, void* ws, size_t ws_bytes,
+                                       dvsr_stream_t stream, float* op_ms) {
+  DVSR_REQUIRE(p && params && x && out && ws && op_ms, DVSR_ERR_INVALID, "edvr_forward_timed: null argument");
+  DVSR_REQUIRE(ws_bytes >= p->arena_floats * sizeof(float), DVSR_ERR_WORKSPACE,
+               "edvr_forward_timed: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = p->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) DVSR_REQUIRE(hipEventCreate(&e) == hipSuccess, DVSR_ERR_HIP, "hipEventCreate failed");
+  Bases bs{(float*)ws, x, out};
+  int rc = DVSR_OK;
+  hipEventRecord(ev[0], st);
+  for (size_t i = 0; i < n && rc == DVSR_OK; ++i) {
+    rc = run_forward_op(p->ops[i], params, bs, st);
+    hipEventRecord(ev[i + 1], st);
+  }
+  if (rc == DVSR_OK && hipStreamSynchronize(st) != hipSuccess) {
+    set_error("edvr_forward_timed: stream synchronize failed");
+    rc = DVSR_ERR_HIP;
+  }
+  if (rc == DVSR_OK)
+    for (size_t i = 0; i < n; ++i) hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]);
+  for (auto& e : ev) hipEventDestroy(e);
+  return rc;
+}
+
+extern "C" int dvsr_edvr_tensor_info(const dvsr_edvr_plan* p, const char* name, long long* offset_floats,
+                                     long long* numel) {
+  DVSR_REQUIRE(p && name && offset_floats && numel, DVSR_ERR_INVALID, "edvr_tensor_info: null argument");
+  for (const auto& kv : p->named)
+    if (kv.first == name && kv.second.space == SP_ARENA) {
+      *offset_floats = (long long)kv.second.off;
+      *numel = (long long)kv.second.numel;
+      return DVSR_OK;
+    }
+  set_error("edvr_tensor_info: no tensor named '%s'", name);
+  return DVSR_ERR_INVALID;
+}

@@ -1,0 +1,66 @@
+// Internal C++ launch API shared by the C-ABI wrappers and the EDVR engine.
+#pragma once
+#include "../../include/dynavsr_hip.h"
+#include "common.h"
+
+namespace dvsr {
+
+int conv2d_run(const dvsr_conv2d_desc& d, int transposed_w, hipStream_t st);
+
+int mdcn_forward_run(const float* x, const float* off, long long off_bs, const float* msk,
+                     long long msk_bs, int mask_logit, const float* w, const float* b, float* out,
+                     int N, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad,
+                     int dil, int groups, int dg, int act, hipStream_t st);
+
+// misc.hip
+int upsample_bilinear_fwd(const float* x, float* y, size_t planes, int H, int W, int S, float mul,
+                          hipStream_t st);
+int upsample_bilinear_bwd(const float* gy, float* gx, size_t planes, int H, int W, int S, float mul,
+                          int accumulate, hipStream_t st);
+int pool3s2_fwd(const float* x, float* ymax, float* yavg, size_t planes, int H, int W, hipStream_t st);
+int pool3s2_bwd(const float* x, const float* gmax, const float* gavg, float* gx, size_t planes,
+                int H, int W, hipStream_t st);
+int tsa_gate_fwd(const float* emb, const float* emb_ref, const float* aligned, float* cor,
+                 float* gated, int B, int N, int C, size_t HW, hipStream_t st);
+int tsa_gate_bwd(const float* emb, const float* emb_ref, const float* aligned, const float* cor,
+                 const float* g_gated, float* g_emb, float* g_emb_ref, float* g_aligned, int B,
+                 int N, int C, size_t HW, hipStream_t st);
+int tsa_blend_fwd(const float* fea, const float* att, const float* add, float* out, size_t n,
+                  hipStream_t st);
+int tsa_blend_bwd(const float* fea, const float* att, const float* g, float* g_fea, float* g_att_io,
+                  size_t n, hipStream_t st);
+int add_inplace(float* dst, const float* src, size_t n, hipStream_t st);
+int act_bwd_inplace(float* g, const float* y, size_t n, int act, hipStream_t st);
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// Sampling geometry of one (pixel, tap) of the deformable conv: 4 corner offsets and weights;
+// an invalid corner contributes 0 (deform_conv_cuda_kernel.cu:479-490).
+struct DcnTap {
+  int o1, o2, o3, o4;    // element offsets inside a plane (0 when the corner is invalid)
+  float w1, w2, w3, w4;  // hh*hw, hh*lw, lh*hw, lh*lw
+  float lh, lw;
+  bool v1, v2, v3, v4;
+};
+
+// false <=> the sample is outside the (-1,H)x(-1,W) gate (kernel.cu:617) and contributes nothing.
+__device__ __forceinline__ bool make_tap(float h_im, float w_im, int H, int W, DcnTap& t) {
+  if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return false;
+  const int h_lo = (int)floorf(h_im), w_lo = (int)floorf(w_im);
+  const int h_hi = h_lo + 1, w_hi = w_lo + 1;
+  t.lh = h_im - (float)h_lo;
+  t.lw = w_im - (float)w_lo;
+  const float hh = 1.f - t.lh, hw = 1.f - t.lw;
+  t.v1 = h_lo >= 0 && w_lo >= 0;
+  t.v2 = h_lo >= 0 && w_hi <= W - 1;
+  t.v3 = h_hi <= H - 1 && w_lo >= 0;
+  t.v4 = h_hi <= H - 1 && w_hi <= W - 1;
+  t.o1 = t.v1 ? h_lo * W + w_lo : 0;
+  t.o2 = t.v2 ? h_lo * W + w_hi : 0;
+  t.o3 = t.v3 ? h_hi * W + w_lo : 0;
+  t.o4 = t.v4 ? h_hi * W + w_hi : 0;
+  t.w1 = hh * hw; t.w2 = hh * t.lw; t.w3 = t.lh * hw; t.w4 = t.lh * t.lw;
+  return true;
+}
+
+}  // namespace dvsr

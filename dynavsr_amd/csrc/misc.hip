@@ -1,0 +1,381 @@
+// HBM-bound streaming kernels of the EDVR hot path: bilinear up-sampling, the 3x3/s2 pooling
+// pair and the TSA gate / blend (EDVR_arch.py:107-120,166-202,311).  One thread per output
+// element (or per pixel for the channel reductions), consecutive lanes = consecutive pixels, so
+// every load/store is a coalesced 256-byte wave access; grids are capped and grid-strided.
+#include "common.h"
+#include "kernels.h"
+
+namespace dvsr {
+
+static inline int stream_grid(size_t n, int block = 256) {
+  size_t g = (n + block - 1) / block;
+  const size_t cap = 256 * 16;  // 256 CUs x 16 resident blocks
+  return (int)(g < cap ? (g ? g : 1) : cap);
+}
+
+// ---- F.interpolate(x, scale_factor=S, mode='bilinear', align_corners=False) * mul ------------
+// Source index rule of ATen's area_pixel_compute_source_index: src = max(0, (dst+0.5)/S - 0.5),
+// i0 = floor(src), i1 = min(i0+1, in-1), lambda = src - i0.
+__device__ __forceinline__ void src_index(int dst, float inv_scale, int in_size, int& i0, int& i1,
+                                          float& l1) {
+  float s = ((float)dst + 0.5f) * inv_scale - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+__global__ void upsample_bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                             size_t planes, int H, int W, int S, float mul) {
+  const int Ho = H * S, Wo = W * S;
+  const size_t total = planes * Ho * Wo;
+  const float inv = 1.f / (float)S;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo);
+    const size_t t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const size_t p = t / Ho;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(oy, inv, H, y0, y1, ly);
+    src_index(ox, inv, W, x0, x1, lx);
+    const float* pl = x + p * (size_t)H * W;
+    const float v = (1.f - ly) * ((1.f - lx) * pl[y0 * W + x0] + lx * pl[y0 * W + x1]) +
+                    ly * ((1.f - lx) * pl[y1 * W + x0] + lx * pl[y1 * W + x1]);
+    y[i] = v * mul;
+  }
+}
+
+// Backward of the above: each input pixel gathers from the <= (S+1)^2 outputs that read it
+// (deterministic, no atomics).  gx = sum_o w(o -> i) * gy[o] * mul.
+__global__ void upsample_bilinear_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                             size_t planes, int H, int W, int S, float mul,
+                                             int accumulate) {
+  const int Ho = H * S, Wo = W * S;
+  const size_t total = planes * H * W;
+  const float inv = 1.f / (float)S;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % W);
+    const size_t t = i / W;
+    const int iy = (int)(t % H);
+    const size_t p = t / H;
+    const float* g = gy + p * (size_t)Ho * Wo;
+    float acc = 0.f;
+    // outputs whose source interval can touch row iy: oy in [(iy-1)*S, (iy+1)*S + S)
+    const int oy_lo = max(0, (iy - 1) * S), oy_hi = min(Ho, (iy + 2) * S);
+    const int ox_lo = max(0, (ix - 1) * S), ox_hi = min(Wo, (ix + 2) * S);
+    for (int oy = oy_lo; oy < oy_hi; ++oy) {
+      int y0, y1;
+      float ly;
+      src_index(oy, inv, H, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == iy) wy += 1.f - ly;
+      if (y1 == iy) wy += ly;
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox < ox_hi; ++ox) {
+        int x0, x1;
+        float lx;
+        src_index(ox, inv, W, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == ix) wx += 1.f - lx;
+        if (x1 == ix) wx += lx;
+        if (wx != 0.f) acc += wy * wx * g[(size_t)oy * Wo + ox];
+      }
+    }
+    acc *= mul;
+    gx[i] = accumulate ? gx[i] + acc : acc;
+  }
+}
+
+// ---- MaxPool2d(3,2,1) and AvgPool2d(3,2,1) of the same input in one pass ---------------------
+// (EDVR_arch.py:149-150,184-185,189-190; max pads with -inf, avg divides by 9 always =
+// count_include_pad=True).  Writes the two results to separate tensors: the following conv
+// consumes them as its two concatenated inputs.
+__global__ void pool3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ ymax,
+                                   float* __restrict__ yavg, size_t planes, int H, int W, int Ho,
+                                   int Wo) {
+  const size_t total = planes * Ho * Wo;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo);
+    const size_t t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const size_t p = t / Ho;
+    const float* pl = x + p * (size_t)H * W;
+    float mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = 2 * oy + dy;
+      if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = 2 * ox + dx;
+        if ((unsigned)xx >= (unsigned)W) continue;
+        const float v = pl[yy * W + xx];
+        mx = fmaxf(mx, v);
+        sum += v;
+      }
+    }
+    ymax[i] = mx;
+    yavg[i] = sum * (1.f / 9.f);
+  }
+}
+
+// Backward: gx[i] = sum over the <= 4 windows containing i of (gavg/9 + gmax * [i is the
+// window's arg-max]).  The arg-max is the FIRST maximal element in row-major window order, which
+// is what ATen's max_pool2d_with_indices records.
+__global__ void pool3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gmax,
+                                   const float* __restrict__ gavg, float* __restrict__ gx,
+                                   size_t planes, int H, int W, int Ho, int Wo) {
+  const size_t total = planes * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % W);
+    const size_t t = i / W;
+    const int iy = (int)(t % H);
+    const size_t p = t / H;
+    const float* pl = x + p * (size_t)H * W;
+    float acc = 0.f;
+    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+      if (oy >= Ho) continue;
+      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox >= Wo) continue;
+        const size_t o = (p * Ho + oy) * (size_t)Wo + ox;
+        acc += gavg[o] * (1.f / 9.f);
+        // locate the window's first maximum
+        float mx = -INFINITY;
+        int ay = -1, ax = -1;
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int yy = 2 * oy + dy;
+          if ((unsigned)yy >= (unsigned)H) continue;
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = 2 * ox + dx;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const float v = pl[yy * W + xx];
+            if (v > mx) { mx = v; ay = yy; ax = xx; }
+          }
+        }
+        if (ay == iy && ax == ix) acc += gmax[o];
+      }
+    }
+    gx[i] = acc;
+  }
+}
+
+// ---- TSA temporal gate (EDVR_arch.py:169-176) ------------------------------------------------
+// cor[b,n,p] = sigmoid(sum_c emb[b,n,c,p] * emb_ref[b,c,p]);  gated[b,n,c,p] = aligned * cor.
+// lane = pixel, so the channel reduction is a private register loop (no cross-lane traffic).
+__global__ void tsa_gate_fwd_kernel(const float* __restrict__ emb, const float* __restrict__ emb_ref,
+                                    const float* __restrict__ aligned, float* __restrict__ cor,
+                                    float* __restrict__ gated, int B, int N, int C, size_t HW) {
+  const size_t total = (size_t)B * N * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i % HW;
+    const size_t bn = i / HW;
+    const size_t b = bn / N;
+    const float* e = emb + bn * C * HW + p;
+    const float* r = emb_ref + b * C * HW + p;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc += e[c * HW] * r[c * HW];
+    const float s = sigmoidf_(acc);
+    cor[i] = s;
+    const float* al = aligned + bn * C * HW + p;
+    float* gt = gated + bn * C * HW + p;
+    for (int c = 0; c < C; ++c) gt[c * HW] = al[c * HW] * s;
+  }
+}
+
+// Backward: g_aligned = g_gated * cor (+= into ga);  g_cor = sum_c g_gated * aligned;
+// g_dot = g_cor * cor * (1 - cor);  g_emb[b,n,c,p] = g_dot * emb_ref;  g_emb_ref accumulates
+// over n -> the thread loops the N frames of its pixel itself (deterministic).
+__global__ void tsa_gate_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ emb_ref,
+                                    const float* __restrict__ aligned, const float* __restrict__ cor,
+                                    const float* __restrict__ g_gated, float* __restrict__ g_emb,
+                                    float* __restrict__ g_emb_ref, float* __restrict__ g_aligned,
+                                    int B, int N, int C, size_t HW) {
+  const size_t total = (size_t)B * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i % HW;
+    const size_t b = i / HW;
+    const float* r = emb_ref + b * C * HW + p;
+    float* gr = g_emb_ref + b * C * HW + p;
+    for (int c = 0; c < C; ++c) gr[c * HW] = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const size_t bn = b * N + n;
+      const float s = cor[bn * HW + p];
+      const float* gg = g_gated + bn * C * HW + p;
+      const float* al = aligned + bn * C * HW + p;
+      float* ga = g_aligned + bn * C * HW + p;
+      float gcor = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float g = gg[c * HW];
+        gcor += g * al[c * HW];
+        ga[c * HW] = g * s;
+      }
+      const float gdot = gcor * s * (1.f - s);
+      const float* e = emb + bn * C * HW + p;
+      float* ge = g_emb + bn * C * HW + p;
+      for (int c = 0; c < C; ++c) {
+        ge[c * HW] = gdot * r[c * HW];
+        gr[c * HW] += gdot * e[c * HW];
+      }
+    }
+  }
+}
+
+// ---- TSA blend: out = fea * sigmoid(att) * 2 + att_add (EDVR_arch.py:200-202) ---------------
+__global__ void tsa_blend_fwd_kernel(const float* __restrict__ fea, const float* __restrict__ att,
+                                     const float* __restrict__ add, float* __restrict__ out,
+                                     size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = fea[i] * sigmoidf_(att[i]) * 2.f + add[i];
+}
+
+// g_fea = g*2*s; g_att = g*fea*2*s*(1-s) (added to g_att_io, which already holds the gradient
+// reaching att through the att_add branch); g_add = g is aliased by the caller.
+__global__ void tsa_blend_bwd_kernel(const float* __restrict__ fea, const float* __restrict__ att,
+                                     const float* __restrict__ g, float* __restrict__ g_fea,
+                                     float* __restrict__ g_att_io, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float s = sigmoidf_(att[i]);
+    const float gi = g[i];
+    g_fea[i] = gi * 2.f * s;
+    g_att_io[i] += gi * fea[i] * 2.f * s * (1.f - s);
+  }
+}
+
+// ---- generic helpers -------------------------------------------------------------------------
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    dst[i] += src[i];
+}
+
+// g *= act'(y) where y is the saved post-activation output.
+__global__ void act_bwd_inplace_kernel(float* __restrict__ g, const float* __restrict__ y, size_t n,
+                                       int act) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    g[i] *= act_grad_from_out(y[i], act);
+}
+
+#define LAUNCH(kern, n, st, ...) \
+  hipLaunchKernelGGL(kern, dim3(stream_grid(n)), dim3(256), 0, st, __VA_ARGS__)
+
+int upsample_bilinear_fwd(const float* x, float* y, size_t planes, int H, int W, int S, float mul,
+                          hipStream_t st) {
+  DVSR_REQUIRE(x && y && planes > 0 && H > 0 && W > 0 && S >= 1, DVSR_ERR_INVALID,
+               "upsample_bilinear_fwd: bad argument");
+  LAUNCH(upsample_bilinear_fwd_kernel, planes * H * W * S * S, st, x, y, planes, H, W, S, mul);
+  return check_launch("upsample_bilinear_fwd_kernel");
+}
+int upsample_bilinear_bwd(const float* gy, float* gx, size_t planes, int H, int W, int S, float mul,
+                          int accumulate, hipStream_t st) {
+  DVSR_REQUIRE(gy && gx && planes > 0 && H > 0 && W > 0 && S >= 1, DVSR_ERR_INVALID,
+               "upsample_bilinear_bwd: bad argument");
+  LAUNCH(upsample_bilinear_bwd_kernel, planes * H * W, st, gy, gx, planes, H, W, S, mul, accumulate);
+  return check_launch("upsample_bilinear_bwd_kernel");
+}
+int pool3s2_fwd(const float* x, float* ymax, float* yavg, size_t planes, int H, int W, hipStream_t st) {
+  DVSR_REQUIRE(x && ymax && yavg && planes > 0 && H > 0 && W > 0, DVSR_ERR_INVALID,
+               "pool3s2_fwd: bad argument");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  LAUNCH(pool3s2_fwd_kernel, planes * Ho * Wo, st, x, ymax, yavg, planes, H, W, Ho, Wo);
+  return check_launch("pool3s2_fwd_kernel");
+}
+int pool3s2_bwd(const float* x, const float* gmax, const float* gavg, float* gx, size_t planes,
+                int H, int W, hipStream_t st) {
+  DVSR_REQUIRE(x && gmax && gavg && gx && planes > 0, DVSR_ERR_INVALID, "pool3s2_bwd: bad argument");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  LAUNCH(pool3s2_bwd_kernel, planes * H * W, st, x, gmax, gavg, gx, planes, H, W, Ho, Wo);
+  return check_launch("pool3s2_bwd_kernel");
+}
+int tsa_gate_fwd(const float* emb, const float* emb_ref, const float* aligned, float* cor,
+                 float* gated, int B, int N, int C, size_t HW, hipStream_t st) {
+  DVSR_REQUIRE(emb && emb_ref && aligned && cor && gated && B > 0 && N > 0 && C > 0 && HW > 0,
+               DVSR_ERR_INVALID, "tsa_gate_fwd: bad argument");
+  LAUNCH(tsa_gate_fwd_kernel, (size_t)B * N * HW, st, emb, emb_ref, aligned, cor, gated, B, N, C, HW);
+  return check_launch("tsa_gate_fwd_kernel");
+}
+int tsa_gate_bwd(const float* emb, const float* emb_ref, const float* aligned, const float* cor,
+                 const float* g_gated, float* g_emb, float* g_emb_ref, float* g_aligned, int B,
+                 int N, int C, size_t HW, hipStream_t st) {
+  DVSR_REQUIRE(emb && emb_ref && aligned && cor && g_gated && g_emb && g_emb_ref && g_aligned,
+               DVSR_ERR_INVALID, "tsa_gate_bwd: null pointer");
+  LAUNCH(tsa_gate_bwd_kernel, (size_t)B * HW, st, emb, emb_ref, aligned, cor, g_gated, g_emb,
+         g_emb_ref, g_aligned, B, N, C, HW);
+  return check_launch("tsa_gate_bwd_kernel");
+}
+int tsa_blend_fwd(const float* fea, const float* att, const float* add, float* out, size_t n,
+                  hipStream_t st) {
+  DVSR_REQUIRE(fea && att && add && out && n > 0, DVSR_ERR_INVALID, "tsa_blend_fwd: bad argument");
+  LAUNCH(tsa_blend_fwd_kernel, n, st, fea, att, add, out, n);
+  return check_launch("tsa_blend_fwd_kernel");
+}
+int tsa_blend_bwd(const float* fea, const float* att, const float* g, float* g_fea, float* g_att_io,
+                  size_t n, hipStream_t st) {
+  DVSR_REQUIRE(fea && att && g && g_fea && g_att_io && n > 0, DVSR_ERR_INVALID,
+               "tsa_blend_bwd: bad argument");
+  LAUNCH(tsa_blend_bwd_kernel, n, st, fea, att, g, g_fea, g_att_io, n);
+  return check_launch("tsa_blend_bwd_kernel");
+}
+int add_inplace(float* dst, const float* src, size_t n, hipStream_t st) {
+  LAUNCH(add_inplace_kernel, n, st, dst, src, n);
+  return check_launch("add_inplace_kernel");
+}
+int act_bwd_inplace(float* g, const float* y, size_t n, int act, hipStream_t st) {
+  if (act == ACT_NONE) return DVSR_OK;
+  LAUNCH(act_bwd_inplace_kernel, n, st, g, y, n, act);
+  return check_launch("act_bwd_inplace_kernel");
+}
+
+}  // namespace dvsr
+
+using namespace dvsr;
+
+extern "C" int dvsr_upsample_bilinear_forward(const float* x, float* y, long long planes, int H,
+                                              int W, int scale, float mul, dvsr_stream_t stream) {
+  return upsample_bilinear_fwd(x, y, (size_t)planes, H, W, scale, mul, (hipStream_t)stream);
+}
+extern "C" int dvsr_upsample_bilinear_backward(const float* gy, float* gx, long long planes, int H,
+                                               int W, int scale, float mul, int accumulate,
+                                               dvsr_stream_t stream) {
+  return upsample_bilinear_bwd(gy, gx, (size_t)planes, H, W, scale, mul, accumulate,
+                               (hipStream_t)stream);
+}
+extern "C" int dvsr_pool3s2_forward(const float* x, float* ymax, float* yavg, long long planes,
+                                    int H, int W, dvsr_stream_t stream) {
+  return pool3s2_fwd(x, ymax, yavg, (size_t)planes, H, W, (hipStream_t)stream);
+}
+extern "C" int dvsr_pool3s2_backward(const float* x, const float* gmax, const float* gavg,
+                                     float* gx, long long planes, int H, int W,
+                                     dvsr_stream_t stream) {
+  return pool3s2_bwd(x, gmax, gavg, gx, (size_t)planes, H, W, (hipStream_t)stream);
+}
+extern "C" int dvsr_tsa_gate_forward(const float* emb, const float* emb_ref, const float* aligned,
+                                     float* cor, float* gated, int B, int N, int C, long long HW,
+                                     dvsr_stream_t stream) {
+  return tsa_gate_fwd(emb, emb_ref, aligned, cor, gated, B, N, C, (size_t)HW, (hipStream_t)stream);
+}
+extern "C" int dvsr_tsa_gate_backward(const float* emb, const float* emb_ref, const float* aligned,
+                                      const float* cor, const float* g_gated, float* g_emb,
+                                      float* g_emb_ref, float* g_aligned, int B, int N, int C,
+                                      long long HW, dvsr_stream_t stream) {
+  return tsa_gate_bwd(emb, emb_ref, aligned, cor, g_gated, g_emb, g_emb_ref, g_aligned, B, N, C,
+                      (size_t)HW, (hipStream_t)stream);
+}
+extern "C" int dvsr_tsa_blend_forward(const float* fea, const float* att, const float* att_add,
+                                      float* out, long long n, dvsr_stream_t stream) {
+  return tsa_blend_fwd(fea, att, att_add, out, (size_t)n, (hipStream_t)stream);
+}
+extern "C" int dvsr_tsa_blend_backward(const float* fea, const float* att, const float* g,
+                                       float* g_fea, float* g_att_io, long long n,
+                                       dvsr_stream_t stream) {
+  return tsa_blend_bwd(fea, att, g, g_fea, g_att_io, (size_t)n, (hipStream_t)stream);
+}

@@ -1,0 +1,117 @@
+"""Python face of the native EDVR execution plan (csrc/engine.hip).
+
+One `torch.autograd.Function` spans the whole backbone: forward enqueues every kernel of
+EDVR.forward with ONE C call, backward (first-order, like the reference's once_differentiable
+DCN, deform_conv.py:123) enqueues the whole backward and returns d/dx and d/d(144 params).
+Parameters stay ordinary leaf nn.Parameters, so external torch.optim objects, deepcopy and
+`param.grad += g` in the DynaVSR drivers keep working.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+_plans = {}
+
+
+class Plan:
+    """Owns one dvsr_edvr_plan (shape-specialised launch tape)."""
+
+    def __init__(self, cfg, b, h, w):
+        self.key = (cfg, b, h, w)
+        self.cfg = dict(zip(("nf", "nframes", "groups", "front_RBs", "back_RBs", "scale", "center"), cfg))
+        self.b, self.h, self.w = b, h, w
+        self._h = ctypes.c_void_p()
+        L.check(L.lib().dvsr_edvr_plan_create(L.EdvrConfig(*cfg), b, h, w, ctypes.byref(self._h)),
+                "dvsr_edvr_plan_create")
+        self.n_params = L.lib().dvsr_edvr_num_params(self._h)
+        self.n_launches = L.lib().dvsr_edvr_num_launches(self._h)
+
+    def workspace_bytes(self, need_grad):
+        return int(L.lib().dvsr_edvr_workspace_bytes(self._h, int(need_grad)))
+
+    def forward(self, params, x, out, ws):
+        arr = (ctypes.c_void_p * len(params))(*[L.ptr(p) for p in params])
+        L.check(L.lib().dvsr_edvr_forward(self._h, arr, L.ptr(x), L.ptr(out), ws.data_ptr(),
+                                          ws.numel() * ws.element_size(), L.stream()),
+                "dvsr_edvr_forward")
+
+    def forward_timed(self, params, x, out, ws):
+        """Per-launch milliseconds (hipEvents on the current stream, stream-synchronising)."""
+        arr = (ctypes.c_void_p * len(params))(*[L.ptr(p) for p in params])
+        ms = (ctypes.c_float * self.n_launches)()
+        L.check(L.lib().dvsr_edvr_forward_timed(self._h, arr, L.ptr(x), L.ptr(out), ws.data_ptr(),
+                                                ws.numel() * ws.element_size(), L.stream(), ms),
+                "dvsr_edvr_forward_timed")
+        return list(ms)
+
+    def op_info(self):
+        """[(kind, name, flops, bytes)] per launch."""
+        out = []
+        kind, name = ctypes.create_string_buffer(32), ctypes.create_string_buffer(64)
+        fl, by = ctypes.c_double(), ctypes.c_double()
+        for i in range(self.n_launches):
+            L.check(L.lib().dvsr_edvr_op_info(self._h, i, kind, 32, name, 64, ctypes.byref(fl),
+                                              ctypes.byref(by)), "dvsr_edvr_op_info")
+            out.append((kind.value.decode(), name.value.decode(), fl.value, by.value))
+        return out
+
+    def tensor(self, ws, name, shape=None):
+        off, n = ctypes.c_longlong(), ctypes.c_longlong()
+        L.check(L.lib().dvsr_edvr_tensor_info(self._h, name.encode(), ctypes.byref(off),
+                                              ctypes.byref(n)), "dvsr_edvr_tensor_info")
+        t = ws.view(torch.float32)[off.value:off.value + n.value]
+        return t.view(shape) if shape is not None else t
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().dvsr_edvr_plan_destroy(self._h)
+        except Exception:
+            pass
+
+
+def get_plan(cfg, b, h, w):
+    key = (tuple(cfg), b, h, w)
+    p = _plans.get(key)
+    if p is None:
+        p = _plans[key] = Plan(tuple(cfg), b, h, w)
+    return p
+
+
+def _prep(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class EdvrFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cfg, keep_ws, *params):
+        if not x.is_cuda:
+            raise RuntimeError("dynavsr_amd EDVR runs on the MI355X only (input is on %s); there is "
+                               "no CPU fallback" % x.device)
+        x = _prep(x)
+        b, n, c, h, w = x.shape
+        if n != cfg[1] or c != 3:
+            raise RuntimeError("EDVR expects [B,%d,3,H,W], got %s" % (cfg[1], tuple(x.shape)))
+        plan = get_plan(cfg, b, h, w)
+        if len(params) != plan.n_params:
+            raise RuntimeError("EDVR engine expects %d parameter tensors, got %d"
+                               % (plan.n_params, len(params)))
+        params = [_prep(p.detach()) for p in params]
+        need_grad = any(ctx.needs_input_grad)
+        ws = torch.empty(plan.workspace_bytes(need_grad), dtype=torch.uint8, device=x.device)
+        out = x.new_empty((b, 3, cfg[5] * h, cfg[5] * w))
+        plan.forward(params, x, out, ws)
+        if need_grad:
+            ctx.plan, ctx.ws, ctx.x, ctx.params = plan, ws, x, params
+        if keep_ws is not None:
+            keep_ws.append((plan, ws))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        raise NotImplementedError("dvsr_edvr_backward is not wired yet")

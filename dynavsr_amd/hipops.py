@@ -1,0 +1,120 @@
+"""Thin functional wrappers over the op-level C ABI (forward ops; no autograd here).
+
+Used by the op-level drop-in (models/archs/dcn) and by the parity tests.  Arguments mirror the
+reference call sites; tensors must be fp32 contiguous CUDA(HIP) tensors.
+"""
+import torch
+
+from . import _lib as L
+
+
+def mdcn_forward(x, offset, mask, weight, bias, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, act=L.ACT_NONE):
+    n, c, h, w = x.shape
+    cout, _, kh, kw = weight.shape
+    ho = (h + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+    wo = (w + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+    out = x.new_empty((n, cout, ho, wo))
+    L.check(L.lib().dvsr_mdcn_forward(L.ptr(x), L.ptr(offset), L.ptr(mask), L.ptr(weight),
+                                      L.ptr(bias), L.ptr(out), n, c, h, w, cout, kh, kw, stride,
+                                      padding, dilation, groups, deformable_groups, act, L.stream()),
+            "dvsr_mdcn_forward")
+    return out
+
+
+def mdcn_pack_forward(x, om, weight, bias, deformable_groups, act=L.ACT_NONE):
+    n, c, h, w = x.shape
+    cout = weight.shape[0]
+    out = x.new_empty((n, cout, h, w))
+    L.check(L.lib().dvsr_mdcn_pack_forward(L.ptr(x), L.ptr(om), L.ptr(weight), L.ptr(bias),
+                                           L.ptr(out), n, c, h, w, cout, 3, 3, 1, 1, 1, 1,
+                                           deformable_groups, act, L.stream()),
+            "dvsr_mdcn_pack_forward")
+    return out
+
+
+def conv2d_forward(x0, weight, bias=None, stride=1, act=L.ACT_NONE, x1=None, res=None,
+                   pixel_shuffle=0, x1_bdiv=1):
+    n, c0, h, w = x0.shape
+    cout, ctot, ks, _ = weight.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    assert ctot == c0 + c1
+    pad = ks // 2
+    ho = (h + 2 * pad - ks) // stride + 1
+    wo = (w + 2 * pad - ks) // stride + 1
+    if pixel_shuffle:
+        y = x0.new_empty((n, cout // 4, 2 * ho, 2 * wo))
+    else:
+        y = x0.new_empty((n, cout, ho, wo))
+    d = L.Conv2dDesc(L.ptr(x0), L.ptr(x1), L.ptr(weight), L.ptr(bias), L.ptr(res), L.ptr(y), n, c0,
+                     c1, h, w, cout, ks, stride, pad, act, pixel_shuffle, x1_bdiv, 0, 0)
+    L.check(L.lib().dvsr_conv2d_forward(d, L.stream()), "dvsr_conv2d_forward")
+    return y
+
+
+def upsample_bilinear(x, scale, mul=1.0):
+    n, c, h, w = x.shape
+    y = x.new_empty((n, c, h * scale, w * scale))
+    L.check(L.lib().dvsr_upsample_bilinear_forward(L.ptr(x), L.ptr(y), n * c, h, w, scale, mul,
+                                                   L.stream()), "dvsr_upsample_bilinear_forward")
+    return y
+
+
+def upsample_bilinear_backward(gy, scale, mul=1.0):
+    n, c, ho, wo = gy.shape
+    h, w = ho // scale, wo // scale
+    gx = gy.new_empty((n, c, h, w))
+    L.check(L.lib().dvsr_upsample_bilinear_backward(L.ptr(gy), L.ptr(gx), n * c, h, w, scale, mul, 0,
+                                                    L.stream()), "dvsr_upsample_bilinear_backward")
+    return gx
+
+
+def pool3s2(x):
+    n, c, h, w = x.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    ymax, yavg = x.new_empty((n, c, ho, wo)), x.new_empty((n, c, ho, wo))
+    L.check(L.lib().dvsr_pool3s2_forward(L.ptr(x), L.ptr(ymax), L.ptr(yavg), n * c, h, w, L.stream()),
+            "dvsr_pool3s2_forward")
+    return ymax, yavg
+
+
+def pool3s2_backward(x, gmax, gavg):
+    n, c, h, w = x.shape
+    gx = torch.empty_like(x)
+    L.check(L.lib().dvsr_pool3s2_backward(L.ptr(x), L.ptr(gmax), L.ptr(gavg), L.ptr(gx), n * c, h, w,
+                                          L.stream()), "dvsr_pool3s2_backward")
+    return gx
+
+
+def tsa_gate(emb, emb_ref, aligned):
+    b, n, c, h, w = aligned.shape
+    cor = aligned.new_empty((b, n, h, w))
+    gated = aligned.new_empty((b, n * c, h, w))
+    L.check(L.lib().dvsr_tsa_gate_forward(L.ptr(emb), L.ptr(emb_ref), L.ptr(aligned), L.ptr(cor),
+                                          L.ptr(gated), b, n, c, h * w, L.stream()),
+            "dvsr_tsa_gate_forward")
+    return cor, gated
+
+
+def tsa_gate_backward(emb, emb_ref, aligned, cor, g_gated):
+    b, n, c, h, w = aligned.shape
+    g_emb, g_ref, g_al = torch.empty_like(emb), torch.empty_like(emb_ref), torch.empty_like(aligned)
+    L.check(L.lib().dvsr_tsa_gate_backward(L.ptr(emb), L.ptr(emb_ref), L.ptr(aligned), L.ptr(cor),
+                                           L.ptr(g_gated), L.ptr(g_emb), L.ptr(g_ref), L.ptr(g_al),
+                                           b, n, c, h * w, L.stream()), "dvsr_tsa_gate_backward")
+    return g_emb, g_ref, g_al
+
+
+def tsa_blend(fea, att, att_add):
+    out = torch.empty_like(fea)
+    L.check(L.lib().dvsr_tsa_blend_forward(L.ptr(fea), L.ptr(att), L.ptr(att_add), L.ptr(out),
+                                           fea.numel(), L.stream()), "dvsr_tsa_blend_forward")
+    return out
+
+
+def tsa_blend_backward(fea, att, g, g_att_io):
+    g_fea = torch.empty_like(fea)
+    L.check(L.lib().dvsr_tsa_blend_backward(L.ptr(fea), L.ptr(att), L.ptr(g), L.ptr(g_fea),
+                                            L.ptr(g_att_io), fea.numel(), L.stream()),
+            "dvsr_tsa_blend_backward")
+    return g_fea

@@ -1,0 +1,153 @@
+/*
+ * dynavsr_hip.h -- C ABI of libdynavsr_hip.so: MI355X (gfx950) kernels for the EDVR hot path of
+ * DynaVSR (PCD deformable alignment, TSA fusion, reconstruction) and its inner MAML step.
+ *
+ * Contract (all entry points):
+ *   - plain C, no C++/torch types; every pointer is a DEVICE pointer on the current HIP device,
+ *     fp32, contiguous NCHW unless stated; tensors are borrowed, never owned or freed;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream), no
+ *     internal synchronisation, no allocation: scratch comes from a caller workspace;
+ *   - returns 0 on success or a negative DVSR_ERR_* code and never throws; the message of the
+ *     last failure on the calling thread is dvsr_last_error();
+ *   - re-entrant; the only global mutable state is that thread-local error string.
+ *
+ * Each declaration cites the reference interface it replaces (paths under codes/ of
+ * esw0116/DynaVSR).  The reference's only native boundary is the pybind11 module
+ * `deform_conv_cuda` (models/archs/dcn/src/deform_conv_cuda.cpp:681-695); everything else the
+ * reference gets from cuDNN/ATen through torch.nn, which these kernels replace one-for-one.
+ */
+#ifndef DYNAVSR_HIP_H_
+#define DYNAVSR_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVSR_OK 0
+#define DVSR_ERR_INVALID (-1)
+#define DVSR_ERR_UNSUPPORTED (-2)
+#define DVSR_ERR_WORKSPACE (-3)
+#define DVSR_ERR_HIP (-4)
+
+#define DVSR_ACT_NONE 0
+#define DVSR_ACT_LRELU 1 /* LeakyReLU(0.1): models/archs/EDVR_arch.py:93,161,252 */
+#define DVSR_ACT_RELU 2  /* models/archs/arch_util.py:50 */
+
+typedef void* dvsr_stream_t; /* hipStream_t */
+
+const char* dvsr_last_error(void);
+int dvsr_version(void);
+
+/* ---- modulated deformable convolution (DCNv2) ------------------------------------------------
+ * Replaces modulated_deform_conv_cuda_forward (deform_conv_cuda.cpp:486-564; kernels
+ * deform_conv_cuda_kernel.cu:466-496,569-632) with ONE fused kernel: bilinear sampling, mask
+ * and the Cout x (C*kh*kw) contraction happen per tile in LDS/MFMA, no im2col buffer in HBM.
+ *   x [N,C,H,W]  offset [N,dg*2*kh*kw,Ho,Wo] ((dy,dx) interleaved per tap)  mask [N,dg*kh*kw,Ho,Wo]
+ *   w [Cout,C/groups,kh,kw]  b [Cout] or NULL  ->  out [N,Cout,Ho,Wo] (overwritten)
+ * Supported: kh=kw=3, groups=1, C/dg in {4,8,16}; anything else returns DVSR_ERR_UNSUPPORTED
+ * (the reference raises through AT_ERROR, cpp:506-511).  `act` is applied to the result
+ * (EDVR_arch.py:103,126 apply LeakyReLU right after the DCN; pass DVSR_ACT_NONE for the op alone).
+ */
+int dvsr_mdcn_forward(const float* x, const float* offset, const float* mask, const float* w,
+                      const float* b, float* out, int N, int C, int H, int W, int Cout, int kh,
+                      int kw, int stride, int pad, int dil, int groups, int dg, int act,
+                      dvsr_stream_t stream);
+
+/* Same op fed by the RAW output `om` [N, 3*dg*kh*kw, Ho, Wo] of ModulatedDeformConvPack's
+ * conv_offset_mask (deform_conv.py:274-291): offset = om[:, :2*dg*K], mask = sigmoid(om[:, 2*dg*K:]);
+ * the chunk/cat/sigmoid launches of the reference are folded into the sampler. */
+int dvsr_mdcn_pack_forward(const float* x, const float* om, const float* w, const float* b,
+                           float* out, int N, int C, int H, int W, int Cout, int kh, int kw,
+                           int stride, int pad, int dil, int groups, int dg, int act,
+                           dvsr_stream_t stream);
+
+/* ---- dense convolution ------------------------------------------------------------------------
+ * Replaces nn.Conv2d (+ the torch.cat feeding it, + the activation / residual add /
+ * nn.PixelShuffle(2) following it) everywhere in EDVR_arch.py / arch_util.py:34-52.
+ * LDS-staged implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), no im2col. */
+typedef struct dvsr_conv2d_desc {
+  const float* x0;   /* [N][c0][H][W] */
+  const float* x1;   /* optional 2nd input, concatenated after x0 along C: [ceil(N/x1_bdiv)][c1][H][W]; NULL if c1==0 */
+  const float* w;    /* [Cout][c0+c1][ks][ks] (OIHW) */
+  const float* bias; /* [Cout] or NULL */
+  const float* res;  /* optional tensor added AFTER the activation, shaped like y; NULL = none */
+  float* y;          /* [N][Cout][Ho][Wo]; with pixel_shuffle=2: [N][Cout/4][2Ho][2Wo] */
+  int N, c0, c1, H, W, Cout;
+  int ks;            /* 1 or 3 */
+  int stride;        /* 1 or 2 */
+  int pad;           /* zero padding, must be ks/2 */
+  int act;           /* DVSR_ACT_* applied to conv+bias */
+  int pixel_shuffle; /* 0, or 2 = nn.PixelShuffle(2) fused into the store (EDVR_arch.py:247,303-305) */
+  int x1_bdiv;       /* x1 batch index = n / x1_bdiv (>=1): one reference frame shared by N frames */
+  long long x0_bstride; /* elements between batch items of x0; 0 = dense (c0*H*W) */
+  long long x1_bstride; /* same for x1; 0 = dense (c1*H*W) */
+} dvsr_conv2d_desc;
+
+int dvsr_conv2d_forward(const dvsr_conv2d_desc* d, dvsr_stream_t stream);
+
+/* ---- streaming (HBM-bound) ops ------------------------------------------------------------------
+ * F.interpolate(scale_factor=S, mode='bilinear', align_corners=False) * mul
+ * (EDVR_arch.py:107-108,111,116-117,120,192,197,311); x [planes,H,W] -> y [planes,S*H,S*W]. */
+int dvsr_upsample_bilinear_forward(const float* x, float* y, long long planes, int H, int W,
+                                   int scale, float mul, dvsr_stream_t stream);
+int dvsr_upsample_bilinear_backward(const float* gy, float* gx, long long planes, int H, int W,
+                                    int scale, float mul, int accumulate, dvsr_stream_t stream);
+/* nn.MaxPool2d(3,2,1) and nn.AvgPool2d(3,2,1) of the same tensor in one pass
+ * (EDVR_arch.py:149-150,184-185,189-190). */
+int dvsr_pool3s2_forward(const float* x, float* ymax, float* yavg, long long planes, int H, int W,
+                         dvsr_stream_t stream);
+int dvsr_pool3s2_backward(const float* x, const float* gmax, const float* gavg, float* gx,
+                          long long planes, int H, int W, dvsr_stream_t stream);
+/* TSA temporal attention gate (EDVR_arch.py:169-176): cor = sigmoid(sum_c emb*emb_ref) [B,N,HW],
+ * gated = aligned * cor [B,N*C,HW]. */
+int dvsr_tsa_gate_forward(const float* emb, const float* emb_ref, const float* aligned, float* cor,
+                          float* gated, int B, int N, int C, long long HW, dvsr_stream_t stream);
+int dvsr_tsa_gate_backward(const float* emb, const float* emb_ref, const float* aligned,
+                           const float* cor, const float* g_gated, float* g_emb, float* g_emb_ref,
+                           float* g_aligned, int B, int N, int C, long long HW,
+                           dvsr_stream_t stream);
+/* out = fea * sigmoid(att) * 2 + att_add (EDVR_arch.py:200-202). */
+int dvsr_tsa_blend_forward(const float* fea, const float* att, const float* att_add, float* out,
+                           long long n, dvsr_stream_t stream);
+int dvsr_tsa_blend_backward(const float* fea, const float* att, const float* g, float* g_fea,
+                            float* g_att_io, long long n, dvsr_stream_t stream);
+
+/* ---- whole-network execution plan ----------------------------------------------------------------
+ * Replaces `netG(var_L)` = EDVR.forward (models/archs/EDVR_arch.py:254-313, incl. PCD_Align :95-128
+ * and TSA_Fusion :163-203) as called from VideoBaseModel.calculate_loss/test
+ * (models/Video_base_model.py:191-201): one call enqueues every kernel of the backbone on `stream`.
+ * `params` is a HOST array of dvsr_edvr_num_params() device pointers in the reference's state-dict
+ * order (conv_first.weight, conv_first.bias, feature_extraction.0.conv1.weight, ... conv_last.bias).
+ * x [B,nframes,3,H,W] -> out [B,3,scale*H,scale*W].  The workspace keeps every activation
+ * (it is what a later backward call reads), so it must stay untouched between the two calls. */
+typedef struct dvsr_edvr_config {
+  int nf, nframes, groups, front_RBs, back_RBs, scale, center;
+} dvsr_edvr_config;
+typedef struct dvsr_edvr_plan dvsr_edvr_plan;
+
+int dvsr_edvr_plan_create(const dvsr_edvr_config* cfg, int B, int H, int W, dvsr_edvr_plan** out);
+void dvsr_edvr_plan_destroy(dvsr_edvr_plan* plan);
+int dvsr_edvr_num_params(const dvsr_edvr_plan* plan);
+int dvsr_edvr_num_launches(const dvsr_edvr_plan* plan);
+size_t dvsr_edvr_workspace_bytes(const dvsr_edvr_plan* plan, int need_grad);
+int dvsr_edvr_forward(const dvsr_edvr_plan* plan, const float* const* params, const float* x,
+                      float* out, void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
+/* Measurement aids: per-launch description (kind = "conv3x3s1", "mdcn", ...; algorithmic FLOPs and
+ * bytes of that launch) and a forward that brackets every launch with hipEvents on `stream`,
+ * synchronises, and returns per-launch milliseconds in op_ms[dvsr_edvr_num_launches()]. */
+int dvsr_edvr_op_info(const dvsr_edvr_plan* plan, int index, char* kind, int kind_cap, char* name,
+                      int name_cap, double* flops, double* bytes);
+int dvsr_edvr_forward_timed(const dvsr_edvr_plan* plan, const float* const* params, const float* x,
+                            float* out, void* workspace, size_t workspace_bytes,
+                            dvsr_stream_t stream, float* op_ms);
+/* Offset (in floats, into the workspace) and size of a named intermediate, for layer-by-layer
+ * parity checks ("L1_fea", "aligned", "tsa_out", "recon", ...). */
+int dvsr_edvr_tensor_info(const dvsr_edvr_plan* plan, const char* name, long long* offset_floats,
+                          long long* numel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNAVSR_HIP_H_ */

@@ -1,0 +1,174 @@
+"""GPU parity of the op-level C ABI (include/dynavsr_hip.h) against the CPU oracle / fp64 torch.
+
+Run on the MI355X box: python -m pytest tests -m gpu.  Tolerances: the kernels compute in exact
+fp32 (v_mfma_f32_32x32x2_f32 == fmaf chain), so the only differences to an fp64 reference are
+fp32 round-off: rel-L2 <= 2e-6 * sqrt(K) is typical; 2e-5 is asserted.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from dynavsr_amd import hipops
+    return hipops
+
+
+def dev(t):
+    return t.float().contiguous().cuda()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape) * scale)
+
+
+ACT = {0: lambda v: v, 1: lambda v: F.leaky_relu(v, 0.1), 2: F.relu}
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,h,w", [
+    (64, 64, 3, 1, 24, 40), (3, 64, 3, 1, 17, 33), (64, 216, 3, 1, 13, 35), (64, 3, 3, 1, 16, 64),
+    (64, 64, 3, 2, 24, 40), (64, 64, 3, 2, 22, 34), (64, 64, 1, 1, 9, 70), (320, 64, 1, 1, 16, 32),
+    (128, 64, 3, 1, 8, 32), (16, 24, 3, 1, 5, 7),
+])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv2d_forward(ops, cin, cout, ks, stride, h, w, act):
+    x = rnd(2, cin, h, w, seed=1)
+    wt = rnd(cout, cin, ks, ks, seed=2, scale=1 / np.sqrt(cin * ks * ks))
+    b = rnd(cout, seed=3, scale=0.1)
+    ref = ACT[act](F.conv2d(x, wt, b, stride, ks // 2))
+    got = ops.conv2d_forward(dev(x), dev(wt), dev(b), stride=stride, act=act)
+    assert got.shape == ref.shape
+    assert relerr(got, ref) < TOL
+
+
+def test_conv2d_two_inputs_broadcast_residual(ops):
+    """cat([nbr, ref]) with ref shared by the 5 frames of a clip + residual add after the act."""
+    x0, x1 = rnd(10, 64, 12, 36, seed=1), rnd(2, 64, 12, 36, seed=2)
+    wt, b = rnd(64, 128, 3, 3, seed=3, scale=0.03), rnd(64, seed=4, scale=0.1)
+    res = rnd(10, 64, 12, 36, seed=5)
+    ref = F.leaky_relu(F.conv2d(torch.cat([x0, x1.repeat_interleave(5, 0)], 1), wt, b, 1, 1), 0.1) + res
+    got = ops.conv2d_forward(dev(x0), dev(wt), dev(b), act=1, x1=dev(x1), res=dev(res), x1_bdiv=5)
+    assert relerr(got, ref) < TOL
+
+
+def test_conv2d_pixel_shuffle(ops):
+    x, wt, b = rnd(1, 64, 10, 34, seed=1), rnd(256, 64, 3, 3, seed=2, scale=0.04), rnd(256, seed=3)
+    ref = F.leaky_relu(F.pixel_shuffle(F.conv2d(x, wt, b, 1, 1), 2), 0.1)
+    got = ops.conv2d_forward(dev(x), dev(wt), dev(b), act=1, pixel_shuffle=2)
+    assert got.shape == ref.shape and relerr(got, ref) < TOL
+
+
+def test_conv2d_no_bias(ops):
+    x, wt = rnd(1, 8, 6, 6, seed=1), rnd(4, 8, 3, 3, seed=2)
+    assert relerr(ops.conv2d_forward(dev(x), dev(wt)), F.conv2d(x, wt, None, 1, 1)) < TOL
+
+
+def test_conv2d_rejects_unsupported(ops):
+    x, wt = dev(rnd(1, 8, 6, 6)), dev(rnd(4, 8, 5, 5))
+    with pytest.raises(RuntimeError, match="ks=5"):
+        ops.conv2d_forward(x, wt)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.conv2d_forward(x.cpu(), dev(rnd(4, 8, 3, 3)))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_mdcn_forward_golden(ops, tag):
+    g = load_golden("dcn_" + tag)
+    x, off, m, w, b = (dev(torch.from_numpy(g[k])) for k in ("x", "offset", "mask", "weight", "bias"))
+    got = ops.mdcn_forward(x, off, m, w, b, 1, 1, 1, 1, int(g["dg"]))
+    assert relerr(got, g["out"]) < TOL
+
+
+@pytest.mark.parametrize("n,c,dg,cout,h,w,stride,pad,dil,std", [
+    (2, 64, 8, 64, 20, 36, 1, 1, 1, 2.0), (1, 64, 8, 64, 45, 80, 1, 1, 1, 0.5),
+    (1, 32, 8, 80, 9, 33, 1, 1, 1, 5.0), (1, 128, 8, 128, 12, 16, 1, 1, 1, 1.0),
+    (1, 16, 4, 12, 11, 13, 2, 1, 1, 1.0), (1, 16, 2, 8, 10, 10, 1, 2, 2, 1.0),
+])
+def test_mdcn_forward_vs_oracle(ops, n, c, dg, cout, h, w, stride, pad, dil, std):
+    from oracle import dcn as odcn
+    ho = (h + 2 * pad - (2 * dil + 1)) // stride + 1
+    wo = (w + 2 * pad - (2 * dil + 1)) // stride + 1
+    x = rnd(n, c, h, w, seed=1)
+    off = rnd(n, dg * 18, ho, wo, seed=2, scale=std)
+    m = torch.from_numpy(np.random.RandomState(3).random_sample((n, dg * 9, ho, wo)))
+    wt, b = rnd(cout, c, 3, 3, seed=4, scale=1 / np.sqrt(9 * c)), rnd(cout, seed=5, scale=0.1)
+    ref = odcn.forward(x, off, m, wt, b, stride, pad, dil, 1, dg)
+    got = ops.mdcn_forward(dev(x), dev(off), dev(m), dev(wt), dev(b), stride, pad, dil, 1, dg)
+    assert relerr(got, ref) < TOL
+    got = ops.mdcn_forward(dev(x), dev(off), dev(m), dev(wt), None, stride, pad, dil, 1, dg, act=1)
+    assert relerr(got, F.leaky_relu(ref - b.view(1, -1, 1, 1), 0.1)) < TOL
+
+
+def test_mdcn_pack_forward(ops):
+    """offset/mask taken from the raw 216-channel conv output, sigmoid inside the sampler."""
+    from oracle import dcn as odcn
+    x, om = rnd(2, 64, 14, 38, seed=1), rnd(2, 216, 14, 38, seed=2, scale=1.5)
+    wt, b = rnd(64, 64, 3, 3, seed=3, scale=0.04), rnd(64, seed=4, scale=0.1)
+    ref = odcn.forward(x, om[:, :144].contiguous(), torch.sigmoid(om[:, 144:]).contiguous(), wt, b, 1, 1,
+                       1, 1, 8)
+    got = ops.mdcn_pack_forward(dev(x), dev(om), dev(wt), dev(b), 8)
+    assert relerr(got, ref) < TOL
+
+
+def test_mdcn_rejects_unsupported(ops):
+    x = dev(rnd(1, 24, 6, 6))
+    with pytest.raises(RuntimeError, match="C/dg"):
+        ops.mdcn_forward(x, dev(rnd(1, 72, 6, 6)), dev(rnd(1, 36, 6, 6)), dev(rnd(8, 24, 3, 3)), None, 1,
+                         1, 1, 1, 4)
+
+
+@pytest.mark.parametrize("scale,mul,h,w", [(2, 1.0, 9, 13), (2, 2.0, 4, 4), (4, 1.0, 16, 16), (4, 1.0, 7, 5)])
+def test_upsample_bilinear(ops, scale, mul, h, w):
+    x = rnd(2, 3, h, w, seed=1).requires_grad_()
+    ref = F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=False) * mul
+    got = ops.upsample_bilinear(dev(x.detach()), scale, mul)
+    assert relerr(got, ref) < 1e-6
+    g = rnd(*ref.shape, seed=2)
+    (gref,) = torch.autograd.grad(ref, x, g)
+    assert relerr(ops.upsample_bilinear_backward(dev(g), scale, mul), gref) < 1e-6
+
+
+@pytest.mark.parametrize("h,w", [(16, 16), (10, 14), (9, 7)])
+def test_pool3s2(ops, h, w):
+    x = rnd(2, 5, h, w, seed=1).requires_grad_()
+    rmax, ravg = F.max_pool2d(x, 3, 2, 1), F.avg_pool2d(x, 3, 2, 1)
+    gmax, gavg = ops.pool3s2(dev(x.detach()))
+    assert relerr(gmax, rmax) == 0 and relerr(gavg, ravg) < 1e-6
+    g1, g2 = rnd(*rmax.shape, seed=2), rnd(*rmax.shape, seed=3)
+    (gref,) = torch.autograd.grad([rmax, ravg], x, [g1, g2])
+    assert relerr(ops.pool3s2_backward(dev(x.detach()), dev(g1), dev(g2)), gref) < 1e-6
+
+
+def test_tsa_gate_and_blend(ops):
+    b, n, c, h, w = 2, 5, 64, 6, 10
+    emb = rnd(b, n, c, h, w, seed=1, scale=0.3).requires_grad_()
+    ref_ = rnd(b, c, h, w, seed=2, scale=0.3).requires_grad_()
+    al = rnd(b, n, c, h, w, seed=3).requires_grad_()
+    cor = torch.sigmoid((emb * ref_.unsqueeze(1)).sum(2))
+    gated = (al * cor.unsqueeze(2)).reshape(b, n * c, h, w)
+    gcor, ggated = ops.tsa_gate(dev(emb.detach()), dev(ref_.detach()), dev(al.detach()))
+    assert relerr(gcor, cor) < 1e-6 and relerr(ggated, gated) < 1e-6
+    g = rnd(*gated.shape, seed=4)
+    r_emb, r_ref, r_al = torch.autograd.grad(gated, [emb, ref_, al], g)
+    g_emb, g_ref, g_al = ops.tsa_gate_backward(dev(emb.detach()), dev(ref_.detach()), dev(al.detach()),
+                                               gcor, dev(g))
+    assert relerr(g_emb, r_emb) < 1e-5 and relerr(g_ref, r_ref) < 1e-5 and relerr(g_al, r_al) < 1e-6
+
+    fea, att, add = (rnd(b, c, h, w, seed=s).requires_grad_() for s in (5, 6, 7))
+    out = fea * torch.sigmoid(att) * 2 + add
+    assert relerr(ops.tsa_blend(dev(fea.detach()), dev(att.detach()), dev(add.detach())), out) < 1e-6
+    go = rnd(*out.shape, seed=8)
+    r_fea, r_att = torch.autograd.grad(out, [fea, att], go)
+    pre = rnd(*out.shape, seed=9)
+    g_att = dev(pre)
+    g_fea = ops.tsa_blend_backward(dev(fea.detach()), dev(att.detach()), dev(go), g_att)
+    assert relerr(g_fea, r_fea) < 1e-6 and relerr(g_att, r_att + pre) < 1e-6
