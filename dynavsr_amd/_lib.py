@@ -53,6 +53,15 @@ def _declare(lib):
         "dvsr_edvr_num_launches": (I, [P]),
         "dvsr_edvr_workspace_bytes": (c_size_t, [P, I]),
         "dvsr_edvr_forward": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P]),
+        "dvsr_edvr_backward": (I, [P, POINTER(c_void_p), P, P, POINTER(c_void_p), P, P, c_size_t, P]),
+        "dvsr_edvr_num_backward_launches": (I, [P]),
+        "dvsr_conv2d_backward_workspace_bytes": (c_size_t, [POINTER(Conv2dDesc)]),
+        "dvsr_conv2d_backward": (I, [POINTER(Conv2dDesc), P, P, P, P, P, P, c_size_t, P]),
+        "dvsr_mdcn_backward_workspace_bytes": (c_size_t, [I] * 10),
+        "dvsr_mdcn_backward": (I, [P] * 10 + [I] * 12 + [P, c_size_t, P]),
+        "dvsr_charbonnier_workspace_bytes": (c_size_t, []),
+        "dvsr_charbonnier_forward": (I, [P, P, P, LL, F, P, c_size_t, P]),
+        "dvsr_charbonnier_backward": (I, [P, P, P, P, LL, F, P]),
         "dvsr_edvr_op_info": (I, [P, I, c_char_p, I, c_char_p, I, POINTER(ctypes.c_double),
                                   POINTER(ctypes.c_double)]),
         "dvsr_edvr_forward_timed": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P, POINTER(c_float)]),

@@ -22,7 +22,12 @@ struct ConvK {
   int N, c0, c1, H, W, Cout, Ho, Wo, pad, act, ps, x1_bdiv;
   long long x0_bs, x1_bs;
   int tiles_x, tiles_y, ntiles, ncb;
-  int wt;        // 0: w is [Cout][Ctot][KK]; 1: transposed+flipped view of [Ctot][Cout][KK] (dgrad)
+  int wt;        // 0: w is [Cout][Ctot][KK]; 1: transposed+flipped view (dgrad), see below
+  int w_ctot, w_coff;  // wt=1: element (ci, co, t) = w[(ci*w_ctot + w_coff + co)*KK + t]
+  int in_ps;     // 1: x0 is stored pixel-shuffled [N][c0/4][2H][2W] (gradient of a PixelShuffle(2) output)
+  int in_dil;    // 2: x0 is a zero-dilated view of a [N][c0][Hs][Ws] tensor (dgrad of a stride-2 conv)
+  int Hs, Ws;    // source dims for in_dil
+  int accum;     // 1: y += result instead of y = result
 };
 
 template <int KS, int S, int CC>
@@ -82,8 +87,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvK a) {
       const int gy = iy0 + iy, gx = ix0 + ix, ci = cbase + c;
       float v = 0.f;
       if (ci < Ctot && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
-        const float* src = ci < a.c0 ? x0n + (size_t)ci * HW : x1n + (size_t)(ci - a.c0) * HW;
-        v = src[(size_t)gy * a.W + gx];
+        if (a.in_ps) {
+          // channel ci = 4*cq + 2*dy + dx of the un-shuffled view lives at [cq][2y+dy][2x+dx]
+          const float* src = x0n + (size_t)(ci >> 2) * (4 * HW);
+          v = src[(size_t)(2 * gy + ((ci >> 1) & 1)) * (2 * a.W) + 2 * gx + (ci & 1)];
+        } else if (a.in_dil) {
+          if (!((gy | gx) & 1) && (gy >> 1) < a.Hs && (gx >> 1) < a.Ws)
+            v = x0n[(size_t)ci * a.Hs * a.Ws + (size_t)(gy >> 1) * a.Ws + (gx >> 1)];
+        } else {
+          const float* src = ci < a.c0 ? x0n + (size_t)ci * HW : x1n + (size_t)(ci - a.c0) * HW;
+          v = src[(size_t)gy * a.W + gx];
+        }
       }
       s_in[idx] = v;
     }
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvK a) {
         const int t = rem - o * KK;
         tap = KK - 1 - t;
         const int co = cb * 64 + o, ci = cbase + c;
-        if (co < a.Cout && ci < Ctot) v = a.w[((size_t)ci * a.Cout + co) * KK + t];
+        if (co < a.Cout && ci < Ctot) v = a.w[((size_t)ci * a.w_ctot + a.w_coff + co) * KK + t];
       }
       s_w[(c * KK + tap) * WROW + o] = v;
     }
@@ -152,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvK a) {
         if (a.ps == 0) {
           const size_t o = ((size_t)n * a.Cout + co) * HWo + (size_t)oy * a.Wo + ox;
           if (a.res) v += a.res[o];
+          if (a.accum) v += a.y[o];
           a.y[o] = v;
         } else {
           const int cq = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
@@ -179,7 +194,8 @@ static int launch_conv(const ConvK& k, hipStream_t st) {
   return check_launch("conv2d_mfma_kernel");
 }
 
-int conv2d_run(const dvsr_conv2d_desc& d, int transposed_w, hipStream_t st) {
+int conv2d_run(const dvsr_conv2d_desc& d, const ConvExtra& ex, hipStream_t st) {
+  const int transposed_w = ex.wt;
   DVSR_REQUIRE(d.x0 && d.w && d.y, DVSR_ERR_INVALID, "conv2d: null x0/w/y");
   DVSR_REQUIRE(d.N > 0 && d.c0 > 0 && d.c1 >= 0 && d.H > 0 && d.W > 0 && d.Cout > 0,
                DVSR_ERR_INVALID, "conv2d: non-positive dimension");
@@ -204,6 +220,12 @@ int conv2d_run(const dvsr_conv2d_desc& d, int transposed_w, hipStream_t st) {
   k.ntiles = k.tiles_x * k.tiles_y * d.N;
   k.ncb = ceil_div(d.Cout, 64);
   k.wt = transposed_w;
+  k.w_ctot = ex.w_ctot; k.w_coff = ex.w_coff; k.in_ps = ex.in_ps; k.in_dil = ex.in_dil;
+  k.Hs = ex.Hs; k.Ws = ex.Ws; k.accum = ex.accum;
+  DVSR_REQUIRE(!(ex.in_ps || ex.in_dil) || d.c1 == 0, DVSR_ERR_INVALID,
+               "conv2d: in_ps/in_dil views take a single input");
+  if (k.in_ps) k.x0_bs = (long long)d.c0 * d.H * d.W;
+  if (k.in_dil) k.x0_bs = (long long)d.c0 * ex.Hs * ex.Ws;
   if (d.ks == 3 && d.stride == 1) return launch_conv<3, 1, 8>(k, st);
   if (d.ks == 3 && d.stride == 2) return launch_conv<3, 2, 8>(k, st);
   return launch_conv<1, 1, 32>(k, st);
@@ -213,5 +235,5 @@ int conv2d_run(const dvsr_conv2d_desc& d, int transposed_w, hipStream_t st) {
 
 extern "C" int dvsr_conv2d_forward(const dvsr_conv2d_desc* d, dvsr_stream_t stream) {
   DVSR_REQUIRE(d, DVSR_ERR_INVALID, "conv2d: null descriptor");
-  return dvsr::conv2d_run(*d, 0, (hipStream_t)stream);
+  return dvsr::conv2d_run(*d, dvsr::ConvExtra(), (hipStream_t)stream);
 }

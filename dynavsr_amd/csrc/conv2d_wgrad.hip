@@ -1,0 +1,258 @@
+// Weight / bias gradient of the dense convolutions (backward of conv2d.hip) on
+// v_mfma_f32_32x32x2_f32:   dW[o][c][tap] = sum_{n,y,x} gy[n][o][y][x] * x[n][c][y*S+ty-pad][x*S+tx-pad]
+//
+// GEMM view per workgroup: D[o 64][c 64] (one D per tap) with K = pixels.  Each of the 4 waves owns
+// one (o-half, c-half) 32x32 tile for ALL taps (9 accumulators = 144 VGPRs) and walks a strided
+// list of 2x32-pixel tiles, so the pixel reduction stays in registers; the per-workgroup partial
+// sums go to a [nsplit][tap][o][c] scratch buffer that a second kernel reduces deterministically
+// (no atomics).  Operand reads are conflict-free: both LDS images use an odd plane stride.
+//   A (lane l): gy[o = l&31][px = 2kk + (l>>5)]   <- s_g[o*65 + px]
+//   B (lane l): x [c = l&31][px shifted by tap]   <- s_x[c*PLANEP + (py*S+ty)*IW + px*S+tx]
+#include "common.h"
+#include "kernels.h"
+
+namespace dvsr {
+
+struct WgradK {
+  const float* x; const float* gy; float* partial; float* dbp;
+  long long x_bs;
+  int x_bdiv;
+  int N, Cin, H, W, Cout, Ho, Wo, pad, gy_ps;
+  int tiles_x, tiles_y, ntiles, nsplit, nob, ncb;
+};
+
+template <int KS, int S>
+struct WgShape {
+  static constexpr int TH = 2, TW = 32, NPX = TH * TW, KK = KS * KS;
+  static constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+  static constexpr int PLANE = IH * IW, PLANEP = PLANE | 1, GROW = NPX + 1;
+  static constexpr size_t LDS_BYTES = (size_t)(64 * GROW + 64 * PLANEP) * sizeof(float);
+};
+
+template <int KS, int S>
+__global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
+  using Sh = WgShape<KS, S>;
+  constexpr int KK = Sh::KK, IW = Sh::IW, PLANE = Sh::PLANE, PLANEP = Sh::PLANEP, GROW = Sh::GROW,
+                NPX = Sh::NPX;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_g = smem;
+  float* s_x = smem + 64 * GROW;
+
+  const int split = blockIdx.x, ob = blockIdx.y, cbk = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int ot = wave >> 1, ct = wave & 1;
+  const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
+
+  f32x16 acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float db = 0.f;
+
+  for (int tile = split; tile < a.ntiles; tile += a.nsplit) {
+    const int tx_ = tile % a.tiles_x;
+    const int t2 = tile / a.tiles_x;
+    const int ty_ = t2 % a.tiles_y;
+    const int n = t2 / a.tiles_y;
+    const int oy0 = ty_ * Sh::TH, ox0 = tx_ * Sh::TW;
+    const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+    __syncthreads();
+    // ---- gy tile: s_g[o][p]
+    for (int idx = tid; idx < 64 * NPX; idx += 256) {
+      const int o = idx / NPX, p = idx - o * NPX;
+      const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31), co = ob * 64 + o;
+      float v = 0.f;
+      if (co < a.Cout && oy < a.Ho && ox < a.Wo) {
+        if (a.gy_ps)
+          v = a.gy[(((size_t)n * (a.Cout >> 2) + (co >> 2)) * (2 * a.Ho) + 2 * oy + ((co >> 1) & 1)) *
+                       (size_t)(2 * a.Wo) + 2 * ox + (co & 1)];
+        else
+          v = a.gy[((size_t)n * a.Cout + co) * HWo + (size_t)oy * a.Wo + ox];
+      }
+      s_g[o * GROW + p] = v;
+    }
+    // ---- x halo tile: s_x[c][iy][ix]
+    const float* xn = a.x + (size_t)(n / a.x_bdiv) * a.x_bs;
+    for (int idx = tid; idx < 64 * PLANE; idx += 256) {
+      const int c = idx / PLANE, r = idx - c * PLANE;
+      const int iy = r / IW, ix = r - iy * IW;
+      const int gy_ = iy0 + iy, gx_ = ix0 + ix, ci = cbk * 64 + c;
+      float v = 0.f;
+      if (ci < a.Cin && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W)
+        v = xn[(size_t)ci * HW + (size_t)gy_ * a.W + gx_];
+      s_x[c * PLANEP + r] = v;
+    }
+    __syncthreads();
+    if (cbk == 0 && tid < 64) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int p = 0; p < NPX; ++p) s += s_g[tid * GROW + p];
+      db += s;
+    }
+#pragma unroll 4
+    for (int kk = 0; kk < NPX / 2; ++kk) {
+      const int p = 2 * kk + hi;
+      const int py = p >> 5, px = p & 31;
+      const float av = s_g[(ot * 32 + lo) * GROW + p];
+      const float* bx = s_x + (ct * 32 + lo) * PLANEP + (py * S) * IW + px * S;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const int ty = t / KS, tx = t - ty * KS;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bx[ty * IW + tx], acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- partial[split][tap][o][c]  (o, c padded to the 64-blocks of the grid)
+  const int OP = a.nob * 64, CP = a.ncb * 64;
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ob * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int c = cbk * 64 + ct * 32 + lo;
+      a.partial[(((size_t)split * KK + t) * OP + o) * CP + c] = acc[t][r];
+    }
+  if (cbk == 0 && tid < 64) a.dbp[(size_t)split * OP + ob * 64 + tid] = db;
+}
+
+// dW[o][c_off + c][tap] = sum_s partial[s][tap][o][c];  db[o] = sum_s dbp[s][o]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ dbp,
+                                    float* __restrict__ dW, float* __restrict__ db, int nsplit, int KK,
+                                    int OP, int CP, int Cout, int Cin, int Ctot, int c_off) {
+  const int total = Cout * Cin * KK;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % Cin;
+    const int t2 = i / Cin;
+    const int o = t2 % Cout;
+    const int t = t2 / Cout;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += partial[(((size_t)sp * KK + t) * OP + o) * CP + c];
+    dW[((size_t)o * Ctot + c_off + c) * KK + t] = s;
+  }
+  if (db) {
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < Cout; o += gridDim.x * blockDim.x) {
+      float s = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) s += dbp[(size_t)sp * OP + o];
+      db[o] = s;
+    }
+  }
+}
+
+template <int KS, int S>
+static void launch_wgrad(const WgradK& k, dim3 grid, hipStream_t st) {
+  using Sh = WgShape<KS, S>;
+  auto kern = conv2d_wgrad_kernel<KS, S>;
+  static bool done = false;
+  if (!done) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
+    done = true;
+  }
+  const size_t lds = Sh::LDS_BYTES;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
+}
+
+static int wgrad_splits(int ntiles, int nob, int ncb, int KK) {
+  // enough workgroups to fill 256 CUs x 2, bounded so that the partial buffer stays <= 64 MiB
+  int s = ceil_div(512, nob * ncb);
+  const size_t per_split = (size_t)KK * nob * 64 * ncb * 64 * sizeof(float);
+  const int cap = (int)((64ull << 20) / per_split);
+  if (s > cap) s = cap;
+  if (s > ntiles) s = ntiles;
+  return s < 1 ? 1 : s;
+}
+
+size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride) {
+  const int pad = ks / 2;
+  const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+  const int ntiles = ceil_div(Wo, 32) * ceil_div(Ho, 2) * N;
+  const int nob = ceil_div(Cout, 64), ncb = ceil_div(Cin, 64), KK = ks * ks;
+  const int ns = wgrad_splits(ntiles, nob, ncb, KK);
+  return ((size_t)ns * KK * nob * 64 * ncb * 64 + (size_t)ns * nob * 64) * sizeof(float);
+}
+
+// x: one input of the conv ([N/x_bdiv][Cin][H][W], batch stride x_bs or dense), gy: gradient of the
+// conv's pre-activation output.  Writes dW[:, c_off:c_off+Cin, :, :] of a [Cout][Ctot][ks][ks]
+// gradient (and db when non-null).
+int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
+                     float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
+                     int stride, void* ws, size_t ws_bytes, hipStream_t st) {
+  DVSR_REQUIRE(x && gy && dW && ws, DVSR_ERR_INVALID, "conv2d_wgrad: null pointer");
+  DVSR_REQUIRE((ks == 1 && stride == 1) || (ks == 3 && (stride == 1 || stride == 2)), DVSR_ERR_UNSUPPORTED,
+               "conv2d_wgrad: ks=%d stride=%d unsupported", ks, stride);
+  const size_t need = conv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ks, stride);
+  DVSR_REQUIRE(ws_bytes >= need, DVSR_ERR_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
+  WgradK k;
+  k.x = x; k.gy = gy; k.x_bs = x_bs > 0 ? x_bs : (long long)Cin * H * W; k.x_bdiv = x_bdiv > 0 ? x_bdiv : 1;
+  k.N = N; k.Cin = Cin; k.H = H; k.W = W; k.Cout = Cout; k.pad = ks / 2; k.gy_ps = gy_ps;
+  k.Ho = (H + 2 * k.pad - ks) / stride + 1;
+  k.Wo = (W + 2 * k.pad - ks) / stride + 1;
+  k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, 2); k.ntiles = k.tiles_x * k.tiles_y * N;
+  k.nob = ceil_div(Cout, 64); k.ncb = ceil_div(Cin, 64);
+  const int KK = ks * ks;
+  k.nsplit = wgrad_splits(k.ntiles, k.nob, k.ncb, KK);
+  k.partial = (float*)ws;
+  k.dbp = k.partial + (size_t)k.nsplit * KK * k.nob * 64 * k.ncb * 64;
+  dim3 grid(k.nsplit, k.nob, k.ncb);
+if (ks == 3 && stride == 1) launch_wgrad<3, 1>(k, grid, st);
+  else if (ks == 3) launch_wgrad<3, 2>(k, grid, st);
+  else launch_wgrad<1, 1>(k, grid, st);
+  int rc = check_launch("conv2d_wgrad_kernel");
+  if (rc) return rc;
+  const int total = Cout * Cin * KK;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, k.partial, k.dbp,
+                     dW, db, k.nsplit, KK, k.nob * 64, k.ncb * 64, Cout, Cin, Ctot, c_off);
+  return check_launch("wgrad_reduce_kernel");
+}
+
+}  // namespace dvsr
+
+extern "C" size_t dvsr_conv2d_backward_workspace_bytes(const dvsr_conv2d_desc* d) {
+  if (!d) return 0;
+  size_t a = dvsr::conv2d_wgrad_workspace_bytes(d->N, d->c0 > d->c1 ? d->c0 : d->c1, d->H, d->W, d->Cout,
+                                                d->ks, d->stride);
+  return a;
+}
+
+// Backward of dvsr_conv2d_forward for the plain layout (no pixel shuffle): `gy` is the gradient
+// w.r.t. the PRE-activation output (the caller multiplies by act' first).  Any of gx0/gx1/gw/gb
+// may be NULL to skip it.  gx1 has the shape of x1 only when x1_bdiv == 1.
+extern "C" int dvsr_conv2d_backward(const dvsr_conv2d_desc* d, const float* gy, float* gx0, float* gx1,
+                                    float* gw, float* gb, void* workspace, size_t workspace_bytes,
+                                    dvsr_stream_t stream) {
+  using namespace dvsr;
+  DVSR_REQUIRE(d && gy, DVSR_ERR_INVALID, "conv2d_backward: null argument");
+  DVSR_REQUIRE(d->pixel_shuffle == 0 && d->x1_bdiv <= 1, DVSR_ERR_UNSUPPORTED,
+               "conv2d_backward: pixel_shuffle / broadcast x1 are handled by the EDVR engine only");
+  hipStream_t st = (hipStream_t)stream;
+  const int pad = d->ks / 2, ctot = d->c0 + d->c1;
+  const int Ho = (d->H + 2 * pad - d->ks) / d->stride + 1, Wo = (d->W + 2 * pad - d->ks) / d->stride + 1;
+  int rc;
+  if (gw) {
+    rc = conv2d_wgrad_run(d->x0, d->x0_bstride, 1, gy, 0, gw, gb, d->N, d->c0, d->H, d->W, d->Cout, ctot, 0,
+                          d->ks, d->stride, workspace, workspace_bytes, st);
+    if (rc) return rc;
+    if (d->c1) {
+      rc = conv2d_wgrad_run(d->x1, d->x1_bstride, 1, gy, 0, gw, nullptr, d->N, d->c1, d->H, d->W, d->Cout,
+                            ctot, d->c0, d->ks, d->stride, workspace, workspace_bytes, st);
+      if (rc) return rc;
+    }
+  }
+  for (int which = 0; which < 2; ++which) {
+    float* gx = which ? gx1 : gx0;
+    const int ci = which ? d->c1 : d->c0;
+    if (!gx || !ci) continue;
+    dvsr_conv2d_desc g = {};
+    g.x0 = gy; g.w = d->w; g.y = gx; g.N = d->N; g.c0 = d->Cout; g.Cout = ci; g.ks = d->ks; g.stride = 1;
+    g.pad = pad; g.act = ACT_NONE; g.x1_bdiv = 1;
+    ConvExtra ex;
+    ex.wt = 1; ex.w_ctot = ctot; ex.w_coff = which ? d->c0 : 0;
+    if (d->stride == 2) { ex.in_dil = 2; ex.Hs = Ho; ex.Ws = Wo; g.H = d->H; g.W = d->W; }
+    else { g.H = Ho; g.W = Wo; }
+    rc = conv2d_run(g, ex, st);
+    if (rc) return rc;
+  }
+  return DVSR_OK;
+}

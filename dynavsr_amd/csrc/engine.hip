@@ -14,6 +14,7 @@
 //    non-issue and remove all allocator traffic from the hot loop.
 //  * Parameters are addressed by their position in the reference's state-dict order
 //    (dynavsr_amd/spec.py mirrors the walk below).
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,24 @@ struct Op {
   size_t gHW = 0;
 };
 
+// ---- backward tape -------------------------------------------------------------------------
+// Pointer spaces of the backward pass.
+enum { R_ACT = 0, R_GRAD = 1, R_X = 2, R_GX = 3, R_GOUT = 4, R_TMP = 5, R_NONE = 6 };
+struct Ref {
+  int space = R_NONE;
+  size_t off = 0;
+};
+enum BType { B_MEMSET, B_COPYADD, B_ACT, B_WGRAD, B_DGRAD, B_REDUCE, B_DCN, B_UP, B_POOL, B_GATE, B_BLEND };
+struct BOp {
+  BType type;
+  int fwd = -1;          // index of the forward op this belongs to
+  Ref a, b, c, d, e, f;  // meaning depends on type
+  size_t n = 0;          // element count for streaming ops
+  int accum = 0, which = 0, cnt = 1, B = 0;
+  long long bs = 0;
+  size_t per = 0;
+};
+
 }  // namespace dvsr
 
 struct dvsr_edvr_plan {
@@ -57,6 +76,10 @@ struct dvsr_edvr_plan {
   size_t arena_floats = 0;
   std::vector<dvsr::Op> ops;
   std::vector<std::pair<std::string, dvsr::T>> named;
+  std::vector<std::pair<size_t, size_t>> allocs;  // (offset, numel) of every arena slot, ascending
+  std::vector<dvsr::BOp> bops;                    // backward tape (already in execution order)
+  size_t tmp_floats = 0;                          // dense dgrad staging for broadcast/strided views
+  size_t scratch_bytes = 0;                       // wgrad partials / DCN column buffer
 };
 
 namespace dvsr {
@@ -71,6 +94,7 @@ struct Builder {
     t.space = SP_ARENA;
     t.off = p.arena_floats;
     t.numel = numel;
+    p.allocs.emplace_back(t.off, numel);
     p.arena_floats += (numel + 63) & ~(size_t)63;  // 256-byte aligned slots
     if (name && *name) p.named.emplace_back(name, t);
     return t;
@@ -267,6 +291,247 @@ static int build_plan(dvsr_edvr_plan& p) {
   return DVSR_OK;
 }
 
+
+// Builds the backward tape by walking the forward tape in reverse.  Gradient buffers mirror the
+// activation arena (same offsets in a second arena).  The first contribution to a gradient
+// buffer writes it when it covers the whole slot with plain stores; partial (views) or atomic
+// (DCN input gradient) first contributions zero the slot first; later ones accumulate.
+struct BackBuilder {
+  dvsr_edvr_plan& p;
+  std::vector<char> written;  // per allocation
+  bool gx_zeroed = false;
+  explicit BackBuilder(dvsr_edvr_plan& plan) : p(plan), written(plan.allocs.size(), 0) {}
+
+  int alloc_index(size_t off) const {
+    int lo = 0, hi = (int)p.allocs.size() - 1, ans = -1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) / 2;
+      if (p.allocs[mid].first <= off) { ans = mid; lo = mid + 1; } else hi = mid - 1;
+    }
+    return ans;
+  }
+  static Ref act(const T& t) {
+    Ref r;
+    r.space = t.space == SP_ARENA ? R_ACT : (t.space == SP_INPUT ? R_X : R_NONE);
+    r.off = t.off;
+    return r;
+  }
+  static Ref grad(const T& t) {
+    Ref r;
+    r.space = t.space == SP_ARENA ? R_GRAD : (t.space == SP_INPUT ? R_GX : (t.space == SP_OUTPUT ? R_GOUT : R_NONE));
+    r.off = t.off;
+    return r;
+  }
+  // Declares a contribution to grad(t); returns the accumulate flag for it.
+  int contribute(const T& t, bool full, int fwd) {
+    if (t.space == SP_INPUT) return 1;  // gx is zeroed once up front, everything accumulates
+    const int ai = alloc_index(t.off);
+    const bool whole = full && t.off == p.allocs[ai].first && t.numel == p.allocs[ai].second;
+    if (written[ai]) return 1;
+    written[ai] = 1;
+    if (whole) return 0;
+    BOp m;
+    m.type = B_MEMSET; m.fwd = fwd; m.a.space = R_GRAD; m.a.off = p.allocs[ai].first; m.n = p.allocs[ai].second;
+    p.bops.push_back(m);
+    return 1;
+  }
+  void copyadd(const T& dst, const Ref& src, size_t n, int fwd) {
+    BOp o;
+    o.type = B_COPYADD; o.fwd = fwd; o.a = grad(dst); o.b = src; o.n = n;
+    o.accum = contribute(dst, true, fwd);
+    p.bops.push_back(o);
+  }
+};
+
+static void build_backward(dvsr_edvr_plan& p) {
+  BackBuilder bb(p);
+  size_t tmp = 0, scratch = 0;
+  for (int i = (int)p.ops.size() - 1; i >= 0; --i) {
+    const Op& o = p.ops[i];
+    const Ref gy = BackBuilder::grad(o.y);
+    switch (o.type) {
+      case OP_CONV: {
+        const int Ho = (o.H + 2 * (o.ks / 2) - o.ks) / o.stride + 1, Wo = (o.W + 2 * (o.ks / 2) - o.ks) / o.stride + 1;
+        if (o.res.valid()) bb.copyadd(o.res, gy, o.y.numel, i);
+        if (o.act != ACT_NONE) {
+          BOp a; a.type = B_ACT; a.fwd = i; a.a = gy; a.b = BackBuilder::act(o.y); a.n = o.y.numel;
+          p.bops.push_back(a);
+        }
+        for (int which = 0; which < 2; ++which) {
+          if (which == 1 && !o.c1) break;
+          BOp w; w.type = B_WGRAD; w.fwd = i; w.which = which; w.a = BackBuilder::act(which ? o.x1 : o.x0); w.b = gy;
+          p.bops.push_back(w);
+          scratch = std::max(scratch, conv2d_wgrad_workspace_bytes(o.N, which ? o.c1 : o.c0, o.H, o.W, o.Cout,
+                                                                   o.ks, o.stride));
+        }
+        for (int which = 0; which < 2; ++which) {
+          if (which == 1 && !o.c1) break;
+          const T& xin = which ? o.x1 : o.x0;
+          const int ci = which ? o.c1 : o.c0;
+          const bool strided = which ? (o.x1_bdiv > 1 || o.x1_bs != 0) : (o.x0_bs != 0);
+          BOp d; d.type = B_DGRAD; d.fwd = i; d.which = which; d.b = gy;
+          if (!strided) {
+            T full = xin; full.numel = (size_t)o.N * ci * o.H * o.W;
+            d.accum = bb.contribute(full, true, i);
+            d.a = BackBuilder::grad(xin);
+            p.bops.push_back(d);
+          } else {
+            // dense dgrad into the staging buffer, then fold frames into the strided view
+            d.accum = 0; d.a.space = R_TMP; d.a.off = 0;
+            p.bops.push_back(d);
+            const int bdiv = which ? o.x1_bdiv : 1;
+            const size_t per = (size_t)ci * o.H * o.W;
+            tmp = std::max(tmp, (size_t)o.N * per);
+            BOp r; r.type = B_REDUCE; r.fwd = i; r.a = BackBuilder::grad(xin); r.b.space = R_TMP; r.b.off = 0;
+            r.B = o.N / bdiv; r.cnt = bdiv; r.per = per;
+            r.bs = which ? (o.x1_bs ? o.x1_bs : (long long)per) : o.x0_bs;
+            T part = xin; part.numel = 1;  // never "whole": forces zero-init when first
+            r.accum = bb.contribute(part, false, i);
+            // the memset (if any) must precede the dgrad+reduce pair: contribute() already pushed it
+            p.bops.push_back(r);
+          }
+        }
+        (void)Ho; (void)Wo;
+        break;
+      }
+      case OP_DCN: {
+        if (o.act != ACT_NONE) {
+          BOp a; a.type = B_ACT; a.fwd = i; a.a = gy; a.b = BackBuilder::act(o.y); a.n = o.y.numel;
+          p.bops.push_back(a);
+        }
+        BOp d; d.type = B_DCN; d.fwd = i; d.b = gy;
+        T xv = o.x0; xv.numel = 1;
+        bb.contribute(xv, false, i);       // atomics: zero first unless already written
+        bb.contribute(o.x1, true, i);      // om gradient is written in full
+        d.a = BackBuilder::grad(o.x0); d.c = BackBuilder::grad(o.x1);
+        p.bops.push_back(d);
+        scratch = std::max(scratch, mdcn_backward_workspace_bytes(o.N, o.c0, o.H, o.W, o.Cout, 1, 1, 1));
+        break;
+      }
+      case OP_UP: {
+        BOp u; u.type = B_UP; u.fwd = i; u.b = gy; u.a = BackBuilder::grad(o.x0);
+        T xin = o.x0; xin.numel = o.planes * o.H * o.W;
+        u.accum = bb.contribute(xin, true, i);
+        p.bops.push_back(u);
+        break;
+      }
+      case OP_POOL: {
+        BOp u; u.type = B_POOL; u.fwd = i; u.a = BackBuilder::grad(o.x0); u.b = BackBuilder::grad(o.y);
+        u.c = BackBuilder::grad(o.y2);
+        u.accum = bb.contribute(o.x0, true, i);
+        p.bops.push_back(u);
+        break;
+      }
+      case OP_GATE: {
+        BOp g; g.type = B_GATE; g.fwd = i; g.b = BackBuilder::grad(o.y2);
+        g.a = BackBuilder::grad(o.x0); g.c = BackBuilder::grad(o.x1); g.d = BackBuilder::grad(o.res);
+        bb.contribute(o.x0, true, i); bb.contribute(o.x1, true, i); bb.contribute(o.res, true, i);
+        p.bops.push_back(g);
+        break;
+      }
+      case OP_BLEND: {
+        bb.copyadd(o.res, gy, o.y.numel, i);  // d/d(att_add) = g
+        BOp b; b.type = B_BLEND; b.fwd = i; b.b = gy; b.a = BackBuilder::grad(o.x0); b.c = BackBuilder::grad(o.x1);
+        bb.contribute(o.x0, true, i);
+        b.accum = bb.contribute(o.x1, true, i);
+        p.bops.push_back(b);
+        break;
+      }
+      case OP_ADD:
+        bb.copyadd(o.x0, gy, o.y.numel, i);
+        bb.copyadd(o.x1, gy, o.y.numel, i);
+        break;
+    }
+  }
+  p.tmp_floats = (tmp + 63) & ~(size_t)63;
+  p.scratch_bytes = (scratch + 255) & ~(size_t)255;
+}
+
+struct BBases {
+  float* arena; float* garena; const float* x; float* gx; const float* gout; float* tmp;
+  float* at(const Ref& r) const {
+    switch (r.space) {
+      case R_ACT: return arena + r.off;
+      case R_GRAD: return garena + r.off;
+      case R_X: return const_cast<float*>(x) + r.off;
+      case R_GX: return gx ? gx + r.off : nullptr;
+      case R_GOUT: return const_cast<float*>(gout) + r.off;
+      case R_TMP: return tmp + r.off;
+      default: return nullptr;
+    }
+  }
+};
+
+static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* const* P, float* const* GP,
+                           const BBases& bs, void* scratch, size_t scratch_bytes, hipStream_t st) {
+  const Op* o = b.fwd >= 0 ? &p.ops[b.fwd] : nullptr;
+  switch (b.type) {
+    case B_MEMSET: {
+      hipError_t e = hipMemsetAsync(bs.at(b.a), 0, b.n * sizeof(float), st);
+      DVSR_REQUIRE(e == hipSuccess, DVSR_ERR_HIP, "backward memset: %s", hipGetErrorString(e));
+      return DVSR_OK;
+    }
+    case B_COPYADD: {
+      float* dst = bs.at(b.a);
+      if (!dst) return DVSR_OK;  // gradient w.r.t. the external input not requested
+      if (b.accum) return add_inplace(dst, bs.at(b.b), b.n, st);
+      hipError_t e = hipMemcpyAsync(dst, bs.at(b.b), b.n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      DVSR_REQUIRE(e == hipSuccess, DVSR_ERR_HIP, "backward copy: %s", hipGetErrorString(e));
+      return DVSR_OK;
+    }
+    case B_ACT:
+      return act_bwd_inplace(bs.at(b.a), bs.at(b.b), b.n, o->act, st);
+    case B_WGRAD: {
+      const int ci = b.which ? o->c1 : o->c0;
+      return conv2d_wgrad_run(bs.at(b.a), b.which ? o->x1_bs : o->x0_bs, b.which ? o->x1_bdiv : 1, bs.at(b.b),
+                              o->ps, GP[o->pw], b.which ? nullptr : GP[o->pb], o->N, ci, o->H, o->W, o->Cout,
+                              o->c0 + o->c1, b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st);
+    }
+    case B_DGRAD: {
+      float* gx = bs.at(b.a);
+      if (!gx) return DVSR_OK;
+      const int Ho = (o->H + 2 * (o->ks / 2) - o->ks) / o->stride + 1, Wo = (o->W + 2 * (o->ks / 2) - o->ks) / o->stride + 1;
+      dvsr_conv2d_desc g = {};
+      g.x0 = bs.at(b.b); g.w = P[o->pw]; g.y = gx; g.N = o->N; g.c0 = o->Cout; g.Cout = b.which ? o->c1 : o->c0;
+      g.ks = o->ks; g.stride = 1; g.pad = o->ks / 2; g.act = ACT_NONE; g.x1_bdiv = 1;
+      ConvExtra ex;
+      ex.wt = 1; ex.w_ctot = o->c0 + o->c1; ex.w_coff = b.which ? o->c0 : 0; ex.accum = b.accum; ex.in_ps = o->ps ? 1 : 0;
+      if (o->stride == 2) { ex.in_dil = 2; ex.Hs = Ho; ex.Ws = Wo; g.H = o->H; g.W = o->W; }
+      else { g.H = Ho; g.W = Wo; }
+      return conv2d_run(g, ex, st);
+    }
+    case B_REDUCE: {
+      float* dst = bs.at(b.a);
+      if (!dst) return DVSR_OK;
+      return reduce_frames(dst, b.bs, bs.at(b.b), b.B, b.cnt, b.per, b.accum, st);
+    }
+    case B_DCN: {
+      const size_t P_ = (size_t)o->H * o->W;
+      const long long bstride = (long long)o->dg * 27 * P_;
+      const float* om = bs.arena + o->x1.off;
+      float* gom = bs.at(b.c);
+      return mdcn_backward_run(bs.arena + o->x0.off, om, bstride, om + (size_t)o->dg * 18 * P_, bstride, 1, P[o->pw],
+                               bs.at(b.b), bs.at(b.a), gom, bstride, gom + (size_t)o->dg * 18 * P_, bstride,
+                               GP[o->pw], GP[o->pb], o->N, o->c0, o->H, o->W, o->Cout, 1, 1, 1, o->dg, scratch,
+                               scratch_bytes, st);
+    }
+    case B_UP: {
+      float* gx = bs.at(b.a);
+      if (!gx) return DVSR_OK;
+      return upsample_bilinear_bwd(bs.at(b.b), gx, o->planes, o->H, o->W, o->S, o->mul, b.accum, st);
+    }
+    case B_POOL:
+      return pool3s2_bwd(bs.arena + o->x0.off, bs.at(b.b), bs.at(b.c), bs.at(b.a), o->planes, o->H, o->W, b.accum, st);
+    case B_GATE:
+      return tsa_gate_bwd(bs.arena + o->x0.off, bs.arena + o->x1.off, bs.arena + o->res.off, bs.arena + o->y.off,
+                          bs.at(b.b), bs.at(b.a), bs.at(b.c), bs.at(b.d), o->gB, o->gN, o->gC, o->gHW, st);
+    case B_BLEND:
+      return tsa_blend_bwd(bs.arena + o->x0.off, bs.arena + o->x1.off, bs.at(b.b), bs.at(b.a), bs.at(b.c),
+                           o->y.numel, b.accum, st);
+  }
+  return DVSR_ERR_INVALID;
+}
+
 struct Bases {
   float* arena; const float* x; float* out;
   float* at(const T& t) const {
@@ -286,7 +551,7 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
       d.N = o.N; d.c0 = o.c0; d.c1 = o.c1; d.H = o.H; d.W = o.W; d.Cout = o.Cout; d.ks = o.ks;
       d.stride = o.stride; d.pad = o.ks / 2; d.act = o.act; d.pixel_shuffle = o.ps;
       d.x1_bdiv = o.x1_bdiv; d.x0_bstride = o.x0_bs; d.x1_bstride = o.x1_bs;
-      return conv2d_run(d, 0, st);
+      return conv2d_run(d, ConvExtra(), st);
     }
     case OP_DCN: {
       const float* om = bs.at(o.x1);
@@ -336,6 +601,7 @@ extern "C" int dvsr_edvr_plan_create(const dvsr_edvr_config* cfg, int B, int H, 
   p->cfg = *cfg; p->B = B; p->H = H; p->W = W;
   int rc = build_plan(*p);
   if (rc != DVSR_OK) { delete p; return rc; }
+  build_backward(*p);
   *out = p;
   return DVSR_OK;
 }
@@ -346,10 +612,40 @@ extern "C" int dvsr_edvr_num_params(const dvsr_edvr_plan* p) { return p ? p->n_p
 
 extern "C" int dvsr_edvr_num_launches(const dvsr_edvr_plan* p) { return p ? (int)p->ops.size() : -1; }
 
+// need_grad = 0: activation arena only.  need_grad = 1: + gradient arena + staging + scratch,
+// laid out [activations | gradients | dgrad staging | wgrad partials / DCN columns].
 extern "C" size_t dvsr_edvr_workspace_bytes(const dvsr_edvr_plan* p, int need_grad) {
-  (void)need_grad;
-  return p ? p->arena_floats * sizeof(float) : 0;
+  if (!p) return 0;
+  size_t b = p->arena_floats * sizeof(float);
+  if (need_grad) b += (p->arena_floats + p->tmp_floats) * sizeof(float) + p->scratch_bytes;
+  return b;
 }
+
+extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* params, const float* x,
+                                  const float* grad_out, float* const* grad_params, float* grad_x, void* ws,
+                                  size_t ws_bytes, dvsr_stream_t stream) {
+  DVSR_REQUIRE(p && params && x && grad_out && grad_params && ws, DVSR_ERR_INVALID, "edvr_backward: null argument");
+  DVSR_REQUIRE(ws_bytes >= dvsr_edvr_workspace_bytes(p, 1), DVSR_ERR_WORKSPACE,
+               "edvr_backward: workspace %zu < %zu bytes (allocate with need_grad=1 BEFORE the forward)", ws_bytes,
+               dvsr_edvr_workspace_bytes(p, 1));
+  hipStream_t st = (hipStream_t)stream;
+  BBases bs;
+  bs.arena = (float*)ws; bs.garena = bs.arena + p->arena_floats; bs.x = x; bs.gx = grad_x; bs.gout = grad_out;
+  bs.tmp = bs.garena + p->arena_floats;
+  void* scratch = bs.tmp + p->tmp_floats;
+  if (grad_x) {
+    const size_t n = (size_t)p->B * p->cfg.nframes * 3 * p->H * p->W;
+    DVSR_REQUIRE(hipMemsetAsync(grad_x, 0, n * sizeof(float), st) == hipSuccess, DVSR_ERR_HIP,
+                 "edvr_backward: memset of grad_x failed");
+  }
+  for (const BOp& b : p->bops) {
+    int rc = run_backward_op(*p, b, params, grad_params, bs, scratch, p->scratch_bytes, st);
+    if (rc != DVSR_OK) return rc;
+  }
+  return DVSR_OK;
+}
+
+extern "C" int dvsr_edvr_num_backward_launches(const dvsr_edvr_plan* p) { return p ? (int)p->bops.size() : -1; }
 
 extern "C" int dvsr_edvr_forward(const dvsr_edvr_plan* p, const float* const* params, const float* x,
                                  float* out, void* ws, size_t ws_bytes, dvsr_stream_t stream) {

@@ -5,12 +5,31 @@
 
 namespace dvsr {
 
-int conv2d_run(const dvsr_conv2d_desc& d, int transposed_w, hipStream_t st);
+// Extra modes of the conv kernel used by backward-data (dgrad) launches.
+struct ConvExtra {
+  int wt = 0;                  // 1: weights read as the transposed, tap-mirrored view (dgrad)
+  int w_ctot = 0, w_coff = 0;  // wt=1: original conv's total input channels / channel offset of this input
+  int in_ps = 0;               // input is stored pixel-shuffled (gradient of a PixelShuffle(2) output)
+  int in_dil = 0, Hs = 0, Ws = 0;  // input is the zero-dilated view of a [N][c0][Hs][Ws] tensor
+  int accum = 0;               // y += result
+};
+int conv2d_run(const dvsr_conv2d_desc& d, const ConvExtra& ex, hipStream_t st);
 
 int mdcn_forward_run(const float* x, const float* off, long long off_bs, const float* msk,
                      long long msk_bs, int mask_logit, const float* w, const float* b, float* out,
                      int N, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad,
                      int dil, int groups, int dg, int act, hipStream_t st);
+
+size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride);
+int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
+                     float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
+                     int stride, void* ws, size_t ws_bytes, hipStream_t st);
+size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int stride, int pad, int dil);
+int mdcn_backward_run(const float* x, const float* off, long long off_bs, const float* msk, long long msk_bs,
+                      int mask_logit, const float* w, const float* gout, float* gx, float* goff,
+                      long long goff_bs, float* gmsk, long long gmsk_bs, float* gw, float* gb, int N, int C,
+                      int H, int W, int Cout, int stride, int pad, int dil, int dg, void* ws,
+                      size_t ws_bytes, hipStream_t st);
 
 // misc.hip
 int upsample_bilinear_fwd(const float* x, float* y, size_t planes, int H, int W, int S, float mul,
@@ -19,7 +38,9 @@ int upsample_bilinear_bwd(const float* gy, float* gx, size_t planes, int H, int 
                           int accumulate, hipStream_t st);
 int pool3s2_fwd(const float* x, float* ymax, float* yavg, size_t planes, int H, int W, hipStream_t st);
 int pool3s2_bwd(const float* x, const float* gmax, const float* gavg, float* gx, size_t planes,
-                int H, int W, hipStream_t st);
+                int H, int W, int accumulate, hipStream_t st);
+int reduce_frames(float* dst, long long dst_bs, const float* src, int B, int cnt, size_t per,
+                  int accumulate, hipStream_t st);
 int tsa_gate_fwd(const float* emb, const float* emb_ref, const float* aligned, float* cor,
                  float* gated, int B, int N, int C, size_t HW, hipStream_t st);
 int tsa_gate_bwd(const float* emb, const float* emb_ref, const float* aligned, const float* cor,
@@ -28,7 +49,7 @@ int tsa_gate_bwd(const float* emb, const float* emb_ref, const float* aligned, c
 int tsa_blend_fwd(const float* fea, const float* att, const float* add, float* out, size_t n,
                   hipStream_t st);
 int tsa_blend_bwd(const float* fea, const float* att, const float* g, float* g_fea, float* g_att_io,
-                  size_t n, hipStream_t st);
+                  size_t n, int accumulate, hipStream_t st);
 int add_inplace(float* dst, const float* src, size_t n, hipStream_t st);
 int act_bwd_inplace(float* g, const float* y, size_t n, int act, hipStream_t st);
 

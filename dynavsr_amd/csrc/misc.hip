@@ -128,7 +128,7 @@ __global__ void pool3s2_fwd_kernel(const float* __restrict__ x, float* __restric
 // is what ATen's max_pool2d_with_indices records.
 __global__ void pool3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gmax,
                                    const float* __restrict__ gavg, float* __restrict__ gx,
-                                   size_t planes, int H, int W, int Ho, int Wo) {
+                                   size_t planes, int H, int W, int Ho, int Wo, int accumulate) {
   const size_t total = planes * H * W;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -160,7 +160,7 @@ __global__ void pool3s2_bwd_kernel(const float* __restrict__ x, const float* __r
         if (ay == iy && ax == ix) acc += gmax[o];
       }
     }
-    gx[i] = acc;
+    gx[i] = accumulate ? gx[i] + acc : acc;
   }
 }
 
@@ -240,13 +240,14 @@ __global__ void tsa_blend_fwd_kernel(const float* __restrict__ fea, const float*
 // reaching att through the att_add branch); g_add = g is aliased by the caller.
 __global__ void tsa_blend_bwd_kernel(const float* __restrict__ fea, const float* __restrict__ att,
                                      const float* __restrict__ g, float* __restrict__ g_fea,
-                                     float* __restrict__ g_att_io, size_t n) {
+                                     float* __restrict__ g_att_io, size_t n, int accumulate) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     const float s = sigmoidf_(att[i]);
     const float gi = g[i];
     g_fea[i] = gi * 2.f * s;
-    g_att_io[i] += gi * fea[i] * 2.f * s * (1.f - s);
+    const float ga = gi * fea[i] * 2.f * s * (1.f - s);
+    g_att_io[i] = accumulate ? g_att_io[i] + ga : ga;
   }
 }
 
@@ -263,6 +264,64 @@ __global__ void act_bwd_inplace_kernel(float* __restrict__ g, const float* __res
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
     g[i] *= act_grad_from_out(y[i], act);
+}
+
+// dst[b*dst_bs + e] (+)= sum_{k<cnt} src[(b*cnt + k)*per + e]: gradient of a tensor that entered a
+// conv as a broadcast / strided view (the reference frame shared by the N frames of a clip).
+__global__ void reduce_frames_kernel(float* __restrict__ dst, long long dst_bs, const float* __restrict__ src,
+                                     int B, int cnt, size_t per, int accumulate) {
+  const size_t total = (size_t)B * per;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i % per, b = i / per;
+    float s = 0.f;
+    for (int k = 0; k < cnt; ++k) s += src[(b * cnt + k) * per + e];
+    float* d = dst + b * dst_bs + e;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+// ---- Charbonnier loss: mean(sqrt((x-y)^2 + eps)) (models/loss.py:26-30), two-stage deterministic
+// reduction: CHARB_BLOCKS per-block partial sums, then one block folds them in a fixed order.
+constexpr int CHARB_BLOCKS = 1024;
+__global__ void charbonnier_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                           float* __restrict__ partial, size_t n, float eps) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = x[i] - y[i];
+    s += sqrtf(d * d + eps);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void charbonnier_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nb,
+                                         float inv_n) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * inv_n;
+}
+// gx = (*gscale / n) * d / sqrt(d^2 + eps)   (gradient w.r.t. x; the one w.r.t. y is its negative)
+__global__ void charbonnier_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                       const float* __restrict__ gscale, float* __restrict__ gx, size_t n,
+                                       float eps, float inv_n) {
+  const float g = gscale[0] * inv_n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = x[i] - y[i];
+    gx[i] = g * d / sqrtf(d * d + eps);
+  }
 }
 
 #define LAUNCH(kern, n, st, ...) \
@@ -290,10 +349,10 @@ int pool3s2_fwd(const float* x, float* ymax, float* yavg, size_t planes, int H, 
   return check_launch("pool3s2_fwd_kernel");
 }
 int pool3s2_bwd(const float* x, const float* gmax, const float* gavg, float* gx, size_t planes,
-                int H, int W, hipStream_t st) {
+                int H, int W, int accumulate, hipStream_t st) {
   DVSR_REQUIRE(x && gmax && gavg && gx && planes > 0, DVSR_ERR_INVALID, "pool3s2_bwd: bad argument");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  LAUNCH(pool3s2_bwd_kernel, planes * H * W, st, x, gmax, gavg, gx, planes, H, W, Ho, Wo);
+  LAUNCH(pool3s2_bwd_kernel, planes * H * W, st, x, gmax, gavg, gx, planes, H, W, Ho, Wo, accumulate);
   return check_launch("pool3s2_bwd_kernel");
 }
 int tsa_gate_fwd(const float* emb, const float* emb_ref, const float* aligned, float* cor,
@@ -319,10 +378,10 @@ int tsa_blend_fwd(const float* fea, const float* att, const float* add, float* o
   return check_launch("tsa_blend_fwd_kernel");
 }
 int tsa_blend_bwd(const float* fea, const float* att, const float* g, float* g_fea, float* g_att_io,
-                  size_t n, hipStream_t st) {
+                  size_t n, int accumulate, hipStream_t st) {
   DVSR_REQUIRE(fea && att && g && g_fea && g_att_io && n > 0, DVSR_ERR_INVALID,
                "tsa_blend_bwd: bad argument");
-  LAUNCH(tsa_blend_bwd_kernel, n, st, fea, att, g, g_fea, g_att_io, n);
+  LAUNCH(tsa_blend_bwd_kernel, n, st, fea, att, g, g_fea, g_att_io, n, accumulate);
   return check_launch("tsa_blend_bwd_kernel");
 }
 int add_inplace(float* dst, const float* src, size_t n, hipStream_t st) {
@@ -335,9 +394,41 @@ int act_bwd_inplace(float* g, const float* y, size_t n, int act, hipStream_t st)
   return check_launch("act_bwd_inplace_kernel");
 }
 
+int reduce_frames(float* dst, long long dst_bs, const float* src, int B, int cnt, size_t per,
+                  int accumulate, hipStream_t st) {
+  DVSR_REQUIRE(dst && src && B > 0 && cnt > 0 && per > 0, DVSR_ERR_INVALID, "reduce_frames: bad argument");
+  LAUNCH(reduce_frames_kernel, (size_t)B * per, st, dst, dst_bs, src, B, cnt, per, accumulate);
+  return check_launch("reduce_frames_kernel");
+}
+
 }  // namespace dvsr
 
 using namespace dvsr;
+
+extern "C" size_t dvsr_charbonnier_workspace_bytes(void) { return CHARB_BLOCKS * sizeof(float); }
+
+extern "C" int dvsr_charbonnier_forward(const float* x, const float* y, float* loss, long long n, float eps,
+                                        void* workspace, size_t workspace_bytes, dvsr_stream_t stream) {
+  DVSR_REQUIRE(x && y && loss && workspace && n > 0, DVSR_ERR_INVALID, "charbonnier_forward: bad argument");
+  DVSR_REQUIRE(workspace_bytes >= CHARB_BLOCKS * sizeof(float), DVSR_ERR_WORKSPACE,
+               "charbonnier_forward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int nb = (int)(((size_t)n + 255) / 256);
+  if (nb > CHARB_BLOCKS) nb = CHARB_BLOCKS;
+  hipLaunchKernelGGL(charbonnier_partial_kernel, dim3(nb), dim3(256), 0, st, x, y, (float*)workspace,
+                     (size_t)n, eps);
+  hipLaunchKernelGGL(charbonnier_final_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, loss, nb,
+                     1.f / (float)n);
+  return check_launch("charbonnier_forward");
+}
+
+extern "C" int dvsr_charbonnier_backward(const float* x, const float* y, const float* grad_loss, float* gx,
+                                         long long n, float eps, dvsr_stream_t stream) {
+  DVSR_REQUIRE(x && y && grad_loss && gx && n > 0, DVSR_ERR_INVALID, "charbonnier_backward: bad argument");
+  LAUNCH(charbonnier_bwd_kernel, (size_t)n, (hipStream_t)stream, x, y, grad_loss, gx, (size_t)n, eps,
+         1.f / (float)n);
+  return check_launch("charbonnier_bwd_kernel");
+}
 
 extern "C" int dvsr_upsample_bilinear_forward(const float* x, float* y, long long planes, int H,
                                               int W, int scale, float mul, dvsr_stream_t stream) {
@@ -356,7 +447,7 @@ extern "C" int dvsr_pool3s2_forward(const float* x, float* ymax, float* yavg, lo
 extern "C" int dvsr_pool3s2_backward(const float* x, const float* gmax, const float* gavg,
                                      float* gx, long long planes, int H, int W,
                                      dvsr_stream_t stream) {
-  return pool3s2_bwd(x, gmax, gavg, gx, (size_t)planes, H, W, (hipStream_t)stream);
+  return pool3s2_bwd(x, gmax, gavg, gx, (size_t)planes, H, W, 0, (hipStream_t)stream);
 }
 extern "C" int dvsr_tsa_gate_forward(const float* emb, const float* emb_ref, const float* aligned,
                                      float* cor, float* gated, int B, int N, int C, long long HW,
@@ -377,5 +468,5 @@ extern "C" int dvsr_tsa_blend_forward(const float* fea, const float* att, const 
 extern "C" int dvsr_tsa_blend_backward(const float* fea, const float* att, const float* g,
                                        float* g_fea, float* g_att_io, long long n,
                                        dvsr_stream_t stream) {
-  return tsa_blend_bwd(fea, att, g, g_fea, g_att_io, (size_t)n, (hipStream_t)stream);
+  return tsa_blend_bwd(fea, att, g, g_fea, g_att_io, (size_t)n, 1, (hipStream_t)stream);
 }

@@ -37,6 +37,13 @@ class Plan:
                                           ws.numel() * ws.element_size(), L.stream()),
                 "dvsr_edvr_forward")
 
+    def backward(self, params, x, gout, gparams, gx, ws):
+        arr = (ctypes.c_void_p * len(params))(*[L.ptr(p) for p in params])
+        garr = (ctypes.c_void_p * len(gparams))(*[L.ptr(g) for g in gparams])
+        L.check(L.lib().dvsr_edvr_backward(self._h, arr, L.ptr(x), L.ptr(gout), garr, L.ptr(gx),
+                                           ws.data_ptr(), ws.numel() * ws.element_size(), L.stream()),
+                "dvsr_edvr_backward")
+
     def forward_timed(self, params, x, out, ws):
         """Per-launch milliseconds (hipEvents on the current stream, stream-synchronising)."""
         arr = (ctypes.c_void_p * len(params))(*[L.ptr(p) for p in params])
@@ -114,4 +121,9 @@ class EdvrFunction(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gout):
-        raise NotImplementedError("dvsr_edvr_backward is not wired yet")
+        gout = _prep(gout)
+        gparams = [torch.empty_like(p) for p in ctx.params]
+        gx = torch.empty_like(ctx.x) if ctx.needs_input_grad[0] else None
+        ctx.plan.backward(ctx.params, ctx.x, gout, gparams, gx, ctx.ws)
+        ctx.ws = None  # release the activation arena
+        return (gx, None, None) + tuple(gparams)

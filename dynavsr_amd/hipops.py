@@ -118,3 +118,66 @@ def tsa_blend_backward(fea, att, g, g_att_io):
                                             L.ptr(g_att_io), fea.numel(), L.stream()),
             "dvsr_tsa_blend_backward")
     return g_fea
+
+
+def conv2d_backward(gy, x0, weight, stride=1, x1=None, need_gx=True):
+    """gy = gradient w.r.t. the pre-activation output.  Returns (gx0, gx1, gw, gb)."""
+    n, c0, h, w = x0.shape
+    cout, ctot, ks, _ = weight.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    d = L.Conv2dDesc(L.ptr(x0), L.ptr(x1), L.ptr(weight), None, None, None, n, c0, c1, h, w, cout, ks, stride,
+                     ks // 2, 0, 0, 1, 0, 0)
+    ws = torch.empty(max(int(L.lib().dvsr_conv2d_backward_workspace_bytes(d)), 16), dtype=torch.uint8,
+                     device=x0.device)
+    gx0 = torch.empty_like(x0) if need_gx else None
+    gx1 = torch.empty_like(x1) if (need_gx and x1 is not None) else None
+    gw, gb = torch.empty_like(weight), weight.new_empty(cout)
+    L.check(L.lib().dvsr_conv2d_backward(d, L.ptr(gy), L.ptr(gx0), L.ptr(gx1), L.ptr(gw), L.ptr(gb),
+                                         ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_backward")
+    return gx0, gx1, gw, gb
+
+
+def mdcn_backward(x, offset, mask, weight, gout, stride=1, padding=0, dilation=1, groups=1,
+                  deformable_groups=1, with_bias=True):
+    """Returns (gx, goffset, gmask, gw, gb) like the reference op's backward (deform_conv.py:122-142)."""
+    n, c, h, w = x.shape
+    cout, _, kh, kw = weight.shape
+    nbytes = int(L.lib().dvsr_mdcn_backward_workspace_bytes(n, c, h, w, cout, kh, kw, stride, padding, dilation))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    gx = torch.zeros_like(x)
+    goff, gmask, gw = torch.empty_like(offset), torch.empty_like(mask), torch.empty_like(weight)
+    gb = weight.new_empty(cout) if with_bias else None
+    L.check(L.lib().dvsr_mdcn_backward(L.ptr(x), L.ptr(offset), L.ptr(mask), L.ptr(weight), L.ptr(gout),
+                                       L.ptr(gx), L.ptr(goff), L.ptr(gmask), L.ptr(gw), L.ptr(gb), n, c, h, w,
+                                       cout, kh, kw, stride, padding, dilation, groups, deformable_groups,
+                                       ws.data_ptr(), nbytes, L.stream()), "dvsr_mdcn_backward")
+    return gx, goff, gmask, gw, gb
+
+
+class _Charbonnier(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, eps):
+        x, y = x.contiguous(), y.contiguous()
+        ws = torch.empty(int(L.lib().dvsr_charbonnier_workspace_bytes()), dtype=torch.uint8, device=x.device)
+        loss = x.new_empty(())
+        L.check(L.lib().dvsr_charbonnier_forward(L.ptr(x), L.ptr(y), loss.data_ptr(), x.numel(), eps,
+                                                 ws.data_ptr(), ws.numel(), L.stream()),
+                "dvsr_charbonnier_forward")
+        ctx.save_for_backward(x, y)
+        ctx.eps = eps
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        g = g.contiguous().float()
+        L.check(L.lib().dvsr_charbonnier_backward(L.ptr(x), L.ptr(y), g.data_ptr(), L.ptr(gx), x.numel(),
+                                                  ctx.eps, L.stream()), "dvsr_charbonnier_backward")
+        return (gx if ctx.needs_input_grad[0] else None, -gx if ctx.needs_input_grad[1] else None, None)
+
+
+def charbonnier(x, y, eps=1e-6):
+    """mean(sqrt((x-y)^2 + eps)) with autograd (models/loss.py:26-30)."""
+    return _Charbonnier.apply(x, y, eps)

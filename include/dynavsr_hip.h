@@ -55,6 +55,17 @@ int dvsr_mdcn_forward(const float* x, const float* offset, const float* mask, co
                       int kw, int stride, int pad, int dil, int groups, int dg, int act,
                       dvsr_stream_t stream);
 
+/* Replaces modulated_deform_conv_cuda_backward (deform_conv_cuda.cpp:566-679).  grad_out = gradient
+ * w.r.t. the op's output (act = NONE).  gx is ACCUMULATED into with fp32 atomics (zero it first, the
+ * reference's caller does: deform_conv.py:128); goffset/gmask/gw/gb are overwritten; gx/gw/gb may
+ * be NULL.  Workspace holds the [C*9, Ho*Wo] column buffer + weight-gradient partials. */
+size_t dvsr_mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int kh, int kw, int stride,
+                                          int pad, int dil);
+int dvsr_mdcn_backward(const float* x, const float* offset, const float* mask, const float* w,
+                       const float* grad_out, float* gx, float* goffset, float* gmask, float* gw, float* gb,
+                       int N, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
+                       int groups, int dg, void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
+
 /* Same op fed by the RAW output `om` [N, 3*dg*kh*kw, Ho, Wo] of ModulatedDeformConvPack's
  * conv_offset_mask (deform_conv.py:274-291): offset = om[:, :2*dg*K], mask = sigmoid(om[:, 2*dg*K:]);
  * the chunk/cat/sigmoid launches of the reference are folded into the sampler. */
@@ -86,6 +97,13 @@ typedef struct dvsr_conv2d_desc {
 } dvsr_conv2d_desc;
 
 int dvsr_conv2d_forward(const dvsr_conv2d_desc* d, dvsr_stream_t stream);
+/* Backward of the plain layout (pixel_shuffle=0, x1_bdiv<=1): `gy` = gradient w.r.t. the
+ * PRE-activation output.  gx0/gx1/gw/gb may be NULL to skip; all are overwritten.  Data gradient =
+ * the same MFMA kernel on the transposed, tap-mirrored weight view (zero-dilated for stride 2);
+ * weight/bias gradient = split-K MFMA kernel + deterministic reduce (conv2d_wgrad.hip). */
+size_t dvsr_conv2d_backward_workspace_bytes(const dvsr_conv2d_desc* d);
+int dvsr_conv2d_backward(const dvsr_conv2d_desc* d, const float* gy, float* gx0, float* gx1, float* gw,
+                         float* gb, void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
 
 /* ---- streaming (HBM-bound) ops ------------------------------------------------------------------
  * F.interpolate(scale_factor=S, mode='bilinear', align_corners=False) * mul
@@ -134,6 +152,16 @@ int dvsr_edvr_num_launches(const dvsr_edvr_plan* plan);
 size_t dvsr_edvr_workspace_bytes(const dvsr_edvr_plan* plan, int need_grad);
 int dvsr_edvr_forward(const dvsr_edvr_plan* plan, const float* const* params, const float* x,
                       float* out, void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
+/* Backward of dvsr_edvr_forward (first-order; replaces autograd through EDVR incl. the 20 calls of
+ * modulated_deform_conv_cuda_backward per clip, deform_conv_cuda.cpp:566-679).  Must follow a forward
+ * on the SAME workspace, which must have been sized with need_grad=1.  grad_out [B,3,sH,sW];
+ * grad_params: HOST array of device pointers shaped like `params`, every entry is OVERWRITTEN;
+ * grad_x [B,nframes,3,H,W] or NULL.  The DCN input gradient uses fp32 atomics (summation order
+ * varies run to run, as in the reference kernel, deform_conv_cuda_kernel.cu:687). */
+int dvsr_edvr_backward(const dvsr_edvr_plan* plan, const float* const* params, const float* x,
+                       const float* grad_out, float* const* grad_params, float* grad_x, void* workspace,
+                       size_t workspace_bytes, dvsr_stream_t stream);
+int dvsr_edvr_num_backward_launches(const dvsr_edvr_plan* plan);
 /* Measurement aids: per-launch description (kind = "conv3x3s1", "mdcn", ...; algorithmic FLOPs and
  * bytes of that launch) and a forward that brackets every launch with hipEvents on `stream`,
  * synchronises, and returns per-launch milliseconds in op_ms[dvsr_edvr_num_launches()]. */
@@ -146,6 +174,15 @@ int dvsr_edvr_forward_timed(const dvsr_edvr_plan* plan, const float* const* para
  * parity checks ("L1_fea", "aligned", "tsa_out", "recon", ...). */
 int dvsr_edvr_tensor_info(const dvsr_edvr_plan* plan, const char* name, long long* offset_floats,
                           long long* numel);
+
+/* ---- Charbonnier loss (models/loss.py:19-30, the `pixel_criterion: cb` of every EDVR YAML) --------
+ * loss[0] = mean(sqrt((x-y)^2 + eps)), deterministic two-stage reduction; backward writes
+ * gx = grad_loss[0]/n * (x-y)/sqrt((x-y)^2+eps) (the gradient w.r.t. y is -gx). */
+size_t dvsr_charbonnier_workspace_bytes(void);
+int dvsr_charbonnier_forward(const float* x, const float* y, float* loss, long long n, float eps,
+                             void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
+int dvsr_charbonnier_backward(const float* x, const float* y, const float* grad_loss, float* gx, long long n,
+                              float eps, dvsr_stream_t stream);
 
 #ifdef __cplusplus
 }

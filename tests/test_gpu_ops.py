@@ -172,3 +172,60 @@ def test_tsa_gate_and_blend(ops):
     g_att = dev(pre)
     g_fea = ops.tsa_blend_backward(dev(fea.detach()), dev(att.detach()), dev(go), g_att)
     assert relerr(g_fea, r_fea) < 1e-6 and relerr(g_att, r_att + pre) < 1e-6
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,h,w", [
+    (64, 64, 3, 1, 12, 40), (3, 64, 3, 1, 9, 33), (64, 216, 3, 1, 7, 35), (64, 3, 3, 1, 8, 32),
+    (64, 64, 3, 2, 12, 40), (64, 64, 1, 1, 9, 70), (320, 64, 1, 1, 8, 32), (16, 24, 3, 1, 5, 7),
+])
+def test_conv2d_backward(ops, cin, cout, ks, stride, h, w):
+    x = rnd(2, cin, h, w, seed=1).requires_grad_()
+    wt = rnd(cout, cin, ks, ks, seed=2, scale=1 / np.sqrt(cin * ks * ks)).requires_grad_()
+    b = rnd(cout, seed=3, scale=0.1).requires_grad_()
+    y = F.conv2d(x, wt, b, stride, ks // 2)
+    gy = rnd(*y.shape, seed=4)
+    rx, rw, rb = torch.autograd.grad(y, [x, wt, b], gy)
+    gx, _, gw, gb = ops.conv2d_backward(dev(gy), dev(x.detach()), dev(wt.detach()), stride=stride)
+    assert relerr(gx, rx) < TOL and relerr(gw, rw) < TOL and relerr(gb, rb) < TOL
+
+
+def test_conv2d_backward_two_inputs(ops):
+    x0, x1 = rnd(3, 64, 10, 36, seed=1).requires_grad_(), rnd(3, 64, 10, 36, seed=2).requires_grad_()
+    wt = rnd(64, 128, 3, 3, seed=3, scale=0.03).requires_grad_()
+    y = F.conv2d(torch.cat([x0, x1], 1), wt, None, 1, 1)
+    gy = rnd(*y.shape, seed=4)
+    r0, r1, rw = torch.autograd.grad(y, [x0, x1, wt], gy)
+    g0, g1, gw, gb = ops.conv2d_backward(dev(gy), dev(x0.detach()), dev(wt.detach()), x1=dev(x1.detach()))
+    assert relerr(g0, r0) < TOL and relerr(g1, r1) < TOL and relerr(gw, rw) < TOL
+    assert relerr(gb, gy.sum((0, 2, 3))) < TOL
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_mdcn_backward_golden(ops, tag):
+    g = load_golden("dcn_" + tag)
+    x, off, m, w, go = (dev(torch.from_numpy(g[k])) for k in ("x", "offset", "mask", "weight", "gout"))
+    gx, goff, gm, gw, gb = ops.mdcn_backward(x, off, m, w, go, 1, 1, 1, 1, int(g["dg"]))
+    for got, key in ((gx, "gx"), (goff, "goffset"), (gm, "gmask"), (gw, "gweight"), (gb, "gbias")):
+        assert relerr(got, g[key]) < TOL, key
+
+
+def test_mdcn_backward_vs_oracle(ops):
+    from oracle import dcn as odcn
+    n, c, dg, cout, h, w = 2, 64, 8, 64, 14, 34
+    x, off = rnd(n, c, h, w, seed=1), rnd(n, dg * 18, h, w, seed=2, scale=1.5)
+    m = torch.from_numpy(np.random.RandomState(3).random_sample((n, dg * 9, h, w)))
+    wt, go = rnd(cout, c, 3, 3, seed=4, scale=0.04), rnd(n, cout, h, w, seed=5)
+    ref = odcn.backward(x, off, m, wt, True, go, 1, 1, 1, 1, dg)
+    got = ops.mdcn_backward(dev(x), dev(off), dev(m), dev(wt), dev(go), 1, 1, 1, 1, dg)
+    for a, b_, name in zip(got, ref, ("gx", "goffset", "gmask", "gw", "gb")):
+        assert relerr(a, b_) < TOL, name
+
+
+def test_charbonnier(ops):
+    x, y = rnd(2, 3, 40, 52, seed=1).requires_grad_(), rnd(2, 3, 40, 52, seed=2)
+    ref = torch.mean(torch.sqrt((x - y) ** 2 + 1e-6))
+    (rg,) = torch.autograd.grad(ref * 3.0, x)
+    xg = dev(x.detach()).requires_grad_()
+    got = ops.charbonnier(xg, dev(y))
+    (gg,) = torch.autograd.grad(got * 3.0, xg)
+    assert abs(float(got) - float(ref)) < 1e-6 * float(ref) and relerr(gg, rg) < 1e-6
