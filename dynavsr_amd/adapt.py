@@ -1,0 +1,66 @@
+"""The per-frame test-time adaptation of DynaVSR as one reusable function.
+
+This is the body of the hot loop of codes/test_dynavsr.py:197-283 (and of the validation loops
+train_dynavsr.py:552-677) expressed over the wrapper API, so that drivers, benchmarks and tests
+share one implementation:
+
+    baseline SR  ->  deepcopy(netG, netE)  ->  inner optimizer over G u E params
+    for adapt_iter steps:  SLR = netE(LR) (with grad);  loss = cri(netG(SLR), LR[:,center])
+                           + 10 * L1(SLR, netE_fixed(LR));  backward;  step
+    adapted SR = netG(LR)
+
+One deviation that the wrapper contract allows and SURVEY.md §8f-1 calls out: the frozen
+estimator's output does not change inside the step loop, so it is computed once per frame.
+"""
+from copy import deepcopy
+
+import torch
+import torch.nn.functional as F
+
+
+def make_inner_optimizer(opt, netG, netE):
+    m = opt['train']['maml']
+    params = [p for p in netG.parameters() if p.requires_grad]
+    if not opt['train']['use_real']:
+        params += [p for p in netE.parameters() if p.requires_grad]
+    if m['optimizer'] == 'Adam':
+        return torch.optim.Adam(params, lr=m['lr_alpha'], betas=(m['beta1'], m['beta2']))
+    if m['optimizer'] == 'SGD':
+        return torch.optim.SGD(params, lr=m['lr_alpha'])
+    raise NotImplementedError()
+
+
+def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, val_data, slr_weight=10.0):
+    """Adapt copies of (model.netG, est_model.netE) on one LR clip and super-resolve it.
+
+    val_data: {'LQs': [1,N,3,H,W] (+ 'SuperLQs' when train.use_real)}.  Returns a dict with the
+    adapted output ``sr`` [1,3,sH,sW] (on device), the per-step ``losses`` and the updated wrappers
+    (modelcp.netG / est_modelcp.netE hold the adapted weights)."""
+    lqs = val_data['LQs']
+    assert lqs.size(0) == 1
+    center = lqs.size(1) // 2
+    steps = opt['train']['maml']['adapt_iter']
+    modelcp.netG, est_modelcp.netE = deepcopy(model.netG), deepcopy(est_model.netE)
+    inner = make_inner_optimizer(opt, modelcp.netG, est_modelcp.netE)
+    est_model_fixed.feed_data(val_data)
+    est_model_fixed.test()
+    slr_fixed = est_model_fixed.fake_L
+    target = lqs[:, center]
+    losses = []
+    for _ in range(steps):
+        if not opt['train']['use_real']:
+            est_modelcp.feed_data(val_data)
+            est_modelcp.forward_without_optim()
+            slr = est_modelcp.fake_L
+        else:
+            slr = val_data['SuperLQs']
+        inner.zero_grad()
+        modelcp.feed_data({'LQs': slr, 'GT': target})
+        loss = modelcp.calculate_loss()
+        loss = loss + slr_weight * F.l1_loss(slr.to(slr_fixed.device), slr_fixed)
+        loss.backward()
+        inner.step()
+        losses.append(loss.detach())
+    modelcp.feed_data({'LQs': lqs}, need_GT=False)
+    modelcp.test()
+    return {'sr': modelcp.fake_H, 'losses': losses, 'slr': slr.detach()}

@@ -1,0 +1,27 @@
+"""Network factories with the reference's signatures (codes/models/networks.py:8-72):
+``define_G(opt)`` builds the EDVR backbone from ``opt['network_G']``, ``define_E(opt)`` the
+down-scaling estimator (MFDN / SFDN) from ``opt['network_E']``."""
+from .archs import EDVR_arch, LRimg_estimator
+
+
+def define_G(opt):
+    net = opt['network_G']
+    which = net['which_model_G']
+    if which != 'EDVR':
+        raise NotImplementedError('Generator model [{:s}] not recognized (this build covers the EDVR '
+                                  'backbone; DUF/TOF are SURVEY.md §8f-4)'.format(str(which)))
+    return EDVR_arch.EDVR(nf=net['nf'], nframes=net['nframes'], groups=net['groups'],
+                          front_RBs=net['front_RBs'], back_RBs=net['back_RBs'], center=net['center'],
+                          predeblur=net['predeblur'], HR_in=net['HR_in'], w_TSA=net['w_TSA'],
+                          scale=opt['scale'])
+
+
+def define_E(opt):
+    net = opt['network_E']
+    which = net['which_model_E']
+    if which == 'MFDN':
+        return LRimg_estimator.DirectKernelEstimatorVideo(in_nc=net['in_nc'], nf=net['nf'],
+                                                          scale=opt['scale'])
+    if which == 'SFDN':
+        return LRimg_estimator.DirectKernelEstimator_CMS(nf=net['nf'])
+    raise NotImplementedError('Estimator model [{:s}] not recognized'.format(str(which)))

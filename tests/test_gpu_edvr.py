@@ -149,3 +149,73 @@ def test_edvr_backward_all_grads_vs_oracle():
     bad = [(n, a, b) for n, a, b in zip(names, e_gpu, e_cpu) if a > 3 * max(b, 3e-4)]
     assert not bad, bad[:10]
     assert np.median(e_gpu) < 2 * np.median(e_cpu) + 1e-4
+
+
+def _gpu_opt(optimizer):
+    import os
+    from conftest import ROOT
+    from dynavsr_amd.options import options as option
+    opt = option.dict_to_nonedict(option.parse(os.path.join(
+        ROOT, "dynavsr_amd", "options", "test", "EDVR", "EDVR_M_S4.yml"), is_train=False))
+    opt["dist"] = False
+    for k in ("pretrain_model_G", "pretrain_model_E"):
+        opt["path"][k] = None
+    opt["train"]["maml"]["optimizer"] = optimizer
+    return opt
+
+
+@pytest.mark.parametrize("optimizer", ["SGD", "Adam"])
+def test_inner_step_golden(optimizer):
+    """BASELINE.json configs[0] on the GPU: one inner MAML step through the wrapper API
+    (create_model / feed_data / forward_without_optim / calculate_loss / test) vs the golden
+    produced by the reference's wrappers on CPU: loss, adapted SR frame, parameter updates."""
+    from dynavsr_amd.adapt import adapt_frame
+    from dynavsr_amd.models import create_model
+    g = load_golden("inner_step_" + optimizer.lower())
+    opt = _gpu_opt(optimizer)
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    PG, PE, PEF = synth.edvr_state_dict(0), synth.mfdn_state_dict(0), synth.mfdn_state_dict(1)
+    model.netG.load_state_dict(PG); est.netE.load_state_dict(PE); est_fixed.netE.load_state_dict(PEF)
+    lqs = synth.clip(1, 1, 5, 64, 64).cuda()
+    r = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, {"LQs": lqs})
+    assert abs(float(r["losses"][0]) - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    assert relerr(r["slr"], g["slr"]) < 1e-5
+    sr = r["sr"] if optimizer == "SGD" else r["sr"][..., 96:160, 96:160]
+    assert relerr(sr, g["sr"]) < 2e-4
+    newG, newE = dict(modelcp.netG.named_parameters()), dict(estcp.netE.named_parameters())
+    tol = 1e-2 if optimizer == "SGD" else 1e-1          # Adam's first step is ~lr*sign(g)
+    for key in g:
+        if key.startswith("dG__") or key.startswith("dE__"):
+            name = key[4:].replace("__", ".")
+            src, new = (PG, newG) if key.startswith("dG__") else (PE, newE)
+            delta = new[name].detach().cpu().double() - src[name].double()
+            assert relerr(delta, g[key]) < tol, name
+    # the meta-parameters themselves must be untouched (adaptation works on deep copies)
+    assert torch.equal(model.netG.state_dict()["conv_first.weight"].cpu(), PG["conv_first.weight"])
+
+
+def test_dcn_dropin_module_matches_engine_and_oracle():
+    """Op-level drop-in (models/archs/dcn) forward+backward vs the C oracle."""
+    from dynavsr_amd.models.archs.dcn import ModulatedDeformConvPack
+    from oracle import edvr as oedvr
+    torch.manual_seed(0)
+    m = ModulatedDeformConvPack(64, 64, 3, stride=1, padding=1, dilation=1, deformable_groups=8,
+                                extra_offset_mask=True).cuda()
+    with torch.no_grad():
+        m.conv_offset_mask.weight.normal_(0, 0.05)
+        m.conv_offset_mask.bias.normal_(0, 0.05)
+    x = torch.randn(2, 64, 12, 20).cuda().requires_grad_()
+    f = torch.randn(2, 64, 12, 20).cuda().requires_grad_()
+    y = m([x, f])
+    go = torch.randn_like(y)
+    y.backward(go)
+    P = {"d." + k: v.detach().cpu().requires_grad_() for k, v in m.named_parameters()}
+    xc, fc = x.detach().cpu().requires_grad_(), f.detach().cpu().requires_grad_()
+    yr = oedvr.dcn_pack(P, "d", xc, fc, 8)
+    yr.backward(go.cpu())
+    assert relerr(y, yr) < 2e-5
+    assert relerr(x.grad, xc.grad) < 1e-4 and relerr(f.grad, fc.grad) < 1e-4
+    for k, v in m.named_parameters():
+        assert relerr(v.grad, P["d." + k].grad) < 1e-4, k
