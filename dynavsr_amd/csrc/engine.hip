@@ -15,6 +15,7 @@
 //  * Parameters are addressed by their position in the reference's state-dict order
 //    (dynavsr_amd/spec.py mirrors the walk below).
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,10 @@ struct Op {
   size_t planes = 0;
   int gB = 0, gN = 0, gC = 0;
   size_t gHW = 0;
+  // packed-weight slots (conv2d_v2.hip): forward pack in the activation arena, the two
+  // data-gradient packs in the backward-only region
+  size_t wp_off = 0, dpk_off[2] = {0, 0};
+  size_t wp_floats = 0, dpk_floats[2] = {0, 0};
 };
 
 // ---- backward tape -------------------------------------------------------------------------
@@ -78,6 +83,8 @@ struct dvsr_edvr_plan {
   std::vector<std::pair<std::string, dvsr::T>> named;
   std::vector<std::pair<size_t, size_t>> allocs;  // (offset, numel) of every arena slot, ascending
   std::vector<dvsr::BOp> bops;                    // backward tape (already in execution order)
+  size_t dpack_floats = 0;                        // packed transposed weights for the dgrad launches
+  bool use_v1 = false;                            // DVSR_CONV_V1=1: un-pipelined conv kernel (A/B aid)
   size_t tmp_floats = 0;                          // dense dgrad staging for broadcast/strided views
   size_t scratch_bytes = 0;                       // wgrad partials / DCN column buffer
 };
@@ -119,6 +126,19 @@ struct Builder {
     o.act = act; o.ps = ps; o.x1_bdiv = x1_bdiv; o.x0_bs = x0_bs; o.x1_bs = x1_bs;
     const int Ho = (H + 2 * (ks / 2) - ks) / stride + 1, Wo = (W + 2 * (ks / 2) - ks) / stride + 1;
     o.y = y_override.valid() ? y_override : alloc(name, (size_t)N * Cout * Ho * Wo);
+    {
+      const int cc = conv2_cc(ks, stride), pch = conv2_pch(ks, stride);
+      o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, cc) * pch;
+      o.wp_off = alloc("", o.wp_floats).off;
+      for (int which = 0; which < 2; ++which) {
+        const int ci = which ? c1 : c0;
+        if (!ci) continue;
+        // dgrad = stride-1 conv with Cout' = ci, Ctot' = Cout
+        o.dpk_floats[which] = (size_t)ceil_div(ci, 64) * ceil_div(Cout, conv2_cc(ks, 1)) * conv2_pch(ks, 1);
+        o.dpk_off[which] = p.dpack_floats;
+        p.dpack_floats += o.dpk_floats[which];
+      }
+    }
     p.ops.push_back(o);
     return o.y;
   }
@@ -448,7 +468,8 @@ static void build_backward(dvsr_edvr_plan& p) {
 }
 
 struct BBases {
-  float* arena; float* garena; const float* x; float* gx; const float* gout; float* tmp;
+  float* arena; float* garena; const float* x; float* gx; const float* gout; float* tmp; float* dpack;
+  bool use_v1;
   float* at(const Ref& r) const {
     switch (r.space) {
       case R_ACT: return arena + r.off;
@@ -498,7 +519,8 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
       ex.wt = 1; ex.w_ctot = o->c0 + o->c1; ex.w_coff = b.which ? o->c0 : 0; ex.accum = b.accum; ex.in_ps = o->ps ? 1 : 0;
       if (o->stride == 2) { ex.in_dil = 2; ex.Hs = Ho; ex.Ws = Wo; g.H = o->H; g.W = o->W; }
       else { g.H = Ho; g.W = Wo; }
-      return conv2d_run(g, ex, st);
+      if (bs.use_v1) return conv2d_run(g, ex, st);
+      return conv2d_packed_run(g, bs.dpack + o->dpk_off[b.which], ex, st);
     }
     case B_REDUCE: {
       float* dst = bs.at(b.a);
@@ -533,7 +555,7 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
 }
 
 struct Bases {
-  float* arena; const float* x; float* out;
+  float* arena; const float* x; float* out; bool use_v1;
   float* at(const T& t) const {
     if (t.space == SP_ARENA) return arena + t.off;
     if (t.space == SP_INPUT) return const_cast<float*>(x) + t.off;
@@ -541,6 +563,37 @@ struct Bases {
     return nullptr;
   }
 };
+
+// Packs the weights of every conv of the tape (forward: wt=0; backward: the two transposed views).
+static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* fwd_base, float* bwd_base,
+                    hipStream_t st) {
+  PackTable t;
+  t.n = 0;
+  auto flush = [&]() { int rc = pack_weights_run(t, st); t.n = 0; return rc; };
+  for (const Op& o : p.ops) {
+    if (o.type != OP_CONV) continue;
+    const int ctot = o.c0 + o.c1, KK = o.ks * o.ks;
+    if (fwd_base) {
+      PackEntry& e = t.e[t.n++];
+      e.w = P[o.pw]; e.P = fwd_base + o.wp_off; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
+      e.CC = conv2_cc(o.ks, o.stride); e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
+      e.nchunks = ceil_div(ctot, e.CC); e.pch = conv2_pch(o.ks, o.stride);
+      if (t.n == 48) { int rc = flush(); if (rc) return rc; }
+    }
+    if (bwd_base) {
+      for (int which = 0; which < 2; ++which) {
+        const int ci = which ? o.c1 : o.c0;
+        if (!ci) continue;
+        PackEntry& e = t.e[t.n++];
+        e.w = P[o.pw]; e.P = bwd_base + o.dpk_off[which]; e.Cout = ci; e.Ctot = o.Cout; e.KK = KK;
+        e.CC = conv2_cc(o.ks, 1); e.wt = 1; e.w_ctot = ctot; e.w_coff = which ? o.c0 : 0;
+        e.ncb = ceil_div(ci, 64); e.nchunks = ceil_div(o.Cout, e.CC); e.pch = conv2_pch(o.ks, 1);
+        if (t.n == 48) { int rc = flush(); if (rc) return rc; }
+      }
+    }
+  }
+  return flush();
+}
 
 static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, hipStream_t st) {
   switch (o.type) {
@@ -551,7 +604,8 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
       d.N = o.N; d.c0 = o.c0; d.c1 = o.c1; d.H = o.H; d.W = o.W; d.Cout = o.Cout; d.ks = o.ks;
       d.stride = o.stride; d.pad = o.ks / 2; d.act = o.act; d.pixel_shuffle = o.ps;
       d.x1_bdiv = o.x1_bdiv; d.x0_bstride = o.x0_bs; d.x1_bstride = o.x1_bs;
-      return conv2d_run(d, ConvExtra(), st);
+      if (bs.use_v1) return conv2d_run(d, ConvExtra(), st);
+      return conv2d_packed_run(d, bs.arena + o.wp_off, ConvExtra(), st);
     }
     case OP_DCN: {
       const float* om = bs.at(o.x1);
@@ -599,6 +653,7 @@ extern "C" int dvsr_edvr_plan_create(const dvsr_edvr_config* cfg, int B, int H, 
                "edvr_plan_create: nf/groups=%d (supported: 4, 8, 16)", cpg);
   dvsr_edvr_plan* p = new dvsr_edvr_plan();
   p->cfg = *cfg; p->B = B; p->H = H; p->W = W;
+  { const char* v = getenv("DVSR_CONV_V1"); p->use_v1 = v && v[0] == '1'; }
   int rc = build_plan(*p);
   if (rc != DVSR_OK) { delete p; return rc; }
   build_backward(*p);
@@ -613,11 +668,11 @@ extern "C" int dvsr_edvr_num_params(const dvsr_edvr_plan* p) { return p ? p->n_p
 extern "C" int dvsr_edvr_num_launches(const dvsr_edvr_plan* p) { return p ? (int)p->ops.size() : -1; }
 
 // need_grad = 0: activation arena only.  need_grad = 1: + gradient arena + staging + scratch,
-// laid out [activations | gradients | dgrad staging | wgrad partials / DCN columns].
+// laid out [activations | gradients | dgrad staging | packed dgrad weights | wgrad partials / DCN columns].
 extern "C" size_t dvsr_edvr_workspace_bytes(const dvsr_edvr_plan* p, int need_grad) {
   if (!p) return 0;
   size_t b = p->arena_floats * sizeof(float);
-  if (need_grad) b += (p->arena_floats + p->tmp_floats) * sizeof(float) + p->scratch_bytes;
+  if (need_grad) b += (p->arena_floats + p->tmp_floats + p->dpack_floats) * sizeof(float) + p->scratch_bytes;
   return b;
 }
 
@@ -632,7 +687,13 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
   BBases bs;
   bs.arena = (float*)ws; bs.garena = bs.arena + p->arena_floats; bs.x = x; bs.gx = grad_x; bs.gout = grad_out;
   bs.tmp = bs.garena + p->arena_floats;
-  void* scratch = bs.tmp + p->tmp_floats;
+  bs.dpack = bs.tmp + p->tmp_floats;
+  bs.use_v1 = p->use_v1;
+  void* scratch = bs.dpack + p->dpack_floats;
+  if (!p->use_v1) {
+    int rc = pack_all(*p, params, nullptr, bs.dpack, st);
+    if (rc != DVSR_OK) return rc;
+  }
   if (grad_x) {
     const size_t n = (size_t)p->B * p->cfg.nframes * 3 * p->H * p->W;
     DVSR_REQUIRE(hipMemsetAsync(grad_x, 0, n * sizeof(float), st) == hipSuccess, DVSR_ERR_HIP,
@@ -652,7 +713,11 @@ extern "C" int dvsr_edvr_forward(const dvsr_edvr_plan* p, const float* const* pa
   DVSR_REQUIRE(p && params && x && out && ws, DVSR_ERR_INVALID, "edvr_forward: null argument");
   DVSR_REQUIRE(ws_bytes >= p->arena_floats * sizeof(float), DVSR_ERR_WORKSPACE,
                "edvr_forward: workspace %zu < %zu bytes", ws_bytes, p->arena_floats * sizeof(float));
-  Bases bs{(float*)ws, x, out};
+  Bases bs{(float*)ws, x, out, p->use_v1};
+  if (!p->use_v1) {
+    int rc = pack_all(*p, params, bs.arena, nullptr, (hipStream_t)stream);
+    if (rc != DVSR_OK) return rc;
+  }
   for (const Op& o : p->ops) {
     int rc = run_forward_op(o, params, bs, (hipStream_t)stream);
     if (rc != DVSR_OK) return rc;
@@ -713,8 +778,8 @@ extern "C" int dvsr_edvr_forward_timed(const dvsr_edvr_plan* p, const float* con
   const size_t n = p->ops.size();
   std::vector<hipEvent_t> ev(n + 1);
   for (auto& e : ev) DVSR_REQUIRE(hipEventCreate(&e) == hipSuccess, DVSR_ERR_HIP, "hipEventCreate failed");
-  Bases bs{(float*)ws, x, out};
-  int rc = DVSR_OK;
+  Bases bs{(float*)ws, x, out, p->use_v1};
+  int rc = p->use_v1 ? DVSR_OK : pack_all(*p, params, bs.arena, nullptr, st);
   hipEventRecord(ev[0], st);
   for (size_t i = 0; i < n && rc == DVSR_OK; ++i) {
     rc = run_forward_op(p->ops[i], params, bs, st);

@@ -20,6 +20,20 @@ int mdcn_forward_run(const float* x, const float* off, long long off_bs, const f
                      int N, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad,
                      int dil, int groups, int dg, int act, hipStream_t st);
 
+// conv2d_v2.hip: pipelined kernel over pre-packed weights
+struct PackEntry {
+  const float* w; float* P;
+  int Cout, Ctot, KK, CC, wt, w_ctot, w_coff, ncb, nchunks, pch;
+};
+struct PackTable {
+  int n;
+  PackEntry e[48];
+};
+int conv2_pch(int ks, int stride);  // floats per packed (cout block, chunk)
+int conv2_cc(int ks, int stride);   // input channels per chunk
+int pack_weights_run(const PackTable& t, hipStream_t st);
+int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, hipStream_t st);
+
 size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride);
 int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
                      float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
