@@ -9,7 +9,12 @@
 //   * the input halo tile of chunk k+1 is fetched into registers and the weight DMA of chunk k+1
 //     is issued BEFORE the MFMAs of chunk k; both LDS images are double buffered, so there is one
 //     barrier per chunk and HBM/L2 latency hides under the 144 MFMAs per wave of a chunk;
-//   * per-thread halo offsets / validity are computed once, not per chunk.
+//   * per-thread halo offsets / validity are computed once, not per chunk;
+//   * both LDS images are laid out so that an MFMA operand set is ONE ds_read_b128 per lane:
+//     weights  [tap][mt][q][hi][lo] x float4(kk = 4q..4q+3)   (channel c = 2kk + hi of the chunk),
+//     inputs   [q][row][hi][x]      x float4(kk = 4q..4q+3),
+//     lanes of a half-wave read consecutive 16-byte slots -> conflict-free; the operands of the next
+//     (tap, q) step are fetched before the 16 MFMAs of the current one (register double buffer).
 #include "common.h"
 #include "kernels.h"
 
@@ -28,38 +33,45 @@ struct Conv2Shape {
   static constexpr int TH = 8, TW = 32, KK = KS * KS;
   static constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
   static constexpr int PLANE = IH * IW, E = (PLANE + 255) / 256;
-  static constexpr int WROW = 65;
-  static constexpr int IN_FLOATS = CC * PLANE;
-  static constexpr int PCH = ((CC * KK * WROW + 1023) / 1024) * 1024;  // packed chunk, DMA granularity
+  static constexpr int KQ4 = CC / 8;                    // float4 groups of channel pairs per chunk
+  static constexpr int IN_FLOATS = CC * PLANE;          // = KQ4 * IH * 2 * IW float4
+  static constexpr int W_FLOATS = KK * 2 * KQ4 * 2 * 32 * 4;
+  static constexpr int PCH = ((W_FLOATS + 1023) / 1024) * 1024;  // packed chunk, DMA granularity
   static constexpr int NDMA = PCH / 1024;
-  static constexpr int BUF_FLOATS = ((IN_FLOATS + 3) & ~3) + PCH;
+  static constexpr int BUF_FLOATS = IN_FLOATS + PCH;
   static constexpr size_t LDS_BYTES = (size_t)2 * BUF_FLOATS * sizeof(float);
 };
 
 int conv2_pch(int ks, int stride) {
   if (ks == 1) return Conv2Shape<1, 1, 32>::PCH;
-  return stride == 2 ? Conv2Shape<3, 2, 4>::PCH : Conv2Shape<3, 1, 8>::PCH;
+  return stride == 2 ? Conv2Shape<3, 2, 8>::PCH : Conv2Shape<3, 1, 8>::PCH;
 }
-int conv2_cc(int ks, int stride) { return ks == 1 ? 32 : (stride == 2 ? 4 : 8); }
+int conv2_cc(int ks, int stride) { (void)stride; return ks == 1 ? 32 : 8; }
 
 // ---- weight packing ---------------------------------------------------------------------------
-// P[cb][k][(c*KK + tap)*65 + o] = W(cout = cb*64 + o, cin = k*CC + c, tap), zero outside.
+// P[cb][k][((((tap*2 + mt)*KQ4 + q)*2 + hi)*32 + lo)*4 + j] = W(cout = cb*64 + mt*32 + lo,
+//   cin = k*CC + 2*(4q + j) + hi, tap), zero outside / in the DMA padding.
 // wt = 1 (data gradient): this conv's (cin, cout, tap) = original (cout, cin slice, mirrored tap).
 __global__ void pack_weights_kernel(PackTable t) {
   const PackEntry& e = t.e[blockIdx.y];
-  const int rows = e.CC * e.KK;
+  const int kq4 = e.CC / 8;
+  const int valid = e.KK * 2 * kq4 * 2 * 32 * 4;
   const size_t per_chunk = (size_t)e.pch;
   const size_t total = (size_t)e.ncb * e.nchunks * per_chunk;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i % per_chunk);
+    int r = (int)(i % per_chunk);
     const size_t ck = i / per_chunk;
     const int k = (int)(ck % e.nchunks), cb = (int)(ck / e.nchunks);
     float v = 0.f;
-    const int row = r / 65, o = r - row * 65;
-    if (row < rows && o < 64) {
-      const int c = row / e.KK, tap = row - c * e.KK;
-      const int co = cb * 64 + o, ci = k * e.CC + c;
+    if (r < valid) {
+      const int j = r & 3; r >>= 2;
+      const int lo = r & 31; r >>= 5;
+      const int hi = r & 1; r >>= 1;
+      const int q = r % kq4; r /= kq4;
+      const int mt = r & 1;
+      const int tap = r >> 1;
+      const int co = cb * 64 + mt * 32 + lo, ci = k * e.CC + 2 * (4 * q + j) + hi;
       if (co < e.Cout && ci < e.Ctot) {
         if (!e.wt) v = e.w[((size_t)co * e.Ctot + ci) * e.KK + tap];
         else v = e.w[((size_t)ci * e.w_ctot + e.w_coff + co) * e.KK + (e.KK - 1 - tap)];
@@ -78,10 +90,10 @@ int pack_weights_run(const PackTable& t, hipStream_t st) {
 template <int KS, int S, int CC>
 __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
   using Sh = Conv2Shape<KS, S, CC>;
-  constexpr int KK = Sh::KK, IW = Sh::IW, PLANE = Sh::PLANE, WROW = Sh::WROW, E = Sh::E;
+  constexpr int KK = Sh::KK, IH = Sh::IH, IW = Sh::IW, PLANE = Sh::PLANE, E = Sh::E, KQ4 = Sh::KQ4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const s_in0 = smem;
-  float* const s_w0 = smem + ((Sh::IN_FLOATS + 3) & ~3);
+  float* const s_w0 = smem + Sh::IN_FLOATS;
 
   const int id = blockIdx.x;
   const int tile = (id / (8 * a.ncb)) * 8 + (id & 7);
@@ -103,12 +115,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
   const size_t cstride0 = a.in_dil ? (size_t)a.Hs * a.Ws : HW;  // x0 channel stride (in_ps: handled below)
 
   // per-thread halo elements: offset inside a channel plane + validity, fixed for all chunks
-  int eoff[E];
+  int eoff[E], elds[E];
   bool evalid[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int idx = tid + 256 * e;
     const int iy = idx / IW, ix = idx - iy * IW;
+    elds[e] = (iy * 2) * IW + ix;  // float4 index of (row iy, hi 0, x ix) inside one q-slab
     const int gy = iy0 + iy, gx = ix0 + ix;
     bool ok = idx < PLANE && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     int off = gy * a.W + gx;
@@ -137,13 +150,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
 #pragma unroll
     for (int c = 0; c < CC; ++c) {
       const int ci = cbase + c;
+      const int cic = ci < Ctot ? ci : 0;  // clamp so that the (unconditional) loads stay in bounds
       const float* src;
-      if (a.in_ps) src = x0n + (size_t)(ci >> 2) * (4 * HW) + ((ci >> 1) & 1) * (2 * a.W) + (ci & 1);
-      else if (ci < a.c0) src = x0n + (size_t)ci * cstride0;
-      else src = x1n + (size_t)(ci - a.c0) * HW;
-      const bool cok = ci < Ctot;
+      if (a.in_ps) src = x0n + (size_t)(cic >> 2) * (4 * HW) + ((cic >> 1) & 1) * (2 * a.W) + (cic & 1);
+      else if (cic < a.c0) src = x0n + (size_t)cic * cstride0;
+      else src = x1n + (size_t)(cic - a.c0) * HW;
 #pragma unroll
-      for (int e = 0; e < E; ++e) rin[c][e] = (cok && evalid[e]) ? src[eoff[e]] : 0.f;
+      for (int e = 0; e < E; ++e) rin[c][e] = src[eoff[e]];  // raw; masked when written to LDS
     }
     // weights of chunk k: LDS-DMA, 16 B per lane, destination = wave-uniform base + lane*16
     const float* wsrc = wp_cb + (size_t)k * Sh::PCH;
@@ -161,30 +174,55 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
     const int buf = k & 1;
     float* s_in = s_in0 + buf * Sh::BUF_FLOATS;
     const float* s_w = s_w0 + buf * Sh::BUF_FLOATS;
+    // halo tile -> LDS, transposed to [q][row][hi][x] x float4(kk): one ds_write_b128 per (q, hi)
 #pragma unroll
-    for (int c = 0; c < CC; ++c)
+    for (int e = 0; e < E; ++e) {
+      if (tid + 256 * e < PLANE) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const int idx = tid + 256 * e;
-        if (idx < PLANE) s_in[c * PLANE + idx] = rin[c][e];
+        for (int q = 0; q < KQ4; ++q)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            // the select is applied HERE, not at load time: consuming a loaded value right after
+            // issuing it would put an s_waitcnt behind every prefetch load
+            const int cb0 = k * CC + 8 * q + h2;
+            const bool ev = evalid[e];
+            f32x4 v = {(ev && cb0 < Ctot) ? rin[8 * q + h2][e] : 0.f,
+                       (ev && cb0 + 2 < Ctot) ? rin[8 * q + 2 + h2][e] : 0.f,
+                       (ev && cb0 + 4 < Ctot) ? rin[8 * q + 4 + h2][e] : 0.f,
+                       (ev && cb0 + 6 < Ctot) ? rin[8 * q + 6 + h2][e] : 0.f};
+            *reinterpret_cast<f32x4*>(s_in + ((size_t)(q * IH * 2 * IW) + elds[e] + h2 * IW) * 4) = v;
+          }
       }
+    }
     __syncthreads();  // also drains this chunk's weight DMA (vmcnt(0) before the barrier)
     if (k + 1 < a.nchunks) prefetch(k + 1, buf ^ 1);
-#pragma unroll
-    for (int tap = 0; tap < KK; ++tap) {
+
+    // ---- MFMA over (tap, q): operands of step i+1 are read before the 16 MFMAs of step i
+    constexpr int NSTEP = KK * KQ4;
+    f32x4 A[2][2], Bv[2][2];
+    auto load_ops = [&](int step, int rb) {
+      const int tap = step / KQ4, q = step - tap * KQ4;
       const int ty = tap / KS, tx = tap - ty * KS;
-      const float* pin = s_in + ((2 * wave) * S + ty) * IW + lo * S + tx;
 #pragma unroll
-      for (int kk = 0; kk < CC / 2; ++kk) {
-        const int c = 2 * kk + hi;
-        const float a0 = s_w[(c * KK + tap) * WROW + lo];
-        const float a1 = s_w[(c * KK + tap) * WROW + 32 + lo];
-        const float b0 = pin[c * PLANE];
-        const float b1 = pin[c * PLANE + S * IW];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      for (int mt = 0; mt < 2; ++mt)
+        A[rb][mt] = *reinterpret_cast<const f32x4*>(
+            s_w + ((size_t)((((tap * 2 + mt) * KQ4 + q) * 2 + hi) * 32 + lo)) * 4);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        Bv[rb][nt] = *reinterpret_cast<const f32x4*>(
+            s_in + ((size_t)(((q * IH + (2 * wave + nt) * S + ty) * 2 + hi) * IW + lo * S + tx)) * 4);
+    };
+    load_ops(0, 0);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      const int rb = step & 1;
+      if (step + 1 < NSTEP) load_ops(step + 1, rb ^ 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][0][j], Bv[rb][0][j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][0][j], Bv[rb][1][j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][1][j], Bv[rb][0][j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][1][j], Bv[rb][1][j], acc[1][1], 0, 0, 0);
       }
     }
   }
@@ -255,7 +293,7 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
   if (k.in_ps) k.x0_bs = (long long)d.c0 * d.H * d.W;
   if (k.in_dil) k.x0_bs = (long long)d.c0 * ex.Hs * ex.Ws;
   if (d.ks == 3 && d.stride == 1) return launch_conv2<3, 1, 8>(k, st);
-  if (d.ks == 3) return launch_conv2<3, 2, 4>(k, st);
+  if (d.ks == 3) return launch_conv2<3, 2, 8>(k, st);
   return launch_conv2<1, 1, 32>(k, st);
 }
 
