@@ -1,20 +1,25 @@
-// Pipelined variant of the MFMA convolution used by the EDVR engine (forward and data-gradient).
+// Pipelined MFMA convolution used by the EDVR engine (forward and data-gradient).
 //
-// Same math and tiling as conv2d.hip (8x32-pixel x 64-cout tile per 4-wave workgroup,
-// v_mfma_f32_32x32x2_f32, D rows = cout / columns = pixels) with the K loop software-pipelined:
-//   * weights are PRE-PACKED once per forward into the exact LDS image of every (cout block,
-//     channel chunk) -- [c*KK + tap][65] floats, zero padded -- by pack_weights_kernel, so staging
-//     them is a straight 16-byte-per-lane LDS-DMA (global_load_lds_dwordx4): no index math, no
-//     VGPRs, no ds_write;
+// Same math as conv2d.hip (implicit GEMM on v_mfma_f32_32x32x2_f32, D rows = cout / columns =
+// pixels, exact fp32) with the K loop software-pipelined and the launch geometry chosen per layer:
+//   * weights are PRE-PACKED once per forward by pack_weights_kernel into the exact LDS image of
+//     every (64-cout block, channel chunk): [mt][tap][q][hi][lo] x float4(kk = 4q..4q+3), channel
+//     c = 2kk + hi of the chunk.  Staging them is a straight 16-byte-per-lane LDS-DMA
+//     (global_load_lds_dwordx4): no index math, no VGPRs, no ds_write;
 //   * the input halo tile of chunk k+1 is fetched into registers and the weight DMA of chunk k+1
-//     is issued BEFORE the MFMAs of chunk k; both LDS images are double buffered, so there is one
-//     barrier per chunk and HBM/L2 latency hides under the 144 MFMAs per wave of a chunk;
-//   * per-thread halo offsets / validity are computed once, not per chunk;
-//   * both LDS images are laid out so that an MFMA operand set is ONE ds_read_b128 per lane:
-//     weights  [tap][mt][q][hi][lo] x float4(kk = 4q..4q+3)   (channel c = 2kk + hi of the chunk),
-//     inputs   [q][row][hi][x]      x float4(kk = 4q..4q+3),
-//     lanes of a half-wave read consecutive 16-byte slots -> conflict-free; the operands of the next
-//     (tap, q) step are fetched before the 16 MFMAs of the current one (register double buffer).
+//     is issued BEFORE the MFMAs of chunk k; both LDS images are double buffered -> one barrier
+//     per chunk, HBM/L2 latency hides under the MFMAs.  Loaded halo values are only consumed
+//     (masked, transposed) when they are written to LDS one iteration later, so no s_waitcnt sits
+//     behind the prefetch loads;
+//   * the halo tile is stored as [q][row][hi][x] x float4(kk): every MFMA operand set (4 k-steps)
+//     is ONE conflict-free ds_read_b128 per lane for A and for B;
+//   * tile geometry is a template: TH x 32 pixels (TH = 8: two pixel rows per wave, TH = 4: one)
+//     by 32*MT output channels (MT = 2 or 1).  The host picks (TH, MT) per launch to minimise
+//     max(MFMA-pipe time of the busiest CU, latency of the serial chunk loop): 8x32x64 for the big
+//     layers, 4x32x64 / 4x32x32 when the grid would not fill 256 CUs x 2-3 workgroups.
+#include <cmath>
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -28,34 +33,32 @@ struct ConvK2 {
   int in_ps, in_dil, Hs, Ws, accum;
 };
 
-template <int KS, int S, int CC>
+template <int KS, int S, int CC, int TH, int MT>
 struct Conv2Shape {
-  static constexpr int TH = 8, TW = 32, KK = KS * KS;
+  static constexpr int TW = 32, KK = KS * KS, NT = TH / 4;  // NT pixel rows per wave
   static constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
   static constexpr int PLANE = IH * IW, E = (PLANE + 255) / 256;
-  static constexpr int KQ4 = CC / 8;                    // float4 groups of channel pairs per chunk
-  static constexpr int IN_FLOATS = CC * PLANE;          // = KQ4 * IH * 2 * IW float4
-  static constexpr int W_FLOATS = KK * 2 * KQ4 * 2 * 32 * 4;
-  static constexpr int PCH = ((W_FLOATS + 1023) / 1024) * 1024;  // packed chunk, DMA granularity
-  static constexpr int NDMA = PCH / 1024;
-  static constexpr int BUF_FLOATS = IN_FLOATS + PCH;
+  static constexpr int KQ4 = CC / 8;                  // float4 groups of channel pairs per chunk
+  static constexpr int IN_FLOATS = CC * PLANE;        // = KQ4 * IH * 2 * IW float4
+  static constexpr int HALF = KK * KQ4 * 2 * 32 * 4;  // packed floats of one 32-cout half
+  static constexpr int W_FLOATS = MT * HALF;
+  static constexpr int NPIECE = W_FLOATS / 256;       // 1-KiB DMA pieces (one wave-instruction each)
+  static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
   static constexpr size_t LDS_BYTES = (size_t)2 * BUF_FLOATS * sizeof(float);
 };
 
-int conv2_pch(int ks, int stride) {
-  if (ks == 1) return Conv2Shape<1, 1, 32>::PCH;
-  return stride == 2 ? Conv2Shape<3, 2, 8>::PCH : Conv2Shape<3, 1, 8>::PCH;
-}
 int conv2_cc(int ks, int stride) { (void)stride; return ks == 1 ? 32 : 8; }
+int conv2_pch(int ks, int stride) {  // packed floats per (64-cout block, chunk): two halves
+  return 2 * ks * ks * (conv2_cc(ks, stride) / 8) * 2 * 32 * 4;
+}
 
 // ---- weight packing ---------------------------------------------------------------------------
-// P[cb][k][((((tap*2 + mt)*KQ4 + q)*2 + hi)*32 + lo)*4 + j] = W(cout = cb*64 + mt*32 + lo,
-//   cin = k*CC + 2*(4q + j) + hi, tap), zero outside / in the DMA padding.
+// P[cb][k][((((mt*KK + tap)*KQ4 + q)*2 + hi)*32 + lo)*4 + j] = W(cout = cb*64 + mt*32 + lo,
+//   cin = k*CC + 2*(4q + j) + hi, tap), zero outside.
 // wt = 1 (data gradient): this conv's (cin, cout, tap) = original (cout, cin slice, mirrored tap).
 __global__ void pack_weights_kernel(PackTable t) {
   const PackEntry& e = t.e[blockIdx.y];
   const int kq4 = e.CC / 8;
-  const int valid = e.KK * 2 * kq4 * 2 * 32 * 4;
   const size_t per_chunk = (size_t)e.pch;
   const size_t total = (size_t)e.ncb * e.nchunks * per_chunk;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
@@ -63,19 +66,17 @@ __global__ void pack_weights_kernel(PackTable t) {
     int r = (int)(i % per_chunk);
     const size_t ck = i / per_chunk;
     const int k = (int)(ck % e.nchunks), cb = (int)(ck / e.nchunks);
+    const int j = r & 3; r >>= 2;
+    const int lo = r & 31; r >>= 5;
+    const int hi = r & 1; r >>= 1;
+    const int q = r % kq4; r /= kq4;
+    const int tap = r % e.KK;
+    const int mt = r / e.KK;
+    const int co = cb * 64 + mt * 32 + lo, ci = k * e.CC + 2 * (4 * q + j) + hi;
     float v = 0.f;
-    if (r < valid) {
-      const int j = r & 3; r >>= 2;
-      const int lo = r & 31; r >>= 5;
-      const int hi = r & 1; r >>= 1;
-      const int q = r % kq4; r /= kq4;
-      const int mt = r & 1;
-      const int tap = r >> 1;
-      const int co = cb * 64 + mt * 32 + lo, ci = k * e.CC + 2 * (4 * q + j) + hi;
-      if (co < e.Cout && ci < e.Ctot) {
-        if (!e.wt) v = e.w[((size_t)co * e.Ctot + ci) * e.KK + tap];
-        else v = e.w[((size_t)ci * e.w_ctot + e.w_coff + co) * e.KK + (e.KK - 1 - tap)];
-      }
+    if (co < e.Cout && ci < e.Ctot) {
+      if (!e.wt) v = e.w[((size_t)co * e.Ctot + ci) * e.KK + tap];
+      else v = e.w[((size_t)ci * e.w_ctot + e.w_coff + co) * e.KK + (e.KK - 1 - tap)];
     }
     e.P[i] = v;
   }
@@ -87,23 +88,25 @@ int pack_weights_run(const PackTable& t, hipStream_t st) {
   return check_launch("pack_weights_kernel");
 }
 
-template <int KS, int S, int CC>
+template <int KS, int S, int CC, int TH, int MT>
 __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
-  using Sh = Conv2Shape<KS, S, CC>;
-  constexpr int KK = Sh::KK, IH = Sh::IH, IW = Sh::IW, PLANE = Sh::PLANE, E = Sh::E, KQ4 = Sh::KQ4;
+  using Sh = Conv2Shape<KS, S, CC, TH, MT>;
+  constexpr int KK = Sh::KK, IH = Sh::IH, IW = Sh::IW, PLANE = Sh::PLANE, E = Sh::E, KQ4 = Sh::KQ4,
+                NT = Sh::NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const s_in0 = smem;
   float* const s_w0 = smem + Sh::IN_FLOATS;
 
+  // XCD-aware order: the ncb cout blocks of one pixel tile get ids that differ by 8 (same XCD/L2)
   const int id = blockIdx.x;
   const int tile = (id / (8 * a.ncb)) * 8 + (id & 7);
-  const int cb = (id >> 3) % a.ncb;
+  const int cbi = (id >> 3) % a.ncb;  // block of 32*MT output channels
   if (tile >= a.ntiles) return;
   const int tx_ = tile % a.tiles_x;
   const int t2 = tile / a.tiles_x;
   const int ty_ = t2 % a.tiles_y;
   const int n = t2 / a.tiles_y;
-  const int oy0 = ty_ * Sh::TH, ox0 = tx_ * Sh::TW;
+  const int oy0 = ty_ * TH, ox0 = tx_ * Sh::TW;
   const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
   const size_t HW = (size_t)a.H * a.W;
   const float* x0n = a.x0 + (size_t)n * a.x0_bs;
   const float* x1n = a.c1 ? a.x1 + (size_t)(n / a.x1_bdiv) * a.x1_bs : nullptr;
-  const size_t cstride0 = a.in_dil ? (size_t)a.Hs * a.Ws : HW;  // x0 channel stride (in_ps: handled below)
+  const size_t cstride0 = a.in_dil ? (size_t)a.Hs * a.Ws : HW;  // x0 channel stride (in_ps: below)
 
   // per-thread halo elements: offset inside a channel plane + validity, fixed for all chunks
   int eoff[E], elds[E];
@@ -134,16 +137,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
     evalid[e] = ok;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float rin[CC][E];
-  const float* wp_cb = a.wp + (size_t)cb * a.nchunks * Sh::PCH;
+  // packed weights of this workgroup's cout block: 64-cout block (cbi*MT)/2, starting half (cbi*MT)%2
+  const float* wp_cb = a.wp + ((size_t)((cbi * MT) >> 1) * a.nchunks * 2 + ((cbi * MT) & 1)) * Sh::HALF;
 
   auto prefetch = [&](int k, int buf) {
     const int cbase = k * CC;
@@ -159,13 +163,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
       for (int e = 0; e < E; ++e) rin[c][e] = src[eoff[e]];  // raw; masked when written to LDS
     }
     // weights of chunk k: LDS-DMA, 16 B per lane, destination = wave-uniform base + lane*16
-    const float* wsrc = wp_cb + (size_t)k * Sh::PCH;
+    const float* wsrc = wp_cb + (size_t)k * (2 * Sh::HALF);
     float* wdst = s_w0 + buf * Sh::BUF_FLOATS;
 #pragma unroll
-    for (int j = 0; j < Sh::NDMA; ++j) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(wsrc + (j * 256 + tid) * 4),
-          (__attribute__((address_space(3))) void*)(wdst + (j * 256 + wave * 64) * 4), 16, 0, 0);
+    for (int j = 0; j < (Sh::NPIECE + 3) / 4; ++j) {
+      const int piece = j * 4 + wave;
+      if (piece < Sh::NPIECE)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(wsrc + piece * 256 + lane * 4),
+            (__attribute__((address_space(3))) void*)(wdst + piece * 256), 16, 0, 0);
     }
   };
 
@@ -182,8 +188,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
         for (int q = 0; q < KQ4; ++q)
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
-            // the select is applied HERE, not at load time: consuming a loaded value right after
-            // issuing it would put an s_waitcnt behind every prefetch load
             const int cb0 = k * CC + 8 * q + h2;
             const bool ev = evalid[e];
             f32x4 v = {(ev && cb0 < Ctot) ? rin[8 * q + h2][e] : 0.f,
@@ -197,20 +201,20 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
     __syncthreads();  // also drains this chunk's weight DMA (vmcnt(0) before the barrier)
     if (k + 1 < a.nchunks) prefetch(k + 1, buf ^ 1);
 
-    // ---- MFMA over (tap, q): operands of step i+1 are read before the 16 MFMAs of step i
+    // ---- MFMA over (tap, q): operands of step i+1 are read before the MFMAs of step i
     constexpr int NSTEP = KK * KQ4;
-    f32x4 A[2][2], Bv[2][2];
+    f32x4 A[2][MT], Bv[2][NT];
     auto load_ops = [&](int step, int rb) {
       const int tap = step / KQ4, q = step - tap * KQ4;
       const int ty = tap / KS, tx = tap - ty * KS;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
         A[rb][mt] = *reinterpret_cast<const f32x4*>(
-            s_w + ((size_t)((((tap * 2 + mt) * KQ4 + q) * 2 + hi) * 32 + lo)) * 4);
+            s_w + ((size_t)((((mt * KK + tap) * KQ4 + q) * 2 + hi) * 32 + lo)) * 4);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
         Bv[rb][nt] = *reinterpret_cast<const f32x4*>(
-            s_in + ((size_t)(((q * IH + (2 * wave + nt) * S + ty) * 2 + hi) * IW + lo * S + tx)) * 4);
+            s_in + ((size_t)(((q * IH + (NT * wave + nt) * S + ty) * 2 + hi) * IW + lo * S + tx)) * 4);
     };
     load_ops(0, 0);
 #pragma unroll
@@ -218,27 +222,28 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
       const int rb = step & 1;
       if (step + 1 < NSTEP) load_ops(step + 1, rb ^ 1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][0][j], Bv[rb][0][j], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][0][j], Bv[rb][1][j], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][1][j], Bv[rb][0][j], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][1][j], Bv[rb][1][j], acc[1][1], 0, 0, 0);
-      }
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][mt][j], Bv[rb][nt][j], acc[mt][nt], 0, 0, 0);
     }
   }
 
+  // ---- epilogue: bias, activation, residual / accumulate, (pixel-shuffled) store
   const int ox = ox0 + lo;
   if (ox >= a.Wo) return;
   const size_t HWo = (size_t)a.Ho * a.Wo;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int oy = oy0 + 2 * wave + nt;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int oy = oy0 + NT * wave + nt;
       if (oy >= a.Ho) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = cb * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int co = (cbi * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (co >= a.Cout) continue;
         float v = acc[mt][nt][r];
         if (a.bias) v += a.bias[co];
@@ -258,26 +263,62 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
   }
 }
 
-template <int KS, int S, int CC>
-static int launch_conv2(const ConvK2& k, hipStream_t st) {
-  using Sh = Conv2Shape<KS, S, CC>;
-  auto kern = conv2d_pipe_kernel<KS, S, CC>;
+template <int KS, int S, int CC, int TH, int MT>
+static int launch_conv2(ConvK2 k, hipStream_t st) {
+  using Sh = Conv2Shape<KS, S, CC, TH, MT>;
+  auto kern = conv2d_pipe_kernel<KS, S, CC, TH, MT>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
     attr_done = true;
   }
+  k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
+  k.ncb = ceil_div(k.Cout, 32 * MT);
   const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
   const size_t lds = Sh::LDS_BYTES;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, k);
   return check_launch("conv2d_pipe_kernel");
 }
 
-// `wp` = weights packed by pack_weights_kernel for this exact (ks, stride, wt) combination.
+// Cost model for choosing the tile geometry (cycles per chunk, arbitrary common scale):
+//   pipe    = workgroups on the busiest CU x MFMA cycles of one wave per chunk (one wave per SIMD per WG)
+//   latency = rounds of resident workgroups x (MFMA cycles + fixed per-chunk overhead)
+template <int KS, int S, int CC, int TH, int MT>
+static double conv2_cost(const ConvK2& k) {
+  using Sh = Conv2Shape<KS, S, CC, TH, MT>;
+  const double wgs = (double)ceil_div(k.Wo, 32) * ceil_div(k.Ho, TH) * k.N * ceil_div(k.Cout, 32 * MT);
+  int occ = (int)((160 * 1024) / Sh::LDS_BYTES);
+  if (occ > 3) occ = 3;  // ~140 VGPRs -> 3 waves per SIMD
+  if (occ < 1) occ = 1;
+  const double mfma = 64.0 * Sh::KK * (CC / 2) * Sh::NT * MT;
+  const double ovh = 2500.0;
+  const double pipe = ceil(wgs / 256.0) * mfma;
+  const double lat = ceil(wgs / (256.0 * occ)) * (mfma + ovh);
+  return pipe > lat ? pipe : lat;
+}
+
+template <int KS, int S, int CC>
+static int dispatch_conv2(const ConvK2& k, int force, hipStream_t st) {
+  const double c82 = conv2_cost<KS, S, CC, 8, 2>(k);
+  const double c42 = conv2_cost<KS, S, CC, 4, 2>(k);
+  const double c41 = conv2_cost<KS, S, CC, 4, 1>(k);
+  int pick = (c82 <= c42 * 1.02 && c82 <= c41 * 1.02) ? 0 : (c42 <= c41 * 1.02 ? 1 : 2);
+  if (force >= 0) pick = force;
+  if (pick == 0) return launch_conv2<KS, S, CC, 8, 2>(k, st);
+  if (pick == 1) return launch_conv2<KS, S, CC, 4, 2>(k, st);
+  return launch_conv2<KS, S, CC, 4, 1>(k, st);
+}
+
+// `wp` = weights packed by pack_weights_kernel for this (ks, wt) combination.
 int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, hipStream_t st) {
   DVSR_REQUIRE(d.x0 && wp && d.y, DVSR_ERR_INVALID, "conv2d_packed: null x0/wp/y");
   DVSR_REQUIRE((d.ks == 1 && d.stride == 1) || (d.ks == 3 && (d.stride == 1 || d.stride == 2)),
                DVSR_ERR_UNSUPPORTED, "conv2d_packed: ks=%d stride=%d", d.ks, d.stride);
+  static int force = -2;  // DVSR_CONV_TILE=0|1|2 pins the geometry (A/B aid); default: cost model
+  if (force == -2) {
+    const char* v = getenv("DVSR_CONV_TILE");
+    force = (v && v[0] >= '0' && v[0] <= '2') ? v[0] - '0' : -1;
+  }
   ConvK2 k;
   k.x0 = d.x0; k.x1 = d.x1; k.wp = wp; k.bias = d.bias; k.res = d.res; k.y = d.y;
   k.N = d.N; k.c0 = d.c0; k.c1 = d.c1; k.H = d.H; k.W = d.W; k.Cout = d.Cout;
@@ -286,15 +327,13 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
   k.x1_bs = d.x1_bstride > 0 ? d.x1_bstride : (long long)d.c1 * d.H * d.W;
   k.Ho = (d.H + 2 * d.pad - d.ks) / d.stride + 1;
   k.Wo = (d.W + 2 * d.pad - d.ks) / d.stride + 1;
-  k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, 8); k.ntiles = k.tiles_x * k.tiles_y * d.N;
-  k.ncb = ceil_div(d.Cout, 64);
   k.nchunks = ceil_div(d.c0 + d.c1, conv2_cc(d.ks, d.stride));
   k.in_ps = ex.in_ps; k.in_dil = ex.in_dil; k.Hs = ex.Hs; k.Ws = ex.Ws; k.accum = ex.accum;
   if (k.in_ps) k.x0_bs = (long long)d.c0 * d.H * d.W;
   if (k.in_dil) k.x0_bs = (long long)d.c0 * ex.Hs * ex.Ws;
-  if (d.ks == 3 && d.stride == 1) return launch_conv2<3, 1, 8>(k, st);
-  if (d.ks == 3) return launch_conv2<3, 2, 8>(k, st);
-  return launch_conv2<1, 1, 32>(k, st);
+  if (d.ks == 3 && d.stride == 1) return dispatch_conv2<3, 1, 8>(k, force, st);
+  if (d.ks == 3) return launch_conv2<3, 2, 8, 8, 2>(k, st);
+  return dispatch_conv2<1, 1, 32>(k, force, st);
 }
 
 }  // namespace dvsr
