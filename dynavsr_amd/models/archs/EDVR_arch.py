@@ -14,8 +14,8 @@ import math
 import torch
 import torch.nn as nn
 
-from ...engine import EdvrFunction
-from ...spec import edvr_param_spec
+from dynavsr_amd.engine import EdvrFunction
+from dynavsr_amd.spec import edvr_param_spec
 
 
 class ParamHolder(nn.Module):

@@ -21,7 +21,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
 
-from .... import hipops
+from dynavsr_amd import hipops
 
 logger = logging.getLogger('base')
 

@@ -3,7 +3,7 @@ is the ``pixel_criterion: cb`` of every EDVR YAML and runs on the HIP reduction 
 GPU-only (no CPU fallback)."""
 import torch.nn as nn
 
-from .. import hipops
+from dynavsr_amd import hipops
 
 
 class CharbonnierLoss(nn.Module):
