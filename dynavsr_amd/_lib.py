@@ -37,6 +37,8 @@ def _declare(lib):
         "dvsr_last_error": (c_char_p, []),
         "dvsr_version": (I, []),
         "dvsr_mdcn_forward": (I, [P] * 6 + [I] * 13 + [P]),
+        "dvsr_mdcn_forward_fast_workspace_bytes": (c_size_t, [I, I, I]),
+        "dvsr_mdcn_forward_fast": (I, [P] * 6 + [I] * 7 + [P, c_size_t, P]),
         "dvsr_mdcn_pack_forward": (I, [P] * 5 + [I] * 13 + [P]),
         "dvsr_conv2d_forward": (I, [POINTER(Conv2dDesc), P]),
         "dvsr_upsample_bilinear_forward": (I, [P, P, LL, I, I, I, F, P]),

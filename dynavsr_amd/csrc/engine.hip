@@ -147,6 +147,10 @@ struct Builder {
     o.type = OP_DCN; o.name = name; o.pw = pw; o.pb = pb; o.x0 = x; o.x1 = om;
     o.N = N; o.c0 = C; o.H = H; o.W = W; o.Cout = C; o.dg = dg; o.act = act;
     o.y = alloc(name, (size_t)N * C * H * W);
+    if (C == dg * 8) {  // LDS-sampler kernel: weights packed like a conv with 8-channel chunks
+      o.wp_floats = (size_t)ceil_div(C, 64) * dg * conv2_pch(3, 1);
+      o.wp_off = alloc("", o.wp_floats).off;
+    }
     p.ops.push_back(o);
     return o.y;
   }
@@ -571,6 +575,12 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* fwd_b
   t.n = 0;
   auto flush = [&]() { int rc = pack_weights_run(t, st); t.n = 0; return rc; };
   for (const Op& o : p.ops) {
+    if (o.type == OP_DCN && fwd_base && o.wp_floats) {
+      PackEntry& e = t.e[t.n++];
+      e.w = P[o.pw]; e.P = fwd_base + o.wp_off; e.Cout = o.Cout; e.Ctot = o.c0; e.KK = 9; e.CC = 8; e.wt = 0;
+      e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64); e.nchunks = o.dg; e.pch = conv2_pch(3, 1);
+      if (t.n == 48) { int rc = flush(); if (rc) return rc; }
+    }
     if (o.type != OP_CONV) continue;
     const int ctot = o.c0 + o.c1, KK = o.ks * o.ks;
     if (fwd_base) {
@@ -610,6 +620,10 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
     case OP_DCN: {
       const float* om = bs.at(o.x1);
       const long long bstride = (long long)o.dg * 27 * o.H * o.W;
+      if (!bs.use_v1 && o.wp_floats)
+        return mdcn_forward_packed_run(bs.at(o.x0), om, bstride, om + (size_t)o.dg * 18 * o.H * o.W, bstride, 1,
+                                       bs.arena + o.wp_off, P[o.pb], bs.at(o.y), o.N, o.c0, o.H, o.W, o.Cout,
+                                       o.dg, o.act, st);
       return mdcn_forward_run(bs.at(o.x0), om, bstride, om + (size_t)o.dg * 18 * o.H * o.W, bstride, 1,
                               P[o.pw], P[o.pb], bs.at(o.y), o.N, o.c0, o.H, o.W, o.Cout, 3, 3, 1, 1,
                               1, 1, o.dg, o.act, st);

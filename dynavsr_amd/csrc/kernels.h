@@ -45,6 +45,10 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
                       int H, int W, int Cout, int stride, int pad, int dil, int dg, void* ws,
                       size_t ws_bytes, hipStream_t st);
 
+int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, const float* msk,
+                            long long msk_bs, int mask_logit, const float* wp, const float* b, float* out,
+                            int N, int C, int H, int W, int Cout, int dg, int act, hipStream_t st);
+
 // misc.hip
 int upsample_bilinear_fwd(const float* x, float* y, size_t planes, int H, int W, int S, float mul,
                           hipStream_t st);

@@ -196,3 +196,257 @@ extern "C" int dvsr_mdcn_pack_forward(const float* x, const float* om, const flo
                                 H, W, Cout, kh, kw, stride, pad, dil, groups, dg, act,
                                 (hipStream_t)stream);
 }
+
+// =================================================================================================
+// LDS-resident sampler variant (engine path, 3x3 / stride 1 / pad 1 / dil 1 / CPG = 8).
+//
+// The r01 profile showed mdcn_fwd_kernel bound by the ISSUE rate of its global gathers (2304
+// wave-level gather instructions per wave per tile; 29 TFLOP/s).  Here, per deformable group, the
+// group's 8 input planes over the tile + (1 + HALO)-pixel ring are staged ONCE into LDS in a
+// pixel-major [y][x][8ch] layout (zero padded outside the image, which also reproduces the
+// reference's (-1,H)x(-1,W) gate: a sample outside it has all four corners outside).  A bilinear
+// corner is then TWO ds_read_b128 (8 channels) instead of 8 global gathers, i.e. 8 LDS reads per
+// (pixel, tap) instead of 32 VMEM gathers.  Lanes whose sample leaves the staged window
+// (|offset| > HALO) fall back to clamped global gathers, so the result is exact for any offset.
+// Weights come from the conv weight pack (a conv chunk of 8 channels == one deformable group) by
+// LDS-DMA; the column tile and both MFMA operands use the float4-of-k layouts of conv2d_v2.hip.
+// The next group's planes are register-prefetched under the MFMA phases.
+// =================================================================================================
+namespace dvsr {
+
+struct DcnK2 {
+  const float* x; const float* off; const float* msk; const float* wp; const float* bias; float* out;
+  long long off_bstride, msk_bstride;
+  int mask_logit;
+  int N, C, H, W, Cout, dg, act;
+  int tiles_x, tiles_y, ntiles, ncb, nchunks;
+};
+
+template <int HALO>
+__global__ __launch_bounds__(256, 2) void mdcn_fwd_lds_kernel(DcnK2 a) {
+  constexpr int CPG = 8, KK = 9, TP = 3, NPX = 256, TH = 8, TW = 32;
+  constexpr int XH = TH + 2 + 2 * HALO, XW = TW + 2 + 2 * HALO, XPX = XH * XW;
+  constexpr int XE = (XPX + 255) / 256;
+  constexpr int HALF = KK * 2 * 32 * 4, WF = 2 * HALF, NPIECE = WF / 256;
+  __shared__ __attribute__((aligned(16))) float s_x[XPX * 8];
+  __shared__ __attribute__((aligned(16))) float s_col[TP * 2 * NPX * 4];
+  __shared__ __attribute__((aligned(16))) float s_w[WF];
+
+  const int id = blockIdx.x;
+  const int tile = (id / (8 * a.ncb)) * 8 + (id & 7);
+  const int cb = (id >> 3) % a.ncb;
+  if (tile >= a.ntiles) return;
+  const int tx_ = tile % a.tiles_x;
+  const int t2 = tile / a.tiles_x;
+  const int ty_ = t2 % a.tiles_y;
+  const int n = t2 / a.tiles_y;
+  const int oy0 = ty_ * TH, ox0 = tx_ * TW;
+  const int wy0 = oy0 - 1 - HALO, wx0 = ox0 - 1 - HALO;  // image coords of the LDS window origin
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const size_t HW = (size_t)a.H * a.W;
+  const int py = oy0 + (tid >> 5), px = ox0 + (tid & 31);
+  const bool pvalid = py < a.H && px < a.W;
+  const size_t pofs = (size_t)py * a.W + px;
+  const float* offn = a.off + (size_t)n * a.off_bstride;
+  const float* mskn = a.msk + (size_t)n * a.msk_bstride;
+
+  // window elements owned by this thread (fixed for all groups)
+  int xoff[XE];
+  bool xok[XE];
+#pragma unroll
+  for (int e = 0; e < XE; ++e) {
+    const int idx = tid + 256 * e;
+    const int ry = idx / XW, rx = idx - ry * XW;
+    const int gy = wy0 + ry, gx = wx0 + rx;
+    xok[e] = idx < XPX && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    xoff[e] = xok[e] ? gy * a.W + gx : 0;
+  }
+  float rx_[CPG][XE];
+  auto prefetch_x = [&](int g) {
+    const float* xg = a.x + ((size_t)n * a.C + g * CPG) * HW;
+#pragma unroll
+    for (int c = 0; c < CPG; ++c)
+#pragma unroll
+      for (int e = 0; e < XE; ++e) rx_[c][e] = xg[(size_t)c * HW + xoff[e]];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* wp_cb = a.wp + (size_t)cb * a.nchunks * WF;
+  prefetch_x(0);
+  for (int g = 0; g < a.dg; ++g) {
+    __syncthreads();  // previous group's MFMAs are done with s_w / s_col, its sampling with s_x
+    // weights of this group: LDS-DMA from the conv pack (chunk g), lands before the first MFMA phase
+    {
+      const float* wsrc = wp_cb + (size_t)g * WF;
+#pragma unroll
+      for (int j = 0; j < (NPIECE + 3) / 4; ++j) {
+        const int piece = j * 4 + wave;
+        if (piece < NPIECE)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(wsrc + piece * 256 + lane * 4),
+              (__attribute__((address_space(3))) void*)(s_w + piece * 256), 16, 0, 0);
+      }
+    }
+    // window of this group -> LDS, pixel-major, zero outside the image
+#pragma unroll
+    for (int e = 0; e < XE; ++e) {
+      const int idx = tid + 256 * e;
+      if (idx < XPX) {
+        const bool ok = xok[e];
+        f32x4 v0 = {ok ? rx_[0][e] : 0.f, ok ? rx_[1][e] : 0.f, ok ? rx_[2][e] : 0.f, ok ? rx_[3][e] : 0.f};
+        f32x4 v1 = {ok ? rx_[4][e] : 0.f, ok ? rx_[5][e] : 0.f, ok ? rx_[6][e] : 0.f, ok ? rx_[7][e] : 0.f};
+        *reinterpret_cast<f32x4*>(s_x + (size_t)idx * 8) = v0;
+        *reinterpret_cast<f32x4*>(s_x + (size_t)idx * 8 + 4) = v1;
+      }
+    }
+    __syncthreads();
+    const float* xg = a.x + ((size_t)n * a.C + g * CPG) * HW;
+    for (int t0 = 0; t0 < KK; t0 += TP) {
+      if (t0) __syncthreads();  // MFMAs of the previous tap triple have consumed s_col
+#pragma unroll
+      for (int t = 0; t < TP; ++t) {
+        const int tap = t0 + t;
+        const int ki = tap / 3, kj = tap - ki * 3;
+        float vals[CPG];
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) vals[c] = 0.f;
+        if (pvalid) {
+          const float oh = offn[(size_t)(g * 2 * KK + 2 * tap) * HW + pofs];
+          const float ow = offn[(size_t)(g * 2 * KK + 2 * tap + 1) * HW + pofs];
+          float m = mskn[(size_t)(g * KK + tap) * HW + pofs];
+          if (a.mask_logit) m = sigmoidf_(m);
+          const float h_im = (float)(py - 1 + ki) + oh;
+          const float w_im = (float)(px - 1 + kj) + ow;
+          const float hf = floorf(h_im), wf = floorf(w_im);
+          const float lh = h_im - hf, lw = w_im - wf;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+          // window-relative corner coordinates; float compare first so that huge offsets cannot overflow
+          const float ryf = hf - (float)wy0, rxf = wf - (float)wx0;
+          if (ryf >= 0.f && ryf <= (float)(XH - 2) && rxf >= 0.f && rxf <= (float)(XW - 2)) {
+            const float* p1 = s_x + ((size_t)((int)ryf * XW + (int)rxf)) * 8;
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(p1), b1 = *reinterpret_cast<const f32x4*>(p1 + 4);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(p1 + 8), b2 = *reinterpret_cast<const f32x4*>(p1 + 12);
+            const f32x4 a3 = *reinterpret_cast<const f32x4*>(p1 + XW * 8),
+                        b3 = *reinterpret_cast<const f32x4*>(p1 + XW * 8 + 4);
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(p1 + XW * 8 + 8),
+                        b4 = *reinterpret_cast<const f32x4*>(p1 + XW * 8 + 12);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              vals[c] = (w1 * a1[c] + w2 * a2[c] + w3 * a3[c] + w4 * a4[c]) * m;
+              vals[4 + c] = (w1 * b1[c] + w2 * b2[c] + w3 * b3[c] + w4 * b4[c]) * m;
+            }
+          } else {
+            DcnTap tp;  // sample leaves the staged window: exact clamped global gathers
+            if (make_tap(h_im, w_im, a.H, a.W, tp)) {
+#pragma unroll
+              for (int c = 0; c < CPG; ++c) {
+                const float* pl = xg + (size_t)c * HW;
+                const float v1 = tp.v1 ? pl[tp.o1] : 0.f, v2 = tp.v2 ? pl[tp.o2] : 0.f;
+                const float v3 = tp.v3 ? pl[tp.o3] : 0.f, v4 = tp.v4 ? pl[tp.o4] : 0.f;
+                vals[c] = (tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4) * m;
+              }
+            }
+          }
+        }
+        // column tile [t][hi][pixel] x float4(kk): channel c = 2kk + hi
+        f32x4 c0 = {vals[0], vals[2], vals[4], vals[6]}, c1 = {vals[1], vals[3], vals[5], vals[7]};
+        *reinterpret_cast<f32x4*>(s_col + ((size_t)((t * 2 + 0) * NPX + tid)) * 4) = c0;
+        *reinterpret_cast<f32x4*>(s_col + ((size_t)((t * 2 + 1) * NPX + tid)) * 4) = c1;
+      }
+      __syncthreads();  // (first triple: also drains the weight DMA)
+      if (t0 == 0 && g + 1 < a.dg) prefetch_x(g + 1);  // in flight under the MFMA/sampling below
+#pragma unroll
+      for (int t = 0; t < TP; ++t) {
+        const int tap = t0 + t;
+        f32x4 A[2], B[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          A[mt] = *reinterpret_cast<const f32x4*>(s_w + ((size_t)(((mt * KK + tap) * 2 + hi) * 32 + lo)) * 4);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          B[nt] = *reinterpret_cast<const f32x4*>(
+              s_col + ((size_t)((t * 2 + hi) * NPX + (2 * wave + nt) * 32 + lo)) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][j], B[0][j], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][j], B[1][j], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][j], B[0][j], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][j], B[1][j], acc[1][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const int ox = ox0 + lo;
+  if (ox >= a.W) return;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int oy = oy0 + 2 * wave + nt;
+      if (oy >= a.H) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cb * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co >= a.Cout) continue;
+        float v = acc[mt][nt][r];
+        if (a.bias) v += a.bias[co];
+        a.out[((size_t)n * a.Cout + co) * HW + (size_t)oy * a.W + ox] = apply_act(v, a.act);
+      }
+    }
+}
+
+// wp = weights packed by pack_weights_kernel with KK=9, CC=8, wt=0 (one chunk per deformable group).
+int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, const float* msk,
+                            long long msk_bs, int mask_logit, const float* wp, const float* b, float* out,
+                            int N, int C, int H, int W, int Cout, int dg, int act, hipStream_t st) {
+  DVSR_REQUIRE(x && off && msk && wp && out, DVSR_ERR_INVALID, "mdcn_forward_packed: null pointer");
+  DVSR_REQUIRE(C == dg * 8, DVSR_ERR_UNSUPPORTED, "mdcn_forward_packed: needs C/dg == 8 (got %d/%d)", C, dg);
+  DcnK2 k;
+  k.x = x; k.off = off; k.msk = msk; k.wp = wp; k.bias = b; k.out = out;
+  k.off_bstride = off_bs; k.msk_bstride = msk_bs; k.mask_logit = mask_logit;
+  k.N = N; k.C = C; k.H = H; k.W = W; k.Cout = Cout; k.dg = dg; k.act = act;
+  k.tiles_x = ceil_div(W, 32); k.tiles_y = ceil_div(H, 8); k.ntiles = k.tiles_x * k.tiles_y * N;
+  k.ncb = ceil_div(Cout, 64); k.nchunks = dg;
+  const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
+  hipLaunchKernelGGL(mdcn_fwd_lds_kernel<4>, dim3(grid), dim3(256), 0, st, k);
+  return check_launch("mdcn_fwd_lds_kernel");
+}
+
+}  // namespace dvsr
+
+// Op-level entry to the LDS-sampler kernel: packs `w` into the caller's workspace first.
+// Same contract as dvsr_mdcn_forward restricted to stride = pad = dil = 1, C/dg = 8.
+extern "C" size_t dvsr_mdcn_forward_fast_workspace_bytes(int C, int Cout, int dg) {
+  return (size_t)dvsr::ceil_div(Cout, 64) * dg * dvsr::conv2_pch(3, 1) * sizeof(float) + (size_t)C * 0;
+}
+
+extern "C" int dvsr_mdcn_forward_fast(const float* x, const float* offset, const float* mask, const float* w,
+                                      const float* b, float* out, int N, int C, int H, int W, int Cout, int dg,
+                                      int act, void* workspace, size_t workspace_bytes, dvsr_stream_t stream) {
+  using namespace dvsr;
+  DVSR_REQUIRE(x && offset && mask && w && out && workspace, DVSR_ERR_INVALID, "mdcn_forward_fast: null pointer");
+  DVSR_REQUIRE(dg > 0 && C == dg * 8, DVSR_ERR_UNSUPPORTED, "mdcn_forward_fast: needs C/dg == 8");
+  DVSR_REQUIRE(workspace_bytes >= dvsr_mdcn_forward_fast_workspace_bytes(C, Cout, dg), DVSR_ERR_WORKSPACE,
+               "mdcn_forward_fast: workspace too small");
+  PackTable t;
+  t.n = 1;
+  PackEntry& e = t.e[0];
+  e.w = w; e.P = (float*)workspace; e.Cout = Cout; e.Ctot = C; e.KK = 9; e.CC = 8; e.wt = 0; e.w_ctot = 0;
+  e.w_coff = 0; e.ncb = ceil_div(Cout, 64); e.nchunks = dg; e.pch = conv2_pch(3, 1);
+  int rc = pack_weights_run(t, (hipStream_t)stream);
+  if (rc) return rc;
+  const long long P = (long long)H * W;
+  return mdcn_forward_packed_run(x, offset, (long long)dg * 18 * P, mask, (long long)dg * 9 * P, 0,
+                                 (const float*)workspace, b, out, N, C, H, W, Cout, dg, act, (hipStream_t)stream);
+}

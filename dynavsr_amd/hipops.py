@@ -22,6 +22,19 @@ def mdcn_forward(x, offset, mask, weight, bias, stride=1, padding=0, dilation=1,
     return out
 
 
+def mdcn_forward_fast(x, offset, mask, weight, bias, deformable_groups, act=L.ACT_NONE):
+    """LDS-sampler kernel (3x3, stride=pad=dil=1, C/dg=8)."""
+    n, c, h, w = x.shape
+    cout = weight.shape[0]
+    out = x.new_empty((n, cout, h, w))
+    nbytes = int(L.lib().dvsr_mdcn_forward_fast_workspace_bytes(c, cout, deformable_groups))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().dvsr_mdcn_forward_fast(L.ptr(x), L.ptr(offset), L.ptr(mask), L.ptr(weight), L.ptr(bias),
+                                           L.ptr(out), n, c, h, w, cout, deformable_groups, act,
+                                           ws.data_ptr(), nbytes, L.stream()), "dvsr_mdcn_forward_fast")
+    return out
+
+
 def mdcn_pack_forward(x, om, weight, bias, deformable_groups, act=L.ACT_NONE):
     n, c, h, w = x.shape
     cout = weight.shape[0]

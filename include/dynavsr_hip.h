@@ -55,6 +55,15 @@ int dvsr_mdcn_forward(const float* x, const float* offset, const float* mask, co
                       int kw, int stride, int pad, int dil, int groups, int dg, int act,
                       dvsr_stream_t stream);
 
+/* Fast path of dvsr_mdcn_forward for the EDVR configuration (3x3, stride = pad = dil = 1, groups = 1,
+ * C/dg = 8): the deformable group's input planes are staged in LDS and sampled from there (8 LDS
+ * reads per (pixel, tap) instead of 32 global gathers); samples that leave the staged window
+ * (|offset| > 4 px) fall back to exact global gathers.  The workspace receives the packed weights. */
+size_t dvsr_mdcn_forward_fast_workspace_bytes(int C, int Cout, int dg);
+int dvsr_mdcn_forward_fast(const float* x, const float* offset, const float* mask, const float* w,
+                           const float* b, float* out, int N, int C, int H, int W, int Cout, int dg, int act,
+                           void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
+
 /* Replaces modulated_deform_conv_cuda_backward (deform_conv_cuda.cpp:566-679).  grad_out = gradient
  * w.r.t. the op's output (act = NONE).  gx is ACCUMULATED into with fp32 atomics (zero it first, the
  * reference's caller does: deform_conv.py:128); goffset/gmask/gw/gb are overwritten; gx/gw/gb may

@@ -108,6 +108,25 @@ def test_mdcn_forward_vs_oracle(ops, n, c, dg, cout, h, w, stride, pad, dil, std
     assert relerr(got, F.leaky_relu(ref - b.view(1, -1, 1, 1), 0.1)) < TOL
 
 
+@pytest.mark.parametrize("n,cout,h,w,std", [(2, 64, 20, 36, 1.0), (1, 64, 45, 80, 3.0), (1, 80, 9, 33, 12.0),
+                                            (1, 64, 8, 32, 200.0)])
+def test_mdcn_forward_fast_vs_oracle(ops, n, cout, h, w, std):
+    """LDS-sampler kernel incl. its global fallback: std=12/200 px pushes most samples outside the
+    staged +-4 px window (and outside the image)."""
+    from oracle import dcn as odcn
+    c, dg = 64, 8
+    x = rnd(n, c, h, w, seed=1)
+    off = rnd(n, dg * 18, h, w, seed=2, scale=std)
+    off[:, :, 0, :] = torch.round(off[:, :, 0, :])          # exactly-integer sampling positions
+    m = torch.from_numpy(np.random.RandomState(3).random_sample((n, dg * 9, h, w)))
+    wt, b = rnd(cout, c, 3, 3, seed=4, scale=1 / np.sqrt(9 * c)), rnd(cout, seed=5, scale=0.1)
+    ref = odcn.forward(x, off, m, wt, b, 1, 1, 1, 1, dg)
+    got = ops.mdcn_forward_fast(dev(x), dev(off), dev(m), dev(wt), dev(b), dg)
+    assert relerr(got, ref) < TOL
+    assert relerr(ops.mdcn_forward_fast(dev(x), dev(off), dev(m), dev(wt), None, dg, act=1),
+                  F.leaky_relu(ref - b.view(1, -1, 1, 1), 0.1)) < TOL
+
+
 def test_mdcn_pack_forward(ops):
     """offset/mask taken from the raw 216-channel conv output, sigmoid inside the sampler."""
     from oracle import dcn as odcn
