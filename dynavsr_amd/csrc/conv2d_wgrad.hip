@@ -155,12 +155,14 @@ static void launch_wgrad(const WgradK& k, dim3 grid, hipStream_t st) {
 }
 
 static int wgrad_splits(int ntiles, int nob, int ncb, int KK) {
-  // enough workgroups to fill 256 CUs x 2, bounded so that the partial buffer stays <= 64 MiB
-  int s = ceil_div(512, nob * ncb);
+  // one workgroup per CU when the pixel grid is small (latency-bound: every extra tile per workgroup
+  // is serial time), two per CU for big grids; partial buffer bounded to 64 MiB
+  const int blocks = nob * ncb;
+  int s = ceil_div(ntiles >= 2048 ? 512 : 256, blocks);
+  if (s > ntiles) s = ntiles;
   const size_t per_split = (size_t)KK * nob * 64 * ncb * 64 * sizeof(float);
   const int cap = (int)((64ull << 20) / per_split);
   if (s > cap) s = cap;
-  if (s > ntiles) s = ntiles;
   return s < 1 ? 1 : s;
 }
 

@@ -5,12 +5,30 @@ First slice: these run on stock PyTorch-ROCm o
 Conv2d/Conv3d) on the GPU; native kernels for them are the declared next step.  The graph is
 expressed with functional calls over the reference's parameter names (conv0..conv6).
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 
 def _lrelu(x):
     return F.leaky_relu(x, 0.1)
+
+
+def conv3d_k3_replicate(x, weight, bias):
+    """nn.Conv3d(k=3, s=1) over ReplicationPad3d(1) input, computed as ONE batched 2-D convolution.
+
+    out[:, :, t] = sum_dt conv2d(pad2d(x[:, :, clamp(t+dt-1)]), W[:, :, dt]): the three temporal taps
+    are folded into the channel axis (3*Cin channels, weight [Cout, 3*Cin, 3, 3]).  Same arithmetic
+    as LRimg_estimator.py:100,113 (summation order aside); it avoids MIOpen's naive Conv3d
+    weight-gradient kernel, which took 43 ms per inner step on MI355X (profiles/r01_*inner*)."""
+    b, c, t, h, w = x.shape
+    xp = F.pad(x.transpose(1, 2).reshape(b * t, c, h, w), (1, 1, 1, 1), mode='replicate')
+    xp = xp.view(b, t, c, h + 2, w + 2)
+    idx = torch.arange(t, device=x.device)
+    frames = torch.cat([xp[:, (idx - 1).clamp(min=0)], xp, xp[:, (idx + 1).clamp(max=t - 1)]], dim=2)
+    w2 = weight.permute(0, 2, 1, 3, 4).reshape(weight.shape[0], 3 * c, 3, 3)
+    y = F.conv2d(frames.reshape(b * t, 3 * c, h + 2, w + 2), w2, bias)
+    return y.view(b, t, -1, h, w).transpose(1, 2)
 
 
 class DirectKernelEstimatorVideo(nn.Module):
@@ -41,12 +59,12 @@ class DirectKernelEstimatorVideo(nn.Module):
         b, c, t, h, w = x.shape
         s = self.scale
         mean = x.mean(-1, keepdim=True).mean(-2, keepdim=True)
-        y = _lrelu(self.conv0(self._rep3(x - mean)))
+        y = _lrelu(conv3d_k3_replicate(x - mean, self.conv0.weight, self.conv0.bias))
         y = y.transpose(1, 2).reshape(b * t, -1, h, w)
         for conv in (self.conv1, self.conv2, self.conv3, self.conv4):
             y = _lrelu(conv(self._ref2(y)))
         y = y.reshape(b, t, -1, h // s, w // s).transpose(1, 2)
-        y = _lrelu(self.conv5(self._rep3(y)))
+        y = _lrelu(conv3d_k3_replicate(y, self.conv5.weight, self.conv5.bias))
         y = self.conv6(y.transpose(1, 2).reshape(b * t, -1, h // s, w // s))
         return y.reshape(b, t, -1, h // s, w // s).transpose(1, 2) + mean
 

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Times the inner MAML step (BASELINE north_star: >= 50 clips/s at LR 176x320 -> SLR 44x80) and the
+full per-frame pipeline of test_dynavsr.py through the wrapper API on synthetic data.
+usage (GPU box): python tools/inner_bench.py [H W [steps]]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dynavsr_amd import synth  # noqa: E402
+from dynavsr_amd.adapt import adapt_frame  # noqa: E402
+from dynavsr_amd.models import create_model  # noqa: E402
+from dynavsr_amd.options import options as option  # noqa: E402
+
+h = int(sys.argv[1]) if len(sys.argv) > 2 else 176
+w = int(sys.argv[2]) if len(sys.argv) > 2 else 320
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+opt = option.dict_to_nonedict(option.parse(os.path.join(ROOT, "dynavsr_amd/options/test/EDVR/EDVR_M_S4.yml"),
+                                           is_train=False))
+opt["dist"] = False
+for k in ("pretrain_model_G", "pretrain_model_E"):
+    opt["path"][k] = None
+model, est = create_model(opt)
+modelcp, estcp = create_model(opt)
+_, est_fixed = create_model(opt)
+model.netG.load_state_dict(synth.edvr_state_dict(0))
+est.netE.load_state_dict(synth.mfdn_state_dict(0))
+est_fixed.netE.load_state_dict(synth.mfdn_state_dict(1))
+lqs = synth.clip(1, 1, 5, h, w, smooth=False).cuda()
+data = {"LQs": lqs}
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def timeit(fn, n):
+    fn(); fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+# (ii) inner step only: MFDN fwd (grad) + EDVR fwd/bwd on SLR + losses + optimizer step
+from copy import deepcopy  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from dynavsr_amd.adapt import make_inner_optimizer  # noqa: E402
+
+modelcp.netG, estcp.netE = deepcopy(model.netG), deepcopy(est.netE)
+inner = make_inner_optimizer(opt, modelcp.netG, estcp.netE)
+est_fixed.feed_data(data); est_fixed.test()
+slr_fixed = est_fixed.fake_L
+
+
+def inner_step():
+    estcp.feed_data(data); estcp.forward_without_optim()
+    slr = estcp.fake_L
+    inner.zero_grad()
+    modelcp.feed_data({"LQs": slr, "GT": lqs[:, 2]})
+    loss = modelcp.calculate_loss() + 10 * F.l1_loss(slr, slr_fixed)
+    loss.backward()
+    inner.step()
+
+
+def edvr_fwd_bwd():
+    slr = estcp.fake_L.detach()
+    modelcp.feed_data({"LQs": slr, "GT": lqs[:, 2]})
+    modelcp.calculate_loss().backward()
+
+
+def mfdn_fwd():
+    estcp.feed_data(data); estcp.test()
+
+
+def full_frame():
+    modelcp.feed_data(data, need_GT=False); modelcp.test()          # baseline forward
+    adapt_frame(opt, model, est, modelcp, estcp, est_fixed, data)   # deepcopy + inner step + adapted forward
+
+
+print("LR %dx%d (SLR %dx%d), EDVR-M x4 + MFDN, fp32" % (h, w, h // 4, w // 4))
+t = timeit(inner_step, steps); print("inner step            %8.2f ms  -> %6.1f clips/s" % (t, 1e3 / t))
+t = timeit(edvr_fwd_bwd, steps); print("  EDVR fwd+bwd on SLR   %8.2f ms" % t)
+t = timeit(mfdn_fwd, steps); print("  MFDN fwd (no grad)    %8.2f ms" % t)
+t = timeit(full_frame, max(2, steps // 3)); print("full per-frame pipeline %8.2f ms -> %6.1f frames/s" % (t, 1e3 / t))
