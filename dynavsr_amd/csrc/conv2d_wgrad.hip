@@ -3,11 +3,17 @@
 //
 // GEMM view per workgroup: D[o 64][c 64] (one D per tap) with K = pixels.  Each of the 4 waves owns
 // one (o-half, c-half) 32x32 tile for ALL taps (9 accumulators = 144 VGPRs) and walks a strided
-// list of 2x32-pixel tiles, so the pixel reduction stays in registers; the per-workgroup partial
-// sums go to a [nsplit][tap][o][c] scratch buffer that a second kernel reduces deterministically
-// (no atomics).  Operand reads are conflict-free: both LDS images use an odd plane stride.
+// list of 2x32-pixel tiles, so the pixel reduction stays in registers.  The per-workgroup sums are
+// folded into NSLOT (<= 8) zero-initialised [tap][o][c] slots with coalesced hardware fp32 atomics
+// (workgroup s -> slot s % NSLOT) and a second kernel sums the slots and transposes to OIHW; this
+// keeps the flush traffic at NSLOT x 147 KB instead of nsplit x 147 KB (the r01 profile had the
+// slot-less reduce at 51 us per call on the 44x80 inner-step shapes).  Summation order across
+// workgroups is therefore not fixed (1e-7-level run-to-run differences, like cuDNN's wgrad).
+// Operand reads are conflict-free: both LDS images use an odd plane stride.
 //   A (lane l): gy[o = l&31][px = 2kk + (l>>5)]   <- s_g[o*65 + px]
 //   B (lane l): x [c = l&31][px shifted by tap]   <- s_x[c*PLANEP + (py*S+ty)*IW + px*S+tx]
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -18,7 +24,7 @@ struct WgradK {
   long long x_bs;
   int x_bdiv;
   int N, Cin, H, W, Cout, Ho, Wo, pad, gy_ps;
-  int tiles_x, tiles_y, ntiles, nsplit, nob, ncb;
+  int tiles_x, tiles_y, ntiles, nsplit, nob, ncb, nslot;
 };
 
 template <int KS, int S>
@@ -105,17 +111,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
     }
   }
 
-  // ---- partial[split][tap][o][c]  (o, c padded to the 64-blocks of the grid)
+  // ---- partial[slot][tap][o][c]  (o, c padded to the 64-blocks of the grid), slot = split % nslot
   const int OP = a.nob * 64, CP = a.ncb * 64;
+  const int slot = split % a.nslot;
 #pragma unroll
   for (int t = 0; t < KK; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = ob * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const int c = cbk * 64 + ct * 32 + lo;
-      a.partial[(((size_t)split * KK + t) * OP + o) * CP + c] = acc[t][r];
+      unsafeAtomicAdd(a.partial + (((size_t)slot * KK + t) * OP + o) * CP + c, acc[t][r]);
     }
-  if (cbk == 0 && tid < 64) a.dbp[(size_t)split * OP + ob * 64 + tid] = db;
+  if (cbk == 0 && tid < 64) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + ob * 64 + tid, db);
 }
 
 // dW[o][c_off + c][tap] = sum_s partial[s][tap][o][c];  db[o] = sum_s dbp[s][o]
@@ -156,13 +163,10 @@ static void launch_wgrad(const WgradK& k, dim3 grid, hipStream_t st) {
 
 static int wgrad_splits(int ntiles, int nob, int ncb, int KK) {
   // one workgroup per CU when the pixel grid is small (latency-bound: every extra tile per workgroup
-  // is serial time), two per CU for big grids; partial buffer bounded to 64 MiB
-  const int blocks = nob * ncb;
-  int s = ceil_div(ntiles >= 2048 ? 512 : 256, blocks);
+  // is serial time), two per CU for big grids
+  (void)KK;
+  int s = ceil_div(ntiles >= 2048 ? 512 : 256, nob * ncb);
   if (s > ntiles) s = ntiles;
-  const size_t per_split = (size_t)KK * nob * 64 * ncb * 64 * sizeof(float);
-  const int cap = (int)((64ull << 20) / per_split);
-  if (s > cap) s = cap;
   return s < 1 ? 1 : s;
 }
 
@@ -171,7 +175,7 @@ size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int 
   const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
   const int ntiles = ceil_div(Wo, 32) * ceil_div(Ho, 2) * N;
   const int nob = ceil_div(Cout, 64), ncb = ceil_div(Cin, 64), KK = ks * ks;
-  const int ns = wgrad_splits(ntiles, nob, ncb, KK);
+  const int ns = wgrad_splits(ntiles, nob, ncb, KK) < 8 ? wgrad_splits(ntiles, nob, ncb, KK) : 8;
   return ((size_t)ns * KK * nob * 64 * ncb * 64 + (size_t)ns * nob * 64) * sizeof(float);
 }
 
@@ -195,8 +199,13 @@ int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy
   k.nob = ceil_div(Cout, 64); k.ncb = ceil_div(Cin, 64);
   const int KK = ks * ks;
   k.nsplit = wgrad_splits(k.ntiles, k.nob, k.ncb, KK);
+  k.nslot = k.nsplit < 8 ? k.nsplit : 8;
   k.partial = (float*)ws;
-  k.dbp = k.partial + (size_t)k.nsplit * KK * k.nob * 64 * k.ncb * 64;
+  k.dbp = k.partial + (size_t)k.nslot * KK * k.nob * 64 * k.ncb * 64;
+  {
+    const size_t zbytes = ((size_t)k.nslot * KK * k.nob * 64 * k.ncb * 64 + (size_t)k.nslot * k.nob * 64) * sizeof(float);
+    DVSR_REQUIRE(hipMemsetAsync(ws, 0, zbytes, st) == hipSuccess, DVSR_ERR_HIP, "conv2d_wgrad: memset failed");
+  }
   dim3 grid(k.nsplit, k.nob, k.ncb);
 if (ks == 3 && stride == 1) launch_wgrad<3, 1>(k, grid, st);
   else if (ks == 3) launch_wgrad<3, 2>(k, grid, st);
@@ -205,7 +214,7 @@ if (ks == 3 && stride == 1) launch_wgrad<3, 1>(k, grid, st);
   if (rc) return rc;
   const int total = Cout * Cin * KK;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, k.partial, k.dbp,
-                     dW, db, k.nsplit, KK, k.nob * 64, k.ncb * 64, Cout, Cin, Ctot, c_off);
+                     dW, db, k.nslot, KK, k.nob * 64, k.ncb * 64, Cout, Cin, Ctot, c_off);
   return check_launch("wgrad_reduce_kernel");
 }
 
