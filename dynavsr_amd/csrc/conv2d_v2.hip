@@ -280,45 +280,44 @@ static int launch_conv2(ConvK2 k, hipStream_t st) {
   return check_launch("conv2d_pipe_kernel");
 }
 
-// Cost model for choosing the tile geometry (cycles per chunk, arbitrary common scale):
-//   pipe    = workgroups on the busiest CU x MFMA cycles of one wave per chunk (one wave per SIMD per WG)
-//   latency = rounds of resident workgroups x (MFMA cycles + fixed per-chunk overhead)
-template <int KS, int S, int CC, int TH, int MT>
-static double conv2_cost(const ConvK2& k) {
-  using Sh = Conv2Shape<KS, S, CC, TH, MT>;
-  const double wgs = (double)ceil_div(k.Wo, 32) * ceil_div(k.Ho, TH) * k.N * ceil_div(k.Cout, 32 * MT);
-  int occ = (int)((160 * 1024) / Sh::LDS_BYTES);
-  if (occ > 3) occ = 3;  // ~140 VGPRs -> 3 waves per SIMD
-  if (occ < 1) occ = 1;
-  const double mfma = 64.0 * Sh::KK * (CC / 2) * Sh::NT * MT;
-  const double ovh = 2500.0;
-  const double pipe = ceil(wgs / 256.0) * mfma;
-  const double lat = ceil(wgs / (256.0 * occ)) * (mfma + ovh);
-  return pipe > lat ? pipe : lat;
+// Launch geometry.  Calibrated on MI355X per-layer timings of all five candidate geometries
+// (profiles/r01_conv_geometry_sweep.txt): the 4x32-pixel tile beats 8x32 on every EDVR layer, 16-channel
+// chunks never beat 8, and between 64 (MT=2) and 32 (MT=1) output channels per workgroup the winner is
+// the one with the smaller MFMA time on the busiest CU,
+//     ceil(workgroups / 256 CUs) x MFMA cycles of one workgroup,
+// i.e. pure tile quantisation (e.g. Cout = 216 wastes 18 % of a 64-wide block but 4 % of 32-wide ones;
+// 575 tiles are 3 rounds of 64-wide but 5 half-size rounds of 32-wide blocks).  Ties go to MT=2 (half
+// the workgroups, half the weight traffic).
+static double conv2_pipe_cost(int TH, int MT, int KK, int CC, int N, int Ho, int Wo, int Cout) {
+  const double wgs = (double)ceil_div(Wo, 32) * ceil_div(Ho, TH) * N * ceil_div(Cout, 32 * MT);
+  return ceil(wgs / 256.0) * 64.0 * KK * (CC / 2) * (TH / 4) * MT;
 }
 
-template <int KS, int S, int CC>
-static int dispatch_conv2(const ConvK2& k, int force, hipStream_t st) {
-  const double c82 = conv2_cost<KS, S, CC, 8, 2>(k);
-  const double c42 = conv2_cost<KS, S, CC, 4, 2>(k);
-  const double c41 = conv2_cost<KS, S, CC, 4, 1>(k);
-  int pick = (c82 <= c42 * 1.02 && c82 <= c41 * 1.02) ? 0 : (c42 <= c41 * 1.02 ? 1 : 2);
-  if (force >= 0) pick = force;
-  if (pick == 0) return launch_conv2<KS, S, CC, 8, 2>(k, st);
-  if (pick == 1) return launch_conv2<KS, S, CC, 4, 2>(k, st);
-  return launch_conv2<KS, S, CC, 4, 1>(k, st);
-}
-
-// `wp` = weights packed by pack_weights_kernel for this (ks, wt) combination.
-int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, hipStream_t st) {
-  DVSR_REQUIRE(d.x0 && wp && d.y, DVSR_ERR_INVALID, "conv2d_packed: null x0/wp/y");
-  DVSR_REQUIRE((d.ks == 1 && d.stride == 1) || (d.ks == 3 && (d.stride == 1 || d.stride == 2)),
-               DVSR_ERR_UNSUPPORTED, "conv2d_packed: ks=%d stride=%d", d.ks, d.stride);
-  static int force = -2;  // DVSR_CONV_TILE=0|1|2 pins the geometry (A/B aid); default: cost model
+ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ctot) {
+  (void)Ctot;
+  static int force = -2;  // DVSR_CONV_TILE=0|1|2 pins (8,2)/(4,2)/(4,1) tiles (A/B aid); default: model
   if (force == -2) {
     const char* v = getenv("DVSR_CONV_TILE");
     force = (v && v[0] >= '0' && v[0] <= '2') ? v[0] - '0' : -1;
   }
+  const int cc = ks == 1 ? 32 : 8;
+  if (ks == 3 && stride == 2) return ConvGeo{8, 8, 2};
+  if (force == 0) return ConvGeo{cc, 8, 2};
+  if (force == 1) return ConvGeo{cc, 4, 2};
+  if (force == 2) return ConvGeo{cc, 4, 1};
+  const double c42 = conv2_pipe_cost(4, 2, ks * ks, cc, N, Ho, Wo, Cout);
+  const double c41 = conv2_pipe_cost(4, 1, ks * ks, cc, N, Ho, Wo, Cout);
+  return c41 < 0.97 * c42 ? ConvGeo{cc, 4, 1} : ConvGeo{cc, 4, 2};
+}
+
+int conv2_pch_cc(int ks, int cc) { return 2 * ks * ks * (cc / 8) * 2 * 32 * 4; }
+
+// `wp` = weights packed by pack_weights_kernel for this (ks, wt, geo.cc) combination.
+int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo,
+                      hipStream_t st) {
+  DVSR_REQUIRE(d.x0 && wp && d.y, DVSR_ERR_INVALID, "conv2d_packed: null x0/wp/y");
+  DVSR_REQUIRE((d.ks == 1 && d.stride == 1) || (d.ks == 3 && (d.stride == 1 || d.stride == 2)),
+               DVSR_ERR_UNSUPPORTED, "conv2d_packed: ks=%d stride=%d", d.ks, d.stride);
   ConvK2 k;
   k.x0 = d.x0; k.x1 = d.x1; k.wp = wp; k.bias = d.bias; k.res = d.res; k.y = d.y;
   k.N = d.N; k.c0 = d.c0; k.c1 = d.c1; k.H = d.H; k.W = d.W; k.Cout = d.Cout;
@@ -327,13 +326,27 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
   k.x1_bs = d.x1_bstride > 0 ? d.x1_bstride : (long long)d.c1 * d.H * d.W;
   k.Ho = (d.H + 2 * d.pad - d.ks) / d.stride + 1;
   k.Wo = (d.W + 2 * d.pad - d.ks) / d.stride + 1;
-  k.nchunks = ceil_div(d.c0 + d.c1, conv2_cc(d.ks, d.stride));
+  k.nchunks = ceil_div(d.c0 + d.c1, geo.cc);
   k.in_ps = ex.in_ps; k.in_dil = ex.in_dil; k.Hs = ex.Hs; k.Ws = ex.Ws; k.accum = ex.accum;
   if (k.in_ps) k.x0_bs = (long long)d.c0 * d.H * d.W;
   if (k.in_dil) k.x0_bs = (long long)d.c0 * ex.Hs * ex.Ws;
-  if (d.ks == 3 && d.stride == 1) return dispatch_conv2<3, 1, 8>(k, force, st);
-  if (d.ks == 3) return launch_conv2<3, 2, 8, 8, 2>(k, st);
-  return dispatch_conv2<1, 1, 32>(k, force, st);
+  const int code = geo.cc * 100 + geo.th * 10 + geo.mt;
+  if (d.ks == 3 && d.stride == 2) return launch_conv2<3, 2, 8, 8, 2>(k, st);
+  if (d.ks == 3) {
+    switch (code) {
+      case 882: return launch_conv2<3, 1, 8, 8, 2>(k, st);
+      case 842: return launch_conv2<3, 1, 8, 4, 2>(k, st);
+      case 841: return launch_conv2<3, 1, 8, 4, 1>(k, st);
+    }
+  } else {
+    switch (code) {
+      case 3282: return launch_conv2<1, 1, 32, 8, 2>(k, st);
+      case 3242: return launch_conv2<1, 1, 32, 4, 2>(k, st);
+      case 3241: return launch_conv2<1, 1, 32, 4, 1>(k, st);
+    }
+  }
+  DVSR_REQUIRE(false, DVSR_ERR_INVALID, "conv2d_packed: no kernel for ks=%d cc=%d th=%d mt=%d", d.ks, geo.cc, geo.th,
+               geo.mt);
 }
 
 }  // namespace dvsr

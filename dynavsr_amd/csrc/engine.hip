@@ -52,6 +52,7 @@ struct Op {
   // data-gradient packs in the backward-only region
   size_t wp_off = 0, dpk_off[2] = {0, 0};
   size_t wp_floats = 0, dpk_floats[2] = {0, 0};
+  ConvGeo geo = {8, 8, 2}, dgeo[2] = {{8, 8, 2}, {8, 8, 2}};  // launch geometry chosen at plan time
 };
 
 // ---- backward tape -------------------------------------------------------------------------
@@ -127,14 +128,16 @@ struct Builder {
     const int Ho = (H + 2 * (ks / 2) - ks) / stride + 1, Wo = (W + 2 * (ks / 2) - ks) / stride + 1;
     o.y = y_override.valid() ? y_override : alloc(name, (size_t)N * Cout * Ho * Wo);
     {
-      const int cc = conv2_cc(ks, stride), pch = conv2_pch(ks, stride);
-      o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, cc) * pch;
+      o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1);
+      o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc);
       o.wp_off = alloc("", o.wp_floats).off;
       for (int which = 0; which < 2; ++which) {
         const int ci = which ? c1 : c0;
         if (!ci) continue;
-        // dgrad = stride-1 conv with Cout' = ci, Ctot' = Cout
-        o.dpk_floats[which] = (size_t)ceil_div(ci, 64) * ceil_div(Cout, conv2_cc(ks, 1)) * conv2_pch(ks, 1);
+        // dgrad = stride-1 conv over the input grid with Cout' = ci, Ctot' = Cout
+        o.dgeo[which] = conv2_choose(ks, 1, N, H, W, ci, Cout);
+        o.dpk_floats[which] = (size_t)ceil_div(ci, 64) * ceil_div(Cout, o.dgeo[which].cc) *
+                              conv2_pch_cc(ks, o.dgeo[which].cc);
         o.dpk_off[which] = p.dpack_floats;
         p.dpack_floats += o.dpk_floats[which];
       }
@@ -524,7 +527,7 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
       if (o->stride == 2) { ex.in_dil = 2; ex.Hs = Ho; ex.Ws = Wo; g.H = o->H; g.W = o->W; }
       else { g.H = Ho; g.W = Wo; }
       if (bs.use_v1) return conv2d_run(g, ex, st);
-      return conv2d_packed_run(g, bs.dpack + o->dpk_off[b.which], ex, st);
+      return conv2d_packed_run(g, bs.dpack + o->dpk_off[b.which], ex, o->dgeo[b.which], st);
     }
     case B_REDUCE: {
       float* dst = bs.at(b.a);
@@ -586,8 +589,8 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* fwd_b
     if (fwd_base) {
       PackEntry& e = t.e[t.n++];
       e.w = P[o.pw]; e.P = fwd_base + o.wp_off; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
-      e.CC = conv2_cc(o.ks, o.stride); e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
-      e.nchunks = ceil_div(ctot, e.CC); e.pch = conv2_pch(o.ks, o.stride);
+      e.CC = o.geo.cc; e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
+      e.nchunks = ceil_div(ctot, e.CC); e.pch = conv2_pch_cc(o.ks, e.CC);
       if (t.n == 48) { int rc = flush(); if (rc) return rc; }
     }
     if (bwd_base) {
@@ -596,8 +599,8 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* fwd_b
         if (!ci) continue;
         PackEntry& e = t.e[t.n++];
         e.w = P[o.pw]; e.P = bwd_base + o.dpk_off[which]; e.Cout = ci; e.Ctot = o.Cout; e.KK = KK;
-        e.CC = conv2_cc(o.ks, 1); e.wt = 1; e.w_ctot = ctot; e.w_coff = which ? o.c0 : 0;
-        e.ncb = ceil_div(ci, 64); e.nchunks = ceil_div(o.Cout, e.CC); e.pch = conv2_pch(o.ks, 1);
+        e.CC = o.dgeo[which].cc; e.wt = 1; e.w_ctot = ctot; e.w_coff = which ? o.c0 : 0;
+        e.ncb = ceil_div(ci, 64); e.nchunks = ceil_div(o.Cout, e.CC); e.pch = conv2_pch_cc(o.ks, e.CC);
         if (t.n == 48) { int rc = flush(); if (rc) return rc; }
       }
     }
@@ -615,7 +618,9 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
       d.stride = o.stride; d.pad = o.ks / 2; d.act = o.act; d.pixel_shuffle = o.ps;
       d.x1_bdiv = o.x1_bdiv; d.x0_bstride = o.x0_bs; d.x1_bstride = o.x1_bs;
       if (bs.use_v1) return conv2d_run(d, ConvExtra(), st);
-      return conv2d_packed_run(d, bs.arena + o.wp_off, ConvExtra(), st);
+      if (o.Cout <= 4 && o.ks == 3 && o.stride == 1 && !o.c1 && !o.ps && !o.x0_bs)  // conv_last
+        return conv3x3_small_cout_run(d.x0, d.w, d.bias, d.res, d.y, o.N, o.c0, o.H, o.W, o.Cout, o.act, st);
+      return conv2d_packed_run(d, bs.arena + o.wp_off, ConvExtra(), o.geo, st);
     }
     case OP_DCN: {
       const float* om = bs.at(o.x1);
@@ -776,7 +781,11 @@ extern "C" int dvsr_edvr_op_info(const dvsr_edvr_plan* p, int index, char* kind,
   const char* k;
   op_work(p->ops[index], &k, flops, bytes);
   snprintf(kind, kind_cap, "%s", k);
-  snprintf(name, name_cap, "%s", p->ops[index].name);
+  if (p->ops[index].type == OP_CONV)
+    snprintf(name, name_cap, "%s[%d/%d/%d]", p->ops[index].name, p->ops[index].geo.cc, p->ops[index].geo.th,
+             p->ops[index].geo.mt);
+  else
+    snprintf(name, name_cap, "%s", p->ops[index].name);
   return DVSR_OK;
 }
 

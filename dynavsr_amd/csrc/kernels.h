@@ -32,7 +32,14 @@ struct PackTable {
 int conv2_pch(int ks, int stride);  // floats per packed (cout block, chunk)
 int conv2_cc(int ks, int stride);   // input channels per chunk
 int pack_weights_run(const PackTable& t, hipStream_t st);
-int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, hipStream_t st);
+struct ConvGeo { int cc, th, mt; };  // channels per chunk, tile rows (x32 px), 32-cout halves per workgroup
+ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ctot);
+int conv2_pch_cc(int ks, int cc);   // floats per packed (64-cout block, chunk of cc channels)
+int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo,
+                      hipStream_t st);
+
+int conv3x3_small_cout_run(const float* x, const float* w, const float* bias, const float* res, float* y, int N,
+                           int C, int H, int W, int Cout, int act, hipStream_t st);
 
 size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride);
 int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,

@@ -27,8 +27,8 @@ for r in range(reps + 1):
     ms = plan.forward_timed(params, x, out, ws)
     if r:
         tot = [a + b for a, b in zip(tot, ms)]
-print("%-4s %-10s %-18s %9s %9s %9s" % ("#", "kind", "name", "us", "TFLOP/s", "GB/s"))
+print("%-4s %-10s %-26s %9s %9s %9s" % ("#", "kind", "name", "us", "TFLOP/s", "GB/s"))
 for i, ((kind, name, fl, by), t) in enumerate(zip(info, tot)):
     us = t / reps * 1e3
-    print("%-4d %-10s %-18s %9.1f %9.2f %9.1f" % (i, kind, name, us, fl / us / 1e6, by / us / 1e3))
+    print("%-4d %-10s %-26s %9.1f %9.2f %9.1f" % (i, kind, name, us, fl / us / 1e6, by / us / 1e3))
 print("total %.3f ms" % (sum(tot) / reps))
