@@ -41,6 +41,55 @@ def cpu_baseline(cfg, h, w, seed):
                       "threads of %d host cpus, no warm-up" % (h, w, threads, os.cpu_count())}
 
 
+def inner_step_rate(dev, steps=8):
+    """Secondary figure (north_star target >= 50 clips/s): one inner MAML step through the wrapper
+    API at LR 176x320 -> SLR 44x80: MFDN forward with grad, EDVR forward+backward on the SLR clip,
+    Charbonnier + 10*L1 losses, Adam step over G u E parameters (test_dynavsr.py:235-277)."""
+    from copy import deepcopy
+    import torch.nn.functional as F
+    from dynavsr_amd import synth
+    from dynavsr_amd.adapt import make_inner_optimizer
+    from dynavsr_amd.models import create_model
+    from dynavsr_amd.options import options as option
+    opt = option.dict_to_nonedict(option.parse(os.path.join(
+        ROOT, "dynavsr_amd", "options", "test", "EDVR", "EDVR_M_S4.yml"), is_train=False))
+    opt["dist"] = False
+    for k in ("pretrain_model_G", "pretrain_model_E"):
+        opt["path"][k] = None
+    model, est = create_model(opt)
+    _, est_fixed = create_model(opt)
+    model.netG.load_state_dict(synth.edvr_state_dict(0))
+    est.netE.load_state_dict(synth.mfdn_state_dict(0))
+    est_fixed.netE.load_state_dict(synth.mfdn_state_dict(1))
+    netG, netE = deepcopy(model.netG), deepcopy(est.netE)
+    model.netG, est.netE = netG, netE
+    inner = make_inner_optimizer(opt, netG, netE)
+    lqs = synth.clip(3, 1, 5, 176, 320, smooth=False).to(dev)
+    data = {"LQs": lqs}
+    est_fixed.feed_data(data); est_fixed.test()
+    slr_fixed = est_fixed.fake_L
+
+    def step():
+        est.feed_data(data); est.forward_without_optim()
+        inner.zero_grad()
+        model.feed_data({"LQs": est.fake_L, "GT": lqs[:, 2]})
+        loss = model.calculate_loss() + 10 * F.l1_loss(est.fake_L, slr_fixed)
+        loss.backward()
+        inner.step()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"value": 1e3 / ms, "unit": "clips/s", "ms_per_step": ms, "steps": steps,
+            "workload": "1 inner MAML step, EDVR-M x4 + MFDN, LR 1x5x3x176x320 -> SLR 44x80, fp32, Adam; "
+                        "MFDN runs on stock PyTorch-ROCm ops (SURVEY 8a A10)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,6 +98,7 @@ def main():
     ap.add_argument("--height", type=int, default=180)
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inner-step", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -134,7 +184,15 @@ def main():
             ach = by / (t_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS}
-        roof.update({"traffic": None, "kernel": dom, "launches_per_step": cnt // reps,
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside this process)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                t = json.load(f).get(dom)
+            if t and (h, w) == (180, 320):
+                traffic, traffic_src = t["bytes_per_launch"], t["source"]
+        except (OSError, ValueError):
+            pass
+        roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": dom, "launches_per_step": cnt // reps,
                      "avg_launch_ms": t_ms / cnt, "share_of_step": t_ms / total_ms,
                      "method": "hipEvent pair around every launch on the launch stream, %d instrumented "
                                "passes after the timed region" % reps})
@@ -142,6 +200,8 @@ def main():
         line["kernel_breakdown_ms_per_step"] = {k: round(a[0] / reps, 4) for k, a in
                                                 sorted(acc.items(), key=lambda kv: -kv[1][0])}
         line["end_to_end_tflops"] = sum(a[1] for a in acc.values()) / reps / (ms * 1e-3) / 1e12
+        if world == 1 and not args.no_inner_step:
+            line["inner_step"] = inner_step_rate(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, h, w, 0)
     if dist is not None:
