@@ -222,3 +222,52 @@ def test_dcn_dropin_module_matches_engine_and_oracle():
     assert relerr(x.grad, xc.grad) < 1e-4 and relerr(f.grad, fc.grad) < 1e-4
     for k, v in m.named_parameters():
         assert relerr(v.grad, P["d." + k].grad) < 1e-4, k
+
+
+def test_edvr_L_forward_backward_vs_oracle():
+    """BASELINE.json configs[4] architecture (EDVR-L: nf=128, 7 frames, 40 reconstruction blocks, x4)
+    in fp32: exercises C/dg = 16 (generic DCN kernel), 128/256-channel convs, 2 cout blocks."""
+    from oracle import edvr as oedvr
+    cfg = dict(nf=128, nframes=7, groups=8, front_RBs=5, back_RBs=40, scale=4)
+    P = OrderedDict((k, v.requires_grad_(True)) for k, v in synth.edvr_state_dict(7, **cfg).items())
+    x = synth.clip(31, 1, 7, 16, 16)
+    go = torch.from_numpy(np.random.RandomState(4).standard_normal((1, 3, 64, 64)).astype(np.float32))
+    y = oedvr.edvr_forward(P, x, **cfg)
+    ref = torch.autograd.grad(y, list(P.values()), go)
+    net = make_net(7, **cfg)
+    assert len(net._names) == 264
+    yg = net(x.cuda())
+    yg.backward(go.cuda())
+    assert relerr(yg, y) < 2e-4
+    errs = np.array([relerr(p.grad, r) for p, r in zip(net.ordered_parameters(), ref)])
+    assert errs.max() < 3e-2 and np.median(errs) < 5e-3, (errs.max(), np.median(errs))
+
+
+def test_config3_psnr_parity_synthetic_video():
+    """BASELINE.json configs[2] substitute (no Vid4 / checkpoints offline): a seeded
+    synthetic clip sequence, 3 inner MAML steps per frame (SGD, larger lr so that adaptation moves
+    the output), PSNR-vs-GT of the adapted frame through this build and through the CPU oracle:
+    |delta PSNR| <= 0.02 dB per frame (north_star), with the reference's uint8 PSNR definition."""
+    from dynavsr_amd.adapt import adapt_frame
+    from dynavsr_amd.models import create_model
+    from dynavsr_amd.utils import util
+    from oracle import inner as oinner
+    opt = _gpu_opt("SGD")
+    opt["train"]["maml"]["adapt_iter"] = 3
+    opt["train"]["maml"]["lr_alpha"] = 1e-3
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    PG, PE, PEF = synth.edvr_state_dict(0), synth.mfdn_state_dict(0), synth.mfdn_state_dict(1)
+    model.netG.load_state_dict(PG); est.netE.load_state_dict(PE); est_fixed.netE.load_state_dict(PEF)
+    video = synth.clip(77, 1, 7, 48, 64)                       # 7 LR frames -> 3 sliding windows of 5
+    gt = synth.clip(78, 1, 7, 192, 256)                        # synthetic HR "ground truth"
+    for t in range(3):
+        lqs = video[:, t:t + 5].contiguous()
+        r = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, {"LQs": lqs.cuda()})
+        _, _, _, sr_ref = oinner.inner_adapt(PG, PE, PEF, lqs, 3, "SGD", 1e-3)
+        hr = util.tensor2img(gt[0, t + 2], mode="rgb")
+        p_gpu = util.calculate_psnr(util.tensor2img(r["sr"][0], mode="rgb"), hr)
+        p_ref = util.calculate_psnr(oinner.tensor2img_rgb(sr_ref[0]), hr)
+        assert abs(p_gpu - p_ref) <= 0.02, (t, p_gpu, p_ref)
+        assert relerr(r["sr"], sr_ref) < 1e-3
