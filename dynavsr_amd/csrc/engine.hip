@@ -88,6 +88,13 @@ struct dvsr_edvr_plan {
   bool use_v1 = false;                            // DVSR_CONV_V1=1: un-pipelined conv kernel (A/B aid)
   size_t tmp_floats = 0;                          // dense dgrad staging for broadcast/strided views
   size_t scratch_bytes = 0;                       // wgrad partials / DCN column buffer
+  size_t wscratch_bytes = 0;                      // private wgrad scratch of the side stream
+  // Backward concurrency: weight gradients do not feed the data-gradient chain, so they run on a
+  // side stream (forked per layer with an event, joined once at the end).  On the small inner-step
+  // clips a single conv launch fills only 25-100 % of the CUs, and the two streams overlap.
+  mutable hipStream_t side = nullptr;
+  mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int side_streams = 1;                           // DVSR_BWD_STREAMS=0 disables
 };
 
 namespace dvsr {
@@ -372,7 +379,7 @@ struct BackBuilder {
 
 static void build_backward(dvsr_edvr_plan& p) {
   BackBuilder bb(p);
-  size_t tmp = 0, scratch = 0;
+  size_t tmp = 0, scratch = 0, wscratch = 0;
   for (int i = (int)p.ops.size() - 1; i >= 0; --i) {
     const Op& o = p.ops[i];
     const Ref gy = BackBuilder::grad(o.y);
@@ -390,6 +397,8 @@ static void build_backward(dvsr_edvr_plan& p) {
           p.bops.push_back(w);
           scratch = std::max(scratch, conv2d_wgrad_workspace_bytes(o.N, which ? o.c1 : o.c0, o.H, o.W, o.Cout,
                                                                    o.ks, o.stride));
+          wscratch = std::max(wscratch, conv2d_wgrad_workspace_bytes(o.N, which ? o.c1 : o.c0, o.H, o.W, o.Cout,
+                                                                     o.ks, o.stride));
         }
         for (int which = 0; which < 2; ++which) {
           if (which == 1 && !o.c1) break;
@@ -472,6 +481,7 @@ static void build_backward(dvsr_edvr_plan& p) {
   }
   p.tmp_floats = (tmp + 63) & ~(size_t)63;
   p.scratch_bytes = (scratch + 255) & ~(size_t)255;
+  p.wscratch_bytes = (wscratch + 255) & ~(size_t)255;
 }
 
 struct BBases {
@@ -673,6 +683,7 @@ extern "C" int dvsr_edvr_plan_create(const dvsr_edvr_config* cfg, int B, int H, 
   dvsr_edvr_plan* p = new dvsr_edvr_plan();
   p->cfg = *cfg; p->B = B; p->H = H; p->W = W;
   { const char* v = getenv("DVSR_CONV_V1"); p->use_v1 = v && v[0] == '1'; }
+  { const char* v = getenv("DVSR_BWD_STREAMS"); p->side_streams = (v && v[0] == '0') ? 0 : 1; }
   int rc = build_plan(*p);
   if (rc != DVSR_OK) { delete p; return rc; }
   build_backward(*p);
@@ -680,7 +691,16 @@ extern "C" int dvsr_edvr_plan_create(const dvsr_edvr_config* cfg, int B, int H, 
   return DVSR_OK;
 }
 
-extern "C" void dvsr_edvr_plan_destroy(dvsr_edvr_plan* p) { delete p; }
+extern "C" void dvsr_edvr_plan_destroy(dvsr_edvr_plan* p) {
+  if (!p) return;
+  if (p->side) {
+    (void)hipStreamSynchronize(p->side);
+    (void)hipEventDestroy(p->ev_fork);
+    (void)hipEventDestroy(p->ev_join);
+    (void)hipStreamDestroy(p->side);
+  }
+  delete p;
+}
 
 extern "C" int dvsr_edvr_num_params(const dvsr_edvr_plan* p) { return p ? p->n_params : -1; }
 
@@ -691,7 +711,8 @@ extern "C" int dvsr_edvr_num_launches(const dvsr_edvr_plan* p) { return p ? (int
 extern "C" size_t dvsr_edvr_workspace_bytes(const dvsr_edvr_plan* p, int need_grad) {
   if (!p) return 0;
   size_t b = p->arena_floats * sizeof(float);
-  if (need_grad) b += (p->arena_floats + p->tmp_floats + p->dpack_floats) * sizeof(float) + p->scratch_bytes;
+  if (need_grad)
+    b += (p->arena_floats + p->tmp_floats + p->dpack_floats) * sizeof(float) + p->scratch_bytes + p->wscratch_bytes;
   return b;
 }
 
@@ -718,10 +739,40 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
     DVSR_REQUIRE(hipMemsetAsync(grad_x, 0, n * sizeof(float), st) == hipSuccess, DVSR_ERR_HIP,
                  "edvr_backward: memset of grad_x failed");
   }
+  // fork/join state of the side stream (created on first use, owned by the plan)
+  bool use_side = p->side_streams != 0;
+  if (use_side && !p->side) {
+    if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      p->side = nullptr;
+      use_side = false;
+    }
+  }
+  void* wscratch = (char*)scratch + p->scratch_bytes;
+  bool forked = false;
+  int last_fork_fwd = -1;
   for (const BOp& b : p->bops) {
-    int rc = run_backward_op(*p, b, params, grad_params, bs, scratch, p->scratch_bytes, st);
+    int rc;
+    if (use_side && b.type == B_WGRAD) {
+      if (b.fwd != last_fork_fwd) {  // gy of this layer is final on `st` at this point of the tape
+        DVSR_REQUIRE(hipEventRecord(p->ev_fork, st) == hipSuccess &&
+                         hipStreamWaitEvent(p->side, p->ev_fork, 0) == hipSuccess,
+                     DVSR_ERR_HIP, "edvr_backward: fork to the wgrad stream failed");
+        last_fork_fwd = b.fwd;
+      }
+      rc = run_backward_op(*p, b, params, grad_params, bs, wscratch, p->wscratch_bytes, p->side);
+      forked = true;
+    } else {
+      rc = run_backward_op(*p, b, params, grad_params, bs, scratch, p->scratch_bytes, st);
+    }
     if (rc != DVSR_OK) return rc;
   }
+  if (forked)
+    DVSR_REQUIRE(hipEventRecord(p->ev_join, p->side) == hipSuccess &&
+                     hipStreamWaitEvent(st, p->ev_join, 0) == hipSuccess,
+                 DVSR_ERR_HIP, "edvr_backward: join of the wgrad stream failed");
   return DVSR_OK;
 }
 
