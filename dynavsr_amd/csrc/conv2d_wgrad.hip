@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
 }
 
 // dW[o][c_off + c][tap] = sum_s partial[s][tap][o][c];  db[o] = sum_s dbp[s][o]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ dbp,
+// The slots are zeroed again while they are read, so the next wgrad launch on the same scratch can
+// accumulate into them without a memset of its own (conv2d_wgrad_run's `scratch_is_zero` contract).
+__global__ void wgrad_reduce_kernel(float* __restrict__ partial, float* __restrict__ dbp,
                                     float* __restrict__ dW, float* __restrict__ db, int nsplit, int KK,
                                     int OP, int CP, int Cout, int Cin, int Ctot, int c_off) {
   const int total = Cout * Cin * KK;
@@ -136,15 +138,20 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
     const int o = t2 % Cout;
     const int t = t2 / Cout;
     float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += partial[(((size_t)sp * KK + t) * OP + o) * CP + c];
+    for (int sp = 0; sp < nsplit; ++sp) {
+      float* q = partial + (((size_t)sp * KK + t) * OP + o) * CP + c;
+      s += *q;
+      *q = 0.f;
+    }
     dW[((size_t)o * Ctot + c_off + c) * KK + t] = s;
   }
-  if (db) {
-    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < Cout; o += gridDim.x * blockDim.x) {
-      float s = 0.f;
-      for (int sp = 0; sp < nsplit; ++sp) s += dbp[(size_t)sp * OP + o];
-      db[o] = s;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < OP; o += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+      s += dbp[(size_t)sp * OP + o];
+      dbp[(size_t)sp * OP + o] = 0.f;
     }
+    if (db && o < Cout) db[o] = s;
   }
 }
 
@@ -184,7 +191,7 @@ size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int 
 // gradient (and db when non-null).
 int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
                      float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
-                     int stride, void* ws, size_t ws_bytes, hipStream_t st) {
+                     int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero) {
   DVSR_REQUIRE(x && gy && dW && ws, DVSR_ERR_INVALID, "conv2d_wgrad: null pointer");
   DVSR_REQUIRE((ks == 1 && stride == 1) || (ks == 3 && (stride == 1 || stride == 2)), DVSR_ERR_UNSUPPORTED,
                "conv2d_wgrad: ks=%d stride=%d unsupported", ks, stride);
@@ -202,7 +209,7 @@ int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy
   k.nslot = k.nsplit < 8 ? k.nsplit : 8;
   k.partial = (float*)ws;
   k.dbp = k.partial + (size_t)k.nslot * KK * k.nob * 64 * k.ncb * 64;
-  {
+  if (!scratch_is_zero) {
     const size_t zbytes = ((size_t)k.nslot * KK * k.nob * 64 * k.ncb * 64 + (size_t)k.nslot * k.nob * 64) * sizeof(float);
     DVSR_REQUIRE(hipMemsetAsync(ws, 0, zbytes, st) == hipSuccess, DVSR_ERR_HIP, "conv2d_wgrad: memset failed");
   }
@@ -243,11 +250,11 @@ extern "C" int dvsr_conv2d_backward(const dvsr_conv2d_desc* d, const float* gy, 
   int rc;
   if (gw) {
     rc = conv2d_wgrad_run(d->x0, d->x0_bstride, 1, gy, 0, gw, gb, d->N, d->c0, d->H, d->W, d->Cout, ctot, 0,
-                          d->ks, d->stride, workspace, workspace_bytes, st);
+                          d->ks, d->stride, workspace, workspace_bytes, st, 0);
     if (rc) return rc;
     if (d->c1) {
       rc = conv2d_wgrad_run(d->x1, d->x1_bstride, 1, gy, 0, gw, nullptr, d->N, d->c1, d->H, d->W, d->Cout,
-                            ctot, d->c0, d->ks, d->stride, workspace, workspace_bytes, st);
+                            ctot, d->c0, d->ks, d->stride, workspace, workspace_bytes, st, 0);
       if (rc) return rc;
     }
   }

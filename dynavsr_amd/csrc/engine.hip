@@ -501,7 +501,8 @@ struct BBases {
 };
 
 static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* const* P, float* const* GP,
-                           const BBases& bs, void* scratch, size_t scratch_bytes, hipStream_t st) {
+                           const BBases& bs, void* scratch, size_t scratch_bytes, hipStream_t st,
+                           int scratch_is_zero = 0) {
   const Op* o = b.fwd >= 0 ? &p.ops[b.fwd] : nullptr;
   switch (b.type) {
     case B_MEMSET: {
@@ -523,7 +524,8 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
       const int ci = b.which ? o->c1 : o->c0;
       return conv2d_wgrad_run(bs.at(b.a), b.which ? o->x1_bs : o->x0_bs, b.which ? o->x1_bdiv : 1, bs.at(b.b),
                               o->ps, GP[o->pw], b.which ? nullptr : GP[o->pb], o->N, ci, o->H, o->W, o->Cout,
-                              o->c0 + o->c1, b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st);
+                              o->c0 + o->c1, b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st,
+                              scratch_is_zero);
     }
     case B_DGRAD: {
       float* gx = bs.at(b.a);
@@ -751,6 +753,9 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
     }
   }
   void* wscratch = (char*)scratch + p->scratch_bytes;
+  if (use_side)  // the side stream's wgrad slots: zeroed once here, every reduce re-zeroes what it read
+    DVSR_REQUIRE(hipMemsetAsync(wscratch, 0, p->wscratch_bytes, st) == hipSuccess, DVSR_ERR_HIP,
+                 "edvr_backward: memset of the wgrad scratch failed");
   bool forked = false;
   int last_fork_fwd = -1;
   for (const BOp& b : p->bops) {
@@ -762,7 +767,7 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
                      DVSR_ERR_HIP, "edvr_backward: fork to the wgrad stream failed");
         last_fork_fwd = b.fwd;
       }
-      rc = run_backward_op(*p, b, params, grad_params, bs, wscratch, p->wscratch_bytes, p->side);
+      rc = run_backward_op(*p, b, params, grad_params, bs, wscratch, p->wscratch_bytes, p->side, 1);
       forked = true;
     } else {
       rc = run_backward_op(*p, b, params, grad_params, bs, scratch, p->scratch_bytes, st);

@@ -44,7 +44,7 @@ int conv3x3_small_cout_run(const float* x, const float* w, const float* bias, co
 size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride);
 int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
                      float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
-                     int stride, void* ws, size_t ws_bytes, hipStream_t st);
+                     int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero = 0);
 size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int stride, int pad, int dil);
 int mdcn_backward_run(const float* x, const float* off, long long off_bs, const float* msk, long long msk_bs,
                       int mask_logit, const float* w, const float* gout, float* gx, float* goff,

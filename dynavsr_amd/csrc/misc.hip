@@ -2,6 +2,8 @@
 // pair and the TSA gate / blend (EDVR_arch.py:107-120,166-202,311).  One thread per output
 // element (or per pixel for the channel reductions), consecutive lanes = consecutive pixels, so
 // every load/store is a coalesced 256-byte wave access; grids are capped and grid-strided.
+#include <cstdint>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -44,6 +46,36 @@ __global__ void upsample_bilinear_fwd_kernel(const float* __restrict__ x, float*
     const float v = (1.f - ly) * ((1.f - lx) * pl[y0 * W + x0] + lx * pl[y0 * W + x1]) +
                     ly * ((1.f - lx) * pl[y1 * W + x0] + lx * pl[y1 * W + x1]);
     y[i] = v * mul;
+  }
+}
+
+// Same op, 4 consecutive outputs per thread (one 16-byte store per lane; requires S*W % 4 == 0 and a
+// 16-byte aligned y).  The scalar kernel above reached 1.3-1.8 TB/s in the r01 profile, dominated by
+// 64-bit index arithmetic and 4-byte stores.
+__global__ void upsample_bilinear_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                              unsigned planes, int H, int W, int S, float mul) {
+  const int Ho = H * S, Wo = W * S, Wq = Wo >> 2;
+  const unsigned total = planes * (unsigned)Ho * (unsigned)Wq;
+  const float inv = 1.f / (float)S;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int oq = (int)(i % (unsigned)Wq);
+    const unsigned t = i / (unsigned)Wq;
+    const int oy = (int)(t % (unsigned)Ho);
+    const unsigned p = t / (unsigned)Ho;
+    int y0, y1;
+    float ly;
+    src_index(oy, inv, H, y0, y1, ly);
+    const float* r0 = x + (size_t)p * H * W + (size_t)y0 * W;
+    const float* r1 = x + (size_t)p * H * W + (size_t)y1 * W;
+    f32x4 out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int x0, x1;
+      float lx;
+      src_index(4 * oq + j, inv, W, x0, x1, lx);
+      out[j] = ((1.f - ly) * ((1.f - lx) * r0[x0] + lx * r0[x1]) + ly * ((1.f - lx) * r1[x0] + lx * r1[x1])) * mul;
+    }
+    *reinterpret_cast<f32x4*>(y + ((size_t)p * Ho + oy) * Wo + 4 * oq) = out;
   }
 }
 
@@ -331,7 +363,12 @@ int upsample_bilinear_fwd(const float* x, float* y, size_t planes, int H, int W,
                           hipStream_t st) {
   DVSR_REQUIRE(x && y && planes > 0 && H > 0 && W > 0 && S >= 1, DVSR_ERR_INVALID,
                "upsample_bilinear_fwd: bad argument");
-  LAUNCH(upsample_bilinear_fwd_kernel, planes * H * W * S * S, st, x, y, planes, H, W, S, mul);
+  const size_t nout = planes * H * W * S * S;
+  if ((W * S) % 4 == 0 && ((uintptr_t)y & 15) == 0 && nout < (1ull << 32)) {
+    LAUNCH(upsample_bilinear_fwd4_kernel, nout / 4, st, x, y, (unsigned)planes, H, W, S, mul);
+    return check_launch("upsample_bilinear_fwd4_kernel");
+  }
+  LAUNCH(upsample_bilinear_fwd_kernel, nout, st, x, y, planes, H, W, S, mul);
   return check_launch("upsample_bilinear_fwd_kernel");
 }
 int upsample_bilinear_bwd(const float* gy, float* gx, size_t planes, int H, int W, int S, float mul,
