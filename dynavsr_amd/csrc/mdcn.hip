@@ -9,6 +9,8 @@
 // D rows = cout, D columns = pixels).  Offsets/masks are read once per (group, tap, pixel) and
 // shared by the CPG channels of the group; the x gathers hit L1/L2 (a group's planes are
 // CPG*H*W*4 bytes, e.g. 1.8 MB at 180x320).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -406,6 +408,193 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_lds_kernel(DcnK2 a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Register-direct variant: no column tile at all.  Each lane samples exactly the MFMA B operands it
+// will feed: lane (lo, hi) of wave w owns pixels (row 2w+nt, col lo), nt = 0..1, and channels
+// c = 2kk + hi (kk = 0..3) of the group, so the staged window is laid out [y][x][hi][kk] and a
+// bilinear corner is ONE ds_read_b128 (4 channels).  Per tap: 8 corner reads + 2 weight reads +
+// 16 MFMAs, no barrier; per group only the two barriers around the window / weight refill remain
+// (the LDS-tile kernel above needs seven).  Offsets and masks of tap t+1 are loaded while the MFMAs
+// of tap t are in flight.  LDS drops to 42.6 KB -> 3 workgroups per CU.
+// -------------------------------------------------------------------------------------------------
+template <int HALO>
+__global__ __launch_bounds__(256, 3) void mdcn_fwd_reg_kernel(DcnK2 a) {
+  constexpr int CPG = 8, KK = 9, TH = 8, TW = 32;
+  constexpr int XH = TH + 2 + 2 * HALO, XW = TW + 2 + 2 * HALO, XPX = XH * XW;
+  constexpr int XE = (XPX + 255) / 256;
+  constexpr int HALF = KK * 2 * 32 * 4, WF = 2 * HALF, NPIECE = WF / 256;
+  __shared__ __attribute__((aligned(16))) float s_x[XPX * 8];
+  __shared__ __attribute__((aligned(16))) float s_w[WF];
+
+  const int id = blockIdx.x;
+  const int tile = (id / (8 * a.ncb)) * 8 + (id & 7);
+  const int cb = (id >> 3) % a.ncb;
+  if (tile >= a.ntiles) return;
+  const int tx_ = tile % a.tiles_x;
+  const int t2 = tile / a.tiles_x;
+  const int ty_ = t2 % a.tiles_y;
+  const int n = t2 / a.tiles_y;
+  const int oy0 = ty_ * TH, ox0 = tx_ * TW;
+  const int wy0 = oy0 - 1 - HALO, wx0 = ox0 - 1 - HALO;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const size_t HW = (size_t)a.H * a.W;
+  const float* offn = a.off + (size_t)n * a.off_bstride;
+  const float* mskn = a.msk + (size_t)n * a.msk_bstride;
+  // the two pixels this lane samples
+  const int px = ox0 + lo;
+  int py[2];
+  bool pv[2];
+  size_t pofs[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    py[nt] = oy0 + 2 * wave + nt;
+    pv[nt] = py[nt] < a.H && px < a.W;
+    pofs[nt] = pv[nt] ? (size_t)py[nt] * a.W + px : 0;
+  }
+
+  int xoff[XE];
+  bool xok[XE];
+#pragma unroll
+  for (int e = 0; e < XE; ++e) {
+    const int idx = tid + 256 * e;
+    const int ry = idx / XW, rx = idx - ry * XW;
+    const int gy = wy0 + ry, gx = wx0 + rx;
+    xok[e] = idx < XPX && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    xoff[e] = xok[e] ? gy * a.W + gx : 0;
+  }
+  float rx_[CPG][XE];
+  auto prefetch_x = [&](int g) {
+    const float* xg = a.x + ((size_t)n * a.C + g * CPG) * HW;
+#pragma unroll
+    for (int c = 0; c < CPG; ++c)
+#pragma unroll
+      for (int e = 0; e < XE; ++e) rx_[c][e] = xg[(size_t)c * HW + xoff[e]];
+  };
+  float oh[2][2], ow[2][2], mm[2][2];  // [buffer][nt]
+  auto load_off = [&](int g, int tap, int rb) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      oh[rb][nt] = offn[(size_t)(g * 2 * KK + 2 * tap) * HW + pofs[nt]];
+      ow[rb][nt] = offn[(size_t)(g * 2 * KK + 2 * tap + 1) * HW + pofs[nt]];
+      mm[rb][nt] = mskn[(size_t)(g * KK + tap) * HW + pofs[nt]];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* wp_cb = a.wp + (size_t)cb * a.nchunks * WF;
+  for (int g = 0; g < a.dg; ++g) {
+    prefetch_x(g);    // no cross-group register prefetch: 24 fewer VGPRs buy the third wave per SIMD
+    __syncthreads();  // previous group's taps are done with s_x / s_w
+    {
+      const float* wsrc = wp_cb + (size_t)g * WF;
+#pragma unroll
+      for (int j = 0; j < (NPIECE + 3) / 4; ++j) {
+        const int piece = j * 4 + wave;
+        if (piece < NPIECE)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(wsrc + piece * 256 + lane * 4),
+              (__attribute__((address_space(3))) void*)(s_w + piece * 256), 16, 0, 0);
+      }
+    }
+    // window -> LDS as [y][x][hi][kk]: channel c = 2kk + hi
+#pragma unroll
+    for (int e = 0; e < XE; ++e) {
+      const int idx = tid + 256 * e;
+      if (idx < XPX) {
+        const bool ok = xok[e];
+        f32x4 v0 = {ok ? rx_[0][e] : 0.f, ok ? rx_[2][e] : 0.f, ok ? rx_[4][e] : 0.f, ok ? rx_[6][e] : 0.f};
+        f32x4 v1 = {ok ? rx_[1][e] : 0.f, ok ? rx_[3][e] : 0.f, ok ? rx_[5][e] : 0.f, ok ? rx_[7][e] : 0.f};
+        *reinterpret_cast<f32x4*>(s_x + (size_t)idx * 8) = v0;
+        *reinterpret_cast<f32x4*>(s_x + (size_t)idx * 8 + 4) = v1;
+      }
+    }
+    load_off(g, 0, 0);
+    __syncthreads();  // window visible, weight DMA drained
+    const float* xg = a.x + ((size_t)n * a.C + g * CPG) * HW;
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) {
+      const int rb = tap & 1;
+      if (tap + 1 < KK) load_off(g, tap + 1, rb ^ 1);
+      const int ki = tap / 3, kj = tap - ki * 3;
+      f32x4 B[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (pv[nt]) {
+          float m = mm[rb][nt];
+          if (a.mask_logit) m = sigmoidf_(m);
+          const float h_im = (float)(py[nt] - 1 + ki) + oh[rb][nt];
+          const float w_im = (float)(px - 1 + kj) + ow[rb][nt];
+          const float hf = floorf(h_im), wf = floorf(w_im);
+          const float lh = h_im - hf, lw = w_im - wf;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+          const float ryf = hf - (float)wy0, rxf = wf - (float)wx0;
+          if (ryf >= 0.f && ryf <= (float)(XH - 2) && rxf >= 0.f && rxf <= (float)(XW - 2)) {
+            const float* p1 = s_x + ((size_t)((int)ryf * XW + (int)rxf)) * 8 + hi * 4;
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p1);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p1 + 8);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p1 + XW * 8);
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(p1 + XW * 8 + 8);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[c] = (w1 * v1[c] + w2 * v2[c] + w3 * v3[c] + w4 * v4[c]) * m;
+          } else {
+            DcnTap tp;  // sample leaves the staged window: exact clamped global gathers
+            if (make_tap(h_im, w_im, a.H, a.W, tp)) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float* pl = xg + (size_t)(2 * c + hi) * HW;
+                const float v1 = tp.v1 ? pl[tp.o1] : 0.f, v2 = tp.v2 ? pl[tp.o2] : 0.f;
+                const float v3 = tp.v3 ? pl[tp.o3] : 0.f, v4 = tp.v4 ? pl[tp.o4] : 0.f;
+                b[c] = (tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4) * m;
+              }
+            }
+          }
+        }
+        B[nt] = b;
+      }
+      f32x4 A[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        A[mt] = *reinterpret_cast<const f32x4*>(s_w + ((size_t)(((mt * KK + tap) * 2 + hi) * 32 + lo)) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][j], B[0][j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][j], B[1][j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][j], B[0][j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][j], B[1][j], acc[1][1], 0, 0, 0);
+      }
+    }
+  }
+
+  const int ox = ox0 + lo;
+  if (ox >= a.W) return;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int oy = oy0 + 2 * wave + nt;
+      if (oy >= a.H) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cb * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co >= a.Cout) continue;
+        float v = acc[mt][nt][r];
+        if (a.bias) v += a.bias[co];
+        a.out[((size_t)n * a.Cout + co) * HW + (size_t)oy * a.W + ox] = apply_act(v, a.act);
+      }
+    }
+}
+
 // wp = weights packed by pack_weights_kernel with KK=9, CC=8, wt=0 (one chunk per deformable group).
 int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, const float* msk,
                             long long msk_bs, int mask_logit, const float* wp, const float* b, float* out,
@@ -419,8 +608,14 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
   k.tiles_x = ceil_div(W, 32); k.tiles_y = ceil_div(H, 8); k.ntiles = k.tiles_x * k.tiles_y * N;
   k.ncb = ceil_div(Cout, 64); k.nchunks = dg;
   const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
-  hipLaunchKernelGGL(mdcn_fwd_lds_kernel<4>, dim3(grid), dim3(256), 0, st, k);
-  return check_launch("mdcn_fwd_lds_kernel");
+  static int variant = -1;  // DVSR_DCN_FWD=lds selects the LDS-column-tile kernel (A/B aid)
+  if (variant < 0) { const char* v = getenv("DVSR_DCN_FWD"); variant = (v && v[0] == 'l') ? 1 : 0; }
+  if (variant == 1) {
+    hipLaunchKernelGGL(mdcn_fwd_lds_kernel<4>, dim3(grid), dim3(256), 0, st, k);
+    return check_launch("mdcn_fwd_lds_kernel");
+  }
+  hipLaunchKernelGGL(mdcn_fwd_reg_kernel<4>, dim3(grid), dim3(256), 0, st, k);
+  return check_launch("mdcn_fwd_reg_kernel");
 }
 
 }  // namespace dvsr
