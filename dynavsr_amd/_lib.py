@@ -67,6 +67,7 @@ def _declare(lib):
         "dvsr_edvr_op_info": (I, [P, I, c_char_p, I, c_char_p, I, POINTER(ctypes.c_double),
                                   POINTER(ctypes.c_double)]),
         "dvsr_edvr_forward_timed": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P, POINTER(c_float)]),
+        "dvsr_debug_mfma_peak": (LL, [P, I, I, I, I, P]),
         "dvsr_edvr_tensor_info": (I, [P, c_char_p, POINTER(LL), POINTER(LL)]),
     }
     for name, (res, args) in sig.items():

@@ -179,6 +179,9 @@ int dvsr_edvr_op_info(const dvsr_edvr_plan* plan, int index, char* kind, int kin
 int dvsr_edvr_forward_timed(const dvsr_edvr_plan* plan, const float* const* params, const float* x,
                             float* out, void* workspace, size_t workspace_bytes,
                             dvsr_stream_t stream, float* op_ms);
+/* Measurement aid: register-only fp32 MFMA loop (256-thread workgroups, `nacc` accumulators per wave,
+ * `lds_bytes` of dynamic LDS to reproduce an occupancy); returns MFMA instructions per wave or -1. */
+long long dvsr_debug_mfma_peak(float* out, int blocks, int iters, int nacc, int lds_bytes, dvsr_stream_t stream);
 /* Offset (in floats, into the workspace) and size of a named intermediate, for layer-by-layer
  * parity checks ("L1_fea", "aligned", "tsa_out", "recon", ...). */
 int dvsr_edvr_tensor_info(const dvsr_edvr_plan* plan, const char* name, long long* offset_floats,
