@@ -48,4 +48,102 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
   return 1.f;
 }
 
+// ---- output-tile writer shared by the MFMA kernels (conv2d*, mdcn forward) -----------------------
+// D layout of v_mfma_f32_32x32x2_f32: register r of lane (lo, hi) holds row (r&3) + 8*(r>>2) + 4*hi,
+// column lo.  Rows are output channels, columns are pixels of one image row.
+// gfx9 counts stores in vmcnt too: a predicated store per basic block makes the compiler put
+// s_waitcnt vmcnt(0) in front of every one of them, i.e. each store waits for the acknowledge of the
+// previous one.  Full tiles therefore take a straight-line path (all loads first, one wait, 16
+// back-to-back stores per accumulator); only edge tiles use the predicated path.
+struct TileOut {
+  float* y;            // NCHW output (or its 2x pixel-shuffled form when ps)
+  const float* bias;   // [Cout] or null
+  const float* res;    // residual added after the activation, same layout as y, or null
+  int act, ps, accum;  // accum: y += result
+  int Cout, Ho, Wo;
+};
+
+template <bool FULL, int MT, int NT>
+__device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT], const TileOut& t, int n,
+                                                     int co_base, int oy_first, int ox) {
+  const size_t HWo = (size_t)t.Ho * t.Wo;
+  const float slope = t.act == ACT_LRELU ? 0.1f : (t.act == ACT_RELU ? 0.f : 1.f);  // branch-free act
+  float bv[MT][16];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[mt][r] = 0.f;
+  if (t.bias) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+        bv[mt][r] = t.bias[(FULL || co < t.Cout) ? co : t.Cout - 1];
+      }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int oy = oy_first + nt;
+      const bool row_ok = FULL || oy < t.Ho;
+      const int oyc = row_ok ? oy : t.Ho - 1;
+      if (t.ps == 0) {
+        const size_t pix = (size_t)n * t.Cout * HWo + (size_t)oyc * t.Wo + ox;  // channel 0 of this pixel
+        float extra[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) extra[r] = 0.f;
+        if (t.res) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+            extra[r] = t.res[pix + (size_t)((FULL || co < t.Cout) ? co : t.Cout - 1) * HWo];
+          }
+        }
+        if (t.accum) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+            extra[r] += t.y[pix + (size_t)((FULL || co < t.Cout) ? co : t.Cout - 1) * HWo];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+          float v = acc[mt][nt][r] + bv[mt][r];
+          v = (v > 0.f ? v : v * slope) + extra[r];
+          if (FULL || (row_ok && co < t.Cout)) t.y[pix + (size_t)co * HWo] = v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+          float v = acc[mt][nt][r] + bv[mt][r];
+          v = v > 0.f ? v : v * slope;
+          const int cq = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
+          if (FULL || (row_ok && co < t.Cout))
+            t.y[(((size_t)n * (t.Cout >> 2) + cq) * (2 * t.Ho) + (2 * oy + dy)) * (size_t)(2 * t.Wo) +
+                (2 * ox + dx)] = v;
+        }
+      }
+    }
+  }
+}
+
+// co_block: first output channel of the workgroup's 32*MT block; (oy0, ox0): tile origin, TH rows;
+// oy_first: first of the NT rows this wave owns; lane = (lo, hi).
+template <int MT, int NT>
+__device__ __forceinline__ void store_mfma_tile(const f32x16 (&acc)[MT][NT], const TileOut& t, int n,
+                                                int co_block, int oy0, int th, int ox0, int oy_first, int lo,
+                                                int hi) {
+  const bool full = oy0 + th <= t.Ho && ox0 + 32 <= t.Wo && co_block + MT * 32 <= t.Cout;
+  const int ox = ox0 + lo;
+  if (full) {
+    store_mfma_tile_impl<true, MT, NT>(acc, t, n, co_block + 4 * hi, oy_first, ox);
+  } else if (ox < t.Wo) {
+    store_mfma_tile_impl<false, MT, NT>(acc, t, n, co_block + 4 * hi, oy_first, ox);
+  }
+}
+
 }  // namespace dvsr

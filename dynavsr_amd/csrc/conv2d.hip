@@ -147,36 +147,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvK a) {
   }
 
   // ---- epilogue: bias, activation, residual, (pixel-shuffled) store
-  const int ox = ox0 + lo;
-  if (ox >= a.Wo) return;
-  const size_t HWo = (size_t)a.Ho * a.Wo;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int oy = oy0 + 2 * wave + nt;
-      if (oy >= a.Ho) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = cb * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (co >= a.Cout) continue;
-        float v = acc[mt][nt][r];
-        if (a.bias) v += a.bias[co];
-        v = apply_act(v, a.act);
-        if (a.ps == 0) {
-          const size_t o = ((size_t)n * a.Cout + co) * HWo + (size_t)oy * a.Wo + ox;
-          if (a.res) v += a.res[o];
-          if (a.accum) v += a.y[o];
-          a.y[o] = v;
-        } else {
-          const int cq = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
-          const size_t o = (((size_t)n * (a.Cout >> 2) + cq) * (2 * a.Ho) + (2 * oy + dy)) *
-                               (size_t)(2 * a.Wo) + (2 * ox + dx);
-          a.y[o] = v;
-        }
-      }
-    }
-  }
+  const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo};
+  store_mfma_tile<2, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
 }
 
 template <int KS, int S, int CC>

@@ -121,23 +121,8 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_kernel(DcnK a) {
     }
   }
 
-  const int ox = ox0 + lo;
-  if (ox >= a.Wo) return;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int oy = oy0 + 2 * wave + nt;
-      if (oy >= a.Ho) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = cb * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (co >= a.Cout) continue;
-        float v = acc[mt][nt][r];
-        if (a.bias) v += a.bias[co];
-        a.out[((size_t)n * a.Cout + co) * P + (size_t)oy * a.Wo + ox] = apply_act(v, a.act);
-      }
-    }
+  const TileOut t{a.out, a.bias, nullptr, a.act, 0, 0, a.Cout, a.Ho, a.Wo};
+  store_mfma_tile<2, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
 }
 
 int mdcn_forward_run(const float* x, const float* off, long long off_bs, const float* msk,
@@ -389,23 +374,8 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_lds_kernel(DcnK2 a) {
     }
   }
 
-  const int ox = ox0 + lo;
-  if (ox >= a.W) return;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int oy = oy0 + 2 * wave + nt;
-      if (oy >= a.H) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = cb * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (co >= a.Cout) continue;
-        float v = acc[mt][nt][r];
-        if (a.bias) v += a.bias[co];
-        a.out[((size_t)n * a.Cout + co) * HW + (size_t)oy * a.W + ox] = apply_act(v, a.act);
-      }
-    }
+  const TileOut t{a.out, a.bias, nullptr, a.act, 0, 0, a.Cout, a.H, a.W};
+  store_mfma_tile<2, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -576,23 +546,8 @@ __global__ __launch_bounds__(256, 3) void mdcn_fwd_reg_kernel(DcnK2 a) {
     }
   }
 
-  const int ox = ox0 + lo;
-  if (ox >= a.W) return;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int oy = oy0 + 2 * wave + nt;
-      if (oy >= a.H) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = cb * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (co >= a.Cout) continue;
-        float v = acc[mt][nt][r];
-        if (a.bias) v += a.bias[co];
-        a.out[((size_t)n * a.Cout + co) * HW + (size_t)oy * a.W + ox] = apply_act(v, a.act);
-      }
-    }
+  const TileOut t{a.out, a.bias, nullptr, a.act, 0, 0, a.Cout, a.H, a.W};
+  store_mfma_tile<2, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
 }
 
 // wp = weights packed by pack_weights_kernel with KK=9, CC=8, wt=0 (one chunk per deformable group).
