@@ -84,7 +84,8 @@ def lib():
             raise RuntimeError(
                 "libdynavsr_hip.so is missing (%s). Build it with `python -m dynavsr_amd.build` "
                 "(hipcc --offload-arch=gfx950); there is no fallback path." % SO_PATH)
-        _lib = ctypes.CDLL(SO_PATH)
+        # DVSR_HIP_LIB: load another build of the same library (tools/ use it for the trace build)
+        _lib = ctypes.CDLL(os.environ.get("DVSR_HIP_LIB", SO_PATH))
         _lib._signatures = _declare(_lib)
     return _lib
 

@@ -26,6 +26,17 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+def build_trace():
+    """Debug library with the conv pipeline's cycle stamps compiled in (tools/conv_trace.py)."""
+    so = os.path.join(HERE, "libdynavsr_hip_trace.so")
+    srcs = [os.path.join(CSRC, s) for s in _sources()]
+    r = subprocess.run([HIPCC] + FLAGS + ["-DDVSR_CONV_TRACE", "-shared", "-o", so] + srcs,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode:
+        raise RuntimeError("trace build failed:\n" + r.stdout)
+    return so
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hdr_m = _deps_mtime()
@@ -59,4 +70,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--trace" in sys.argv:
+        print(build_trace())
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

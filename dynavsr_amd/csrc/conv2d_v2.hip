@@ -17,8 +17,10 @@
 //     by 32*MT output channels (MT = 2 or 1).  The host picks (TH, MT) per launch to minimise
 //     max(MFMA-pipe time of the busiest CU, latency of the serial chunk loop): 8x32x64 for the big
 //     layers, 4x32x64 / 4x32x32 when the grid would not fill 256 CUs x 2-3 workgroups.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -31,7 +33,23 @@ struct ConvK2 {
   long long x0_bs, x1_bs;
   int tiles_x, tiles_y, ntiles, ncb, nchunks;
   int in_ps, in_dil, Hs, Ws, accum;
+#ifdef DVSR_CONV_TRACE
+  long long* trace;  // debug build only (tools/conv_trace.py): 64 cycle stamps per workgroup
+#endif
 };
+
+// Debug timeline: thread 0 of every workgroup stamps s_memtime at the phase boundaries of the
+// pipeline.  Compiled in only with -DDVSR_CONV_TRACE (a separate library; the product build has none).
+#ifdef DVSR_CONV_TRACE
+#define DVSR_STAMP(i)                                                                              \
+  do {                                                                                             \
+    if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define DVSR_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
 
 template <int KS, int S, int CC, int TH, int MT>
 struct Conv2Shape {
@@ -109,16 +127,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
   const int oy0 = ty_ * TH, ox0 = tx_ * Sh::TW;
   const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: DMA addressing stays scalar
   const int lo = lane & 31, hi = lane >> 5;
   const int Ctot = a.c0 + a.c1;
   const size_t HW = (size_t)a.H * a.W;
   const float* x0n = a.x0 + (size_t)n * a.x0_bs;
-  const float* x1n = a.c1 ? a.x1 + (size_t)(n / a.x1_bdiv) * a.x1_bs : nullptr;
-  const size_t cstride0 = a.in_dil ? (size_t)a.Hs * a.Ws : HW;  // x0 channel stride (in_ps: below)
+  const float* x1n = a.c1 ? a.x1 + (size_t)(n / a.x1_bdiv) * a.x1_bs : x0n;
+  const size_t cstride0 = a.in_dil ? (size_t)a.Hs * a.Ws : HW;  // x0 channel stride
 
-  // per-thread halo elements: offset inside a channel plane + validity, fixed for all chunks
-  int eoff[E], elds[E];
+  // per-thread halo elements: byte offset inside a channel plane + validity, fixed for all chunks
+  unsigned eoffb[E];
+  int elds[E];
   bool evalid[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -133,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
       ok = ok && !((gy | gx) & 1) && (gy >> 1) < a.Hs && (gx >> 1) < a.Ws;
       off = (gy >> 1) * a.Ws + (gx >> 1);
     }
-    eoff[e] = ok ? off : 0;
+    eoffb[e] = ok ? (unsigned)off * 4u : 0u;
     evalid[e] = ok;
   }
 
@@ -149,38 +169,50 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
   // packed weights of this workgroup's cout block: 64-cout block (cbi*MT)/2, starting half (cbi*MT)%2
   const float* wp_cb = a.wp + ((size_t)((cbi * MT) >> 1) * a.nchunks * 2 + ((cbi * MT) & 1)) * Sh::HALF;
 
-  auto prefetch = [&](int k, int buf) {
+  // Halo loads of chunk k into registers (raw; masked when they are written to LDS).  All address
+  // math is wave-uniform scalar work: one base pointer per chunk (a chunk never straddles the two
+  // inputs: the host checks c0 % CC == 0), then a pointer increment per channel -- the channel
+  // stride, or the (+1, +2W-1, +1, +4HW-2W-1) walk of a pixel-shuffled input.  The lane part is the
+  // fixed 32-bit byte offset eoffb: global_load_dword v, v_off, s[base:base+1], no VALU at all.
+  auto issue_halo = [&](int k) {
     const int cbase = k * CC;
+    const bool second = cbase >= a.c0;  // only possible when c1 > 0
+    const float* b = second ? x1n : x0n;
+    const int ci = second ? cbase - a.c0 : cbase;
+    const size_t cs = second ? HW : cstride0;
+    const char* p = reinterpret_cast<const char*>(b + (size_t)ci * cs);
+    const size_t inc0 = a.in_ps ? 4 : cs * 4;                                    // c even -> c + 1
+    const size_t inc1 = a.in_ps ? ((size_t)2 * a.W - 1) * 4 : cs * 4;            // c % 4 == 1
+    const size_t inc3 = a.in_ps ? ((size_t)4 * HW - 2 * a.W - 1) * 4 : cs * 4;   // c % 4 == 3
 #pragma unroll
     for (int c = 0; c < CC; ++c) {
-      const int ci = cbase + c;
-      const int cic = ci < Ctot ? ci : 0;  // clamp so that the (unconditional) loads stay in bounds
-      const float* src;
-      if (a.in_ps) src = x0n + (size_t)(cic >> 2) * (4 * HW) + ((cic >> 1) & 1) * (2 * a.W) + (cic & 1);
-      else if (cic < a.c0) src = x0n + (size_t)cic * cstride0;
-      else src = x1n + (size_t)(cic - a.c0) * HW;
 #pragma unroll
-      for (int e = 0; e < E; ++e) rin[c][e] = src[eoff[e]];  // raw; masked when written to LDS
+      for (int e = 0; e < E; ++e) rin[c][e] = *reinterpret_cast<const float*>(p + eoffb[e]);
+      if (c + 1 < CC) {
+        const size_t inc = (c & 1) == 0 ? inc0 : ((c & 3) == 1 ? inc1 : inc3);
+        p += (cbase + c + 1 < Ctot) ? inc : 0;  // channels past the end re-read the last one (masked later)
+      }
     }
-    // weights of chunk k: LDS-DMA, 16 B per lane, destination = wave-uniform base + lane*16
+  };
+  // Weights of chunk k: LDS-DMA, 16 B per lane, destination = wave-uniform base + lane*16.  Every wave
+  // issues the same number of DMAs (the last piece is re-sent when NPIECE % 4 != 0), so the loop body
+  // stays one basic block and the compiler's vmcnt bookkeeping stays exact.
+  auto issue_dma = [&](int k, int buf) {
     const float* wsrc = wp_cb + (size_t)k * (2 * Sh::HALF);
     float* wdst = s_w0 + buf * Sh::BUF_FLOATS;
 #pragma unroll
     for (int j = 0; j < (Sh::NPIECE + 3) / 4; ++j) {
-      const int piece = j * 4 + wave;
-      if (piece < Sh::NPIECE)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(wsrc + piece * 256 + lane * 4),
-            (__attribute__((address_space(3))) void*)(wdst + piece * 256), 16, 0, 0);
+      int piece = j * 4 + wave;
+      piece = piece < Sh::NPIECE ? piece : Sh::NPIECE - 1;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(wsrc + piece * 256 + lane * 4),
+          (__attribute__((address_space(3))) void*)(wdst + piece * 256), 16, 0, 0);
     }
   };
-
-  prefetch(0, 0);
-  for (int k = 0; k < a.nchunks; ++k) {
-    const int buf = k & 1;
+  // halo registers of chunk k -> LDS buffer, transposed to [q][row][hi][x] x float4(kk): one
+  // ds_write_b128 per (q, hi)
+  auto write_halo = [&](int k, int buf) {
     float* s_in = s_in0 + buf * Sh::BUF_FLOATS;
-    const float* s_w = s_w0 + buf * Sh::BUF_FLOATS;
-    // halo tile -> LDS, transposed to [q][row][hi][x] x float4(kk): one ds_write_b128 per (q, hi)
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       if (tid + 256 * e < PLANE) {
@@ -198,11 +230,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
           }
       }
     }
-    __syncthreads();  // also drains this chunk's weight DMA (vmcnt(0) before the barrier)
-    if (k + 1 < a.nchunks) prefetch(k + 1, buf ^ 1);
+  };
 
-    // ---- MFMA over (tap, q): operands of step i+1 are read before the MFMAs of step i
-    constexpr int NSTEP = KK * KQ4;
+  // One chunk.  The non-MFMA work of the pipeline lives INSIDE the wave's MFMA stream: a wave that
+  // streams MFMAs keeps the SIMD's vector issue port, so work parked in another wave (or in a
+  // separate phase of this one) is not overlapped by the hardware -- measured with
+  // tools/conv_trace.py, a separate prefetch phase cost as much as the MFMA block itself.
+  //   top of the block : weight DMA + halo loads of chunk k+1 are issued (scalar address math only)
+  //   after 3/4 of it  : the halo registers (long since arrived) are masked and written to LDS
+  //   end              : one barrier
+  constexpr int NSTEP = KK * KQ4;
+  constexpr int SPLIT = (3 * NSTEP) / 4;
+  auto block = [&](int k, auto has_next_tag) {
+    constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
+    const int buf = k & 1;
+    const float* s_in = s_in0 + buf * Sh::BUF_FLOATS;
+    const float* s_w = s_w0 + buf * Sh::BUF_FLOATS;
+    if (k < 8) DVSR_STAMP(2 + 4 * k);
+    if (HAS_NEXT) {
+      issue_dma(k + 1, buf ^ 1);
+      issue_halo(k + 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: the scheduler would sink them to their use
+    }
+    if (k < 8) DVSR_STAMP(3 + 4 * k);
+    // MFMA over (tap, q): operands of step i+1 are read before the MFMAs of step i
     f32x4 A[2][MT], Bv[2][NT];
     auto load_ops = [&](int step, int rb) {
       const int tap = step / KQ4, q = step - tap * KQ4;
@@ -221,6 +272,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
     for (int step = 0; step < NSTEP; ++step) {
       const int rb = step & 1;
       if (step + 1 < NSTEP) load_ops(step + 1, rb ^ 1);
+      if (HAS_NEXT && step == SPLIT) {
+        if (k < 8) DVSR_STAMP(4 + 4 * k);
+        __builtin_amdgcn_sched_barrier(0);
+        write_halo(k + 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k < 8) DVSR_STAMP(5 + 4 * k);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -229,11 +287,29 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][mt][j], Bv[rb][nt][j], acc[mt][nt], 0, 0, 0);
     }
-  }
+    if (HAS_NEXT) __syncthreads();  // next buffers complete (the barrier's vmcnt(0) covers the DMA)
+  };
+
+  DVSR_STAMP(0);
+  issue_dma(0, 0);
+  issue_halo(0);
+  write_halo(0, 0);
+  DVSR_STAMP(1);
+  __syncthreads();
+  for (int k = 0; k + 1 < a.nchunks; ++k) block(k, std::true_type{});
+  block(a.nchunks - 1, std::false_type{});
 
   // ---- epilogue: bias, activation, residual / accumulate, (pixel-shuffled) store
+  DVSR_STAMP(40);
   const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo};
   store_mfma_tile<MT, NT>(acc, t, n, cbi * MT * 32, oy0, TH, ox0, oy0 + NT * wave, lo, hi);
+#ifdef DVSR_CONV_TRACE
+  DVSR_STAMP(41);
+  __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged
+  DVSR_STAMP(42);
+  if (a.trace && threadIdx.x == 0)
+    a.trace[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_ID
+#endif
 }
 
 template <int KS, int S, int CC, int TH, int MT>
@@ -241,14 +317,18 @@ static int launch_conv2(ConvK2 k, hipStream_t st) {
   using Sh = Conv2Shape<KS, S, CC, TH, MT>;
   auto kern = conv2d_pipe_kernel<KS, S, CC, TH, MT>;
   static bool attr_done = false;
+  size_t lds = Sh::LDS_BYTES;
+#ifdef DVSR_CONV_TRACE
+  // debug: DVSR_CONV_LDS=<bytes> inflates the LDS request to force fewer workgroups per CU
+  if (const char* e = getenv("DVSR_CONV_LDS")) lds = std::max(lds, (size_t)atol(e));
+#endif
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 32 * MT);
   const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
-  const size_t lds = Sh::LDS_BYTES;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, k);
   return check_launch("conv2d_pipe_kernel");
 }
@@ -286,11 +366,24 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
 int conv2_pch_cc(int ks, int cc) { return 2 * ks * ks * (cc / 8) * 2 * 32 * 4; }
 
 // `wp` = weights packed by pack_weights_kernel for this (ks, wt, geo.cc) combination.
+#ifdef DVSR_CONV_TRACE
+static long long* g_trace_buf = nullptr;
+static int g_trace_countdown = -1;
+// the launch_index-th conv2d_packed_run call from now on writes its timeline to buf
+extern "C" int dvsr_debug_conv_trace(void* buf, int launch_index) {
+  g_trace_buf = (long long*)buf;
+  g_trace_countdown = launch_index;
+  return 0;
+}
+#endif
+
 int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo,
                       hipStream_t st) {
   DVSR_REQUIRE(d.x0 && wp && d.y, DVSR_ERR_INVALID, "conv2d_packed: null x0/wp/y");
   DVSR_REQUIRE((d.ks == 1 && d.stride == 1) || (d.ks == 3 && (d.stride == 1 || d.stride == 2)),
                DVSR_ERR_UNSUPPORTED, "conv2d_packed: ks=%d stride=%d", d.ks, d.stride);
+  DVSR_REQUIRE(d.c1 == 0 || (d.c0 % geo.cc == 0 && !ex.in_ps && !ex.in_dil), DVSR_ERR_UNSUPPORTED,
+               "conv2d_packed: two inputs need c0 %% %d == 0 and a plain first input (c0=%d)", geo.cc, d.c0);
   ConvK2 k;
   k.x0 = d.x0; k.x1 = d.x1; k.wp = wp; k.bias = d.bias; k.res = d.res; k.y = d.y;
   k.N = d.N; k.c0 = d.c0; k.c1 = d.c1; k.H = d.H; k.W = d.W; k.Cout = d.Cout;
@@ -303,6 +396,10 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
   k.in_ps = ex.in_ps; k.in_dil = ex.in_dil; k.Hs = ex.Hs; k.Ws = ex.Ws; k.accum = ex.accum;
   if (k.in_ps) k.x0_bs = (long long)d.c0 * d.H * d.W;
   if (k.in_dil) k.x0_bs = (long long)d.c0 * ex.Hs * ex.Ws;
+#ifdef DVSR_CONV_TRACE
+  k.trace = (g_trace_countdown == 0) ? g_trace_buf : nullptr;
+  if (g_trace_countdown >= 0) --g_trace_countdown;
+#endif
   const int code = geo.cc * 100 + geo.th * 10 + geo.mt;
   if (d.ks == 3 && d.stride == 2) return launch_conv2<3, 2, 8, 8, 2>(k, st);
   if (d.ks == 3) {

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Cycle-stamp timeline of one conv2d_pipe_kernel launch inside the EDVR forward.
+
+Needs the debug build (python -m dynavsr_amd.build --trace); run on the GPU box:
+    python tools/conv_trace.py [launch_index [H W]]
+Stamps (s_memtime, thread 0 of each workgroup): 0 start, 1 first prefetch issued, per chunk k:
+2+4k loop top, 3+4k halo written to LDS, 4+4k barrier passed, 5+4k next prefetch issued (then the
+MFMAs run until the next loop top), 40 loop done, 41 stores issued, 42 stores acknowledged.
+"""
+import ctypes
+import os
+import sys
+
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("DVSR_HIP_LIB", os.path.join(HERE, "dynavsr_amd", "libdynavsr_hip_trace.so"))
+sys.path.insert(0, HERE)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from dynavsr_amd import _lib, engine, synth  # noqa: E402
+from dynavsr_amd.models.archs.EDVR_arch import EDVR  # noqa: E402
+
+idx = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+h = int(sys.argv[2]) if len(sys.argv) > 3 else 180
+w = int(sys.argv[3]) if len(sys.argv) > 3 else 320
+net = EDVR()
+net.load_state_dict(synth.edvr_state_dict(0))
+net = net.cuda()
+x = synth.clip(1, 1, 5, h, w, smooth=False).cuda()
+plan = engine.get_plan(net._cfg(), 1, h, w)
+params = [p.detach().contiguous() for p in net.ordered_parameters()]
+ws = torch.empty(plan.workspace_bytes(False), dtype=torch.uint8, device="cuda")
+out = torch.empty(1, 3, 4 * h, 4 * w, device="cuda")
+for _ in range(2):
+    plan.forward(params, x, out, ws)
+torch.cuda.synchronize()
+NB = 1 << 16
+buf = torch.zeros(NB * 64, dtype=torch.int64, device="cuda")
+fn = _lib.lib().dvsr_debug_conv_trace
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+fn(buf.data_ptr(), idx)
+plan.forward(params, x, out, ws)
+torch.cuda.synchronize()
+t = buf.cpu().numpy().reshape(NB, 64)
+used = t[:, 0] != 0
+t = t[used]
+print("workgroups traced: %d" % len(t))
+t0 = t[:, 0].min()
+hw = t[:, 63]
+# HW_ID (gfx9): wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13] ... ; XCC in a separate reg
+cu = (hw >> 8) & 0xF
+se = (hw >> 13) & 0x7
+start = t[:, 0] - t0
+end = t[:, 42] - t0
+print("kernel span (cycles): %d   [stamps are s_memtime ticks]" % end.max())
+
+
+def stat(name, d):
+    d = np.asarray(d, dtype=np.float64)
+    print("%-34s median %8.0f  p10 %8.0f  p90 %8.0f  mean %8.0f" % (name, np.median(d), np.percentile(d, 10),
+                                                                    np.percentile(d, 90), d.mean()))
+
+
+stat("workgroup lifetime", t[:, 42] - t[:, 0])
+stat("prologue: first prefetch issue", t[:, 1] - t[:, 0])
+nch = 8
+for k in range(nch):
+    b = 2 + 4 * k
+    if not t[:, b].any():
+        nch = k
+        break
+halo = np.stack([t[:, 3 + 4 * k] - t[:, 2 + 4 * k] for k in range(nch)], 1)
+barr = np.stack([t[:, 4 + 4 * k] - t[:, 3 + 4 * k] for k in range(nch)], 1)
+pref = np.stack([t[:, 5 + 4 * k] - t[:, 4 + 4 * k] for k in range(nch)], 1)
+nxt = [t[:, 2 + 4 * (k + 1)] if k + 1 < nch else t[:, 40] for k in range(nch)]
+mfma = np.stack([nxt[k] - t[:, 5 + 4 * k] for k in range(nch)], 1)
+for k in range(nch):
+    print("chunk %d: wait+LDS write %7.0f | barrier %7.0f | prefetch issue %7.0f | MFMA block %7.0f   (medians)" %
+          (k, np.median(halo[:, k]), np.median(barr[:, k]), np.median(pref[:, k]), np.median(mfma[:, k])))
+for k in range(1, nch):
+    if t[:, 48 + k].any():
+        print("prefetch of chunk %d: halo-load issue %7.0f | weight-DMA issue %7.0f   (medians)" %
+              (k, np.median(t[:, 48 + k] - t[:, 4 + 4 * (k - 1)]), np.median(t[:, 5 + 4 * (k - 1)] - t[:, 48 + k])))
+stat("sum wait+LDS write / wg", halo.sum(1))
+stat("sum barrier / wg", barr.sum(1))
+stat("sum prefetch issue / wg", pref.sum(1))
+stat("sum MFMA block / wg", mfma.sum(1))
+stat("epilogue issue", t[:, 41] - t[:, 40])
+stat("epilogue store ack", t[:, 42] - t[:, 41])
+# start-time histogram: how many rounds of workgroups
+order = np.argsort(start)
+print("start times (cycles) deciles:", np.percentile(start, [0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100]).astype(int))
+print("end   times (cycles) deciles:", np.percentile(end, [0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100]).astype(int))
