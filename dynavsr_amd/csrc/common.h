@@ -65,9 +65,10 @@ struct TileOut {
 
 template <bool FULL, int MT, int NT>
 __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT], const TileOut& t, int n,
-                                                     int co_base, int oy_first, int ox) {
+                                                     int co_block, int hi, int oy_first, int ox) {
   const size_t HWo = (size_t)t.Ho * t.Wo;
   const float slope = t.act == ACT_LRELU ? 0.1f : (t.act == ACT_RELU ? 0.f : 1.f);  // branch-free act
+  const int co_base = co_block + 4 * hi;
   float bv[MT][16];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -90,37 +91,44 @@ __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT]
       const bool row_ok = FULL || oy < t.Ho;
       const int oyc = row_ok ? oy : t.Ho - 1;
       if (t.ps == 0) {
+        // Full tiles: address = wave-uniform channel plane (scalar registers) + one per-lane 32-bit byte
+        // offset shared by all 16 registers, i.e. no vector address arithmetic per store.  Edge tiles
+        // compute (and clamp) the channel per lane.
+        const unsigned voff = (unsigned)(((size_t)(4 * hi) * HWo + (size_t)oyc * t.Wo + ox) * 4);
         const size_t pix = (size_t)n * t.Cout * HWo + (size_t)oyc * t.Wo + ox;  // channel 0 of this pixel
+        auto addr = [&](const float* base, int r) -> const float* {
+          if (FULL) {
+            const int cu = co_block + mt * 32 + (r & 3) + 8 * (r >> 2);  // uniform part of the channel
+            return reinterpret_cast<const float*>(
+                reinterpret_cast<const char*>(base + ((size_t)n * t.Cout + cu) * HWo) + voff);
+          }
+          const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+          return base + pix + (size_t)(co < t.Cout ? co : t.Cout - 1) * HWo;
+        };
         float extra[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) extra[r] = 0.f;
         if (t.res) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
-            extra[r] = t.res[pix + (size_t)((FULL || co < t.Cout) ? co : t.Cout - 1) * HWo];
-          }
+          for (int r = 0; r < 16; ++r) extra[r] = *addr(t.res, r);
         }
         if (t.accum) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
-            extra[r] += t.y[pix + (size_t)((FULL || co < t.Cout) ? co : t.Cout - 1) * HWo];
-          }
+          for (int r = 0; r < 16; ++r) extra[r] += *addr(t.y, r);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
           float v = acc[mt][nt][r] + bv[mt][r];
-          v = (v > 0.f ? v : v * slope) + extra[r];
-          if (FULL || (row_ok && co < t.Cout)) t.y[pix + (size_t)co * HWo] = v;
+          v = fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)) + extra[r];  // == v > 0 ? v : slope * v, no VCC round trip
+          if (FULL || (row_ok && co < t.Cout)) *const_cast<float*>(addr(t.y, r)) = v;
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
           float v = acc[mt][nt][r] + bv[mt][r];
-          v = v > 0.f ? v : v * slope;
+          v = fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f));
           const int cq = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
           if (FULL || (row_ok && co < t.Cout))
             t.y[(((size_t)n * (t.Cout >> 2) + cq) * (2 * t.Ho) + (2 * oy + dy)) * (size_t)(2 * t.Wo) +
@@ -140,9 +148,9 @@ __device__ __forceinline__ void store_mfma_tile(const f32x16 (&acc)[MT][NT], con
   const bool full = oy0 + th <= t.Ho && ox0 + 32 <= t.Wo && co_block + MT * 32 <= t.Cout;
   const int ox = ox0 + lo;
   if (full) {
-    store_mfma_tile_impl<true, MT, NT>(acc, t, n, co_block + 4 * hi, oy_first, ox);
+    store_mfma_tile_impl<true, MT, NT>(acc, t, n, co_block, hi, oy_first, ox);
   } else if (ox < t.Wo) {
-    store_mfma_tile_impl<false, MT, NT>(acc, t, n, co_block + 4 * hi, oy_first, ox);
+    store_mfma_tile_impl<false, MT, NT>(acc, t, n, co_block, hi, oy_first, ox);
   }
 }
 

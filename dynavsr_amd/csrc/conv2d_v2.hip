@@ -291,6 +291,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
   };
 
   DVSR_STAMP(0);
+#ifdef DVSR_CONV_TRACE
+  if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + 60] = __builtin_amdgcn_s_memrealtime();
+#endif
   issue_dma(0, 0);
   issue_halo(0);
   write_halo(0, 0);
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
   DVSR_STAMP(41);
   __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged
   DVSR_STAMP(42);
+  if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + 61] = __builtin_amdgcn_s_memrealtime();
   if (a.trace && threadIdx.x == 0)
     a.trace[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_ID
 #endif

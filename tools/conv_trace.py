@@ -3,9 +3,9 @@
 
 Needs the debug build (python -m dynavsr_amd.build --trace); run on the GPU box:
     python tools/conv_trace.py [launch_index [H W]]
-Stamps (s_memtime, thread 0 of each workgroup): 0 start, 1 first prefetch issued, per chunk k:
-2+4k loop top, 3+4k halo written to LDS, 4+4k barrier passed, 5+4k next prefetch issued (then the
-MFMAs run until the next loop top), 40 loop done, 41 stores issued, 42 stores acknowledged.
+Stamps (s_memtime, thread 0 of each workgroup): 0 start, 1 chunk 0 staged, per chunk k: 2+4k block top,
+3+4k next chunk's DMA + halo loads issued, 4+4k 3/4 of the MFMAs issued, 5+4k next halo written to LDS
+(then the rest of the MFMAs and the barrier), 40 loop done, 41 stores issued, 42 stores acknowledged.
 """
 import ctypes
 import os
@@ -20,7 +20,7 @@ import torch  # noqa: E402
 from dynavsr_amd import _lib, engine, synth  # noqa: E402
 from dynavsr_amd.models.archs.EDVR_arch import EDVR  # noqa: E402
 
-idx = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+sel = sys.argv[1] if len(sys.argv) > 1 else "1"  # launch index among the packed convs, or an op name
 h = int(sys.argv[2]) if len(sys.argv) > 3 else 180
 w = int(sys.argv[3]) if len(sys.argv) > 3 else 320
 net = EDVR()
@@ -38,6 +38,13 @@ NB = 1 << 16
 buf = torch.zeros(NB * 64, dtype=torch.int64, device="cuda")
 fn = _lib.lib().dvsr_debug_conv_trace
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+if sel.isdigit():
+    idx = int(sel)
+else:
+    kinds = [(k, nm) for (k, nm, _, _) in plan.op_info()]
+    pos = next(i for i, (k, nm) in enumerate(kinds) if nm.split("[")[0] == sel)
+    idx = sum(1 for k, nm in kinds[:pos] if k.startswith("conv"))
+    print("op %s = tape position %d, packed-conv launch %d" % (sel, pos, idx))
 fn(buf.data_ptr(), idx)
 plan.forward(params, x, out, ws)
 torch.cuda.synchronize()
@@ -62,29 +69,29 @@ def stat(name, d):
 
 
 stat("workgroup lifetime", t[:, 42] - t[:, 0])
-stat("prologue: first prefetch issue", t[:, 1] - t[:, 0])
+rt = (t[:, 61] - t[:, 60]).astype(np.float64)  # s_memrealtime: constant 100 MHz
+print("core clock from s_memtime / s_memrealtime: %.0f MHz (median over workgroups); kernel wall span %.1f us" %
+      (np.median((t[:, 42] - t[:, 0]) / np.maximum(rt, 1)) * 100.0, (t[:, 61].max() - t[:, 60].min()) / 100.0))
+stat("prologue: chunk 0 staged", t[:, 1] - t[:, 0])
 nch = 8
 for k in range(nch):
     b = 2 + 4 * k
     if not t[:, b].any():
         nch = k
         break
-halo = np.stack([t[:, 3 + 4 * k] - t[:, 2 + 4 * k] for k in range(nch)], 1)
-barr = np.stack([t[:, 4 + 4 * k] - t[:, 3 + 4 * k] for k in range(nch)], 1)
-pref = np.stack([t[:, 5 + 4 * k] - t[:, 4 + 4 * k] for k in range(nch)], 1)
+pref = np.stack([t[:, 3 + 4 * k] - t[:, 2 + 4 * k] for k in range(nch)], 1)
+has_w = [t[:, 4 + 4 * k].any() for k in range(nch)]
+m1 = np.stack([(t[:, 4 + 4 * k] if has_w[k] else t[:, 3 + 4 * k]) - t[:, 3 + 4 * k] for k in range(nch)], 1)
+wr = np.stack([(t[:, 5 + 4 * k] - t[:, 4 + 4 * k]) if has_w[k] else 0 * t[:, 0] for k in range(nch)], 1)
 nxt = [t[:, 2 + 4 * (k + 1)] if k + 1 < nch else t[:, 40] for k in range(nch)]
-mfma = np.stack([nxt[k] - t[:, 5 + 4 * k] for k in range(nch)], 1)
+m2 = np.stack([nxt[k] - (t[:, 5 + 4 * k] if has_w[k] else t[:, 3 + 4 * k]) for k in range(nch)], 1)
 for k in range(nch):
-    print("chunk %d: wait+LDS write %7.0f | barrier %7.0f | prefetch issue %7.0f | MFMA block %7.0f   (medians)" %
-          (k, np.median(halo[:, k]), np.median(barr[:, k]), np.median(pref[:, k]), np.median(mfma[:, k])))
-for k in range(1, nch):
-    if t[:, 48 + k].any():
-        print("prefetch of chunk %d: halo-load issue %7.0f | weight-DMA issue %7.0f   (medians)" %
-              (k, np.median(t[:, 48 + k] - t[:, 4 + 4 * (k - 1)]), np.median(t[:, 5 + 4 * (k - 1)] - t[:, 48 + k])))
-stat("sum wait+LDS write / wg", halo.sum(1))
-stat("sum barrier / wg", barr.sum(1))
+    print("chunk %d: prefetch issue %6.0f | MFMA part 1 %6.0f | wait+LDS write %6.0f | MFMA part 2 + barrier %6.0f   (medians)" %
+          (k, np.median(pref[:, k]), np.median(m1[:, k]), np.median(wr[:, k]), np.median(m2[:, k])))
 stat("sum prefetch issue / wg", pref.sum(1))
-stat("sum MFMA block / wg", mfma.sum(1))
+stat("sum MFMA part 1 / wg", m1.sum(1))
+stat("sum wait+LDS write / wg", wr.sum(1))
+stat("sum MFMA part 2 + barrier / wg", m2.sum(1))
 stat("epilogue issue", t[:, 41] - t[:, 40])
 stat("epilogue store ack", t[:, 42] - t[:, 41])
 # start-time histogram: how many rounds of workgroups
