@@ -14,6 +14,8 @@
 //   B (lane l): x [c = l&31][px shifted by tap]   <- s_x[c*PLANEP + (py*S+ty)*IW + px*S+tx]
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -114,6 +116,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
   // ---- partial[slot][tap][o][c]  (o, c padded to the 64-blocks of the grid), slot = split % nslot
   const int OP = a.nob * 64, CP = a.ncb * 64;
   const int slot = split % a.nslot;
+#ifdef DVSR_WGRAD_NOFLUSH  // debug ablation: keep the accumulators alive with one atomic per lane
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < KK; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[t][r];
+    unsafeAtomicAdd(a.partial + lane, s);
+    return;
+  }
+#endif
 #pragma unroll
   for (int t = 0; t < KK; ++t)
 #pragma unroll
@@ -123,6 +136,155 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
       unsafeAtomicAdd(a.partial + (((size_t)slot * KK + t) * OP + o) * CP + c, acc[t][r]);
     }
   if (cbk == 0 && tid < 64) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + ob * 64 + tid, db);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Pipelined variant for the 3x3 stride-1 layers (all but two of EDVR's convolutions).  Same
+// decomposition and flush as above; what changes is how a tile gets into LDS:
+//   * the tile of the NEXT iteration is fetched into registers before the MFMAs of the current one
+//     (64 loads per lane, all in flight together) and written to the other LDS buffer after 3/4 of
+//     them -- the simple kernel above pays a full memory latency per loop iteration of its staging
+//     loops (measured: ~55 us per 64-pixel tile at 44x80, against 8.5 us of MFMA work);
+//   * every wave stages whole channels (wave w: channels 16w..16w+15 of both operands), so a load's
+//     address is a scalar channel-plane base plus a per-lane 32-bit offset that is fixed for the tile;
+//   * the bias gradient falls out of the A operands the MFMA loop reads anyway (one v_add per k-step).
+// 2 x 51.7 KB of LDS: one workgroup per CU, which is also what the pixel split produces.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void conv2d_wgrad_pipe_kernel(WgradK a) {
+  using Sh = WgShape<3, 1>;
+  constexpr int KK = 9, IW = Sh::IW, PLANE = Sh::PLANE, PLANEP = Sh::PLANEP, GROW = Sh::GROW, NPX = Sh::NPX;
+  constexpr int XM = (PLANE + 63) / 64;  // wave-instructions per channel plane of the x tile
+  constexpr int BUF = 64 * GROW + 64 * PLANEP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int split = blockIdx.x, ob = blockIdx.y, cbk = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int ot = wave >> 1, ct = wave & 1;
+  const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
+
+  // lane-fixed parts of the staging addresses
+  const int gpy = lane >> 5, gpx = lane & 31;  // gy tile: lane = pixel
+  const unsigned g_lane = a.gy_ps ? (unsigned)((2 * gpy) * (2 * a.Wo) + 2 * gpx) : (unsigned)(gpy * a.Wo + gpx);
+  int xiy[XM], xix[XM];
+#pragma unroll
+  for (int m = 0; m < XM; ++m) {
+    const int e = lane + 64 * m;
+    xiy[m] = e / IW;
+    xix[m] = e - xiy[m] * IW;
+  }
+
+  f32x16 acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float db = 0.f;
+  const bool do_db = cbk == 0 && ct == 0;
+
+  float rg[16], rx[16][XM];
+  bool g_ok, x_ok[XM];
+  auto issue_loads = [&](int tile) {
+    const int tx_ = tile % a.tiles_x;
+    const int t2 = tile / a.tiles_x;
+    const int ty_ = t2 % a.tiles_y;
+    const int n = t2 / a.tiles_y;
+    const int oy0 = ty_ * Sh::TH, ox0 = tx_ * Sh::TW;
+    // gy: 16 channels per wave, one pixel per lane
+    g_ok = oy0 + gpy < a.Ho && ox0 + gpx < a.Wo;
+    const unsigned g_off = g_ok ? g_lane * 4u : 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int co = ob * 64 + wave * 16 + j;
+      co = co < a.Cout ? co : a.Cout - 1;  // clamped channels are masked at the LDS write
+      const float* base;
+      if (a.gy_ps)
+        base = a.gy + (((size_t)n * (a.Cout >> 2) + (co >> 2)) * (2 * a.Ho) + 2 * oy0 + ((co >> 1) & 1)) *
+                          (size_t)(2 * a.Wo) + 2 * ox0 + (co & 1);
+      else
+        base = a.gy + ((size_t)n * a.Cout + co) * HWo + (size_t)oy0 * a.Wo + ox0;
+      rg[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + g_off);
+    }
+    // x halo: 16 channels per wave, XM x 64 plane elements per channel
+    const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
+    unsigned x_off[XM];
+#pragma unroll
+    for (int m = 0; m < XM; ++m) {
+      const int gy_ = iy0 + xiy[m], gx_ = ix0 + xix[m];
+      x_ok[m] = lane + 64 * m < PLANE && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W;
+      x_off[m] = x_ok[m] ? (unsigned)(gy_ * a.W + gx_) * 4u : 0u;
+    }
+    const float* xn = a.x + (size_t)(n / a.x_bdiv) * a.x_bs;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int ci = cbk * 64 + wave * 16 + j;
+      ci = ci < a.Cin ? ci : a.Cin - 1;
+      const char* base = reinterpret_cast<const char*>(xn + (size_t)ci * HW);
+#pragma unroll
+      for (int m = 0; m < XM; ++m) rx[j][m] = *reinterpret_cast<const float*>(base + x_off[m]);
+    }
+  };
+  auto write_lds = [&](int buf) {
+    float* s_g = smem + buf * BUF;
+    float* s_x = s_g + 64 * GROW;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int o = wave * 16 + j;
+      s_g[o * GROW + lane] = (g_ok && ob * 64 + o < a.Cout) ? rg[j] : 0.f;
+#pragma unroll
+      for (int m = 0; m < XM; ++m)
+        if (lane + 64 * m < PLANE) s_x[o * PLANEP + lane + 64 * m] = (x_ok[m] && cbk * 64 + o < a.Cin) ? rx[j][m] : 0.f;
+    }
+  };
+  auto mfma_steps = [&](int buf, int k0, int k1) {
+    const float* s_g = smem + buf * BUF;
+    const float* s_x = s_g + 64 * GROW;
+#pragma unroll 4
+    for (int kk = k0; kk < k1; ++kk) {
+      const int p = 2 * kk + hi;
+      const int py = p >> 5, px = p & 31;
+      const float av = s_g[(ot * 32 + lo) * GROW + p];
+      const float* bx = s_x + (ct * 32 + lo) * PLANEP + py * IW + px;
+      db += av;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const int ty = t / 3, tx = t - ty * 3;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bx[ty * IW + tx], acc[t], 0, 0, 0);
+      }
+    }
+  };
+
+  int tile = split;
+  if (tile < a.ntiles) {
+    issue_loads(tile);
+    write_lds(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < a.ntiles; tile += a.nsplit) {
+    const bool has_next = tile + a.nsplit < a.ntiles;
+    if (has_next) issue_loads(tile + a.nsplit);
+    mfma_steps(buf, 0, 3 * NPX / 8);
+    if (has_next) write_lds(buf ^ 1);
+    mfma_steps(buf, 3 * NPX / 8, NPX / 2);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- partial[slot][tap][o][c]  (o, c padded to the 64-blocks of the grid), slot = split % nslot
+  const int OP = a.nob * 64, CP = a.ncb * 64;
+  const int slot = split % a.nslot;
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ob * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int c = cbk * 64 + ct * 32 + lo;
+      unsafeAtomicAdd(a.partial + (((size_t)slot * KK + t) * OP + o) * CP + c, acc[t][r]);
+    }
+  // lane (lo, hi) summed gy[o = ot*32 + lo] over the pixels of parity hi
+  if (do_db) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + ob * 64 + ot * 32 + lo, db);
 }
 
 // dW[o][c_off + c][tap] = sum_s partial[s][tap][o][c];  db[o] = sum_s dbp[s][o]
@@ -168,11 +330,16 @@ static void launch_wgrad(const WgradK& k, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
 }
 
-static int wgrad_splits(int ntiles, int nob, int ncb, int KK) {
+static int wgrad_splits(int ntiles, int nob, int ncb, int KK, bool one_per_cu = false) {
   // one workgroup per CU when the pixel grid is small (latency-bound: every extra tile per workgroup
   // is serial time), two per CU for big grids
   (void)KK;
-  int s = ceil_div(ntiles >= 2048 ? 512 : 256, nob * ncb);
+  static int force = -2;  // DVSR_WGRAD_SPLITS=<n> pins the number of pixel splits (A/B aid)
+  if (force == -2) {
+    const char* v = getenv("DVSR_WGRAD_SPLITS");
+    force = v ? atoi(v) : -1;
+  }
+  int s = force > 0 ? force : ceil_div((ntiles >= 2048 && !one_per_cu) ? 512 : 256, nob * ncb);
   if (s > ntiles) s = ntiles;
   return s < 1 ? 1 : s;
 }
@@ -205,7 +372,7 @@ int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, 2); k.ntiles = k.tiles_x * k.tiles_y * N;
   k.nob = ceil_div(Cout, 64); k.ncb = ceil_div(Cin, 64);
   const int KK = ks * ks;
-  k.nsplit = wgrad_splits(k.ntiles, k.nob, k.ncb, KK);
+  k.nsplit = wgrad_splits(k.ntiles, k.nob, k.ncb, KK, ks == 3 && stride == 1);
   k.nslot = k.nsplit < 8 ? k.nsplit : 8;
   k.partial = (float*)ws;
   k.dbp = k.partial + (size_t)k.nslot * KK * k.nob * 64 * k.ncb * 64;
@@ -214,7 +381,20 @@ int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy
     DVSR_REQUIRE(hipMemsetAsync(ws, 0, zbytes, st) == hipSuccess, DVSR_ERR_HIP, "conv2d_wgrad: memset failed");
   }
   dim3 grid(k.nsplit, k.nob, k.ncb);
-if (ks == 3 && stride == 1) launch_wgrad<3, 1>(k, grid, st);
+  static int use_simple = -1;  // DVSR_WGRAD_SIMPLE=1: the non-pipelined kernel for every shape (A/B aid)
+  if (use_simple < 0) {
+    const char* v = getenv("DVSR_WGRAD_SIMPLE");
+    use_simple = (v && v[0] == '1') ? 1 : 0;
+  }
+  if (ks == 3 && stride == 1 && !use_simple) {
+    constexpr size_t lds = 2 * (size_t)(64 * WgShape<3, 1>::GROW + 64 * WgShape<3, 1>::PLANEP) * sizeof(float);
+    static bool done = false;
+    if (!done) {
+      hipFuncSetAttribute((const void*)conv2d_wgrad_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      done = true;
+    }
+    hipLaunchKernelGGL(conv2d_wgrad_pipe_kernel, grid, dim3(256), lds, st, k);
+  } else if (ks == 3 && stride == 1) launch_wgrad<3, 1>(k, grid, st);
   else if (ks == 3) launch_wgrad<3, 2>(k, grid, st);
   else launch_wgrad<1, 1>(k, grid, st);
   int rc = check_launch("conv2d_wgrad_kernel");

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Weight-gradient kernel alone (dvsr_conv2d_backward with gx = NULL) at the inner-step and bench sizes.
+usage (GPU box): python tools/wgrad_bench.py [reps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dynavsr_amd import hipops  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3
+
+
+torch.manual_seed(0)
+for (n, cin, cout, h, w, ks) in [(5, 64, 64, 44, 80, 3), (5, 128, 64, 44, 80, 3), (5, 64, 216, 44, 80, 3),
+                                 (1, 64, 64, 176, 320, 3), (1, 320, 64, 44, 80, 1), (5, 64, 64, 22, 40, 3),
+                                 (5, 64, 64, 180, 320, 3), (1, 64, 64, 720, 1280, 3)]:
+    x = torch.randn(n, cin, h, w, device="cuda")
+    gy = torch.randn(n, cout, h, w, device="cuda")
+    wt = torch.randn(cout, cin, ks, ks, device="cuda")
+    us = timeit(lambda: hipops.conv2d_backward(gy, x, wt, need_gx=False))
+    fl = 2.0 * n * h * w * cin * cout * ks * ks
+    print("wgrad %dx%d %3d->%3d k%d %4dx%-4d %9.1f us  %7.2f TFLOP/s" % (n, cin, cin, cout, ks, h, w, us, fl / us / 1e6),
+          flush=True)
