@@ -65,7 +65,8 @@ struct Conv2Shape {
   static constexpr size_t LDS_BYTES = (size_t)2 * BUF_FLOATS * sizeof(float);
 };
 
-int conv2_cc(int ks, int stride) { (void)stride; return ks == 1 ? 32 : 8; }
+// channels per chunk: enough k-steps per barrier (72 MFMAs per wave for 3x3, 64 for 2x2 and 1x1)
+int conv2_cc(int ks, int stride) { (void)stride; return ks == 1 ? 32 : (ks == 2 ? 16 : 8); }
 int conv2_pch(int ks, int stride) {  // packed floats per (64-cout block, chunk): two halves
   return 2 * ks * ks * (conv2_cc(ks, stride) / 8) * 2 * 32 * 4;
 }
@@ -357,9 +358,9 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
     const char* v = getenv("DVSR_CONV_TILE");
     force = (v && v[0] >= '0' && v[0] <= '2') ? v[0] - '0' : -1;
   }
-  const int cc = ks == 1 ? 32 : 8;
+  const int cc = conv2_cc(ks, stride);
   if (ks == 3 && stride == 2) return ConvGeo{8, 8, 2};
-  if (force == 0) return ConvGeo{cc, 8, 2};
+  if (force == 0 && ks != 2) return ConvGeo{cc, 8, 2};
   if (force == 1) return ConvGeo{cc, 4, 2};
   if (force == 2) return ConvGeo{cc, 4, 1};
   const double c42 = conv2_pipe_cost(4, 2, ks * ks, cc, N, Ho, Wo, Cout);
@@ -384,7 +385,7 @@ extern "C" int dvsr_debug_conv_trace(void* buf, int launch_index) {
 int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo,
                       hipStream_t st) {
   DVSR_REQUIRE(d.x0 && wp && d.y, DVSR_ERR_INVALID, "conv2d_packed: null x0/wp/y");
-  DVSR_REQUIRE((d.ks == 1 && d.stride == 1) || (d.ks == 3 && (d.stride == 1 || d.stride == 2)),
+  DVSR_REQUIRE(((d.ks == 1 || d.ks == 2) && d.stride == 1) || (d.ks == 3 && (d.stride == 1 || d.stride == 2)),
                DVSR_ERR_UNSUPPORTED, "conv2d_packed: ks=%d stride=%d", d.ks, d.stride);
   DVSR_REQUIRE(d.c1 == 0 || (d.c0 % geo.cc == 0 && !ex.in_ps && !ex.in_dil), DVSR_ERR_UNSUPPORTED,
                "conv2d_packed: two inputs need c0 %% %d == 0 and a plain first input (c0=%d)", geo.cc, d.c0);
@@ -411,6 +412,11 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
       case 882: return launch_conv2<3, 1, 8, 8, 2>(k, st);
       case 842: return launch_conv2<3, 1, 8, 4, 2>(k, st);
       case 841: return launch_conv2<3, 1, 8, 4, 1>(k, st);
+    }
+  } else if (d.ks == 2) {  // the estimator's 4x4 stride-2 convs, re-expressed over a space-to-depth input
+    switch (code) {
+      case 1642: return launch_conv2<2, 1, 16, 4, 2>(k, st);
+      case 1641: return launch_conv2<2, 1, 16, 4, 1>(k, st);
     }
   } else {
     switch (code) {

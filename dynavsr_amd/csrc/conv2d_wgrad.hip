@@ -15,6 +15,7 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Pipelined variant for the 3x3 stride-1 layers (all but two of EDVR's convolutions).  Same
+// Pipelined variant for the stride-1 layers (3x3: all but two of EDVR's convolutions; 2x2 and 1x1: the
+// estimator's re-expressed 4x4 convs, the TSA / fusion 1x1s and the DCN weight gradient).  Same
 // decomposition and flush as above; what changes is how a tile gets into LDS:
 //   * the tile of the NEXT iteration is fetched into registers before the MFMAs of the current one
 //     (64 loads per lane, all in flight together) and written to the other LDS buffer after 3/4 of
@@ -150,9 +152,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
 //   * the bias gradient falls out of the A operands the MFMA loop reads anyway (one v_add per k-step).
 // 2 x 51.7 KB of LDS: one workgroup per CU, which is also what the pixel split produces.
 // -------------------------------------------------------------------------------------------------
+template <int KS>
 __global__ __launch_bounds__(256, 1) void conv2d_wgrad_pipe_kernel(WgradK a) {
-  using Sh = WgShape<3, 1>;
-  constexpr int KK = 9, IW = Sh::IW, PLANE = Sh::PLANE, PLANEP = Sh::PLANEP, GROW = Sh::GROW, NPX = Sh::NPX;
+  using Sh = WgShape<KS, 1>;
+  constexpr int KK = KS * KS, IW = Sh::IW, PLANE = Sh::PLANE, PLANEP = Sh::PLANEP, GROW = Sh::GROW, NPX = Sh::NPX;
   constexpr int XM = (PLANE + 63) / 64;  // wave-instructions per channel plane of the x tile
   constexpr int BUF = 64 * GROW + 64 * PLANEP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_pipe_kernel(WgradK a) {
       db += av;
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
-        const int ty = t / 3, tx = t - ty * 3;
+        const int ty = t / KS, tx = t - ty * KS;
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bx[ty * IW + tx], acc[t], 0, 0, 0);
       }
     }
@@ -344,8 +347,8 @@ static int wgrad_splits(int ntiles, int nob, int ncb, int KK, bool one_per_cu = 
   return s < 1 ? 1 : s;
 }
 
-size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride) {
-  const int pad = ks / 2;
+size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad) {
+  if (pad < 0) pad = ks / 2;
   const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
   const int ntiles = ceil_div(Wo, 32) * ceil_div(Ho, 2) * N;
   const int nob = ceil_div(Cout, 64), ncb = ceil_div(Cin, 64), KK = ks * ks;
@@ -358,21 +361,22 @@ size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int 
 // gradient (and db when non-null).
 int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
                      float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
-                     int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero) {
+                     int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad) {
   DVSR_REQUIRE(x && gy && dW && ws, DVSR_ERR_INVALID, "conv2d_wgrad: null pointer");
-  DVSR_REQUIRE((ks == 1 && stride == 1) || (ks == 3 && (stride == 1 || stride == 2)), DVSR_ERR_UNSUPPORTED,
-               "conv2d_wgrad: ks=%d stride=%d unsupported", ks, stride);
-  const size_t need = conv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ks, stride);
+  DVSR_REQUIRE(((ks == 1 || ks == 2) && stride == 1) || (ks == 3 && (stride == 1 || stride == 2)),
+               DVSR_ERR_UNSUPPORTED, "conv2d_wgrad: ks=%d stride=%d unsupported", ks, stride);
+  if (pad < 0) pad = ks / 2;
+  const size_t need = conv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ks, stride, pad);
   DVSR_REQUIRE(ws_bytes >= need, DVSR_ERR_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
   WgradK k;
   k.x = x; k.gy = gy; k.x_bs = x_bs > 0 ? x_bs : (long long)Cin * H * W; k.x_bdiv = x_bdiv > 0 ? x_bdiv : 1;
-  k.N = N; k.Cin = Cin; k.H = H; k.W = W; k.Cout = Cout; k.pad = ks / 2; k.gy_ps = gy_ps;
+  k.N = N; k.Cin = Cin; k.H = H; k.W = W; k.Cout = Cout; k.pad = pad; k.gy_ps = gy_ps;
   k.Ho = (H + 2 * k.pad - ks) / stride + 1;
   k.Wo = (W + 2 * k.pad - ks) / stride + 1;
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, 2); k.ntiles = k.tiles_x * k.tiles_y * N;
   k.nob = ceil_div(Cout, 64); k.ncb = ceil_div(Cin, 64);
   const int KK = ks * ks;
-  k.nsplit = wgrad_splits(k.ntiles, k.nob, k.ncb, KK, ks == 3 && stride == 1);
+  k.nsplit = wgrad_splits(k.ntiles, k.nob, k.ncb, KK, stride == 1);
   k.nslot = k.nsplit < 8 ? k.nsplit : 8;
   k.partial = (float*)ws;
   k.dbp = k.partial + (size_t)k.nslot * KK * k.nob * 64 * k.ncb * 64;
@@ -386,16 +390,25 @@ int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy
     const char* v = getenv("DVSR_WGRAD_SIMPLE");
     use_simple = (v && v[0] == '1') ? 1 : 0;
   }
-  if (ks == 3 && stride == 1 && !use_simple) {
-    constexpr size_t lds = 2 * (size_t)(64 * WgShape<3, 1>::GROW + 64 * WgShape<3, 1>::PLANEP) * sizeof(float);
-    static bool done = false;
-    if (!done) {
-      hipFuncSetAttribute((const void*)conv2d_wgrad_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      done = true;
-    }
-    hipLaunchKernelGGL(conv2d_wgrad_pipe_kernel, grid, dim3(256), lds, st, k);
+  if (stride == 1 && !use_simple) {
+    auto launch_pipe = [&](auto ks_tag) {
+      constexpr int KS_ = decltype(ks_tag)::value;
+      using Sh = WgShape<KS_, 1>;
+      constexpr size_t lds = 2 * (size_t)(64 * Sh::GROW + 64 * Sh::PLANEP) * sizeof(float);
+      static bool done = false;
+      if (!done) {
+        hipFuncSetAttribute((const void*)conv2d_wgrad_pipe_kernel<KS_>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        done = true;
+      }
+      hipLaunchKernelGGL(conv2d_wgrad_pipe_kernel<KS_>, grid, dim3(256), lds, st, k);
+    };
+    if (ks == 3) launch_pipe(std::integral_constant<int, 3>{});
+    else if (ks == 2) launch_pipe(std::integral_constant<int, 2>{});
+    else launch_pipe(std::integral_constant<int, 1>{});
   } else if (ks == 3 && stride == 1) launch_wgrad<3, 1>(k, grid, st);
   else if (ks == 3) launch_wgrad<3, 2>(k, grid, st);
+  else if (ks == 2) launch_wgrad<2, 1>(k, grid, st);
   else launch_wgrad<1, 1>(k, grid, st);
   int rc = check_launch("conv2d_wgrad_kernel");
   if (rc) return rc;

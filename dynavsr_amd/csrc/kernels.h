@@ -41,10 +41,11 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
 int conv3x3_small_cout_run(const float* x, const float* w, const float* bias, const float* res, float* y, int N,
                            int C, int H, int W, int Cout, int act, hipStream_t st);
 
-size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride);
+size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad = -1);
 int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
                      float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
-                     int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero = 0);
+                     int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero = 0,
+                     int pad = -1);  // pad < 0: ks / 2
 size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int stride, int pad, int dil);
 int mdcn_backward_run(const float* x, const float* off, long long off_bs, const float* msk, long long msk_bs,
                       int mask_logit, const float* w, const float* gout, float* gx, float* goff,
@@ -77,6 +78,17 @@ int tsa_blend_bwd(const float* fea, const float* att, const float* g, float* g_f
                   size_t n, int accumulate, hipStream_t st);
 int add_inplace(float* dst, const float* src, size_t n, hipStream_t st);
 int act_bwd_inplace(float* g, const float* y, size_t n, int act, hipStream_t st);
+
+// pad.hip: explicit padding / layout changes of the MFDN estimator and their adjoints
+enum : int { PAD_REFLECT = 0, PAD_REFLECT_S2D = 1, PAD_REPL_T3 = 2 };
+size_t pad_out_numel(int mode, size_t N, int C, int H, int W);
+int pad_fwd(const float* x, float* y, int mode, int N, int C, int H, int W, int T, hipStream_t st);
+int pad_bwd(const float* gy, float* gx, int mode, int N, int C, int H, int W, int T, int accumulate,
+            hipStream_t st);
+int meansub_fwd(const float* x, float* xm, float* mean, int B, int C, int T, int H, int W, hipStream_t st);
+int addmean_fwd(const float* y, const float* mean, float* out, int B, int C, int T, size_t HW, hipStream_t st);
+int addmean_bwd(const float* gout, float* gy, int B, int C, int T, size_t HW, hipStream_t st);
+int w4_to_s2d(const float* w, float* w2, int Cout, int C, int inverse, hipStream_t st);
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
