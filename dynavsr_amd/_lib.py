@@ -31,6 +31,10 @@ class EdvrConfig(Structure):
                                      "center")]
 
 
+class EstimatorConfig(Structure):
+    _fields_ = [(k, c_int) for k in ("kind", "nf", "in_nc", "scale", "nframes")]
+
+
 def _declare(lib):
     P, I, F, LL = c_void_p, c_int, c_float, c_longlong
     sig = {
@@ -57,6 +61,12 @@ def _declare(lib):
         "dvsr_edvr_forward": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P]),
         "dvsr_edvr_backward": (I, [P, POINTER(c_void_p), P, P, POINTER(c_void_p), P, P, c_size_t, P]),
         "dvsr_edvr_num_backward_launches": (I, [P]),
+        "dvsr_estimator_plan_create": (I, [POINTER(EstimatorConfig), I, I, I, POINTER(c_void_p)]),
+        "dvsr_estimator_plan_destroy": (None, [P]),
+        "dvsr_estimator_num_params": (I, [P]),
+        "dvsr_estimator_workspace_bytes": (c_size_t, [P, I]),
+        "dvsr_estimator_forward": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P]),
+        "dvsr_estimator_backward": (I, [P, POINTER(c_void_p), P, P, POINTER(c_void_p), P, c_size_t, P]),
         "dvsr_conv2d_backward_workspace_bytes": (c_size_t, [POINTER(Conv2dDesc)]),
         "dvsr_conv2d_backward": (I, [POINTER(Conv2dDesc), P, P, P, P, P, P, c_size_t, P]),
         "dvsr_mdcn_backward_workspace_bytes": (c_size_t, [I] * 10),

@@ -31,7 +31,7 @@ struct T {
   bool valid() const { return space != SP_NONE; }
 };
 
-enum OpType { OP_CONV, OP_DCN, OP_UP, OP_POOL, OP_GATE, OP_BLEND, OP_ADD };
+enum OpType { OP_CONV, OP_DCN, OP_UP, OP_POOL, OP_GATE, OP_BLEND, OP_ADD, OP_PAD, OP_MEANSUB, OP_ADDMEAN };
 
 struct Op {
   OpType type;
@@ -41,6 +41,13 @@ struct Op {
   // conv / dcn geometry
   int N = 0, c0 = 0, c1 = 0, H = 0, W = 0, Cout = 0, ks = 3, stride = 1, act = 0, ps = 0;
   int x1_bdiv = 1, dg = 8;
+  int pad = -1;        // conv: < 0 = ks / 2 (EDVR); the estimator convolves explicitly padded tensors with 0
+  int pmode = 0, T = 1;  // OP_PAD: PAD_* mode; frames per clip (OP_PAD / OP_MEANSUB / OP_ADDMEAN)
+  // wmap: the parameter is a [Cout][c0/4][4][4] stride-2 kernel, run as 2x2 over the space-to-depth
+  // input; its re-laid-out copy (and the gradient of that copy) live at w2_off of the two arenas
+  int wmap = 0;
+  size_t w2_off = 0;
+  int no_dgrad = 0;  // the input does not need a gradient (it derives from the network input only)
   long long x0_bs = 0, x1_bs = 0;
   // streaming ops
   int S = 1;
@@ -62,7 +69,8 @@ struct Ref {
   int space = R_NONE;
   size_t off = 0;
 };
-enum BType { B_MEMSET, B_COPYADD, B_ACT, B_WGRAD, B_DGRAD, B_REDUCE, B_DCN, B_UP, B_POOL, B_GATE, B_BLEND };
+enum BType { B_MEMSET, B_COPYADD, B_ACT, B_WGRAD, B_DGRAD, B_REDUCE, B_DCN, B_UP, B_POOL, B_GATE, B_BLEND,
+             B_PADFOLD, B_ADDMEAN, B_WUNMAP };
 struct BOp {
   BType type;
   int fwd = -1;          // index of the forward op this belongs to
@@ -72,6 +80,9 @@ struct BOp {
   long long bs = 0;
   size_t per = 0;
 };
+
+static inline int conv_pad(const Op& o) { return o.pad < 0 ? o.ks / 2 : o.pad; }
+static inline int conv_out(const Op& o, int in) { return (in + 2 * conv_pad(o) - o.ks) / o.stride + 1; }
 
 }  // namespace dvsr
 
@@ -126,14 +137,15 @@ struct Builder {
   // y = act(conv(cat(x0, x1)) + b) [+ res]   (optionally pixel-shuffled)
   T conv(const char* name, CP cp, T x0, int c0, T x1, int c1, int N, int H, int W, int Cout, int ks,
          int stride, int act, T res = T(), int ps = 0, int x1_bdiv = 1, long long x0_bs = 0,
-         long long x1_bs = 0, T y_override = T()) {
+         long long x1_bs = 0, T y_override = T(), int pad = -1, int wmap = 0) {
     Op o;
-    o.type = OP_CONV; o.name = name; o.pw = cp.w; o.pb = cp.b;
+    o.type = OP_CONV; o.name = name; o.pw = cp.w; o.pb = cp.b; o.pad = pad; o.wmap = wmap;
     o.x0 = x0; o.x1 = x1; o.res = res;
     o.N = N; o.c0 = c0; o.c1 = c1; o.H = H; o.W = W; o.Cout = Cout; o.ks = ks; o.stride = stride;
     o.act = act; o.ps = ps; o.x1_bdiv = x1_bdiv; o.x0_bs = x0_bs; o.x1_bs = x1_bs;
-    const int Ho = (H + 2 * (ks / 2) - ks) / stride + 1, Wo = (W + 2 * (ks / 2) - ks) / stride + 1;
+    const int Ho = conv_out(o, H), Wo = conv_out(o, W);
     o.y = y_override.valid() ? y_override : alloc(name, (size_t)N * Cout * Ho * Wo);
+    if (wmap) o.w2_off = alloc("", (size_t)Cout * (c0 + c1) * ks * ks).off;
     {
       o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1);
       o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc);
@@ -168,6 +180,14 @@ struct Builder {
     Op o;
     o.type = OP_UP; o.name = name; o.x0 = x; o.planes = planes; o.H = H; o.W = W; o.S = S; o.mul = mul;
     o.y = alloc(name, planes * H * W * S * S);
+    p.ops.push_back(o);
+    return o.y;
+  }
+  // explicit padding / space-to-depth / temporal gather (pad.hip); x: [N][C][H][W]
+  T padop(const char* name, T x, int mode, int N, int C, int H, int W, int Tn) {
+    Op o;
+    o.type = OP_PAD; o.name = name; o.x0 = x; o.pmode = mode; o.N = N; o.c0 = C; o.H = H; o.W = W; o.T = Tn;
+    o.y = alloc(name, pad_out_numel(mode, (size_t)N, C, H, W));
     p.ops.push_back(o);
     return o.y;
   }
@@ -385,7 +405,7 @@ static void build_backward(dvsr_edvr_plan& p) {
     const Ref gy = BackBuilder::grad(o.y);
     switch (o.type) {
       case OP_CONV: {
-        const int Ho = (o.H + 2 * (o.ks / 2) - o.ks) / o.stride + 1, Wo = (o.W + 2 * (o.ks / 2) - o.ks) / o.stride + 1;
+        const int Ho = conv_out(o, o.H), Wo = conv_out(o, o.W);
         if (o.res.valid()) bb.copyadd(o.res, gy, o.y.numel, i);
         if (o.act != ACT_NONE) {
           BOp a; a.type = B_ACT; a.fwd = i; a.a = gy; a.b = BackBuilder::act(o.y); a.n = o.y.numel;
@@ -396,12 +416,16 @@ static void build_backward(dvsr_edvr_plan& p) {
           BOp w; w.type = B_WGRAD; w.fwd = i; w.which = which; w.a = BackBuilder::act(which ? o.x1 : o.x0); w.b = gy;
           p.bops.push_back(w);
           scratch = std::max(scratch, conv2d_wgrad_workspace_bytes(o.N, which ? o.c1 : o.c0, o.H, o.W, o.Cout,
-                                                                   o.ks, o.stride));
+                                                                   o.ks, o.stride, conv_pad(o)));
           wscratch = std::max(wscratch, conv2d_wgrad_workspace_bytes(o.N, which ? o.c1 : o.c0, o.H, o.W, o.Cout,
-                                                                     o.ks, o.stride));
+                                                                     o.ks, o.stride, conv_pad(o)));
+          if (o.wmap) {  // dW of the re-laid-out copy -> gradient of the 4x4 parameter (same stream as the wgrad)
+            BOp u; u.type = B_WUNMAP; u.fwd = i;
+            p.bops.push_back(u);
+          }
         }
         for (int which = 0; which < 2; ++which) {
-          if (which == 1 && !o.c1) break;
+          if ((which == 1 && !o.c1) || o.no_dgrad) break;
           const T& xin = which ? o.x1 : o.x0;
           const int ci = which ? o.c1 : o.c0;
           const bool strided = which ? (o.x1_bdiv > 1 || o.x1_bs != 0) : (o.x0_bs != 0);
@@ -477,6 +501,22 @@ static void build_backward(dvsr_edvr_plan& p) {
         bb.copyadd(o.x0, gy, o.y.numel, i);
         bb.copyadd(o.x1, gy, o.y.numel, i);
         break;
+      case OP_PAD: {
+        if (o.x0.space == SP_INPUT || o.no_dgrad) break;  // no gradient w.r.t. the network input
+        BOp f; f.type = B_PADFOLD; f.fwd = i; f.b = gy; f.a = BackBuilder::grad(o.x0);
+        T xin = o.x0; xin.numel = (size_t)o.N * o.c0 * o.H * o.W;
+        f.accum = bb.contribute(xin, true, i);
+        p.bops.push_back(f);
+        break;
+      }
+      case OP_MEANSUB:
+        break;  // x is data: no gradient
+      case OP_ADDMEAN: {
+        BOp f; f.type = B_ADDMEAN; f.fwd = i; f.b = gy; f.a = BackBuilder::grad(o.x0);
+        bb.contribute(o.x0, true, i);
+        p.bops.push_back(f);
+        break;
+      }
     }
   }
   p.tmp_floats = (tmp + 63) & ~(size_t)63;
@@ -485,8 +525,9 @@ static void build_backward(dvsr_edvr_plan& p) {
 }
 
 struct BBases {
-  float* arena; float* garena; const float* x; float* gx; const float* gout; float* tmp; float* dpack;
-  bool use_v1;
+  float* arena = nullptr; float* garena = nullptr; const float* x = nullptr; float* gx = nullptr;
+  const float* gout = nullptr; float* tmp = nullptr; float* dpack = nullptr;
+  bool use_v1 = false;
   float* at(const Ref& r) const {
     switch (r.space) {
       case R_ACT: return arena + r.off;
@@ -522,18 +563,29 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
       return act_bwd_inplace(bs.at(b.a), bs.at(b.b), b.n, o->act, st);
     case B_WGRAD: {
       const int ci = b.which ? o->c1 : o->c0;
+      float* dW = o->wmap ? bs.garena + o->w2_off : GP[o->pw];
       return conv2d_wgrad_run(bs.at(b.a), b.which ? o->x1_bs : o->x0_bs, b.which ? o->x1_bdiv : 1, bs.at(b.b),
-                              o->ps, GP[o->pw], b.which ? nullptr : GP[o->pb], o->N, ci, o->H, o->W, o->Cout,
+                              o->ps, dW, b.which ? nullptr : GP[o->pb], o->N, ci, o->H, o->W, o->Cout,
                               o->c0 + o->c1, b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st,
-                              scratch_is_zero);
+                              scratch_is_zero, conv_pad(*o));
     }
+    case B_WUNMAP:
+      return w4_to_s2d(bs.garena + o->w2_off, GP[o->pw], o->Cout, o->c0 / 4, 1, st);
+    case B_PADFOLD: {
+      float* gx = bs.at(b.a);
+      if (!gx) return DVSR_OK;
+      return pad_bwd(bs.at(b.b), gx, o->pmode, o->N, o->c0, o->H, o->W, o->T, b.accum, st);
+    }
+    case B_ADDMEAN:
+      return addmean_bwd(bs.at(b.b), bs.at(b.a), o->N / o->T, o->c0, o->T, (size_t)o->H * o->W, st);
     case B_DGRAD: {
       float* gx = bs.at(b.a);
       if (!gx) return DVSR_OK;
-      const int Ho = (o->H + 2 * (o->ks / 2) - o->ks) / o->stride + 1, Wo = (o->W + 2 * (o->ks / 2) - o->ks) / o->stride + 1;
+      const int Ho = conv_out(*o, o->H), Wo = conv_out(*o, o->W);
       dvsr_conv2d_desc g = {};
-      g.x0 = bs.at(b.b); g.w = P[o->pw]; g.y = gx; g.N = o->N; g.c0 = o->Cout; g.Cout = b.which ? o->c1 : o->c0;
-      g.ks = o->ks; g.stride = 1; g.pad = o->ks / 2; g.act = ACT_NONE; g.x1_bdiv = 1;
+      g.x0 = bs.at(b.b); g.w = o->wmap ? bs.arena + o->w2_off : P[o->pw]; g.y = gx; g.N = o->N; g.c0 = o->Cout;
+      g.Cout = b.which ? o->c1 : o->c0;
+      g.ks = o->ks; g.stride = 1; g.pad = o->ks - 1 - conv_pad(*o); g.act = ACT_NONE; g.x1_bdiv = 1;
       ConvExtra ex;
       ex.wt = 1; ex.w_ctot = o->c0 + o->c1; ex.w_coff = b.which ? o->c0 : 0; ex.accum = b.accum; ex.in_ps = o->ps ? 1 : 0;
       if (o->stride == 2) { ex.in_dil = 2; ex.Hs = Ho; ex.Ws = Wo; g.H = o->H; g.W = o->W; }
@@ -584,8 +636,8 @@ struct Bases {
 };
 
 // Packs the weights of every conv of the tape (forward: wt=0; backward: the two transposed views).
-static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* fwd_base, float* bwd_base,
-                    hipStream_t st) {
+static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena_base, float* fwd_base,
+                    float* bwd_base, hipStream_t st) {
   PackTable t;
   t.n = 0;
   auto flush = [&]() { int rc = pack_weights_run(t, st); t.n = 0; return rc; };
@@ -598,9 +650,17 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* fwd_b
     }
     if (o.type != OP_CONV) continue;
     const int ctot = o.c0 + o.c1, KK = o.ks * o.ks;
+    const float* wsrc = P[o.pw];
+    if (o.wmap) {  // the re-laid-out copy is (re)built by the forward; the backward packs read the same slot
+      wsrc = arena_base + o.w2_off;
+      if (fwd_base) {
+        int rc = w4_to_s2d(P[o.pw], arena_base + o.w2_off, o.Cout, ctot / 4, 0, st);
+        if (rc) return rc;
+      }
+    }
     if (fwd_base) {
       PackEntry& e = t.e[t.n++];
-      e.w = P[o.pw]; e.P = fwd_base + o.wp_off; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
+      e.w = wsrc; e.P = fwd_base + o.wp_off; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
       e.CC = o.geo.cc; e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
       e.nchunks = ceil_div(ctot, e.CC); e.pch = conv2_pch_cc(o.ks, e.CC);
       if (t.n == 48) { int rc = flush(); if (rc) return rc; }
@@ -610,7 +670,7 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* fwd_b
         const int ci = which ? o.c1 : o.c0;
         if (!ci) continue;
         PackEntry& e = t.e[t.n++];
-        e.w = P[o.pw]; e.P = bwd_base + o.dpk_off[which]; e.Cout = ci; e.Ctot = o.Cout; e.KK = KK;
+        e.w = wsrc; e.P = bwd_base + o.dpk_off[which]; e.Cout = ci; e.Ctot = o.Cout; e.KK = KK;
         e.CC = o.dgeo[which].cc; e.wt = 1; e.w_ctot = ctot; e.w_coff = which ? o.c0 : 0;
         e.ncb = ceil_div(ci, 64); e.nchunks = ceil_div(o.Cout, e.CC); e.pch = conv2_pch_cc(o.ks, e.CC);
         if (t.n == 48) { int rc = flush(); if (rc) return rc; }
@@ -627,10 +687,11 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
       d.x0 = bs.at(o.x0); d.x1 = bs.at(o.x1); d.w = P[o.pw]; d.bias = P[o.pb]; d.res = bs.at(o.res);
       d.y = bs.at(o.y);
       d.N = o.N; d.c0 = o.c0; d.c1 = o.c1; d.H = o.H; d.W = o.W; d.Cout = o.Cout; d.ks = o.ks;
-      d.stride = o.stride; d.pad = o.ks / 2; d.act = o.act; d.pixel_shuffle = o.ps;
+      d.stride = o.stride; d.pad = conv_pad(o); d.act = o.act; d.pixel_shuffle = o.ps;
+      if (o.wmap) d.w = bs.arena + o.w2_off;
       d.x1_bdiv = o.x1_bdiv; d.x0_bstride = o.x0_bs; d.x1_bstride = o.x1_bs;
       if (bs.use_v1) return conv2d_run(d, ConvExtra(), st);
-      if (o.Cout <= 4 && o.ks == 3 && o.stride == 1 && !o.c1 && !o.ps && !o.x0_bs)  // conv_last
+      if (o.Cout <= 4 && o.ks == 3 && o.stride == 1 && !o.c1 && !o.ps && !o.x0_bs && o.pad < 0)  // conv_last
         return conv3x3_small_cout_run(d.x0, d.w, d.bias, d.res, d.y, o.N, o.c0, o.H, o.W, o.Cout, o.act, st);
       return conv2d_packed_run(d, bs.arena + o.wp_off, ConvExtra(), o.geo, st);
     }
@@ -654,6 +715,12 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
                           o.gC, o.gHW, st);
     case OP_BLEND:
       return tsa_blend_fwd(bs.at(o.x0), bs.at(o.x1), bs.at(o.res), bs.at(o.y), o.y.numel, st);
+    case OP_PAD:
+      return pad_fwd(bs.at(o.x0), bs.at(o.y), o.pmode, o.N, o.c0, o.H, o.W, o.T, st);
+    case OP_MEANSUB:
+      return meansub_fwd(bs.at(o.x0), bs.at(o.y), bs.at(o.y2), o.N / o.T, o.c0, o.T, o.H, o.W, st);
+    case OP_ADDMEAN:
+      return addmean_fwd(bs.at(o.x0), bs.at(o.x1), bs.at(o.y), o.N / o.T, o.c0, o.T, (size_t)o.H * o.W, st);
     case OP_ADD: {
       hipError_t e = hipMemcpyAsync(bs.at(o.y), bs.at(o.x0), o.y.numel * sizeof(float),
                                     hipMemcpyDeviceToDevice, st);
@@ -733,7 +800,7 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
   bs.use_v1 = p->use_v1;
   void* scratch = bs.dpack + p->dpack_floats;
   if (!p->use_v1) {
-    int rc = pack_all(*p, params, nullptr, bs.dpack, st);
+    int rc = pack_all(*p, params, bs.arena, nullptr, bs.dpack, st);
     if (rc != DVSR_OK) return rc;
   }
   if (grad_x) {
@@ -760,7 +827,7 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
   int last_fork_fwd = -1;
   for (const BOp& b : p->bops) {
     int rc;
-    if (use_side && b.type == B_WGRAD) {
+    if (use_side && (b.type == B_WGRAD || b.type == B_WUNMAP)) {
       if (b.fwd != last_fork_fwd) {  // gy of this layer is final on `st` at this point of the tape
         DVSR_REQUIRE(hipEventRecord(p->ev_fork, st) == hipSuccess &&
                          hipStreamWaitEvent(p->side, p->ev_fork, 0) == hipSuccess,
@@ -790,7 +857,7 @@ extern "C" int dvsr_edvr_forward(const dvsr_edvr_plan* p, const float* const* pa
                "edvr_forward: workspace %zu < %zu bytes", ws_bytes, p->arena_floats * sizeof(float));
   Bases bs{(float*)ws, x, out, p->use_v1};
   if (!p->use_v1) {
-    int rc = pack_all(*p, params, bs.arena, nullptr, (hipStream_t)stream);
+    int rc = pack_all(*p, params, bs.arena, bs.arena, nullptr, (hipStream_t)stream);
     if (rc != DVSR_OK) return rc;
   }
   for (const Op& o : p->ops) {
@@ -806,12 +873,12 @@ static void op_work(const Op& o, const char** kind, double* flops, double* bytes
   *flops = 0; *bytes = 0; *kind = "other";
   switch (o.type) {
     case OP_CONV: {
-      const int Ho = (o.H + 2 * (o.ks / 2) - o.ks) / o.stride + 1, Wo = (o.W + 2 * (o.ks / 2) - o.ks) / o.stride + 1;
+      const int Ho = conv_out(o, o.H), Wo = conv_out(o, o.W);
       const double ctot = o.c0 + o.c1, px = (double)o.N * Ho * Wo;
       *flops = 2.0 * px * o.Cout * ctot * o.ks * o.ks;
       *bytes = 4.0 * ((double)o.N * o.c0 * o.H * o.W + (double)(o.N / o.x1_bdiv) * o.c1 * o.H * o.W +
                       px * o.Cout * (o.res.valid() ? 2 : 1) + (double)o.Cout * ctot * o.ks * o.ks);
-      *kind = o.ks == 1 ? "conv1x1" : (o.stride == 2 ? "conv3x3s2" : "conv3x3s1");
+      *kind = o.ks == 1 ? "conv1x1" : (o.ks == 2 ? "conv2x2" : (o.stride == 2 ? "conv3x3s2" : "conv3x3s1"));
       break;
     }
     case OP_DCN: {
@@ -827,6 +894,9 @@ static void op_work(const Op& o, const char** kind, double* flops, double* bytes
                                  (double)o.gB * o.gN * o.gHW); *kind = "tsa_gate"; break;
     case OP_BLEND: *bytes = 4.0 * o.y.numel * 4; *kind = "tsa_blend"; break;
     case OP_ADD: *bytes = 4.0 * o.y.numel * 3; *kind = "add"; break;
+    case OP_PAD: *bytes = 4.0 * ((double)o.N * o.c0 * o.H * o.W + (double)o.y.numel); *kind = "pad"; break;
+    case OP_MEANSUB: *bytes = 4.0 * o.y.numel * 3; *kind = "meansub"; break;
+    case OP_ADDMEAN: *bytes = 4.0 * o.y.numel * 2; *kind = "addmean"; break;
   }
 }
 
@@ -858,7 +928,7 @@ extern "C" int dvsr_edvr_forward_timed(const dvsr_edvr_plan* p, const float* con
   std::vector<hipEvent_t> ev(n + 1);
   for (auto& e : ev) DVSR_REQUIRE(hipEventCreate(&e) == hipSuccess, DVSR_ERR_HIP, "hipEventCreate failed");
   Bases bs{(float*)ws, x, out, p->use_v1};
-  int rc = p->use_v1 ? DVSR_OK : pack_all(*p, params, bs.arena, nullptr, st);
+  int rc = p->use_v1 ? DVSR_OK : pack_all(*p, params, bs.arena, bs.arena, nullptr, st);
   hipEventRecord(ev[0], st);
   for (size_t i = 0; i < n && rc == DVSR_OK; ++i) {
     rc = run_forward_op(p->ops[i], params, bs, st);
@@ -885,4 +955,145 @@ extern "C" int dvsr_edvr_tensor_info(const dvsr_edvr_plan* p, const char* name, 
     }
   set_error("edvr_tensor_info: no tensor named '%s'", name);
   return DVSR_ERR_INVALID;
+}
+
+
+// =================================================================================================
+// Down-scaling estimators MFDN / SFDN (LRimg_estimator.py:38-117) on the same tape machinery.
+// Every convolution runs on the dense stride-1 MFMA kernels over explicitly padded tensors
+// (pad.hip): ReflectionPad2d(1) -> PAD_REFLECT, the 4x4 stride-2 convs -> PAD_REFLECT_S2D + a 2x2
+// conv over 4C channels, Conv3d(k3) over ReplicationPad3d(1) -> PAD_REPL_T3 + a 3x3 conv over 3C
+// channels (the Conv3d weight [Cout][C][3][3][3] IS the [Cout][3C][3][3] tensor that needs).
+// Input x: [B][in_nc][T][H][W] (T = 1 for SFDN, i.e. [B][in_nc][H][W]); output [B][in_nc][T][H/s][W/s].
+// Parameters in state-dict order conv0.weight, conv0.bias, ... conv6.bias.
+// =================================================================================================
+struct dvsr_estimator_plan {
+  dvsr_edvr_plan core;
+  dvsr_estimator_config ecfg;
+};
+
+namespace dvsr {
+
+static int build_estimator(dvsr_estimator_plan& ep) {
+  dvsr_edvr_plan& p = ep.core;
+  const dvsr_estimator_config& c = ep.ecfg;
+  const int video = c.kind == DVSR_ESTIMATOR_MFDN;
+  const int B = p.B, Tn = video ? c.nframes : 1, BT = B * Tn, nf = c.nf, ic = c.in_nc;
+  int H = p.H, W = p.W;
+  Builder b(p);
+  const int L = ACT_LRELU, NO = ACT_NONE;
+  T none;
+  T xin; xin.space = SP_INPUT; xin.off = 0; xin.numel = (size_t)BT * ic * H * W;
+  // x - mean, frames become the batch axis
+  T xm = b.alloc("xm", xin.numel);
+  T mean = b.alloc("mean", (size_t)BT * ic);
+  {
+    Op o; o.type = OP_MEANSUB; o.name = "meansub"; o.x0 = xin; o.y = xm; o.y2 = mean;
+    o.N = BT; o.c0 = ic; o.H = H; o.W = W; o.T = Tn;
+    p.ops.push_back(o);
+  }
+  auto conv3 = [&](const char* pn, const char* cn, T x, int cin, int cout, int mode, bool first) {
+    T xp = b.padop(pn, x, mode, BT, cin, H, W, Tn);
+    if (first) p.ops.back().no_dgrad = 1;
+    const int cin_eff = mode == PAD_REPL_T3 ? 3 * cin : cin;
+    T y = b.conv(cn, b.take(), xp, cin_eff, none, 0, BT, H + 2, W + 2, cout, 3, 1, L, none, 0, 1, 0, 0, T(), 0);
+    if (first) p.ops.back().no_dgrad = 1;
+    return y;
+  };
+  auto conv4s2 = [&](const char* pn, const char* cn, T x, int cin, int cout) {
+    T xp = b.padop(pn, x, PAD_REFLECT_S2D, BT, cin, H, W, Tn);
+    T y = b.conv(cn, b.take(), xp, 4 * cin, none, 0, BT, (H + 2) / 2, (W + 2) / 2, cout, 2, 1, L, none, 0, 1, 0, 0,
+                 T(), 0, 1);
+    H /= 2; W /= 2;
+    return y;
+  };
+  T y;
+  if (video) {
+    y = conv3("pad0", "conv0", xm, ic, nf, PAD_REPL_T3, true);        // Conv3d(in_nc, nf, 3) :76
+    y = conv3("pad1", "conv1", y, nf, nf, PAD_REFLECT, false);         // :82
+    y = conv4s2("pad2", "conv2", y, nf, 2 * nf);                       // :83
+    if (c.scale == 4) y = conv4s2("pad3", "conv3", y, 2 * nf, nf);     // :85
+    else y = conv3("pad3", "conv3", y, 2 * nf, nf, PAD_REFLECT, false);  // :84
+    y = conv3("pad4", "conv4", y, nf, nf, PAD_REFLECT, false);         // :86
+    y = conv3("pad5", "conv5", y, nf, nf, PAD_REPL_T3, false);         // Conv3d(nf, nf, 3) :88
+  } else {  // SFDN :44-53
+    y = conv3("pad0", "conv0", xm, ic, nf, PAD_REFLECT, true);
+    y = conv3("pad1", "conv1", y, nf, nf, PAD_REFLECT, false);
+    y = conv3("pad2", "conv2", y, nf, nf, PAD_REFLECT, false);
+    y = conv4s2("pad3", "conv3", y, nf, 2 * nf);
+    y = conv3("pad4", "conv4", y, 2 * nf, 2 * nf, PAD_REFLECT, false);
+    y = conv3("pad5", "conv5", y, 2 * nf, nf, PAD_REFLECT, false);
+  }
+  y = b.conv("conv6", b.take(), y, nf, none, 0, BT, H, W, ic, 1, 1, NO, none, 0, 1, 0, 0, T(), 0);
+  {
+    Op o; o.type = OP_ADDMEAN; o.name = "addmean"; o.x0 = y; o.x1 = mean;
+    o.y.space = SP_OUTPUT; o.y.off = 0; o.y.numel = (size_t)BT * ic * H * W;
+    o.N = BT; o.c0 = ic; o.H = H; o.W = W; o.T = Tn;
+    p.ops.push_back(o);
+  }
+  p.n_params = b.pcur;
+  return DVSR_OK;
+}
+
+}  // namespace dvsr
+
+extern "C" int dvsr_estimator_plan_create(const dvsr_estimator_config* cfg, int B, int H, int W,
+                                          dvsr_estimator_plan** out) {
+  DVSR_REQUIRE(cfg && out, DVSR_ERR_INVALID, "estimator_plan_create: null argument");
+  DVSR_REQUIRE(cfg->kind == DVSR_ESTIMATOR_MFDN || cfg->kind == DVSR_ESTIMATOR_SFDN, DVSR_ERR_INVALID,
+               "estimator_plan_create: kind=%d", cfg->kind);
+  DVSR_REQUIRE(cfg->nf > 0 && cfg->in_nc > 0, DVSR_ERR_INVALID, "estimator_plan_create: nf=%d in_nc=%d", cfg->nf,
+               cfg->in_nc);
+  if (cfg->kind == DVSR_ESTIMATOR_MFDN) {
+    DVSR_REQUIRE(cfg->scale == 2 || cfg->scale == 4, DVSR_ERR_UNSUPPORTED,
+                 "estimator_plan_create: MFDN scale=%d (2 or 4, LRimg_estimator.py:72)", cfg->scale);
+    DVSR_REQUIRE(cfg->nframes > 0, DVSR_ERR_INVALID, "estimator_plan_create: nframes=%d", cfg->nframes);
+  } else {
+    DVSR_REQUIRE(cfg->scale == 2, DVSR_ERR_UNSUPPORTED, "estimator_plan_create: SFDN is x2 only (got %d)", cfg->scale);
+  }
+  const int s = cfg->scale;
+  DVSR_REQUIRE(B > 0 && H >= 2 * s && W >= 2 * s && H % s == 0 && W % s == 0, DVSR_ERR_INVALID,
+               "estimator_plan_create: B=%d H=%d W=%d (H, W must be multiples of the scale %d)", B, H, W, s);
+  dvsr_estimator_plan* ep = new dvsr_estimator_plan();
+  ep->ecfg = *cfg;
+  dvsr_edvr_plan& p = ep->core;
+  p.cfg = dvsr_edvr_config{cfg->nf, cfg->nframes, 1, 0, 0, cfg->scale, 0};
+  p.B = B; p.H = H; p.W = W;
+  { const char* v = getenv("DVSR_BWD_STREAMS"); p.side_streams = (v && v[0] == '0') ? 0 : 1; }
+  int rc = build_estimator(*ep);
+  if (rc != DVSR_OK) { delete ep; return rc; }
+  build_backward(p);
+  *out = ep;
+  return DVSR_OK;
+}
+
+extern "C" void dvsr_estimator_plan_destroy(dvsr_estimator_plan* ep) {
+  if (!ep) return;
+  dvsr_edvr_plan& p = ep->core;
+  if (p.side) {
+    (void)hipStreamSynchronize(p.side);
+    (void)hipEventDestroy(p.ev_fork);
+    (void)hipEventDestroy(p.ev_join);
+    (void)hipStreamDestroy(p.side);
+  }
+  delete ep;
+}
+
+extern "C" int dvsr_estimator_num_params(const dvsr_estimator_plan* ep) { return ep ? ep->core.n_params : -1; }
+
+extern "C" size_t dvsr_estimator_workspace_bytes(const dvsr_estimator_plan* ep, int need_grad) {
+  return ep ? dvsr_edvr_workspace_bytes(&ep->core, need_grad) : 0;
+}
+
+extern "C" int dvsr_estimator_forward(const dvsr_estimator_plan* ep, const float* const* params, const float* x,
+                                      float* out, void* ws, size_t ws_bytes, dvsr_stream_t stream) {
+  DVSR_REQUIRE(ep, DVSR_ERR_INVALID, "estimator_forward: null plan");
+  return dvsr_edvr_forward(&ep->core, params, x, out, ws, ws_bytes, stream);
+}
+
+extern "C" int dvsr_estimator_backward(const dvsr_estimator_plan* ep, const float* const* params, const float* x,
+                                       const float* grad_out, float* const* grad_params, void* ws, size_t ws_bytes,
+                                       dvsr_stream_t stream) {
+  DVSR_REQUIRE(ep, DVSR_ERR_INVALID, "estimator_backward: null plan");
+  return dvsr_edvr_backward(&ep->core, params, x, grad_out, grad_params, nullptr, ws, ws_bytes, stream);
 }

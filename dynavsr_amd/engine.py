@@ -127,3 +127,94 @@ class EdvrFunction(torch.autograd.Function):
         ctx.plan.backward(ctx.params, ctx.x, gout, gparams, gx, ctx.ws)
         ctx.ws = None  # release the activation arena
         return (gx, None, None) + tuple(gparams)
+
+
+# ---- down-scaling estimators (csrc/engine.hip: dvsr_estimator_*) ---------------------------------
+MFDN, SFDN = 0, 1
+_eplans = {}
+
+
+class EstimatorPlan:
+    """Owns one dvsr_estimator_plan: MFDN / SFDN forward + parameter-gradient tape for one shape."""
+
+    def __init__(self, cfg, b, h, w):
+        self.cfg = dict(zip(("kind", "nf", "in_nc", "scale", "nframes"), cfg))
+        self.b, self.h, self.w = b, h, w
+        self._h = ctypes.c_void_p()
+        L.check(L.lib().dvsr_estimator_plan_create(L.EstimatorConfig(*cfg), b, h, w, ctypes.byref(self._h)),
+                "dvsr_estimator_plan_create")
+        self.n_params = L.lib().dvsr_estimator_num_params(self._h)
+
+    def workspace_bytes(self, need_grad):
+        return int(L.lib().dvsr_estimator_workspace_bytes(self._h, int(need_grad)))
+
+    def forward(self, params, x, out, ws):
+        arr = (ctypes.c_void_p * len(params))(*[L.ptr(p) for p in params])
+        L.check(L.lib().dvsr_estimator_forward(self._h, arr, L.ptr(x), L.ptr(out), ws.data_ptr(),
+                                               ws.numel() * ws.element_size(), L.stream()),
+                "dvsr_estimator_forward")
+
+    def backward(self, params, x, gout, gparams, ws):
+        arr = (ctypes.c_void_p * len(params))(*[L.ptr(p) for p in params])
+        garr = (ctypes.c_void_p * len(gparams))(*[L.ptr(g) for g in gparams])
+        L.check(L.lib().dvsr_estimator_backward(self._h, arr, L.ptr(x), L.ptr(gout), garr, ws.data_ptr(),
+                                                ws.numel() * ws.element_size(), L.stream()),
+                "dvsr_estimator_backward")
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().dvsr_estimator_plan_destroy(self._h)
+        except Exception:
+            pass
+
+
+def get_estimator_plan(cfg, b, h, w):
+    key = (tuple(cfg), b, h, w)
+    p = _eplans.get(key)
+    if p is None:
+        p = _eplans[key] = EstimatorPlan(tuple(cfg), b, h, w)
+    return p
+
+
+class EstimatorFunction(torch.autograd.Function):
+    """x: [B,C,T,H,W] (MFDN) or [B,C,H,W] (SFDN) -> same rank, spatially / scale.  The clip is data:
+    no gradient is produced for x (LRestimator_model.py feeds `LQs`, test_dynavsr.py:237-241)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        if not x.is_cuda:
+            raise RuntimeError("dynavsr_amd estimator (MFDN/SFDN) runs on the MI355X only (input is on %s); "
+                               "there is no CPU fallback" % x.device)
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("the estimator's input clip is data: gradients w.r.t. it are not provided")
+        x = _prep(x)
+        kind, nf, in_nc, scale, nframes = cfg
+        if kind == MFDN:
+            b, c, t, h, w = x.shape
+            if t != nframes or c != in_nc:
+                raise RuntimeError("MFDN expects [B,%d,%d,H,W], got %s" % (in_nc, nframes, tuple(x.shape)))
+            oshape = (b, c, t, h // scale, w // scale)
+        else:
+            b, c, h, w = x.shape
+            oshape = (b, c, h // scale, w // scale)
+        plan = get_estimator_plan(cfg, b, h, w)
+        if len(params) != plan.n_params:
+            raise RuntimeError("estimator engine expects %d parameter tensors, got %d" % (plan.n_params, len(params)))
+        params = [_prep(p.detach()) for p in params]
+        need_grad = any(ctx.needs_input_grad)
+        ws = torch.empty(plan.workspace_bytes(need_grad), dtype=torch.uint8, device=x.device)
+        out = x.new_empty(oshape)
+        plan.forward(params, x, out, ws)
+        if need_grad:
+            ctx.plan, ctx.ws, ctx.x, ctx.params = plan, ws, x, params
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        gout = _prep(gout)
+        gparams = [torch.empty_like(p) for p in ctx.params]
+        ctx.plan.backward(ctx.params, ctx.x, gout, gparams, ctx.ws)
+        ctx.ws = None
+        return (None, None) + tuple(gparams)

@@ -81,3 +81,16 @@ def mfdn_param_spec(nf=64, in_nc=3, scale=4):
     s["conv5.bias"] = (nf,)
     _conv(s, "conv6", in_nc, nf, 1)
     return s
+
+
+def sfdn_param_spec(nf=64):
+    """OrderedDict name -> shape for SFDN (DirectKernelEstimator_CMS, LRimg_estimator.py:38-53)."""
+    s = OrderedDict()
+    _conv(s, "conv0", nf, 3, 3)
+    _conv(s, "conv1", nf, nf, 3)
+    _conv(s, "conv2", nf, nf, 3)
+    _conv(s, "conv3", nf * 2, nf, 4)
+    _conv(s, "conv4", nf * 2, nf * 2, 3)
+    _conv(s, "conv5", nf, nf * 2, 3)
+    _conv(s, "conv6", 3, nf, 1)
+    return s

@@ -11,7 +11,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .spec import edvr_param_spec, mfdn_param_spec
+from .spec import edvr_param_spec, mfdn_param_spec, sfdn_param_spec
 
 
 def _rs(seed, name):
@@ -48,6 +48,18 @@ def mfdn_state_dict(seed=0, dtype=torch.float32, **cfg):
     sd = OrderedDict()
     for name, shape in mfdn_param_spec(**cfg).items():
         r = _rs(seed + 7919, name)
+        if name.endswith(".bias"):
+            a = r.standard_normal(shape) * 0.01
+        else:
+            a = r.standard_normal(shape) * np.sqrt(2.0 / _fan_in(shape))
+        sd[name] = torch.from_numpy(a).to(dtype)
+    return sd
+
+
+def sfdn_state_dict(seed=0, dtype=torch.float32, **cfg):
+    sd = OrderedDict()
+    for name, shape in sfdn_param_spec(**cfg).items():
+        r = _rs(seed + 104729, name)
         if name.endswith(".bias"):
             a = r.standard_normal(shape) * 0.01
         else:

@@ -187,6 +187,37 @@ long long dvsr_debug_mfma_peak(float* out, int blocks, int iters, int nacc, int 
 int dvsr_edvr_tensor_info(const dvsr_edvr_plan* plan, const char* name, long long* offset_floats,
                           long long* numel);
 
+/* ---- Down-scaling estimators MFDN / SFDN as one launch tape ------------------------------------
+ * Replaces DirectKernelEstimatorVideo.forward (models/archs/LRimg_estimator.py:92-117, "MFDN":
+ * Conv3d(k3)+ReplicationPad3d, ReflectionPad2d + 3x3 / 4x4-stride-2 Conv2d, Conv3d, 1x1, per-frame
+ * mean subtraction / re-addition) and DirectKernelEstimator_CMS.forward (:55-67, "SFDN", x2) plus their
+ * autograd backward w.r.t. the parameters -- the estimator sits inside the inner-step graph
+ * (test_dynavsr.py:237-241) but its input clip is data, so no input gradient is produced.
+ * x: [B][in_nc][T][H][W] fp32 for MFDN (the layout feed_data builds, LRestimator_model.py:103),
+ * [B][in_nc][H][W] for SFDN; out: [B][in_nc][T][H/scale][W/scale] (SFDN: [B][in_nc][H/2][W/2]).
+ * params / grad_params: host arrays of dvsr_estimator_num_params() (= 14) device pointers in
+ * state-dict order conv0.weight, conv0.bias, ..., conv6.bias; gradients are overwritten.
+ * Workspace protocol as for the EDVR plan (need_grad=1 before the forward whose backward follows). */
+#define DVSR_ESTIMATOR_MFDN 0
+#define DVSR_ESTIMATOR_SFDN 1
+typedef struct dvsr_estimator_config {
+  int kind;    /* DVSR_ESTIMATOR_* */
+  int nf;      /* 64 in every shipped YAML */
+  int in_nc;   /* 3 */
+  int scale;   /* MFDN: 2 or 4; SFDN: 2 */
+  int nframes; /* T (MFDN); ignored for SFDN */
+} dvsr_estimator_config;
+typedef struct dvsr_estimator_plan dvsr_estimator_plan;
+int dvsr_estimator_plan_create(const dvsr_estimator_config* cfg, int B, int H, int W, dvsr_estimator_plan** out);
+void dvsr_estimator_plan_destroy(dvsr_estimator_plan* plan);
+int dvsr_estimator_num_params(const dvsr_estimator_plan* plan);
+size_t dvsr_estimator_workspace_bytes(const dvsr_estimator_plan* plan, int need_grad);
+int dvsr_estimator_forward(const dvsr_estimator_plan* plan, const float* const* params, const float* x, float* out,
+                           void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
+int dvsr_estimator_backward(const dvsr_estimator_plan* plan, const float* const* params, const float* x,
+                            const float* grad_out, float* const* grad_params, void* workspace,
+                            size_t workspace_bytes, dvsr_stream_t stream);
+
 /* ---- Charbonnier loss (models/loss.py:19-30, the `pixel_criterion: cb` of every EDVR YAML) --------
  * loss[0] = mean(sqrt((x-y)^2 + eps)), deterministic two-stage reduction; backward writes
  * gx = grad_loss[0]/n * (x-y)/sqrt((x-y)^2+eps) (the gradient w.r.t. y is -gx). */

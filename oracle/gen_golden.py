@@ -176,6 +176,41 @@ def mfdn_full(L):
          grad__conv6__weight=net.conv6.weight.grad, grad__conv0__bias=net.conv0.bias.grad)
 
 
+def estimator_variants(L):
+    """G5b: MFDN x2 on 1x3x3x24x40 (3x3 conv3 variant, T = 3) and SFDN on 2x3x20x28 through the reference
+    modules; every parameter gradient is stored (the nets are small at nf = 16)."""
+    nf = 16
+    M = synth.mfdn_state_dict(3, nf=nf, scale=2)
+    net = load_sd(L.DirectKernelEstimatorVideo(nf=nf, in_nc=3, scale=2), M)
+    lq = synth.clip(15, 1, 3, 24, 40)
+    y = net(lq.transpose(1, 2)).transpose(1, 2)
+    go = torch.from_numpy(np.random.RandomState(16).standard_normal(tuple(y.shape)).astype(np.float32))
+    y.backward(go)
+    MO = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in M.items())
+    yo = omfdn.mfdn_forward(MO, lq, scale=2)
+    og = torch.autograd.grad(yo, list(MO.values()), go)
+    assert relerr(yo, y) < 1e-6
+    for (k, p), g in zip(net.named_parameters(), og):
+        assert relerr(g, p.grad) < 1e-4, (k, relerr(g, p.grad))
+    save("mfdn_x2_24x40", wseed=3, xseed=15, goseed=16, nf=nf, out=y,
+         **{"grad__" + k.replace(".", "__"): p.grad for k, p in net.named_parameters()})
+
+    S = synth.sfdn_state_dict(4, nf=nf)
+    net = load_sd(L.DirectKernelEstimator_CMS(nf=nf), S)
+    x = synth.clip(17, 2, 1, 20, 28)[:, 0]
+    y = net(x)
+    go = torch.from_numpy(np.random.RandomState(18).standard_normal(tuple(y.shape)).astype(np.float32))
+    y.backward(go)
+    SO = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in S.items())
+    yo = omfdn.sfdn_forward(SO, x)
+    og = torch.autograd.grad(yo, list(SO.values()), go)
+    assert relerr(yo, y) < 1e-6
+    for (k, p), g in zip(net.named_parameters(), og):
+        assert relerr(g, p.grad) < 1e-4, (k, relerr(g, p.grad))
+    save("sfdn_20x28", wseed=4, xseed=17, goseed=18, nf=nf, out=y,
+         **{"grad__" + k.replace(".", "__"): p.grad for k, p in net.named_parameters()})
+
+
 def make_opt(optimizer):
     from options.options import dict_to_nonedict
     return dict_to_nonedict({
@@ -256,9 +291,10 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     E, L, models, U = import_reference()
-    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "inner"]
+    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "estimators", "inner"]
     if "dcn" in which: dcn_cases()
     if "pcd" in which: pcd_tsa(E)
     if "edvr" in which: edvr_full(E)
     if "mfdn" in which: mfdn_full(L)
+    if "estimators" in which: estimator_variants(L)
     if "inner" in which: inner_step(models, U)

@@ -40,3 +40,15 @@ def mfdn_forward(P, lqs, scale=4):
     fea = F.conv2d(fea, P["conv6.weight"], P["conv6.bias"])
     fea = fea.reshape(b, t, -1, hs, ws).transpose(1, 2)
     return (fea + m).transpose(1, 2)                          # LRestimator_model.py:128
+
+
+def sfdn_forward(P, x):
+    """SFDN (DirectKernelEstimator_CMS.forward, LRimg_estimator.py:55-67): x [N,3,H,W] -> [N,3,H/2,W/2]."""
+    m = x.mean(2, keepdim=True).mean(3, keepdim=True)
+    fea = _lrelu(_c2(P, "conv0", x - m))
+    fea = _lrelu(_c2(P, "conv1", fea))
+    fea = _lrelu(_c2(P, "conv2", fea))
+    fea = _lrelu(_c2(P, "conv3", fea, stride=2))
+    fea = _lrelu(_c2(P, "conv4", fea))
+    fea = _lrelu(_c2(P, "conv5", fea))
+    return F.conv2d(fea, P["conv6.weight"], P["conv6.bias"]) + m

@@ -87,18 +87,22 @@ def test_train_mode_builds_optimizers():
     assert model.get_current_learning_rate() == [1e-5]
 
 
-def test_mfdn_module_matches_golden():
-    """The estimator runs on stock torch ops, so its restatement can be checked on CPU."""
-    from dynavsr_amd.models.archs.LRimg_estimator import DirectKernelEstimatorVideo
-    g = load_golden("mfdn_32x32")
-    net = DirectKernelEstimatorVideo(nf=64, in_nc=3, scale=4)
-    net.load_state_dict(synth.mfdn_state_dict(int(g["wseed"])), strict=True)
-    lq = synth.clip(int(g["xseed"]), 1, 5, 32, 32)
-    y = net(lq.transpose(1, 2)).transpose(1, 2)
-    assert relerr(y, g["out"]) < 1e-6
-    go = torch.from_numpy(np.random.RandomState(int(g["goseed"])).standard_normal(tuple(y.shape)).astype(np.float32))
-    y.backward(go)
-    assert np.allclose([float(p.grad.norm()) for p in net.parameters()], g["grad_norms"], rtol=2e-4)
+def test_estimator_modules_state_dict_and_no_cpu_path():
+    """MFDN / SFDN keep the reference's parameter names and shapes (reference *_E.pth load strict) and,
+    like the EDVR backbone, refuse to run without the MI355X: there is no CPU fallback to hide behind."""
+    from dynavsr_amd.models.archs.LRimg_estimator import DirectKernelEstimator_CMS, DirectKernelEstimatorVideo
+    for scale in (2, 4):
+        net = DirectKernelEstimatorVideo(nf=64, in_nc=3, scale=scale)
+        net.load_state_dict(synth.mfdn_state_dict(0, scale=scale), strict=True)
+        assert [tuple(p.shape) for p in net.ordered_parameters()] == \
+            [tuple(v.shape) for v in synth.mfdn_state_dict(0, scale=scale).values()]
+    assert sum(p.numel() for p in DirectKernelEstimatorVideo(64, 3, 4).parameters()) == 452291  # SURVEY 8a A10
+    sf = DirectKernelEstimator_CMS(nf=16)
+    sf.load_state_dict(synth.sfdn_state_dict(0, nf=16), strict=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(synth.clip(1, 1, 5, 16, 16).transpose(1, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sf(synth.clip(1, 1, 1, 16, 16)[:, 0])
 
 
 def test_util_metrics_golden():

@@ -64,6 +64,31 @@ def test_mfdn_golden():
     assert np.allclose([float(x.norm()) for x in grads], g["grad_norms"], rtol=2e-4)
 
 
+def _check_all_grads(g, names, grads, tol=2e-4):
+    for name, gr in zip(names, grads):
+        assert relerr(gr, g["grad__" + name.replace(".", "__")]) < tol, name
+
+
+def test_mfdn_x2_golden():
+    """scale 2 (3x3 conv3) and T = 3: every parameter gradient of the reference module."""
+    g = load_golden("mfdn_x2_24x40")
+    M = OrderedDict((k, v.requires_grad_(True))
+                    for k, v in synth.mfdn_state_dict(int(g["wseed"]), nf=int(g["nf"]), scale=2).items())
+    y = mfdn.mfdn_forward(M, synth.clip(int(g["xseed"]), 1, 3, 24, 40), scale=2)
+    assert relerr(y, g["out"]) < 1e-6
+    go = _t(np.random.RandomState(int(g["goseed"])).standard_normal(tuple(y.shape)).astype(np.float32))
+    _check_all_grads(g, list(M), torch.autograd.grad(y, list(M.values()), go))
+
+
+def test_sfdn_golden():
+    g = load_golden("sfdn_20x28")
+    S = OrderedDict((k, v.requires_grad_(True)) for k, v in synth.sfdn_state_dict(int(g["wseed"]), nf=int(g["nf"])).items())
+    y = mfdn.sfdn_forward(S, synth.clip(int(g["xseed"]), 2, 1, 20, 28)[:, 0])
+    assert relerr(y, g["out"]) < 1e-6
+    go = _t(np.random.RandomState(int(g["goseed"])).standard_normal(tuple(y.shape)).astype(np.float32))
+    _check_all_grads(g, list(S), torch.autograd.grad(y, list(S.values()), go))
+
+
 @pytest.mark.parametrize("optimizer", ["SGD", "Adam"])
 def test_inner_step_golden(optimizer):
     """BASELINE.json configs[0]: EDVR-M x4, LR 64x64 -> SLR 16x16, one inner step."""
