@@ -718,7 +718,7 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
     case OP_PAD:
       return pad_fwd(bs.at(o.x0), bs.at(o.y), o.pmode, o.N, o.c0, o.H, o.W, o.T, st);
     case OP_MEANSUB:
-      return meansub_fwd(bs.at(o.x0), bs.at(o.y), bs.at(o.y2), o.N / o.T, o.c0, o.T, o.H, o.W, st);
+      return meansub_fwd(bs.at(o.x0), bs.at(o.y), bs.at(o.y2), bs.at(o.res), o.N / o.T, o.c0, o.T, o.H, o.W, st);
     case OP_ADDMEAN:
       return addmean_fwd(bs.at(o.x0), bs.at(o.x1), bs.at(o.y), o.N / o.T, o.c0, o.T, (size_t)o.H * o.W, st);
     case OP_ADD: {
@@ -989,6 +989,7 @@ static int build_estimator(dvsr_estimator_plan& ep) {
   T mean = b.alloc("mean", (size_t)BT * ic);
   {
     Op o; o.type = OP_MEANSUB; o.name = "meansub"; o.x0 = xin; o.y = xm; o.y2 = mean;
+    o.res = b.alloc("", (size_t)BT * ic * meansub_slices());  // row-mean partial sums
     o.N = BT; o.c0 = ic; o.H = H; o.W = W; o.T = Tn;
     p.ops.push_back(o);
   }

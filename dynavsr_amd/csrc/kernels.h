@@ -85,7 +85,9 @@ size_t pad_out_numel(int mode, size_t N, int C, int H, int W);
 int pad_fwd(const float* x, float* y, int mode, int N, int C, int H, int W, int T, hipStream_t st);
 int pad_bwd(const float* gy, float* gx, int mode, int N, int C, int H, int W, int T, int accumulate,
             hipStream_t st);
-int meansub_fwd(const float* x, float* xm, float* mean, int B, int C, int T, int H, int W, hipStream_t st);
+int meansub_slices();  // scratch floats per plane
+int meansub_fwd(const float* x, float* xm, float* mean, float* part, int B, int C, int T, int H, int W,
+                hipStream_t st);
 int addmean_fwd(const float* y, const float* mean, float* out, int B, int C, int T, size_t HW, hipStream_t st);
 int addmean_bwd(const float* gout, float* gy, int B, int C, int T, size_t HW, hipStream_t st);
 int w4_to_s2d(const float* w, float* w2, int Cout, int C, int inverse, hipStream_t st);

@@ -18,94 +18,94 @@ namespace dvsr {
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 __device__ __forceinline__ int clamp0(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 
-// one thread per output element
-__global__ void pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int mode,
-                               int C, int H, int W, int T) {
+// one thread per output element; blockIdx.y walks the output planes (n, output channel), so the only
+// per-thread integer division is pixel -> (row, column)
+__global__ void pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int mode, int C, int H,
+                               int W, int T) {
   const int Hp = H + 2, Wp = W + 2;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  const int Ho = mode == PAD_REFLECT_S2D ? Hp / 2 : Hp, Wo = mode == PAD_REFLECT_S2D ? Wp / 2 : Wp;
+  const int opix = Ho * Wo;
+  const int cmul = mode == PAD_REFLECT ? 1 : (mode == PAD_REFLECT_S2D ? 4 : 3);
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const int n = plane / (cmul * C), cc = plane - n * cmul * C;
+    const float* src;
+    int dy = 0, dx = 0;
     if (mode == PAD_REFLECT) {
-      const int q = (int)(i % Wp);
-      size_t t = i / Wp;
-      const int r = (int)(t % Hp);
-      const size_t plane = t / Hp;  // n*C + c
-      y[i] = x[(plane * H + reflect1(r - 1, H)) * W + reflect1(q - 1, W)];
+      src = x + (size_t)plane * H * W;
     } else if (mode == PAD_REFLECT_S2D) {
-      const int Wh = Wp / 2, Hh = Hp / 2;
-      const int X = (int)(i % Wh);
-      size_t t = i / Wh;
-      const int Y = (int)(t % Hh); t /= Hh;
-      const int c4 = (int)(t % (4 * C));
-      const size_t n = t / (4 * C);
-      const int c = c4 >> 2, dy = (c4 >> 1) & 1, dx = c4 & 1;
-      y[i] = x[((n * C + c) * H + reflect1(2 * Y + dy - 1, H)) * W + reflect1(2 * X + dx - 1, W)];
-    } else {  // PAD_REPL_T3
-      const int q = (int)(i % Wp);
-      size_t t = i / Wp;
-      const int r = (int)(t % Hp); t /= Hp;
-      const int c3 = (int)(t % (3 * C));
-      const size_t n = t / (3 * C);
-      const int c = c3 / 3, dt = c3 - 3 * c;
-      const int b = (int)(n / T), tt = (int)(n - (size_t)b * T);
-      const size_t src = (size_t)b * T + clamp0(tt + dt - 1, T);
-      y[i] = x[((src * C + c) * H + clamp0(r - 1, H)) * W + clamp0(q - 1, W)];
+      src = x + ((size_t)n * C + (cc >> 2)) * H * W;
+      dy = (cc >> 1) & 1; dx = cc & 1;
+    } else {
+      const int c = cc / 3, dt = cc - 3 * c;
+      const int b = n / T, tt = n - b * T;
+      src = x + (((size_t)b * T + clamp0(tt + dt - 1, T)) * C + c) * H * W;
+    }
+    float* dst = y + (size_t)plane * opix;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < opix; i += gridDim.x * blockDim.x) {
+      const int r = i / Wo, q = i - r * Wo;
+      int sy, sx;
+      if (mode == PAD_REFLECT) { sy = reflect1(r - 1, H); sx = reflect1(q - 1, W); }
+      else if (mode == PAD_REFLECT_S2D) { sy = reflect1(2 * r + dy - 1, H); sx = reflect1(2 * q + dx - 1, W); }
+      else { sy = clamp0(r - 1, H); sx = clamp0(q - 1, W); }
+      dst[i] = src[sy * W + sx];
     }
   }
 }
 
 // adjoint: one thread per INPUT element, gathering every padded position that maps to it
-__global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, size_t total, int mode,
-                               int C, int H, int W, int T, int accumulate) {
-  const int Hp = H + 2, Wp = W + 2;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int xx = (int)(i % W);
-    size_t t = i / W;
-    const int yy = (int)(t % H); t /= H;
-    const int c = (int)(t % C);
-    const size_t n = t / C;
-    // padded rows / columns that read this element
-    int rows[3], cols[3], nr = 0, nc = 0;
-    rows[nr++] = yy + 1;
-    cols[nc++] = xx + 1;
-    if (mode == PAD_REPL_T3) {
-      if (yy == 0) rows[nr++] = 0;
-      if (yy == H - 1) rows[nr++] = Hp - 1;
-      if (xx == 0) cols[nc++] = 0;
-      if (xx == W - 1) cols[nc++] = Wp - 1;
-    } else {
-      if (yy == 1) rows[nr++] = 0;
-      if (yy == H - 2) rows[nr++] = Hp - 1;
-      if (xx == 1) cols[nc++] = 0;
-      if (xx == W - 2) cols[nc++] = Wp - 1;
-    }
-    float s = 0.f;
+__global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int planes, int mode, int C,
+                               int H, int W, int T, int accumulate) {
+  const int Hp = H + 2, Wp = W + 2, ipix = H * W;
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {  // plane = n*C + c
+    const int n = plane / C, c = plane - n * C;
+    // source planes: 1 (reflect), 4 interleaved (space-to-depth) or up to 5 (t, dt) pairs (temporal gather)
+    const float* sp[5];
+    int np = 0;
     if (mode == PAD_REFLECT) {
-      const float* p = gy + (n * C + c) * (size_t)Hp * Wp;
-      for (int a = 0; a < nr; ++a)
-        for (int b = 0; b < nc; ++b) s += p[(size_t)rows[a] * Wp + cols[b]];
+      sp[np++] = gy + (size_t)plane * Hp * Wp;
     } else if (mode == PAD_REFLECT_S2D) {
-      const int Wh = Wp / 2, Hh = Hp / 2;
-      for (int a = 0; a < nr; ++a)
-        for (int b = 0; b < nc; ++b) {
-          const int r = rows[a], q = cols[b];
-          s += gy[((n * 4 * C + c * 4 + (r & 1) * 2 + (q & 1)) * Hh + (r >> 1)) * (size_t)Wh + (q >> 1)];
-        }
+      sp[np++] = gy + ((size_t)n * 4 * C + c * 4) * (size_t)(Hp / 2) * (Wp / 2);
     } else {
-      const int b_ = (int)(n / T), tt = (int)(n - (size_t)b_ * T);
-      // (t, dt) pairs with clamp(t + dt - 1) == tt
-      int ts[5], ds[5], np = 0;
-      for (int dt = 0; dt < 3; ++dt) {
+      const int b = n / T, tt = n - b * T;
+      for (int dt = 0; dt < 3; ++dt) {  // (t, dt) with clamp(t + dt - 1) == tt
         const int t0 = tt - dt + 1;
-        if (t0 >= 0 && t0 < T) { ts[np] = t0; ds[np] = dt; ++np; }
+        if (t0 >= 0 && t0 < T) sp[np++] = gy + (((size_t)b * T + t0) * 3 * C + c * 3 + dt) * (size_t)Hp * Wp;
       }
-      if (tt == 0) { ts[np] = 0; ds[np] = 0; ++np; }          // t + dt - 1 = -1 clamps to 0
-      if (tt == T - 1) { ts[np] = T - 1; ds[np] = 2; ++np; }  // = T clamps to T - 1
-      for (int k = 0; k < np; ++k) {
-        const float* p = gy + (((size_t)b_ * T + ts[k]) * 3 * C + c * 3 + ds[k]) * (size_t)Hp * Wp;
-        for (int a = 0; a < nr; ++a)
-          for (int b = 0; b < nc; ++b) s += p[(size_t)rows[a] * Wp + cols[b]];
-      }
+      if (tt == 0) sp[np++] = gy + (((size_t)b * T) * 3 * C + c * 3) * (size_t)Hp * Wp;                  // -1 -> 0
+      if (tt == T - 1) sp[np++] = gy + (((size_t)b * T + T - 1) * 3 * C + c * 3 + 2) * (size_t)Hp * Wp;  // T -> T-1
     }
-    gx[i] = accumulate ? gx[i] + s : s;
+    float* dst = gx + (size_t)plane * ipix;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ipix; i += gridDim.x * blockDim.x) {
+      const int yy = i / W, xx = i - yy * W;
+      int rows[3], cols[3], nr = 0, nc = 0;  // padded rows / columns that read this element
+      rows[nr++] = yy + 1;
+      cols[nc++] = xx + 1;
+      if (mode == PAD_REPL_T3) {
+        if (yy == 0) rows[nr++] = 0;
+        if (yy == H - 1) rows[nr++] = Hp - 1;
+        if (xx == 0) cols[nc++] = 0;
+        if (xx == W - 1) cols[nc++] = Wp - 1;
+      } else {
+        if (yy == 1) rows[nr++] = 0;
+        if (yy == H - 2) rows[nr++] = Hp - 1;
+        if (xx == 1) cols[nc++] = 0;
+        if (xx == W - 2) cols[nc++] = Wp - 1;
+      }
+      float s = 0.f;
+      if (mode == PAD_REFLECT_S2D) {
+        const int Wh = Wp / 2, Hh = Hp / 2;
+        for (int a = 0; a < nr; ++a)
+          for (int b = 0; b < nc; ++b) {
+            const int r = rows[a], q = cols[b];
+            s += sp[0][((size_t)((r & 1) * 2 + (q & 1)) * Hh + (r >> 1)) * Wh + (q >> 1)];
+          }
+      } else {
+        for (int k = 0; k < np; ++k)
+          for (int a = 0; a < nr; ++a)
+            for (int b = 0; b < nc; ++b) s += sp[k][rows[a] * Wp + cols[b]];
+      }
+      dst[i] = accumulate ? dst[i] + s : s;
+    }
   }
 }
 
@@ -127,8 +127,11 @@ int pad_fwd(const float* x, float* y, int mode, int N, int C, int H, int W, int 
   DVSR_REQUIRE(mode != PAD_REFLECT_S2D || (H % 2 == 0 && W % 2 == 0), DVSR_ERR_INVALID,
                "pad_fwd: space-to-depth needs even H, W (got %dx%d)", H, W);
   DVSR_REQUIRE(mode != PAD_REPL_T3 || (T > 0 && N % T == 0), DVSR_ERR_INVALID, "pad_fwd: N=%d not a multiple of T=%d", N, T);
-  const size_t total = pad_out_numel(mode, (size_t)N, C, H, W);
-  hipLaunchKernelGGL(pad_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, y, total, mode, C, H, W, T);
+  const int cmul = mode == PAD_REFLECT ? 1 : (mode == PAD_REFLECT_S2D ? 4 : 3);
+  const int planes = N * C * cmul;
+  const int opix = (int)(pad_out_numel(mode, 1, 1, H, W) / cmul);
+  const dim3 grid(ceil_div(opix, 1024) > 0 ? ceil_div(opix, 1024) : 1, planes < 65535 ? planes : 65535);
+  hipLaunchKernelGGL(pad_fwd_kernel, grid, dim3(256), 0, st, x, y, planes, mode, C, H, W, T);
   return check_launch("pad_fwd_kernel");
 }
 
@@ -136,40 +139,48 @@ int pad_bwd(const float* gy, float* gx, int mode, int N, int C, int H, int W, in
             hipStream_t st) {
   DVSR_REQUIRE(gy && gx, DVSR_ERR_INVALID, "pad_bwd: null pointer");
   DVSR_REQUIRE(mode >= PAD_REFLECT && mode <= PAD_REPL_T3, DVSR_ERR_INVALID, "pad_bwd: mode %d", mode);
-  const size_t total = (size_t)N * C * H * W;
-  hipLaunchKernelGGL(pad_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, gy, gx, total, mode, C, H, W, T,
-                     accumulate);
+  const int planes = N * C;
+  const dim3 grid(ceil_div(H * W, 1024), planes < 65535 ? planes : 65535);
+  hipLaunchKernelGGL(pad_bwd_kernel, grid, dim3(256), 0, st, gy, gx, planes, mode, C, H, W, T, accumulate);
   return check_launch("pad_bwd_kernel");
 }
 
 // ---- per-frame mean (LRimg_estimator.py:93: x.mean(-1).mean(-2)) ------------------------------------
-// x: [B][C][T][H][W]  ->  xm: [(B*T)][C][H][W] = x - mean,  mean: [B][C][T].  One workgroup per plane.
-__global__ __launch_bounds__(256) void meansub_kernel(const float* __restrict__ x, float* __restrict__ xm,
-                                                      float* __restrict__ mean, int C, int T, int H, int W) {
-  const int plane = blockIdx.x;  // (b*C + c)*T + t
-  const int t = plane % T, c = (plane / T) % C, b = plane / (T * C);
-  const size_t HW = (size_t)H * W;
-  const float* src = x + (size_t)plane * HW;
-  // mean over W, then over H, like the reference (row means are averaged)
-  __shared__ float s_part[256];
+// x: [B][C][T][H][W]  ->  xm: [(B*T)][C][H][W] = x - mean,  mean: [B][C][T].
+// Pass 1: MS_SLICES workgroups per plane sum the row means of their rows (mean over W, then over H, like
+// the reference); pass 2 finishes the mean from the slice sums and subtracts.
+constexpr int MS_SLICES = 16;
+__global__ __launch_bounds__(256) void rowmean_kernel(const float* __restrict__ x, float* __restrict__ part, int H,
+                                                      int W) {
+  const int plane = blockIdx.y, slice = blockIdx.x;
+  const float* src = x + (size_t)plane * H * W;
+  __shared__ float s_part[4];
   float acc = 0.f;
-  for (int row = threadIdx.x >> 6; row < H; row += 4) {  // one wave per row
+  for (int row = slice * 4 + (threadIdx.x >> 6); row < H; row += 4 * MS_SLICES) {  // one wave per row
     float s = 0.f;
     for (int col = threadIdx.x & 63; col < W; col += 64) s += src[(size_t)row * W + col];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((threadIdx.x & 63) == 0) acc += s / (float)W;
+    acc += s / (float)W;
   }
-  s_part[threadIdx.x] = acc;
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float m = (s_part[0] + s_part[64] + s_part[128] + s_part[192]) / (float)H;
-    s_part[0] = m;
-    mean[plane] = m;
-  }
-  __syncthreads();
-  const float m = s_part[0];
+  if (threadIdx.x == 0) part[plane * MS_SLICES + slice] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ __launch_bounds__(256) void meansub_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                      float* __restrict__ xm, float* __restrict__ mean, int C, int T,
+                                                      int H, int W) {
+  const int plane = blockIdx.y;  // (b*C + c)*T + t
+  const int t = plane % T, c = (plane / T) % C, b = plane / (T * C);
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < MS_SLICES; ++k) m += part[plane * MS_SLICES + k];
+  m /= (float)H;
+  if (blockIdx.x == 0 && threadIdx.x == 0) mean[plane] = m;
+  const int HW = H * W;
+  const float* src = x + (size_t)plane * HW;
   float* dst = xm + (((size_t)b * T + t) * C + c) * HW;
-  for (size_t i = threadIdx.x; i < HW; i += 256) dst[i] = src[i] - m;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) dst[i] = src[i] - m;
 }
 
 // out[b][c][t][p] = y[(b*T+t)][c][p] + mean[b][c][t]
@@ -200,11 +211,20 @@ __global__ void addmean_bwd_kernel(const float* __restrict__ gout, float* __rest
   }
 }
 
-int meansub_fwd(const float* x, float* xm, float* mean, int B, int C, int T, int H, int W, hipStream_t st) {
-  DVSR_REQUIRE(x && xm && mean, DVSR_ERR_INVALID, "meansub_fwd: null pointer");
-  hipLaunchKernelGGL(meansub_kernel, dim3(B * C * T), dim3(256), 0, st, x, xm, mean, C, T, H, W);
+// part: B*C*T*MS_SLICES floats of scratch
+int meansub_fwd(const float* x, float* xm, float* mean, float* part, int B, int C, int T, int H, int W,
+                hipStream_t st) {
+  DVSR_REQUIRE(x && xm && mean && part, DVSR_ERR_INVALID, "meansub_fwd: null pointer");
+  const int planes = B * C * T;
+  DVSR_REQUIRE(planes <= 65535, DVSR_ERR_UNSUPPORTED, "meansub_fwd: %d planes", planes);
+  hipLaunchKernelGGL(rowmean_kernel, dim3(MS_SLICES, planes), dim3(256), 0, st, x, part, H, W);
+  int rc = check_launch("rowmean_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(meansub_kernel, dim3(ceil_div(H * W, 1024), planes), dim3(256), 0, st, x, part, xm, mean, C, T,
+                     H, W);
   return check_launch("meansub_kernel");
 }
+int meansub_slices() { return MS_SLICES; }
 
 int addmean_fwd(const float* y, const float* mean, float* out, int B, int C, int T, size_t HW, hipStream_t st) {
   DVSR_REQUIRE(y && mean && out, DVSR_ERR_INVALID, "addmean_fwd: null pointer");
