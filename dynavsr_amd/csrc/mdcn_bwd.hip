@@ -13,6 +13,8 @@
 // into LDS is the planned next step (DESIGN.md "DCN backward").
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -117,6 +119,203 @@ __global__ void mdcn_col2im_coord_kernel(DcnB a, const float* __restrict__ dcol,
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Fused backward for the EDVR configuration (8 channels per deformable group, 3x3, stride 1, pad 1,
+// dilation 1).  One workgroup = one 8x32-pixel tile of one (frame, group):
+//   1. dcol tile on MFMA, kept in registers: D[m = tap*8 + c][pixel] = sum_o W[o][g*8+c][tap] * gout[o][pixel]
+//      (3 M-tiles of 32 rows, 72 used; 2 pixel rows per wave; K = Cout).  With this row order a lane
+//      holds, for each of its pixels, 4 channels (c = 4*hi + 0..3) of 4 taps per M-tile -- the lane pair
+//      (l, l+32) holds the 8 channels of a (pixel, tap).  dcol never touches HBM.
+//   2. per (pixel, tap): bilinear geometry once, 4 corner x 4 channel reads from the LDS-staged input
+//      window, mask / offset gradient = in-register sums + one exchange with the partner lane, the
+//      modulated sample is written to the column buffer for the weight gradient, and the input gradient
+//      is accumulated with LDS atomics (ds_add_f32) into a window of the same shape, laid out
+//      [channel][y][x] so that the lanes of a wave (adjacent pixels) hit adjacent banks;
+//   3. the window is flushed with ONE global atomic per touched element: ~6 k per workgroup instead of
+//      the 74 k (256 px x 9 taps x 4 corners x 8 channels) of the unfused kernel.
+// Samples whose 2x2 footprint leaves the window (|offset| > HALO) take exact global gathers / atomics.
+// -------------------------------------------------------------------------------------------------
+struct DcnF {
+  const float* x; const float* off; const float* msk; const float* w; const float* gout;
+  float* gx; float* goff; float* gmsk; float* col;
+  long long off_bs, msk_bs, goff_bs, gmsk_bs;
+  int mask_logit, N, C, H, W, Cout, dg, tiles_x, tiles_y;
+};
+
+template <int HALO>
+__global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
+  constexpr int TH = 8, TW = 32, XH = TH + 2 + 2 * HALO, XW = TW + 2 + 2 * HALO, XPX = XH * XW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const s_x = smem;              // [8][XPX]
+  float* const s_gx = smem + 8 * XPX;   // [8][XPX]
+  float* const s_wt = smem + 16 * XPX;  // [3][Cout/2][64]: A operands, lane-major
+  const int KST = a.Cout >> 1;
+
+  const int tile = blockIdx.x, g = blockIdx.y, n = blockIdx.z;
+  const int tx_ = tile % a.tiles_x, ty_ = tile / a.tiles_x;
+  const int oy0 = ty_ * TH, ox0 = tx_ * TW;
+  const int wy0 = oy0 - 1 - HALO, wx0 = ox0 - 1 - HALO;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const size_t HW = (size_t)a.H * a.W;
+  const float* xg = a.x + ((size_t)n * a.C + g * 8) * HW;
+
+  // ---- stage the input window (zero outside the image), clear the gradient window, stage W^T
+  for (int idx = tid; idx < 8 * XPX; idx += 256) {
+    const int c = idx / XPX, r = idx - c * XPX;
+    const int ry = r / XW, rx = r - ry * XW;
+    const int gy_ = wy0 + ry, gx_ = wx0 + rx;
+    const bool ok = (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W;
+    s_x[idx] = ok ? xg[(size_t)c * HW + (size_t)gy_ * a.W + gx_] : 0.f;
+    s_gx[idx] = 0.f;
+  }
+  for (int idx = tid; idx < 3 * KST * 64; idx += 256) {
+    const int l = idx & 63, kk = (idx >> 6) % KST, mt = idx / (64 * KST);
+    const int m = mt * 32 + (l & 31), o = 2 * kk + (l >> 5);
+    float v = 0.f;
+    if (m < 72) v = a.w[((size_t)o * a.C + g * 8 + (m & 7)) * 9 + (m >> 3)];
+    s_wt[idx] = v;
+  }
+  __syncthreads();
+
+  // ---- 1. dcol tile: D[mt][nt], pixel row 2*wave + nt, column lo
+  const int px = ox0 + lo;
+  int py[2];
+  bool pv[2];
+  size_t pofs[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    py[nt] = oy0 + 2 * wave + nt;
+    pv[nt] = py[nt] < a.H && px < a.W;
+    pofs[nt] = pv[nt] ? (size_t)py[nt] * a.W + px : 0;
+  }
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const float* gon = a.gout + (size_t)n * a.Cout * HW;
+  float bnext[2] = {gon[(size_t)hi * HW + pofs[0]], gon[(size_t)hi * HW + pofs[1]]};
+  for (int kk = 0; kk < KST; ++kk) {
+    const float b0 = pv[0] ? bnext[0] : 0.f, b1 = pv[1] ? bnext[1] : 0.f;
+    if (kk + 1 < KST) {
+      const size_t ob = (size_t)(2 * (kk + 1) + hi) * HW;
+      bnext[0] = gon[ob + pofs[0]];
+      bnext[1] = gon[ob + pofs[1]];
+    }
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+      const float av = s_wt[(mt * KST + kk) * 64 + lane];
+      acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[mt][0], 0, 0, 0);
+      acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[mt][1], 0, 0, 0);
+    }
+  }
+
+  // ---- 2. sampling: this lane's 4 channels (4*hi .. 4*hi+3) of every (pixel, tap)
+  const float* offn = a.off + (size_t)n * a.off_bs;
+  const float* mskn = a.msk + (size_t)n * a.msk_bs;
+  float* goffn = a.goff + (size_t)n * a.goff_bs;
+  float* gmskn = a.gmsk + (size_t)n * a.gmsk_bs;
+  float* coln = a.col + (size_t)n * a.C * 9 * HW;
+  float* gxg = a.gx ? a.gx + ((size_t)n * a.C + g * 8) * HW : nullptr;
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) {
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const int tap = mt * 4 + t4;
+      if (tap >= 9) continue;
+      const int ki = tap / 3, kj = tap - 3 * ki;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        // both lanes of a pair run the geometry (same pixel); pv is pair-uniform
+        float gm = 0.f, gh = 0.f, gw = 0.f, m = 0.f;
+        float colv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pv[nt]) {
+          const float oh = offn[(size_t)(g * 18 + 2 * tap) * HW + pofs[nt]];
+          const float ow = offn[(size_t)(g * 18 + 2 * tap + 1) * HW + pofs[nt]];
+          const float mraw = mskn[(size_t)(g * 9 + tap) * HW + pofs[nt]];
+          m = a.mask_logit ? sigmoidf_(mraw) : mraw;
+          const float h_im = (float)(py[nt] - 1 + ki) + oh;
+          const float w_im = (float)(px - 1 + kj) + ow;
+          if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+            const int ry = (int)hf - wy0, rx = (int)wf - wx0;
+            const bool inwin = ry >= 0 && ry <= XH - 2 && rx >= 0 && rx <= XW - 2;
+            DcnTap tp;
+            if (!inwin) make_tap(h_im, w_im, a.H, a.W, tp);
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+              const int c = 4 * hi + cq;
+              const float d = acc[mt][nt][t4 * 4 + cq];
+              float v1, v2, v3, v4;
+              if (inwin) {
+                const float* p1 = s_x + c * XPX + ry * XW + rx;
+                v1 = p1[0]; v2 = p1[1]; v3 = p1[XW]; v4 = p1[XW + 1];
+              } else {
+                const float* pl = xg + (size_t)c * HW;
+                v1 = tp.v1 ? pl[tp.o1] : 0.f; v2 = tp.v2 ? pl[tp.o2] : 0.f;
+                v3 = tp.v3 ? pl[tp.o3] : 0.f; v4 = tp.v4 ? pl[tp.o4] : 0.f;
+              }
+              const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+              colv[cq] = val * m;
+              gm += d * val;                                              // kernel.cu:752
+              gh += (-hw * v1 - lw * v2 + hw * v3 + lw * v4) * d * m;     // :541-550
+              gw += (-hh * v1 + hh * v2 - lh * v3 + lh * v4) * d * m;     // :552-561
+              const float top = d * m;                                    // :672
+              if (gxg) {
+                if (inwin) {
+                  float* q1 = s_gx + c * XPX + ry * XW + rx;
+                  unsafeAtomicAdd(q1, w1 * top);
+                  unsafeAtomicAdd(q1 + 1, w2 * top);
+                  unsafeAtomicAdd(q1 + XW, w3 * top);
+                  unsafeAtomicAdd(q1 + XW + 1, w4 * top);
+                } else {
+                  float* gp = gxg + (size_t)c * HW;
+                  if (tp.v1) unsafeAtomicAdd(gp + tp.o1, w1 * top);
+                  if (tp.v2) unsafeAtomicAdd(gp + tp.o2, w2 * top);
+                  if (tp.v3) unsafeAtomicAdd(gp + tp.o3, w3 * top);
+                  if (tp.v4) unsafeAtomicAdd(gp + tp.o4, w4 * top);
+                }
+              }
+            }
+          }
+        }
+        // the partner lane (other 4 channels of the same pixel) completes the sums
+        gm += __shfl_xor(gm, 32, 64);
+        gh += __shfl_xor(gh, 32, 64);
+        gw += __shfl_xor(gw, 32, 64);
+        if (pv[nt]) {
+          if (hi == 0) {
+            goffn[(size_t)(g * 18 + 2 * tap) * HW + pofs[nt]] = gh;
+            goffn[(size_t)(g * 18 + 2 * tap + 1) * HW + pofs[nt]] = gw;
+            gmskn[(size_t)(g * 9 + tap) * HW + pofs[nt]] = a.mask_logit ? gm * m * (1.f - m) : gm;
+          }
+#pragma unroll
+          for (int cq = 0; cq < 4; ++cq)
+            coln[((size_t)(g * 8 + 4 * hi + cq) * 9 + tap) * HW + pofs[nt]] = colv[cq];
+        }
+      }
+    }
+  }
+  if (!gxg) return;
+  __syncthreads();
+  // ---- 3. flush the gradient window
+  for (int idx = tid; idx < 8 * XPX; idx += 256) {
+    const float v = s_gx[idx];
+    if (v == 0.f) continue;
+    const int c = idx / XPX, r = idx - c * XPX;
+    const int ry = r / XW, rx = r - ry * XW;
+    const int gy_ = wy0 + ry, gx_ = wx0 + rx;
+    if ((unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W)
+      unsafeAtomicAdd(gxg + (size_t)c * HW + (size_t)gy_ * a.W + gx_, v);
+  }
+}
+
 size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int stride, int pad, int dil) {
   const int Ho = (H + 2 * pad - (dil * 2 + 1)) / stride + 1, Wo = (W + 2 * pad - (dil * 2 + 1)) / stride + 1;
   const size_t col = (size_t)N * C * 9 * Ho * Wo * sizeof(float);
@@ -148,6 +347,32 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
   float* col = (float*)ws;
   void* ws2 = (char*)ws + (size_t)N * C * 9 * P * sizeof(float);
   const size_t ws2_bytes = ws_bytes - (size_t)N * C * 9 * P * sizeof(float);
+  static int use_fused = -1;  // DVSR_DCN_BWD=unfused: the three-kernel path for every shape (A/B aid)
+  if (use_fused < 0) {
+    const char* v = getenv("DVSR_DCN_BWD");
+    use_fused = (v && v[0] == 'u') ? 0 : 1;
+  }
+  if (use_fused && a.cpg == 8 && stride == 1 && pad == 1 && dil == 1 && Cout % 2 == 0 && Cout <= 128) {
+    constexpr int HALO = 4, XPX = (8 + 2 + 2 * HALO) * (32 + 2 + 2 * HALO);
+    DcnF f;
+    f.x = x; f.off = off; f.msk = msk; f.w = w; f.gout = gout; f.gx = gx; f.goff = goff; f.gmsk = gmsk; f.col = col;
+    f.off_bs = a.off_bs; f.msk_bs = a.msk_bs; f.goff_bs = goff_bs; f.gmsk_bs = gmsk_bs;
+    f.mask_logit = mask_logit; f.N = N; f.C = C; f.H = H; f.W = W; f.Cout = Cout; f.dg = dg;
+    f.tiles_x = ceil_div(W, 32); f.tiles_y = ceil_div(H, 8);
+    const size_t lds = (size_t)(16 * XPX + 3 * (Cout / 2) * 64) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipFuncSetAttribute((const void*)mdcn_bwd_fused_kernel<HALO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)((16 * XPX + 3 * 64 * 64) * sizeof(float)));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(mdcn_bwd_fused_kernel<HALO>, dim3(f.tiles_x * f.tiles_y, dg, N), dim3(256), lds, st, f);
+    int rc = check_launch("mdcn_bwd_fused_kernel");
+    if (rc) return rc;
+    if (gw)  // dW = gout . col^T, db = gout . 1 (the kernel above wrote the modulated samples to col)
+      rc = conv2d_wgrad_run(col, 0, 1, gout, 0, gw, gb, N, C * 9, a.Ho, a.Wo, Cout, C * 9, 0, 1, 1, ws2, ws2_bytes, st);
+    return rc;
+  }
   // 1) dcol[n][C*9][P] = W^T . gout  as a 1x1 conv with the transposed weight view
   dvsr_conv2d_desc g = {};
   g.x0 = gout; g.w = w; g.y = col; g.N = N; g.c0 = Cout; g.H = a.Ho; g.W = a.Wo; g.Cout = C * 9; g.ks = 1;
