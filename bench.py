@@ -87,7 +87,7 @@ def inner_step_rate(dev, steps=8):
     ms = (time.perf_counter() - t0) / steps * 1e3
     return {"value": 1e3 / ms, "unit": "clips/s", "ms_per_step": ms, "steps": steps,
             "workload": "1 inner MAML step, EDVR-M x4 + MFDN, LR 1x5x3x176x320 -> SLR 44x80, fp32, Adam; "
-                        "MFDN runs on stock PyTorch-ROCm ops (SURVEY 8a A10)"}
+                        "MFDN runs on the native estimator tape (dvsr_estimator_*)"}
 
 
 def main():
