@@ -61,6 +61,10 @@ struct TileOut {
   const float* res;    // residual added after the activation, same layout as y, or null
   int act, ps, accum;  // accum: y += result
   int Cout, Ho, Wo;
+  // data-gradient launches: multiply the result by act'(gmask) -- the saved OUTPUT of the layer whose
+  // gradient this is (same layout as y) -- i.e. the activation backward of the producer, fused
+  const float* gmask = nullptr;
+  int gmask_act = 0;
 };
 
 template <bool FULL, int MT, int NT>
@@ -116,11 +120,19 @@ __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT]
 #pragma unroll
           for (int r = 0; r < 16; ++r) extra[r] += *addr(t.y, r);
         }
+        float gm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm[r] = 1.f;
+        if (t.gmask) {
+          const float neg = t.gmask_act == ACT_LRELU ? 0.1f : (t.gmask_act == ACT_RELU ? 0.f : 1.f);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gm[r] = *addr(t.gmask, r) > 0.f ? 1.f : neg;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
           float v = acc[mt][nt][r] + bv[mt][r];
-          v = fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)) + extra[r];  // == v > 0 ? v : slope * v, no VCC round trip
+          v = (fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)) + extra[r]) * gm[r];  // act: v > 0 ? v : slope * v
           if (FULL || (row_ok && co < t.Cout)) *const_cast<float*>(addr(t.y, r)) = v;
         }
       } else {

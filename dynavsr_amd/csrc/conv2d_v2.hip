@@ -33,6 +33,7 @@ struct ConvK2 {
   long long x0_bs, x1_bs;
   int tiles_x, tiles_y, ntiles, ncb, nchunks;
   int in_ps, in_dil, Hs, Ws, accum;
+  const float* gmask; int gmask_act;
 #ifdef DVSR_CONV_TRACE
   long long* trace;  // debug build only (tools/conv_trace.py): 64 cycle stamps per workgroup
 #endif
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
 
   // ---- epilogue: bias, activation, residual / accumulate, (pixel-shuffled) store
   DVSR_STAMP(40);
-  const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo};
+  const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
   store_mfma_tile<MT, NT>(acc, t, n, cbi * MT * 32, oy0, TH, ox0, oy0 + NT * wave, lo, hi);
 #ifdef DVSR_CONV_TRACE
   DVSR_STAMP(41);
@@ -399,6 +400,7 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
   k.Wo = (d.W + 2 * d.pad - d.ks) / d.stride + 1;
   k.nchunks = ceil_div(d.c0 + d.c1, geo.cc);
   k.in_ps = ex.in_ps; k.in_dil = ex.in_dil; k.Hs = ex.Hs; k.Ws = ex.Ws; k.accum = ex.accum;
+  k.gmask = ex.gmask; k.gmask_act = ex.gmask_act;
   if (k.in_ps) k.x0_bs = (long long)d.c0 * d.H * d.W;
   if (k.in_dil) k.x0_bs = (long long)d.c0 * ex.Hs * ex.Ws;
 #ifdef DVSR_CONV_TRACE

@@ -77,6 +77,7 @@ struct BOp {
   Ref a, b, c, d, e, f;  // meaning depends on type
   size_t n = 0;          // element count for streaming ops
   int accum = 0, which = 0, cnt = 1, B = 0;
+  int mask_op = -1;  // B_DGRAD / B_PADFOLD: forward op whose activation backward is fused into this launch
   long long bs = 0;
   size_t per = 0;
 };
@@ -397,9 +398,36 @@ struct BackBuilder {
   }
 };
 
+// Index of the conv whose activated output is exactly tensor `t`, if the op at `consumer` is the ONLY reader of
+// that output: then the consumer's gradient launch is the sole, final contribution to grad(t) and can apply
+// the producer's activation backward itself (one launch less per layer).  -1 otherwise.
+static int sole_producer_with_act(const dvsr_edvr_plan& p, const T& t, int consumer) {
+  if (t.space != SP_ARENA) return -1;
+  int prod = -1;
+  for (int j = 0; j < consumer; ++j) {
+    const Op& q = p.ops[j];
+    if (q.type == OP_CONV && q.act != ACT_NONE && q.y.space == SP_ARENA && q.y.off == t.off && q.y.numel == t.numel &&
+        !q.ps)
+      prod = j;
+  }
+  if (prod < 0) return -1;
+  const Op& q = p.ops[prod];
+  int readers = 0;
+  for (size_t j = 0; j < p.ops.size(); ++j) {
+    const Op& r = p.ops[j];
+    for (const T* in : {&r.x0, &r.x1, &r.res})
+      if (in->space == SP_ARENA && in->off < q.y.off + q.y.numel && in->off + in->numel > q.y.off) ++readers;
+  }
+  return readers == 1 ? prod : -1;
+}
+
 static void build_backward(dvsr_edvr_plan& p) {
   BackBuilder bb(p);
   size_t tmp = 0, scratch = 0, wscratch = 0;
+  std::vector<char> act_fused(p.ops.size(), 0);  // the producer's B_ACT is done by its consumer's launch
+  // DVSR_FUSE_ACT_BWD=0 keeps every activation backward a separate launch (A/B aid); the un-pipelined conv
+  // kernel (DVSR_CONV_V1) has no mask input
+  const bool fuse_act = !p.use_v1 && [] { const char* v = getenv("DVSR_FUSE_ACT_BWD"); return !(v && v[0] == '0'); }();
   for (int i = (int)p.ops.size() - 1; i >= 0; --i) {
     const Op& o = p.ops[i];
     const Ref gy = BackBuilder::grad(o.y);
@@ -407,7 +435,7 @@ static void build_backward(dvsr_edvr_plan& p) {
       case OP_CONV: {
         const int Ho = conv_out(o, o.H), Wo = conv_out(o, o.W);
         if (o.res.valid()) bb.copyadd(o.res, gy, o.y.numel, i);
-        if (o.act != ACT_NONE) {
+        if (o.act != ACT_NONE && !act_fused[i]) {
           BOp a; a.type = B_ACT; a.fwd = i; a.a = gy; a.b = BackBuilder::act(o.y); a.n = o.y.numel;
           p.bops.push_back(a);
         }
@@ -434,6 +462,10 @@ static void build_backward(dvsr_edvr_plan& p) {
             T full = xin; full.numel = (size_t)o.N * ci * o.H * o.W;
             d.accum = bb.contribute(full, true, i);
             d.a = BackBuilder::grad(xin);
+            if (!d.accum && !o.c1 && fuse_act) {
+              const int prod = sole_producer_with_act(p, full, i);
+              if (prod >= 0) { d.mask_op = prod; act_fused[prod] = 1; }
+            }
             p.bops.push_back(d);
           } else {
             // dense dgrad into the staging buffer, then fold frames into the strided view
@@ -506,6 +538,10 @@ static void build_backward(dvsr_edvr_plan& p) {
         BOp f; f.type = B_PADFOLD; f.fwd = i; f.b = gy; f.a = BackBuilder::grad(o.x0);
         T xin = o.x0; xin.numel = (size_t)o.N * o.c0 * o.H * o.W;
         f.accum = bb.contribute(xin, true, i);
+        if (!f.accum && fuse_act) {
+          const int prod = sole_producer_with_act(p, xin, i);
+          if (prod >= 0) { f.mask_op = prod; act_fused[prod] = 1; }
+        }
         p.bops.push_back(f);
         break;
       }
@@ -574,7 +610,9 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
     case B_PADFOLD: {
       float* gx = bs.at(b.a);
       if (!gx) return DVSR_OK;
-      return pad_bwd(bs.at(b.b), gx, o->pmode, o->N, o->c0, o->H, o->W, o->T, b.accum, st);
+      return pad_bwd(bs.at(b.b), gx, o->pmode, o->N, o->c0, o->H, o->W, o->T, b.accum, st,
+                     b.mask_op >= 0 ? bs.arena + p.ops[b.mask_op].y.off : nullptr,
+                     b.mask_op >= 0 ? p.ops[b.mask_op].act : 0);
     }
     case B_ADDMEAN:
       return addmean_bwd(bs.at(b.b), bs.at(b.a), o->N / o->T, o->c0, o->T, (size_t)o->H * o->W, st);
@@ -588,6 +626,7 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
       g.ks = o->ks; g.stride = 1; g.pad = o->ks - 1 - conv_pad(*o); g.act = ACT_NONE; g.x1_bdiv = 1;
       ConvExtra ex;
       ex.wt = 1; ex.w_ctot = o->c0 + o->c1; ex.w_coff = b.which ? o->c0 : 0; ex.accum = b.accum; ex.in_ps = o->ps ? 1 : 0;
+      if (b.mask_op >= 0 && !bs.use_v1) { ex.gmask = bs.arena + p.ops[b.mask_op].y.off; ex.gmask_act = p.ops[b.mask_op].act; }
       if (o->stride == 2) { ex.in_dil = 2; ex.Hs = Ho; ex.Ws = Wo; g.H = o->H; g.W = o->W; }
       else { g.H = Ho; g.W = Wo; }
       if (bs.use_v1) return conv2d_run(g, ex, st);

@@ -12,6 +12,8 @@ struct ConvExtra {
   int in_ps = 0;               // input is stored pixel-shuffled (gradient of a PixelShuffle(2) output)
   int in_dil = 0, Hs = 0, Ws = 0;  // input is the zero-dilated view of a [N][c0][Hs][Ws] tensor
   int accum = 0;               // y += result
+  const float* gmask = nullptr;  // dgrad: multiply by act'(gmask) (fused activation backward of the producer)
+  int gmask_act = 0;
 };
 int conv2d_run(const dvsr_conv2d_desc& d, const ConvExtra& ex, hipStream_t st);
 
@@ -84,7 +86,7 @@ enum : int { PAD_REFLECT = 0, PAD_REFLECT_S2D = 1, PAD_REPL_T3 = 2 };
 size_t pad_out_numel(int mode, size_t N, int C, int H, int W);
 int pad_fwd(const float* x, float* y, int mode, int N, int C, int H, int W, int T, hipStream_t st);
 int pad_bwd(const float* gy, float* gx, int mode, int N, int C, int H, int W, int T, int accumulate,
-            hipStream_t st);
+            hipStream_t st, const float* gmask = nullptr, int gmask_act = 0);
 int meansub_slices();  // scratch floats per plane
 int meansub_fwd(const float* x, float* xm, float* mean, float* part, int B, int C, int T, int H, int W,
                 hipStream_t st);

@@ -54,7 +54,8 @@ __global__ void pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
 
 // adjoint: one thread per INPUT element, gathering every padded position that maps to it
 __global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int planes, int mode, int C,
-                               int H, int W, int T, int accumulate) {
+                               int H, int W, int T, int accumulate, const float* __restrict__ gmask,
+                               int gmask_act) {
   const int Hp = H + 2, Wp = W + 2, ipix = H * W;
   for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {  // plane = n*C + c
     const int n = plane / C, c = plane - n * C;
@@ -104,7 +105,12 @@ __global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__
           for (int a = 0; a < nr; ++a)
             for (int b = 0; b < nc; ++b) s += sp[k][rows[a] * Wp + cols[b]];
       }
-      dst[i] = accumulate ? dst[i] + s : s;
+      if (accumulate) s += dst[i];
+      if (gmask) {  // fused activation backward of the layer that produced the padded tensor
+        const float neg = gmask_act == ACT_LRELU ? 0.1f : (gmask_act == ACT_RELU ? 0.f : 1.f);
+        s *= gmask[(size_t)plane * ipix + i] > 0.f ? 1.f : neg;
+      }
+      dst[i] = s;
     }
   }
 }
@@ -136,12 +142,13 @@ int pad_fwd(const float* x, float* y, int mode, int N, int C, int H, int W, int 
 }
 
 int pad_bwd(const float* gy, float* gx, int mode, int N, int C, int H, int W, int T, int accumulate,
-            hipStream_t st) {
+            hipStream_t st, const float* gmask, int gmask_act) {
   DVSR_REQUIRE(gy && gx, DVSR_ERR_INVALID, "pad_bwd: null pointer");
   DVSR_REQUIRE(mode >= PAD_REFLECT && mode <= PAD_REPL_T3, DVSR_ERR_INVALID, "pad_bwd: mode %d", mode);
   const int planes = N * C;
   const dim3 grid(ceil_div(H * W, 1024), planes < 65535 ? planes : 65535);
-  hipLaunchKernelGGL(pad_bwd_kernel, grid, dim3(256), 0, st, gy, gx, planes, mode, C, H, W, T, accumulate);
+  hipLaunchKernelGGL(pad_bwd_kernel, grid, dim3(256), 0, st, gy, gx, planes, mode, C, H, W, T, accumulate, gmask,
+                     gmask_act);
   return check_launch("pad_bwd_kernel");
 }
 
