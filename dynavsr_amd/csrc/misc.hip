@@ -79,6 +79,52 @@ __global__ void upsample_bilinear_fwd4_kernel(const float* __restrict__ x, float
   }
 }
 
+// S = 2 (every PCD / TSA up-sampling): one thread = 4 input columns of one input row -> the 2 x 8 output
+// block they generate.  Three input rows x (one 16-byte load + the two neighbour columns) in, four
+// 16-byte stores out; no integer division beyond thread -> (row, column group), no gathers.  Same
+// arithmetic as src_index() above: even outputs blend (i-1, i) with lambda 0.75 (index 0: exactly in[0]),
+// odd outputs blend (i, min(i+1, n-1)) with lambda 0.25.
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned planes, int H,
+                                      int W, float mul) {
+  const int Wq = W >> 2, Wo = 2 * W;
+  const unsigned total = planes * (unsigned)H * (unsigned)Wq;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int xq = (int)(i % (unsigned)Wq);
+    const unsigned t = i / (unsigned)Wq;
+    const int iy = (int)(t % (unsigned)H);
+    const unsigned p = t / (unsigned)H;
+    const float* pl = x + (size_t)p * H * W;
+    const int x0 = 4 * xq;
+    const int rows[3] = {iy > 0 ? iy - 1 : 0, iy, iy < H - 1 ? iy + 1 : H - 1};
+    float h[3][8];  // horizontally interpolated rows: output columns 2*x0 .. 2*x0 + 7
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float* row = pl + (size_t)rows[r] * W;
+      const f32x4 c = *reinterpret_cast<const f32x4*>(row + x0);
+      const float in[6] = {row[x0 > 0 ? x0 - 1 : 0], c[0], c[1], c[2], c[3], row[x0 + 4 < W ? x0 + 4 : W - 1]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // even output 2(x0+j): (in[j-1], in[j]) with lambda 0.75, except output 0 = in[0]
+        h[r][2 * j] = (x0 + j > 0) ? 0.25f * in[j] + 0.75f * in[j + 1] : in[j + 1];
+        // odd output 2(x0+j)+1: (in[j], in[min(j+1)]) with lambda 0.25
+        h[r][2 * j + 1] = 0.75f * in[j + 1] + 0.25f * in[j + 2];
+      }
+    }
+    float* o0 = y + ((size_t)p * 2 * H + 2 * iy) * Wo + 2 * x0;
+    f32x4 a0, a1, b0, b1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float ev = iy > 0 ? 0.25f * h[0][j] + 0.75f * h[1][j] : h[1][j];
+      const float od = 0.75f * h[1][j] + 0.25f * h[2][j];
+      if (j < 4) { a0[j] = ev * mul; b0[j] = od * mul; } else { a1[j - 4] = ev * mul; b1[j - 4] = od * mul; }
+    }
+    *reinterpret_cast<f32x4*>(o0) = a0;
+    *reinterpret_cast<f32x4*>(o0 + 4) = a1;
+    *reinterpret_cast<f32x4*>(o0 + Wo) = b0;
+    *reinterpret_cast<f32x4*>(o0 + Wo + 4) = b1;
+  }
+}
+
 // Backward of the above: each input pixel gathers from the <= (S+1)^2 outputs that read it
 // (deterministic, no atomics).  gx = sum_o w(o -> i) * gy[o] * mul.
 __global__ void upsample_bilinear_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
@@ -364,6 +410,10 @@ int upsample_bilinear_fwd(const float* x, float* y, size_t planes, int H, int W,
   DVSR_REQUIRE(x && y && planes > 0 && H > 0 && W > 0 && S >= 1, DVSR_ERR_INVALID,
                "upsample_bilinear_fwd: bad argument");
   const size_t nout = planes * H * W * S * S;
+  if (S == 2 && W % 4 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)x & 15) == 0 && nout < (1ull << 32)) {
+    LAUNCH(upsample2x_fwd_kernel, planes * H * (W / 4), st, x, y, (unsigned)planes, H, W, mul);
+    return check_launch("upsample2x_fwd_kernel");
+  }
   if ((W * S) % 4 == 0 && ((uintptr_t)y & 15) == 0 && nout < (1ull << 32)) {
     LAUNCH(upsample_bilinear_fwd4_kernel, nout / 4, st, x, y, (unsigned)planes, H, W, S, mul);
     return check_launch("upsample_bilinear_fwd4_kernel");
