@@ -760,12 +760,8 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
       return meansub_fwd(bs.at(o.x0), bs.at(o.y), bs.at(o.y2), bs.at(o.res), o.N / o.T, o.c0, o.T, o.H, o.W, st);
     case OP_ADDMEAN:
       return addmean_fwd(bs.at(o.x0), bs.at(o.x1), bs.at(o.y), o.N / o.T, o.c0, o.T, (size_t)o.H * o.W, st);
-    case OP_ADD: {
-      hipError_t e = hipMemcpyAsync(bs.at(o.y), bs.at(o.x0), o.y.numel * sizeof(float),
-                                    hipMemcpyDeviceToDevice, st);
-      DVSR_REQUIRE(e == hipSuccess, DVSR_ERR_HIP, "add: memcpy failed: %s", hipGetErrorString(e));
-      return add_inplace(bs.at(o.y), bs.at(o.x1), o.y.numel, st);
-    }
+    case OP_ADD:
+      return add_out(bs.at(o.y), bs.at(o.x0), bs.at(o.x1), o.y.numel, st);
   }
   return DVSR_ERR_INVALID;
 }

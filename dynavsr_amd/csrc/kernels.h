@@ -79,6 +79,7 @@ int tsa_blend_fwd(const float* fea, const float* att, const float* add, float* o
 int tsa_blend_bwd(const float* fea, const float* att, const float* g, float* g_fea, float* g_att_io,
                   size_t n, int accumulate, hipStream_t st);
 int add_inplace(float* dst, const float* src, size_t n, hipStream_t st);
+int add_out(float* y, const float* a, const float* b, size_t n, hipStream_t st);
 int act_bwd_inplace(float* g, const float* y, size_t n, int act, hipStream_t st);
 
 // pad.hip: explicit padding / layout changes of the MFDN estimator and their adjoints

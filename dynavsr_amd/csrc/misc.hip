@@ -3,6 +3,7 @@
 // element (or per pixel for the channel reductions), consecutive lanes = consecutive pixels, so
 // every load/store is a coalesced 256-byte wave access; grids are capped and grid-strided.
 #include <cstdint>
+#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -266,6 +267,36 @@ __global__ void tsa_gate_fwd_kernel(const float* __restrict__ emb, const float* 
   }
 }
 
+// V consecutive pixels per thread (8- / 16-byte loads and stores): same arithmetic, fewer and wider
+// memory instructions.  Requires HW % V == 0 and V*4-byte aligned planes.
+template <int V>
+__global__ void tsa_gate_fwd_vec_kernel(const float* __restrict__ emb, const float* __restrict__ emb_ref,
+                                        const float* __restrict__ aligned, float* __restrict__ cor,
+                                        float* __restrict__ gated, int B, int N, int C, size_t HW) {
+  typedef float vec __attribute__((ext_vector_type(V)));
+  const size_t HWv = HW / V, total = (size_t)B * N * HWv;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = (i % HWv) * V;
+    const size_t bn = i / HWv;
+    const size_t b = bn / N;
+    const float* e = emb + bn * C * HW + p;
+    const float* r = emb_ref + b * C * HW + p;
+    vec acc = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c)
+      acc += *reinterpret_cast<const vec*>(e + c * HW) * *reinterpret_cast<const vec*>(r + c * HW);
+    vec s;
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = sigmoidf_(acc[j]);
+    *reinterpret_cast<vec*>(cor + bn * HW + p) = s;
+    const float* al = aligned + bn * C * HW + p;
+    float* gt = gated + bn * C * HW + p;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) *reinterpret_cast<vec*>(gt + c * HW) = *reinterpret_cast<const vec*>(al + c * HW) * s;
+  }
+}
+
 // Backward: g_aligned = g_gated * cor (+= into ga);  g_cor = sum_c g_gated * aligned;
 // g_dot = g_cor * cor * (1 - cor);  g_emb[b,n,c,p] = g_dot * emb_ref;  g_emb_ref accumulates
 // over n -> the thread loops the N frames of its pixel itself (deterministic).
@@ -312,6 +343,31 @@ __global__ void tsa_blend_fwd_kernel(const float* __restrict__ fea, const float*
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
     out[i] = fea[i] * sigmoidf_(att[i]) * 2.f + add[i];
+}
+
+// 16-byte variants of the pure elementwise kernels (n % 4 == 0, 16-byte aligned pointers)
+__global__ void tsa_blend_fwd4_kernel(const f32x4* __restrict__ fea, const f32x4* __restrict__ att,
+                                      const f32x4* __restrict__ add, f32x4* __restrict__ out, size_t n4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 f = fea[i], a = att[i], d = add[i];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f[j] * sigmoidf_(a[j]) * 2.f + d[j];
+    out[i] = o;
+  }
+}
+__global__ void add_inplace4_kernel(f32x4* __restrict__ dst, const f32x4* __restrict__ src, size_t n4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] += src[i];
+}
+__global__ void act_bwd_inplace4_kernel(f32x4* __restrict__ g, const f32x4* __restrict__ y, size_t n4, int act) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 v = g[i];
+    const f32x4 yy = y[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_out(yy[j], act);
+    g[i] = v;
+  }
 }
 
 // g_fea = g*2*s; g_att = g*fea*2*s*(1-s) (added to g_att_io, which already holds the gradient
@@ -446,6 +502,17 @@ int tsa_gate_fwd(const float* emb, const float* emb_ref, const float* aligned, f
                  float* gated, int B, int N, int C, size_t HW, hipStream_t st) {
   DVSR_REQUIRE(emb && emb_ref && aligned && cor && gated && B > 0 && N > 0 && C > 0 && HW > 0,
                DVSR_ERR_INVALID, "tsa_gate_fwd: bad argument");
+  const bool al16 = (((uintptr_t)emb | (uintptr_t)emb_ref | (uintptr_t)aligned | (uintptr_t)cor | (uintptr_t)gated) & 15) == 0;
+  static int vsel = -1;
+  if (vsel < 0) { const char* v = getenv("DVSR_TSA_V"); vsel = v ? atoi(v) : 2; }  // 2 measured best: 54.9 (scalar) / 45.1 (x2) / 47.5 us (x4)
+  if (HW % 4 == 0 && al16 && vsel == 4) {
+    LAUNCH(tsa_gate_fwd_vec_kernel<4>, (size_t)B * N * HW / 4, st, emb, emb_ref, aligned, cor, gated, B, N, C, HW);
+    return check_launch("tsa_gate_fwd_vec_kernel");
+  }
+  if (HW % 2 == 0 && al16 && vsel == 2) {
+    LAUNCH(tsa_gate_fwd_vec_kernel<2>, (size_t)B * N * HW / 2, st, emb, emb_ref, aligned, cor, gated, B, N, C, HW);
+    return check_launch("tsa_gate_fwd_vec_kernel");
+  }
   LAUNCH(tsa_gate_fwd_kernel, (size_t)B * N * HW, st, emb, emb_ref, aligned, cor, gated, B, N, C, HW);
   return check_launch("tsa_gate_fwd_kernel");
 }
@@ -461,6 +528,10 @@ int tsa_gate_bwd(const float* emb, const float* emb_ref, const float* aligned, c
 int tsa_blend_fwd(const float* fea, const float* att, const float* add, float* out, size_t n,
                   hipStream_t st) {
   DVSR_REQUIRE(fea && att && add && out && n > 0, DVSR_ERR_INVALID, "tsa_blend_fwd: bad argument");
+  if (n % 4 == 0 && (((uintptr_t)fea | (uintptr_t)att | (uintptr_t)add | (uintptr_t)out) & 15) == 0) {
+    LAUNCH(tsa_blend_fwd4_kernel, n / 4, st, (const f32x4*)fea, (const f32x4*)att, (const f32x4*)add, (f32x4*)out, n / 4);
+    return check_launch("tsa_blend_fwd4_kernel");
+  }
   LAUNCH(tsa_blend_fwd_kernel, n, st, fea, att, add, out, n);
   return check_launch("tsa_blend_fwd_kernel");
 }
@@ -471,12 +542,39 @@ int tsa_blend_bwd(const float* fea, const float* att, const float* g, float* g_f
   LAUNCH(tsa_blend_bwd_kernel, n, st, fea, att, g, g_fea, g_att_io, n, accumulate);
   return check_launch("tsa_blend_bwd_kernel");
 }
+__global__ void add_out_kernel(float* __restrict__ y, const float* __restrict__ a, const float* __restrict__ b,
+                               size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = a[i] + b[i];
+}
+__global__ void add_out4_kernel(f32x4* __restrict__ y, const f32x4* __restrict__ a, const f32x4* __restrict__ b,
+                                size_t n4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = a[i] + b[i];
+}
+int add_out(float* y, const float* a, const float* b, size_t n, hipStream_t st) {
+  DVSR_REQUIRE(y && a && b && n > 0, DVSR_ERR_INVALID, "add_out: bad argument");
+  if (n % 4 == 0 && (((uintptr_t)y | (uintptr_t)a | (uintptr_t)b) & 15) == 0) {
+    LAUNCH(add_out4_kernel, n / 4, st, (f32x4*)y, (const f32x4*)a, (const f32x4*)b, n / 4);
+    return check_launch("add_out4_kernel");
+  }
+  LAUNCH(add_out_kernel, n, st, y, a, b, n);
+  return check_launch("add_out_kernel");
+}
 int add_inplace(float* dst, const float* src, size_t n, hipStream_t st) {
+  if (n % 4 == 0 && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+    LAUNCH(add_inplace4_kernel, n / 4, st, (f32x4*)dst, (const f32x4*)src, n / 4);
+    return check_launch("add_inplace4_kernel");
+  }
   LAUNCH(add_inplace_kernel, n, st, dst, src, n);
   return check_launch("add_inplace_kernel");
 }
 int act_bwd_inplace(float* g, const float* y, size_t n, int act, hipStream_t st) {
   if (act == ACT_NONE) return DVSR_OK;
+  if (n % 4 == 0 && (((uintptr_t)g | (uintptr_t)y) & 15) == 0) {
+    LAUNCH(act_bwd_inplace4_kernel, n / 4, st, (f32x4*)g, (const f32x4*)y, n / 4, act);
+    return check_launch("act_bwd_inplace4_kernel");
+  }
   LAUNCH(act_bwd_inplace_kernel, n, st, g, y, n, act);
   return check_launch("act_bwd_inplace_kernel");
 }
