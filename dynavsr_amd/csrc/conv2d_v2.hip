@@ -360,7 +360,14 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
     force = (v && v[0] >= '0' && v[0] <= '2') ? v[0] - '0' : -1;
   }
   const int cc = conv2_cc(ks, stride);
-  if (ks == 3 && stride == 2) return ConvGeo{8, 8, 2};
+  if (ks == 3 && stride == 2) {  // the two pyramid convs: few tiles, pick by tile quantisation alone
+    const double c82 = conv2_pipe_cost(8, 2, 9, cc, N, Ho, Wo, Cout);
+    const double c42 = conv2_pipe_cost(4, 2, 9, cc, N, Ho, Wo, Cout);
+    const double c41 = conv2_pipe_cost(4, 1, 9, cc, N, Ho, Wo, Cout);
+    if (force == 0 || (force < 0 && c82 <= c42 && c82 <= c41)) return ConvGeo{cc, 8, 2};
+    if (force == 2 || (force < 0 && c41 < 0.97 * c42)) return ConvGeo{cc, 4, 1};
+    return ConvGeo{cc, 4, 2};
+  }
   if (force == 0 && ks != 2) return ConvGeo{cc, 8, 2};
   if (force == 1) return ConvGeo{cc, 4, 2};
   if (force == 2) return ConvGeo{cc, 4, 1};
@@ -408,7 +415,13 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
   if (g_trace_countdown >= 0) --g_trace_countdown;
 #endif
   const int code = geo.cc * 100 + geo.th * 10 + geo.mt;
-  if (d.ks == 3 && d.stride == 2) return launch_conv2<3, 2, 8, 8, 2>(k, st);
+  if (d.ks == 3 && d.stride == 2) {
+    switch (code) {
+      case 882: return launch_conv2<3, 2, 8, 8, 2>(k, st);
+      case 842: return launch_conv2<3, 2, 8, 4, 2>(k, st);
+      case 841: return launch_conv2<3, 2, 8, 4, 1>(k, st);
+    }
+  } else
   if (d.ks == 3) {
     switch (code) {
       case 882: return launch_conv2<3, 1, 8, 8, 2>(k, st);

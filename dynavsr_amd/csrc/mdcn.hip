@@ -569,7 +569,11 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
     hipLaunchKernelGGL(mdcn_fwd_lds_kernel<4>, dim3(grid), dim3(256), 0, st, k);
     return check_launch("mdcn_fwd_lds_kernel");
   }
-  hipLaunchKernelGGL(mdcn_fwd_reg_kernel<4>, dim3(grid), dim3(256), 0, st, k);
+  static int halo = -1;  // DVSR_DCN_HALO=4|5|6: window ring around the tile (A/B aid)
+  if (halo < 0) { const char* v = getenv("DVSR_DCN_HALO"); halo = v ? atoi(v) : 4; }
+  if (halo == 6) hipLaunchKernelGGL(mdcn_fwd_reg_kernel<6>, dim3(grid), dim3(256), 0, st, k);
+  else if (halo == 5) hipLaunchKernelGGL(mdcn_fwd_reg_kernel<5>, dim3(grid), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL(mdcn_fwd_reg_kernel<4>, dim3(grid), dim3(256), 0, st, k);
   return check_launch("mdcn_fwd_reg_kernel");
 }
 
