@@ -207,7 +207,27 @@ struct DcnK2 {
   int mask_logit;
   int N, C, H, W, Cout, dg, act;
   int tiles_x, tiles_y, ntiles, ncb, nchunks;
+#ifdef DVSR_CONV_TRACE
+  long long* trace;  // debug build only (tools/dcn_trace.py): 64 cycle stamps per workgroup
+#endif
 };
+#ifdef DVSR_CONV_TRACE
+#define DCN_STAMP(i)                                                                               \
+  do {                                                                                             \
+    if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+static long long* g_dcn_trace = nullptr;
+static int g_dcn_countdown = -1;
+extern "C" int dvsr_debug_dcn_trace(void* buf, int launch_index) {
+  g_dcn_trace = (long long*)buf;
+  g_dcn_countdown = launch_index;
+  return 0;
+}
+#else
+#define DCN_STAMP(i) \
+  do {               \
+  } while (0)
+#endif
 
 template <int HALO>
 __global__ __launch_bounds__(256, 2) void mdcn_fwd_lds_kernel(DcnK2 a) {
@@ -387,8 +407,8 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_lds_kernel(DcnK2 a) {
 // (the LDS-tile kernel above needs seven).  Offsets and masks of tap t+1 are loaded while the MFMAs
 // of tap t are in flight.  LDS drops to 42.6 KB -> 3 workgroups per CU.
 // -------------------------------------------------------------------------------------------------
-template <int HALO>
-__global__ __launch_bounds__(256, 3) void mdcn_fwd_reg_kernel(DcnK2 a) {
+template <int HALO, bool MASK_LOGIT>
+__global__ __launch_bounds__(256, 2) void mdcn_fwd_reg_kernel(DcnK2 a) {
   constexpr int CPG = 8, KK = 9, TH = 8, TW = 32;
   constexpr int XH = TH + 2 + 2 * HALO, XW = TW + 2 + 2 * HALO, XPX = XH * XW;
   constexpr int XE = (XPX + 255) / 256;
@@ -442,14 +462,19 @@ __global__ __launch_bounds__(256, 3) void mdcn_fwd_reg_kernel(DcnK2 a) {
 #pragma unroll
       for (int e = 0; e < XE; ++e) rx_[c][e] = xg[(size_t)c * HW + xoff[e]];
   };
-  float oh[2][2], ow[2][2], mm[2][2];  // [buffer][nt]
-  auto load_off = [&](int g, int tap, int rb) {
+  // offsets / masks of ALL nine taps of a group are fetched together, before the window is staged: a
+  // per-tap prefetch made the compiler wait for vmcnt(0) behind the sampler's branches, i.e. one full
+  // memory latency per tap (1.6-2.9 k cycles of "sampling" per tap in the cycle-stamp trace)
+  float oh[KK][2], ow[KK][2], mm[KK][2];  // [tap][nt]
+  auto load_off = [&](int g) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      oh[rb][nt] = offn[(size_t)(g * 2 * KK + 2 * tap) * HW + pofs[nt]];
-      ow[rb][nt] = offn[(size_t)(g * 2 * KK + 2 * tap + 1) * HW + pofs[nt]];
-      mm[rb][nt] = mskn[(size_t)(g * KK + tap) * HW + pofs[nt]];
-    }
+    for (int tap = 0; tap < KK; ++tap)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        oh[tap][nt] = offn[(size_t)(g * 2 * KK + 2 * tap) * HW + pofs[nt]];
+        ow[tap][nt] = offn[(size_t)(g * 2 * KK + 2 * tap + 1) * HW + pofs[nt]];
+        mm[tap][nt] = mskn[(size_t)(g * KK + tap) * HW + pofs[nt]];
+      }
   };
 
   f32x16 acc[2][2];
@@ -461,7 +486,9 @@ __global__ __launch_bounds__(256, 3) void mdcn_fwd_reg_kernel(DcnK2 a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const float* wp_cb = a.wp + (size_t)cb * a.nchunks * WF;
+  DCN_STAMP(0);
   for (int g = 0; g < a.dg; ++g) {
+    if (g < 2) DCN_STAMP(1 + 30 * g);
     prefetch_x(g);    // no cross-group register prefetch: 24 fewer VGPRs buy the third wave per SIMD
     __syncthreads();  // previous group's taps are done with s_x / s_w
     {
@@ -487,67 +514,113 @@ __global__ __launch_bounds__(256, 3) void mdcn_fwd_reg_kernel(DcnK2 a) {
         *reinterpret_cast<f32x4*>(s_x + (size_t)idx * 8 + 4) = v1;
       }
     }
-    load_off(g, 0, 0);
+    load_off(g);
+    if (g < 2) DCN_STAMP(2 + 30 * g);
     __syncthreads();  // window visible, weight DMA drained
+    if (g < 2) DCN_STAMP(3 + 30 * g);
     const float* xg = a.x + ((size_t)n * a.C + g * CPG) * HW;
-#pragma unroll
-    for (int tap = 0; tap < KK; ++tap) {
-      const int rb = tap & 1;
-      if (tap + 1 < KK) load_off(g, tap + 1, rb ^ 1);
+    // Fast sampler of one tap, BRANCH-FREE: window coordinates are clamped (always a legal LDS read), lanes
+    // whose footprint leaves the window get 0 and are flagged; the exact global-gather path for them runs
+    // in a rare fix-up below.  Being straight-line code, the sampler of tap t+1 shares a basic block with
+    // the 16 MFMAs of tap t, so the scheduler can interleave the two (VALU/LDS next to the matrix pipe).
+    auto sample = [&](int tap, f32x4 (&B)[2], bool& fix) {
       const int ki = tap / 3, kj = tap - ki * 3;
-      f32x4 B[2];
+      fix = false;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
+        float m = mm[tap][nt];
+        if (MASK_LOGIT) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));  // compile-time: keeps the sampler one basic block
+        const float h_im = (float)(py[nt] - 1 + ki) + oh[tap][nt];
+        const float w_im = (float)(px - 1 + kj) + ow[tap][nt];
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const float lh = h_im - hf, lw = w_im - wf;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const int ry = (int)hf - wy0, rx = (int)wf - wx0;
+        const bool inwin = ry >= 0 && ry <= XH - 2 && rx >= 0 && rx <= XW - 2;
+        const int ryc = min(max(ry, 0), XH - 2), rxc = min(max(rx, 0), XW - 2);
+        const float ms = (pv[nt] && inwin) ? m : 0.f;
+        const float w1 = hh * hw * ms, w2 = hh * lw * ms, w3 = lh * hw * ms, w4 = lh * lw * ms;
+        const float* p1 = s_x + ((size_t)(ryc * XW + rxc)) * 8 + hi * 4;
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(p1);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(p1 + 8);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(p1 + XW * 8);
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(p1 + XW * 8 + 8);
+        B[nt] = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        // outside the window AND possibly inside the image gate: needs the exact path
+        fix = fix || (pv[nt] && !inwin && h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W);
+      }
+    };
+    auto fixup = [&](int tap, f32x4 (&B)[2]) {
+      const int ki = tap / 3, kj = tap - ki * 3;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        if (!pv[nt]) continue;
+        const float h_im = (float)(py[nt] - 1 + ki) + oh[tap][nt];
+        const float w_im = (float)(px - 1 + kj) + ow[tap][nt];
+        const int ry = (int)floorf(h_im) - wy0, rx = (int)floorf(w_im) - wx0;
+        if (ry >= 0 && ry <= XH - 2 && rx >= 0 && rx <= XW - 2) continue;
+        float m = mm[tap][nt];
+        if (MASK_LOGIT) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
+        DcnTap tp;  // sample leaves the staged window: exact clamped global gathers
         f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (pv[nt]) {
-          float m = mm[rb][nt];
-          if (a.mask_logit) m = sigmoidf_(m);
-          const float h_im = (float)(py[nt] - 1 + ki) + oh[rb][nt];
-          const float w_im = (float)(px - 1 + kj) + ow[rb][nt];
-          const float hf = floorf(h_im), wf = floorf(w_im);
-          const float lh = h_im - hf, lw = w_im - wf;
-          const float hh = 1.f - lh, hw = 1.f - lw;
-          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-          const float ryf = hf - (float)wy0, rxf = wf - (float)wx0;
-          if (ryf >= 0.f && ryf <= (float)(XH - 2) && rxf >= 0.f && rxf <= (float)(XW - 2)) {
-            const float* p1 = s_x + ((size_t)((int)ryf * XW + (int)rxf)) * 8 + hi * 4;
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p1);
-            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p1 + 8);
-            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p1 + XW * 8);
-            const f32x4 v4 = *reinterpret_cast<const f32x4*>(p1 + XW * 8 + 8);
+        if (make_tap(h_im, w_im, a.H, a.W, tp)) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) b[c] = (w1 * v1[c] + w2 * v2[c] + w3 * v3[c] + w4 * v4[c]) * m;
-          } else {
-            DcnTap tp;  // sample leaves the staged window: exact clamped global gathers
-            if (make_tap(h_im, w_im, a.H, a.W, tp)) {
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const float* pl = xg + (size_t)(2 * c + hi) * HW;
-                const float v1 = tp.v1 ? pl[tp.o1] : 0.f, v2 = tp.v2 ? pl[tp.o2] : 0.f;
-                const float v3 = tp.v3 ? pl[tp.o3] : 0.f, v4 = tp.v4 ? pl[tp.o4] : 0.f;
-                b[c] = (tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4) * m;
-              }
-            }
+          for (int c = 0; c < 4; ++c) {
+            const float* pl = xg + (size_t)(2 * c + hi) * HW;
+            const float v1 = tp.v1 ? pl[tp.o1] : 0.f, v2 = tp.v2 ? pl[tp.o2] : 0.f;
+            const float v3 = tp.v3 ? pl[tp.o3] : 0.f, v4 = tp.v4 ? pl[tp.o4] : 0.f;
+            b[c] = (tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4) * m;
           }
         }
         B[nt] = b;
       }
+    };
+    f32x4 Bc[2], Bn[2];
+    bool fix;
+    sample(0, Bc, fix);
+    if (fix) fixup(0, Bc);
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) {
+      if (g < 2) DCN_STAMP(4 + 30 * g + 2 * tap);
       f32x4 A[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
         A[mt] = *reinterpret_cast<const f32x4*>(s_w + ((size_t)(((mt * KK + tap) * 2 + hi) * 32 + lo)) * 4);
+      if (tap + 1 < KK) sample(tap + 1, Bn, fix);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][j], B[0][j], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][j], B[1][j], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][j], B[0][j], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][j], B[1][j], acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][j], Bc[0][j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][j], Bc[1][j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][j], Bc[0][j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][j], Bc[1][j], acc[1][1], 0, 0, 0);
+      }
+      if (tap + 1 < KK) {
+        // ask for the interleave explicitly: MFMAs of this tap between the sampler's geometry VALU ops, its
+        // 8 corner reads (+2 weight reads of the next tap), and its blend VALU ops
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+        }
+      }
+      if (g < 2) DCN_STAMP(5 + 30 * g + 2 * tap);
+      if (tap + 1 < KK) {
+        if (fix) fixup(tap + 1, Bn);
+        Bc[0] = Bn[0]; Bc[1] = Bn[1];
       }
     }
   }
 
+  DCN_STAMP(62);
   const TileOut t{a.out, a.bias, nullptr, a.act, 0, 0, a.Cout, a.H, a.W};
   store_mfma_tile<2, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
+  DCN_STAMP(63);
 }
 
 // wp = weights packed by pack_weights_kernel with KK=9, CC=8, wt=0 (one chunk per deformable group).
@@ -562,6 +635,10 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
   k.N = N; k.C = C; k.H = H; k.W = W; k.Cout = Cout; k.dg = dg; k.act = act;
   k.tiles_x = ceil_div(W, 32); k.tiles_y = ceil_div(H, 8); k.ntiles = k.tiles_x * k.tiles_y * N;
   k.ncb = ceil_div(Cout, 64); k.nchunks = dg;
+#ifdef DVSR_CONV_TRACE
+  k.trace = (g_dcn_countdown == 0) ? g_dcn_trace : nullptr;
+  if (g_dcn_countdown >= 0) --g_dcn_countdown;
+#endif
   const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
   static int variant = -1;  // DVSR_DCN_FWD=lds selects the LDS-column-tile kernel (A/B aid)
   if (variant < 0) { const char* v = getenv("DVSR_DCN_FWD"); variant = (v && v[0] == 'l') ? 1 : 0; }
@@ -569,11 +646,10 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
     hipLaunchKernelGGL(mdcn_fwd_lds_kernel<4>, dim3(grid), dim3(256), 0, st, k);
     return check_launch("mdcn_fwd_lds_kernel");
   }
-  static int halo = -1;  // DVSR_DCN_HALO=4|5|6: window ring around the tile (A/B aid)
-  if (halo < 0) { const char* v = getenv("DVSR_DCN_HALO"); halo = v ? atoi(v) : 4; }
-  if (halo == 6) hipLaunchKernelGGL(mdcn_fwd_reg_kernel<6>, dim3(grid), dim3(256), 0, st, k);
-  else if (halo == 5) hipLaunchKernelGGL(mdcn_fwd_reg_kernel<5>, dim3(grid), dim3(256), 0, st, k);
-  else hipLaunchKernelGGL(mdcn_fwd_reg_kernel<4>, dim3(grid), dim3(256), 0, st, k);
+  // (window ring: 5 and 6 pixels were measured 4-5 % slower than 4 -- the staging cost outweighs the rarer
+  // fall-back)
+  if (mask_logit) hipLaunchKernelGGL((mdcn_fwd_reg_kernel<4, true>), dim3(grid), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((mdcn_fwd_reg_kernel<4, false>), dim3(grid), dim3(256), 0, st, k);
   return check_launch("mdcn_fwd_reg_kernel");
 }
 
