@@ -28,7 +28,7 @@ class Conv2dDesc(Structure):
 
 class EdvrConfig(Structure):
     _fields_ = [(k, c_int) for k in ("nf", "nframes", "groups", "front_RBs", "back_RBs", "scale",
-                                     "center")]
+                                     "center", "bf16_mfma")]
 
 
 class EstimatorConfig(Structure):

@@ -52,13 +52,16 @@ struct ConvK2 {
   } while (0)
 #endif
 
-template <int KS, int S, int CC, int TH, int MT>
+// BF = bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): a 16-byte LDS operand then holds 8
+// consecutive channels (k = 8*hi .. 8*hi+7 of a 16-channel block) instead of the 4 of the fp32 layout
+// (k = 2kk + hi), everything else -- tiles, double buffering, DMA pieces, epilogue -- is shared.
+template <int KS, int S, int CC, int TH, int MT, bool BF = false>
 struct Conv2Shape {
   static constexpr int TW = 32, KK = KS * KS, NT = TH / 4;  // NT pixel rows per wave
   static constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
   static constexpr int PLANE = IH * IW, E = (PLANE + 255) / 256;
-  static constexpr int KQ4 = CC / 8;                  // float4 groups of channel pairs per chunk
-  static constexpr int IN_FLOATS = CC * PLANE;        // = KQ4 * IH * 2 * IW float4
+  static constexpr int KQ4 = BF ? CC / 16 : CC / 8;   // 16-byte operand groups (x 2 lane halves) per chunk
+  static constexpr int IN_FLOATS = KQ4 * PLANE * 8;   // = KQ4 * IH * 2 * IW float4
   static constexpr int HALF = KK * KQ4 * 2 * 32 * 4;  // packed floats of one 32-cout half
   static constexpr int W_FLOATS = MT * HALF;
   static constexpr int NPIECE = W_FLOATS / 256;       // 1-KiB DMA pieces (one wave-instruction each)
@@ -78,6 +81,7 @@ int conv2_pch(int ks, int stride) {  // packed floats per (64-cout block, chunk)
 // wt = 1 (data gradient): this conv's (cin, cout, tap) = original (cout, cin slice, mirrored tap).
 __global__ void pack_weights_kernel(PackTable t) {
   const PackEntry& e = t.e[blockIdx.y];
+  if (e.bf) return;  // packed by pack_weights_bf16_kernel
   const int kq4 = e.CC / 8;
   const size_t per_chunk = (size_t)e.pch;
   const size_t total = (size_t)e.ncb * e.nchunks * per_chunk;
@@ -102,15 +106,57 @@ __global__ void pack_weights_kernel(PackTable t) {
   }
 }
 
-int pack_weights_run(const PackTable& t, hipStream_t st) {
-  if (t.n <= 0) return DVSR_OK;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(48, t.n), dim3(256), 0, st, t);
-  return check_launch("pack_weights_kernel");
+// bf16 image: P16[cb][k][((((mt*KK + tap)*KB + q)*2 + hi)*32 + lo)*8 + i] = bf16(W(cout = cb*64 + mt*32 + lo,
+//   cin = k*CC + 16q + 8hi + i, tap)); e.pch counts fp32-sized slots, i.e. 2 bf16 each.
+__global__ void pack_weights_bf16_kernel(PackTable t) {
+  const PackEntry& e = t.e[blockIdx.y];
+  if (!e.bf) return;
+  const int kb = e.CC / 16;
+  const size_t per_chunk = (size_t)e.pch * 2;
+  const size_t total = (size_t)e.ncb * e.nchunks * per_chunk;
+  __bf16* P16 = reinterpret_cast<__bf16*>(e.P);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int r = (int)(i % per_chunk);
+    const size_t ck = i / per_chunk;
+    const int k = (int)(ck % e.nchunks), cb = (int)(ck / e.nchunks);
+    const int j = r & 7; r >>= 3;
+    const int lo = r & 31; r >>= 5;
+    const int hi = r & 1; r >>= 1;
+    const int q = r % kb; r /= kb;
+    const int tap = r % e.KK;
+    const int mt = r / e.KK;
+    const int co = cb * 64 + mt * 32 + lo, ci = k * e.CC + 16 * q + 8 * hi + j;
+    float v = 0.f;
+    if (co < e.Cout && ci < e.Ctot) {
+      if (!e.wt) v = e.w[((size_t)co * e.Ctot + ci) * e.KK + tap];
+      else v = e.w[((size_t)ci * e.w_ctot + e.w_coff + co) * e.KK + (e.KK - 1 - tap)];
+    }
+    P16[i] = (__bf16)v;
+  }
 }
 
-template <int KS, int S, int CC, int TH, int MT>
+int pack_weights_run(const PackTable& t, hipStream_t st) {
+  if (t.n <= 0) return DVSR_OK;
+  bool any_f32 = false, any_bf = false;
+  for (int i = 0; i < t.n; ++i) (t.e[i].bf ? any_bf : any_f32) = true;
+  if (any_f32) {
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(48, t.n), dim3(256), 0, st, t);
+    int rc = check_launch("pack_weights_kernel");
+    if (rc) return rc;
+  }
+  if (any_bf) {
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(48, t.n), dim3(256), 0, st, t);
+    return check_launch("pack_weights_bf16_kernel");
+  }
+  return DVSR_OK;
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int KS, int S, int CC, int TH, int MT, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
-  using Sh = Conv2Shape<KS, S, CC, TH, MT>;
+  using Sh = Conv2Shape<KS, S, CC, TH, MT, BF>;
   constexpr int KK = Sh::KK, IH = Sh::IH, IW = Sh::IW, PLANE = Sh::PLANE, E = Sh::E, KQ4 = Sh::KQ4,
                 NT = Sh::NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -222,12 +268,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
         for (int q = 0; q < KQ4; ++q)
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
-            const int cb0 = k * CC + 8 * q + h2;
             const bool ev = evalid[e];
-            f32x4 v = {(ev && cb0 < Ctot) ? rin[8 * q + h2][e] : 0.f,
-                       (ev && cb0 + 2 < Ctot) ? rin[8 * q + 2 + h2][e] : 0.f,
-                       (ev && cb0 + 4 < Ctot) ? rin[8 * q + 4 + h2][e] : 0.f,
-                       (ev && cb0 + 6 < Ctot) ? rin[8 * q + 6 + h2][e] : 0.f};
+            f32x4 v;
+            if (BF) {  // 8 consecutive channels, rounded to bf16 (RNE)
+              const int cb0 = k * CC + 16 * q + 8 * h2;
+              bf16x8 hv;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) hv[i] = (__bf16)((ev && cb0 + i < Ctot) ? rin[16 * q + 8 * h2 + i][e] : 0.f);
+              v = __builtin_bit_cast(f32x4, hv);
+            } else {
+              const int cb0 = k * CC + 8 * q + h2;
+              v = f32x4{(ev && cb0 < Ctot) ? rin[8 * q + h2][e] : 0.f,
+                        (ev && cb0 + 2 < Ctot) ? rin[8 * q + 2 + h2][e] : 0.f,
+                        (ev && cb0 + 4 < Ctot) ? rin[8 * q + 4 + h2][e] : 0.f,
+                        (ev && cb0 + 6 < Ctot) ? rin[8 * q + 6 + h2][e] : 0.f};
+            }
             *reinterpret_cast<f32x4*>(s_in + ((size_t)(q * IH * 2 * IW) + elds[e] + h2 * IW) * 4) = v;
           }
       }
@@ -281,13 +336,23 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
         __builtin_amdgcn_sched_barrier(0);
         if (k < 8) DVSR_STAMP(5 + 4 * k);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
+      if (BF) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][mt][j], Bv[rb][nt][j], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[rb][mt]),
+                                                                  __builtin_bit_cast(bf16x8, Bv[rb][nt]), acc[mt][nt],
+                                                                  0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][mt][j], Bv[rb][nt][j], acc[mt][nt], 0, 0, 0);
+      }
     }
     if (HAS_NEXT) __syncthreads();  // next buffers complete (the barrier's vmcnt(0) covers the DMA)
   };
@@ -318,10 +383,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
 #endif
 }
 
-template <int KS, int S, int CC, int TH, int MT>
+template <int KS, int S, int CC, int TH, int MT, bool BF = false>
 static int launch_conv2(ConvK2 k, hipStream_t st) {
-  using Sh = Conv2Shape<KS, S, CC, TH, MT>;
-  auto kern = conv2d_pipe_kernel<KS, S, CC, TH, MT>;
+  using Sh = Conv2Shape<KS, S, CC, TH, MT, BF>;
+  auto kern = conv2d_pipe_kernel<KS, S, CC, TH, MT, BF>;
   static bool attr_done = false;
   size_t lds = Sh::LDS_BYTES;
 #ifdef DVSR_CONV_TRACE
@@ -376,7 +441,7 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
   return c41 < 0.97 * c42 ? ConvGeo{cc, 4, 1} : ConvGeo{cc, 4, 2};
 }
 
-int conv2_pch_cc(int ks, int cc) { return 2 * ks * ks * (cc / 8) * 2 * 32 * 4; }
+int conv2_pch_cc(int ks, int cc, int bf) { return 2 * ks * ks * (bf ? cc / 16 : cc / 8) * 2 * 32 * 4; }
 
 // `wp` = weights packed by pack_weights_kernel for this (ks, wt, geo.cc) combination.
 #ifdef DVSR_CONV_TRACE
@@ -415,6 +480,12 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
   if (g_trace_countdown >= 0) --g_trace_countdown;
 #endif
   const int code = geo.cc * 100 + geo.th * 10 + geo.mt;
+  if (geo.bf) {
+    DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && geo.cc == 16 && geo.th == 4, DVSR_ERR_UNSUPPORTED,
+                 "conv2d_packed: the bf16 kernel exists for 3x3 stride-1 convs with 16-channel chunks");
+    if (geo.mt == 2) return launch_conv2<3, 1, 16, 4, 2, true>(k, st);
+    return launch_conv2<3, 1, 16, 4, 1, true>(k, st);
+  }
   if (d.ks == 3 && d.stride == 2) {
     switch (code) {
       case 882: return launch_conv2<3, 2, 8, 8, 2>(k, st);

@@ -148,16 +148,18 @@ struct Builder {
     o.y = y_override.valid() ? y_override : alloc(name, (size_t)N * Cout * Ho * Wo);
     if (wmap) o.w2_off = alloc("", (size_t)Cout * (c0 + c1) * ks * ks).off;
     {
-      o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1);
-      o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc);
+      const bool bf = p.cfg.bf16_mfma && ks == 3 && stride == 1 && pad < 0 && (c1 == 0 || c0 % 16 == 0);
+      auto as_bf = [&](ConvGeo g) { if (bf) { g.cc = 16; g.th = 4; g.bf = 1; } return g; };
+      o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1));
+      o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, o.geo.bf);
       o.wp_off = alloc("", o.wp_floats).off;
       for (int which = 0; which < 2; ++which) {
         const int ci = which ? c1 : c0;
         if (!ci) continue;
         // dgrad = stride-1 conv over the input grid with Cout' = ci, Ctot' = Cout
-        o.dgeo[which] = conv2_choose(ks, 1, N, H, W, ci, Cout);
+        o.dgeo[which] = as_bf(conv2_choose(ks, 1, N, H, W, ci, Cout));
         o.dpk_floats[which] = (size_t)ceil_div(ci, 64) * ceil_div(Cout, o.dgeo[which].cc) *
-                              conv2_pch_cc(ks, o.dgeo[which].cc);
+                              conv2_pch_cc(ks, o.dgeo[which].cc, o.dgeo[which].bf);
         o.dpk_off[which] = p.dpack_floats;
         p.dpack_floats += o.dpk_floats[which];
       }
@@ -684,7 +686,7 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
     if (o.type == OP_DCN && fwd_base && o.wp_floats) {
       PackEntry& e = t.e[t.n++];
       e.w = P[o.pw]; e.P = fwd_base + o.wp_off; e.Cout = o.Cout; e.Ctot = o.c0; e.KK = 9; e.CC = 8; e.wt = 0;
-      e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64); e.nchunks = o.dg; e.pch = conv2_pch(3, 1);
+      e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64); e.nchunks = o.dg; e.pch = conv2_pch(3, 1); e.bf = 0;
       if (t.n == 48) { int rc = flush(); if (rc) return rc; }
     }
     if (o.type != OP_CONV) continue;
@@ -701,7 +703,7 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
       PackEntry& e = t.e[t.n++];
       e.w = wsrc; e.P = fwd_base + o.wp_off; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
       e.CC = o.geo.cc; e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
-      e.nchunks = ceil_div(ctot, e.CC); e.pch = conv2_pch_cc(o.ks, e.CC);
+      e.nchunks = ceil_div(ctot, e.CC); e.bf = o.geo.bf; e.pch = conv2_pch_cc(o.ks, e.CC, e.bf);
       if (t.n == 48) { int rc = flush(); if (rc) return rc; }
     }
     if (bwd_base) {
@@ -711,7 +713,8 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
         PackEntry& e = t.e[t.n++];
         e.w = wsrc; e.P = bwd_base + o.dpk_off[which]; e.Cout = ci; e.Ctot = o.Cout; e.KK = KK;
         e.CC = o.dgeo[which].cc; e.wt = 1; e.w_ctot = ctot; e.w_coff = which ? o.c0 : 0;
-        e.ncb = ceil_div(ci, 64); e.nchunks = ceil_div(o.Cout, e.CC); e.pch = conv2_pch_cc(o.ks, e.CC);
+        e.ncb = ceil_div(ci, 64); e.nchunks = ceil_div(o.Cout, e.CC); e.bf = o.dgeo[which].bf;
+        e.pch = conv2_pch_cc(o.ks, e.CC, e.bf);
         if (t.n == 48) { int rc = flush(); if (rc) return rc; }
       }
     }
@@ -1093,7 +1096,7 @@ extern "C" int dvsr_estimator_plan_create(const dvsr_estimator_config* cfg, int 
   dvsr_estimator_plan* ep = new dvsr_estimator_plan();
   ep->ecfg = *cfg;
   dvsr_edvr_plan& p = ep->core;
-  p.cfg = dvsr_edvr_config{cfg->nf, cfg->nframes, 1, 0, 0, cfg->scale, 0};
+  p.cfg = dvsr_edvr_config{cfg->nf, cfg->nframes, 1, 0, 0, cfg->scale, 0, 0};
   p.B = B; p.H = H; p.W = W;
   { const char* v = getenv("DVSR_BWD_STREAMS"); p.side_streams = (v && v[0] == '0') ? 0 : 1; }
   int rc = build_estimator(*ep);

@@ -673,7 +673,7 @@ extern "C" int dvsr_mdcn_forward_fast(const float* x, const float* offset, const
   t.n = 1;
   PackEntry& e = t.e[0];
   e.w = w; e.P = (float*)workspace; e.Cout = Cout; e.Ctot = C; e.KK = 9; e.CC = 8; e.wt = 0; e.w_ctot = 0;
-  e.w_coff = 0; e.ncb = ceil_div(Cout, 64); e.nchunks = dg; e.pch = conv2_pch(3, 1);
+  e.w_coff = 0; e.ncb = ceil_div(Cout, 64); e.nchunks = dg; e.pch = conv2_pch(3, 1); e.bf = 0;
   int rc = pack_weights_run(t, (hipStream_t)stream);
   if (rc) return rc;
   const long long P = (long long)H * W;

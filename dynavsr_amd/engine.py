@@ -20,7 +20,8 @@ class Plan:
 
     def __init__(self, cfg, b, h, w):
         self.key = (cfg, b, h, w)
-        self.cfg = dict(zip(("nf", "nframes", "groups", "front_RBs", "back_RBs", "scale", "center"), cfg))
+        cfg = tuple(cfg) + (0,) * (8 - len(cfg))  # older 7-tuples: fp32 MFMA
+        self.cfg = dict(zip(("nf", "nframes", "groups", "front_RBs", "back_RBs", "scale", "center", "bf16_mfma"), cfg))
         self.b, self.h, self.w = b, h, w
         self._h = ctypes.c_void_p()
         L.check(L.lib().dvsr_edvr_plan_create(L.EdvrConfig(*cfg), b, h, w, ctypes.byref(self._h)),

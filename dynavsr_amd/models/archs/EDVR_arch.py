@@ -58,8 +58,11 @@ def _init_tensor(name, shape):
 
 class EDVR(nn.Module):
     def __init__(self, nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, center=None,
-                 predeblur=False, HR_in=False, w_TSA=True, scale=4):
+                 predeblur=False, HR_in=False, w_TSA=True, scale=4, bf16_mfma=False):
+        """bf16_mfma (not a reference option): run the 3x3 stride-1 convolutions on the bf16 MFMA with fp32
+        accumulation (network_G.bf16_mfma in the YAML; BASELINE configs[4])."""
         super().__init__()
+        self.bf16_mfma = bool(bf16_mfma)
         if predeblur or HR_in or not w_TSA:
             raise NotImplementedError("dynavsr_amd EDVR supports predeblur=False, HR_in=False, "
                                       "w_TSA=True (the only configuration DynaVSR ships)")
@@ -80,7 +83,7 @@ class EDVR(nn.Module):
 
     def _cfg(self):
         return (self.nf, self.nframes, self.groups, self.front_RBs, self.back_RBs, self.scale,
-                self.center)
+                self.center, int(self.bf16_mfma))
 
     def ordered_parameters(self):
         d = dict(self.named_parameters())

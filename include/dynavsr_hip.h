@@ -151,6 +151,11 @@ int dvsr_tsa_blend_backward(const float* fea, const float* att, const float* g, 
  * (it is what a later backward call reads), so it must stay untouched between the two calls. */
 typedef struct dvsr_edvr_config {
   int nf, nframes, groups, front_RBs, back_RBs, scale, center;
+  /* 0: every contraction on the exact-fp32 MFMA (default; the parity configuration).
+   * 1: the 3x3 stride-1 convolutions (forward and data gradient) round their operands to bf16 and run on
+   *    v_mfma_f32_32x32x16_bf16 with fp32 accumulation; activations, weights, gradients, the DCN, the 1x1 /
+   *    stride-2 convs and all weight gradients stay fp32 (BASELINE configs[4], "EDVR-L, bf16 MFMA path"). */
+  int bf16_mfma;
 } dvsr_edvr_config;
 typedef struct dvsr_edvr_plan dvsr_edvr_plan;
 
