@@ -320,6 +320,46 @@ __global__ void wgrad_reduce_kernel(float* __restrict__ partial, float* __restri
   }
 }
 
+// Same reduction for a table of layers in ONE launch (blockIdx.y = layer): on the small inner-step clips a
+// per-layer reduce is a 6 us kernel plus a launch gap behind every 44 us weight-gradient kernel.
+__global__ void wgrad_reduce_batch_kernel(WgradReduceTable t) {
+  const WgradReduceEntry& e = t.e[blockIdx.y];
+  const int total = e.Cout * e.Cin * e.KK;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % e.Cin;
+    const int t2 = i / e.Cin;
+    const int o = t2 % e.Cout;
+    const int tp = t2 / e.Cout;
+    float s = 0.f;
+    for (int sp = 0; sp < e.nslot; ++sp) {
+      float* q = e.partial + (((size_t)sp * e.KK + tp) * e.OP + o) * e.CP + c;
+      s += *q;
+      *q = 0.f;
+    }
+    e.dW[((size_t)o * e.Ctot + e.c_off + c) * e.KK + tp] = s;
+  }
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < e.OP; o += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int sp = 0; sp < e.nslot; ++sp) {
+      s += e.dbp[(size_t)sp * e.OP + o];
+      e.dbp[(size_t)sp * e.OP + o] = 0.f;
+    }
+    if (e.db && o < e.Cout) e.db[o] = s;
+  }
+}
+
+int wgrad_reduce_batch(const WgradReduceEntry* entries, int n, hipStream_t st) {
+  for (int base = 0; base < n; base += WGRAD_REDUCE_BATCH) {
+    WgradReduceTable t;
+    t.n = n - base < WGRAD_REDUCE_BATCH ? n - base : WGRAD_REDUCE_BATCH;
+    for (int i = 0; i < t.n; ++i) t.e[i] = entries[base + i];
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(96, t.n), dim3(256), 0, st, t);
+    int rc = check_launch("wgrad_reduce_batch_kernel");
+    if (rc) return rc;
+  }
+  return DVSR_OK;
+}
+
 template <int KS, int S>
 static void launch_wgrad(const WgradK& k, dim3 grid, hipStream_t st) {
   using Sh = WgShape<KS, S>;
@@ -361,7 +401,8 @@ size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int 
 // gradient (and db when non-null).
 int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
                      float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
-                     int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad) {
+                     int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad,
+                     WgradReduceEntry* defer) {
   DVSR_REQUIRE(x && gy && dW && ws, DVSR_ERR_INVALID, "conv2d_wgrad: null pointer");
   DVSR_REQUIRE(((ks == 1 || ks == 2) && stride == 1) || (ks == 3 && (stride == 1 || stride == 2)),
                DVSR_ERR_UNSUPPORTED, "conv2d_wgrad: ks=%d stride=%d unsupported", ks, stride);
@@ -412,6 +453,10 @@ int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy
   else launch_wgrad<1, 1>(k, grid, st);
   int rc = check_launch("conv2d_wgrad_kernel");
   if (rc) return rc;
+  if (defer) {  // the caller reduces a batch of layers later (wgrad_reduce_batch); `ws` must stay untouched until then
+    *defer = WgradReduceEntry{k.partial, k.dbp, dW, db, k.nslot, KK, k.nob * 64, k.ncb * 64, Cout, Cin, Ctot, c_off};
+    return DVSR_OK;
+  }
   const int total = Cout * Cin * KK;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, k.partial, k.dbp,
                      dW, db, k.nslot, KK, k.nob * 64, k.ncb * 64, Cout, Cin, Ctot, c_off);

@@ -78,6 +78,7 @@ struct BOp {
   size_t n = 0;          // element count for streaming ops
   int accum = 0, which = 0, cnt = 1, B = 0;
   int mask_op = -1;  // B_DGRAD / B_PADFOLD: forward op whose activation backward is fused into this launch
+  size_t ws_off = 0, ws_bytes = 0;  // B_WGRAD: this launch's private slot region inside the wgrad scratch
   long long bs = 0;
   size_t per = 0;
 };
@@ -445,10 +446,13 @@ static void build_backward(dvsr_edvr_plan& p) {
           if (which == 1 && !o.c1) break;
           BOp w; w.type = B_WGRAD; w.fwd = i; w.which = which; w.a = BackBuilder::act(which ? o.x1 : o.x0); w.b = gy;
           p.bops.push_back(w);
-          scratch = std::max(scratch, conv2d_wgrad_workspace_bytes(o.N, which ? o.c1 : o.c0, o.H, o.W, o.Cout,
-                                                                   o.ks, o.stride, conv_pad(o)));
-          wscratch = std::max(wscratch, conv2d_wgrad_workspace_bytes(o.N, which ? o.c1 : o.c0, o.H, o.W, o.Cout,
-                                                                     o.ks, o.stride, conv_pad(o)));
+          // every weight gradient owns its slot region: the slot sums of ALL layers are reduced by one
+          // batched launch at the end of the backward (wgrad_reduce_batch)
+          BOp& wr = p.bops.back();
+          wr.ws_bytes = (conv2d_wgrad_workspace_bytes(o.N, which ? o.c1 : o.c0, o.H, o.W, o.Cout, o.ks, o.stride,
+                                                      conv_pad(o)) + 255) & ~(size_t)255;
+          wr.ws_off = wscratch;
+          wscratch += wr.ws_bytes;
           if (o.wmap) {  // dW of the re-laid-out copy -> gradient of the 4x4 parameter (same stream as the wgrad)
             BOp u; u.type = B_WUNMAP; u.fwd = i;
             p.bops.push_back(u);
@@ -581,7 +585,7 @@ struct BBases {
 
 static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* const* P, float* const* GP,
                            const BBases& bs, void* scratch, size_t scratch_bytes, hipStream_t st,
-                           int scratch_is_zero = 0) {
+                           int scratch_is_zero = 0, WgradReduceEntry* defer = nullptr) {
   const Op* o = b.fwd >= 0 ? &p.ops[b.fwd] : nullptr;
   switch (b.type) {
     case B_MEMSET: {
@@ -605,7 +609,7 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
       return conv2d_wgrad_run(bs.at(b.a), b.which ? o->x1_bs : o->x0_bs, b.which ? o->x1_bdiv : 1, bs.at(b.b),
                               o->ps, dW, b.which ? nullptr : GP[o->pb], o->N, ci, o->H, o->W, o->Cout,
                               o->c0 + o->c1, b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st,
-                              scratch_is_zero, conv_pad(*o));
+                              scratch_is_zero, conv_pad(*o), defer);
     }
     case B_WUNMAP:
       return w4_to_s2d(bs.garena + o->w2_off, GP[o->pw], o->Cout, o->c0 / 4, 1, st);
@@ -858,26 +862,45 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
     }
   }
   void* wscratch = (char*)scratch + p->scratch_bytes;
-  if (use_side)  // the side stream's wgrad slots: zeroed once here, every reduce re-zeroes what it read
-    DVSR_REQUIRE(hipMemsetAsync(wscratch, 0, p->wscratch_bytes, st) == hipSuccess, DVSR_ERR_HIP,
-                 "edvr_backward: memset of the wgrad scratch failed");
+  // the weight-gradient slot regions: zeroed once here, every reduce re-zeroes what it read
+  DVSR_REQUIRE(hipMemsetAsync(wscratch, 0, p->wscratch_bytes, st) == hipSuccess, DVSR_ERR_HIP,
+               "edvr_backward: memset of the wgrad scratch failed");
   bool forked = false;
   int last_fork_fwd = -1;
+  std::vector<WgradReduceEntry> reduces;
+  std::vector<const BOp*> unmaps;
+  reduces.reserve(p->bops.size());
   for (const BOp& b : p->bops) {
-    int rc;
-    if (use_side && (b.type == B_WGRAD || b.type == B_WUNMAP)) {
-      if (b.fwd != last_fork_fwd) {  // gy of this layer is final on `st` at this point of the tape
-        DVSR_REQUIRE(hipEventRecord(p->ev_fork, st) == hipSuccess &&
-                         hipStreamWaitEvent(p->side, p->ev_fork, 0) == hipSuccess,
-                     DVSR_ERR_HIP, "edvr_backward: fork to the wgrad stream failed");
-        last_fork_fwd = b.fwd;
+    int rc = DVSR_OK;
+    if (b.type == B_WGRAD) {
+      hipStream_t ws = st;
+      if (use_side) {
+        if (b.fwd != last_fork_fwd) {  // gy of this layer is final on `st` at this point of the tape
+          DVSR_REQUIRE(hipEventRecord(p->ev_fork, st) == hipSuccess &&
+                           hipStreamWaitEvent(p->side, p->ev_fork, 0) == hipSuccess,
+                       DVSR_ERR_HIP, "edvr_backward: fork to the wgrad stream failed");
+          last_fork_fwd = b.fwd;
+        }
+        ws = p->side;
+        forked = true;
       }
-      rc = run_backward_op(*p, b, params, grad_params, bs, wscratch, p->wscratch_bytes, p->side, 1);
-      forked = true;
+      reduces.emplace_back();
+      rc = run_backward_op(*p, b, params, grad_params, bs, (char*)wscratch + b.ws_off, b.ws_bytes, ws, 1, &reduces.back());
+    } else if (b.type == B_WUNMAP) {
+      unmaps.push_back(&b);  // needs the reduced gradient: after the batched reduce below
     } else {
       rc = run_backward_op(*p, b, params, grad_params, bs, scratch, p->scratch_bytes, st);
     }
     if (rc != DVSR_OK) return rc;
+  }
+  {
+    hipStream_t ws = use_side && forked ? p->side : st;
+    int rc = wgrad_reduce_batch(reduces.data(), (int)reduces.size(), ws);
+    if (rc != DVSR_OK) return rc;
+    for (const BOp* b : unmaps) {
+      rc = run_backward_op(*p, *b, params, grad_params, bs, nullptr, 0, ws);
+      if (rc != DVSR_OK) return rc;
+    }
   }
   if (forked)
     DVSR_REQUIRE(hipEventRecord(p->ev_join, p->side) == hipSuccess &&

@@ -44,11 +44,22 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
 int conv3x3_small_cout_run(const float* x, const float* w, const float* bias, const float* res, float* y, int N,
                            int C, int H, int W, int Cout, int act, hipStream_t st);
 
+// Deferred slot reduction of a weight gradient (conv2d_wgrad_run(..., defer = &entry) + wgrad_reduce_batch)
+struct WgradReduceEntry {
+  float* partial; float* dbp; float* dW; float* db;
+  int nslot, KK, OP, CP, Cout, Cin, Ctot, c_off;
+};
+constexpr int WGRAD_REDUCE_BATCH = 56;  // entries per launch (kernel-argument limit: 56 x 64 B < 4 KB)
+struct WgradReduceTable {
+  int n;
+  WgradReduceEntry e[WGRAD_REDUCE_BATCH];
+};
+int wgrad_reduce_batch(const WgradReduceEntry* entries, int n, hipStream_t st);
 size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad = -1);
 int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
                      float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
                      int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero = 0,
-                     int pad = -1);  // pad < 0: ks / 2
+                     int pad = -1, WgradReduceEntry* defer = nullptr);  // pad < 0: ks / 2
 size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int stride, int pad, int dil);
 int mdcn_backward_run(const float* x, const float* off, long long off_bs, const float* msk, long long msk_bs,
                       int mask_logit, const float* w, const float* gout, float* gx, float* goff,
