@@ -117,17 +117,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
   // ---- partial[slot][tap][o][c]  (o, c padded to the 64-blocks of the grid), slot = split % nslot
   const int OP = a.nob * 64, CP = a.ncb * 64;
   const int slot = split % a.nslot;
-#ifdef DVSR_WGRAD_NOFLUSH  // debug ablation: keep the accumulators alive with one atomic per lane
-  {
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < KK; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s += acc[t][r];
-    unsafeAtomicAdd(a.partial + lane, s);
-    return;
-  }
-#endif
 #pragma unroll
   for (int t = 0; t < KK; ++t)
 #pragma unroll
