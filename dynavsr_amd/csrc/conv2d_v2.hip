@@ -307,7 +307,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
     if (HAS_NEXT) {
       issue_dma(k + 1, buf ^ 1);
       issue_halo(k + 1);
-      __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: the scheduler would sink them to their use
+      // keep the loads up here: the scheduler would sink them to their use (a sched_group_barrier pattern
+      // "one prefetch load behind each of the first MFMAs" was tried: it also let them sink)
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (k < 8) DVSR_STAMP(3 + 4 * k);
     // MFMA over (tap, q): operands of step i+1 are read before the MFMAs of step i
