@@ -10,6 +10,8 @@
 // and their adjoints (gradient folds), the per-frame mean subtraction / re-addition (:93,116) with
 // the B,C,T,H,W <-> (B*T),C,H,W transposes folded in, and the 4x4 -> 2x2-over-4C weight re-layout.
 // All of these are HBM-bound elementwise kernels (<1 FLOP/B).
+#include <cstdint>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -53,7 +55,8 @@ __global__ void pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 
 // adjoint: one thread per INPUT element, gathering every padded position that maps to it
-__global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int planes, int mode, int C,
+template <int mode>
+__global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int planes, int C,
                                int H, int W, int T, int accumulate, const float* __restrict__ gmask,
                                int gmask_act) {
   const int Hp = H + 2, Wp = W + 2, ipix = H * W;
@@ -78,32 +81,38 @@ __global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__
     float* dst = gx + (size_t)plane * ipix;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ipix; i += gridDim.x * blockDim.x) {
       const int yy = i / W, xx = i - yy * W;
-      int rows[3], cols[3], nr = 0, nc = 0;  // padded rows / columns that read this element
-      rows[nr++] = yy + 1;
-      cols[nc++] = xx + 1;
-      if (mode == PAD_REPL_T3) {
-        if (yy == 0) rows[nr++] = 0;
-        if (yy == H - 1) rows[nr++] = Hp - 1;
-        if (xx == 0) cols[nc++] = 0;
-        if (xx == W - 1) cols[nc++] = Wp - 1;
-      } else {
-        if (yy == 1) rows[nr++] = 0;
-        if (yy == H - 2) rows[nr++] = Hp - 1;
-        if (xx == 1) cols[nc++] = 0;
-        if (xx == W - 2) cols[nc++] = Wp - 1;
-      }
+      // the padded position every element is read at: (yy + 1, xx + 1); elements next to the border are
+      // read a second (third) time through the padding ring -- handled in the rare branch below
+      auto at = [&](int k, int r, int q) -> float {
+        if (mode == PAD_REFLECT_S2D) {
+          const int Wh = Wp / 2, Hh = Hp / 2;
+          return sp[0][((size_t)((r & 1) * 2 + (q & 1)) * Hh + (r >> 1)) * Wh + (q >> 1)];
+        }
+        return sp[k][r * Wp + q];
+      };
+      constexpr int NPL = mode == PAD_REPL_T3 ? 5 : 1;  // compile-time bound: sp[] stays in registers
       float s = 0.f;
-      if (mode == PAD_REFLECT_S2D) {
-        const int Wh = Wp / 2, Hh = Hp / 2;
-        for (int a = 0; a < nr; ++a)
-          for (int b = 0; b < nc; ++b) {
-            const int r = rows[a], q = cols[b];
-            s += sp[0][((size_t)((r & 1) * 2 + (q & 1)) * Hh + (r >> 1)) * Wh + (q >> 1)];
-          }
-      } else {
-        for (int k = 0; k < np; ++k)
-          for (int a = 0; a < nr; ++a)
-            for (int b = 0; b < nc; ++b) s += sp[k][rows[a] * Wp + cols[b]];
+#pragma unroll
+      for (int k = 0; k < NPL; ++k)
+        if (k < np) s += at(k, yy + 1, xx + 1);
+      const int lo_edge = mode == PAD_REPL_T3 ? 0 : 1;  // replicate: the border itself; reflect: one inside
+      const bool ry0 = yy == lo_edge, ry1 = yy == H - 1 - lo_edge, cx0 = xx == lo_edge, cx1 = xx == W - 1 - lo_edge;
+      if (ry0 || ry1 || cx0 || cx1) {
+        int rows[3], cols[3], nr = 0, nc = 0;
+        rows[nr++] = yy + 1;
+        cols[nc++] = xx + 1;
+        if (ry0) rows[nr++] = 0;
+        if (ry1) rows[nr++] = Hp - 1;
+        if (cx0) cols[nc++] = 0;
+        if (cx1) cols[nc++] = Wp - 1;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k)
+          if (k < np)
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int b = 0; b < 3; ++b)
+                if (a < nr && b < nc && (a || b)) s += at(k, rows[a], cols[b]);
       }
       if (accumulate) s += dst[i];
       if (gmask) {  // fused activation backward of the layer that produced the padded tensor
@@ -111,6 +120,90 @@ __global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__
         s *= gmask[(size_t)plane * ipix + i] > 0.f ? 1.f : neg;
       }
       dst[i] = s;
+    }
+  }
+}
+
+// Four consecutive columns per thread (W % 4 == 0): the interior loads of the four elements are issued
+// together and the mask / output move as 16-byte accesses.  The one-element kernel above is latency-bound
+// (two dependent round trips per thread: 235 us for 217 MB at 5x64x176x320).
+template <int mode>
+__global__ void pad_bwd4_kernel(const float* __restrict__ gy, float* __restrict__ gx, int planes, int C,
+                                int H, int W, int T, int accumulate, const float* __restrict__ gmask,
+                                int gmask_act) {
+  const int Hp = H + 2, Wp = W + 2, Wq = W >> 2, iq = H * Wq;
+  constexpr int NPL = mode == PAD_REPL_T3 ? 5 : 1;
+  const int lo_edge = mode == PAD_REPL_T3 ? 0 : 1;
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const int n = plane / C, c = plane - n * C;
+    const float* sp[NPL];
+    int np = 0;
+    if (mode == PAD_REFLECT) {
+      sp[np++] = gy + (size_t)plane * Hp * Wp;
+    } else if (mode == PAD_REFLECT_S2D) {
+      sp[np++] = gy + ((size_t)n * 4 * C + c * 4) * (size_t)(Hp / 2) * (Wp / 2);
+    } else {
+      const int b = n / T, tt = n - b * T;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) sp[k] = gy;
+      for (int dt = 0; dt < 3; ++dt) {
+        const int t0 = tt - dt + 1;
+        if (t0 >= 0 && t0 < T) sp[np++] = gy + (((size_t)b * T + t0) * 3 * C + c * 3 + dt) * (size_t)Hp * Wp;
+      }
+      if (tt == 0) sp[np++] = gy + (((size_t)b * T) * 3 * C + c * 3) * (size_t)Hp * Wp;
+      if (tt == T - 1) sp[np++] = gy + (((size_t)b * T + T - 1) * 3 * C + c * 3 + 2) * (size_t)Hp * Wp;
+    }
+    auto at = [&](int k, int r, int q) -> float {
+      if (mode == PAD_REFLECT_S2D) {
+        const int Wh = Wp / 2, Hh = Hp / 2;
+        return sp[0][((size_t)((r & 1) * 2 + (q & 1)) * Hh + (r >> 1)) * Wh + (q >> 1)];
+      }
+      return sp[k][r * Wp + q];
+    };
+    float* dst = gx + (size_t)plane * H * W;
+    const float* msk = gmask ? gmask + (size_t)plane * H * W : nullptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < iq; i += gridDim.x * blockDim.x) {
+      const int yy = i / Wq, x0 = (i - yy * Wq) * 4;
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < NPL; ++k)
+        if (k < np) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[j] += at(k, yy + 1, x0 + j + 1);
+        }
+      const bool ry0 = yy == lo_edge, ry1 = yy == H - 1 - lo_edge;
+      const bool cx0 = x0 <= lo_edge, cx1 = x0 + 3 >= W - 1 - lo_edge;
+      if (ry0 || ry1 || cx0 || cx1) {  // next to the border: the padding ring reads these elements again
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int xx = x0 + j;
+          int rows[3], cols[3], nr = 0, nc = 0;
+          rows[nr++] = yy + 1;
+          cols[nc++] = xx + 1;
+          if (ry0) rows[nr++] = 0;
+          if (ry1) rows[nr++] = Hp - 1;
+          if (xx == lo_edge) cols[nc++] = 0;
+          if (xx == W - 1 - lo_edge) cols[nc++] = Wp - 1;
+#pragma unroll
+          for (int k = 0; k < NPL; ++k)
+            if (k < np)
+#pragma unroll
+              for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                  if (a < nr && b < nc && (a || b)) s[j] += at(k, rows[a], cols[b]);
+        }
+      }
+      f32x4 o = {s[0], s[1], s[2], s[3]};
+      f32x4* d4 = reinterpret_cast<f32x4*>(dst + (size_t)yy * W + x0);
+      if (accumulate) o += *d4;
+      if (msk) {
+        const float neg = gmask_act == ACT_LRELU ? 0.1f : (gmask_act == ACT_RELU ? 0.f : 1.f);
+        const f32x4 m = *reinterpret_cast<const f32x4*>(msk + (size_t)yy * W + x0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] *= m[j] > 0.f ? 1.f : neg;
+      }
+      *d4 = o;
     }
   }
 }
@@ -146,9 +239,29 @@ int pad_bwd(const float* gy, float* gx, int mode, int N, int C, int H, int W, in
   DVSR_REQUIRE(gy && gx, DVSR_ERR_INVALID, "pad_bwd: null pointer");
   DVSR_REQUIRE(mode >= PAD_REFLECT && mode <= PAD_REPL_T3, DVSR_ERR_INVALID, "pad_bwd: mode %d", mode);
   const int planes = N * C;
-  const dim3 grid(ceil_div(H * W, 1024), planes < 65535 ? planes : 65535);
-  hipLaunchKernelGGL(pad_bwd_kernel, grid, dim3(256), 0, st, gy, gx, planes, mode, C, H, W, T, accumulate, gmask,
-                     gmask_act);
+  if (W % 4 == 0 && (((uintptr_t)gx | (uintptr_t)gmask) & 15) == 0) {
+    const dim3 g4(ceil_div(H * (W / 4), 256), planes < 65535 ? planes : 65535);
+    if (mode == PAD_REFLECT)
+      hipLaunchKernelGGL(pad_bwd4_kernel<PAD_REFLECT>, g4, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate, gmask,
+                         gmask_act);
+    else if (mode == PAD_REFLECT_S2D)
+      hipLaunchKernelGGL(pad_bwd4_kernel<PAD_REFLECT_S2D>, g4, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate,
+                         gmask, gmask_act);
+    else
+      hipLaunchKernelGGL(pad_bwd4_kernel<PAD_REPL_T3>, g4, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate, gmask,
+                         gmask_act);
+    return check_launch("pad_bwd4_kernel");
+  }
+  const dim3 grid(ceil_div(H * W, 256), planes < 65535 ? planes : 65535);
+  if (mode == PAD_REFLECT)
+    hipLaunchKernelGGL(pad_bwd_kernel<PAD_REFLECT>, grid, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate, gmask,
+                       gmask_act);
+  else if (mode == PAD_REFLECT_S2D)
+    hipLaunchKernelGGL(pad_bwd_kernel<PAD_REFLECT_S2D>, grid, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate,
+                       gmask, gmask_act);
+  else
+    hipLaunchKernelGGL(pad_bwd_kernel<PAD_REPL_T3>, grid, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate, gmask,
+                       gmask_act);
   return check_launch("pad_bwd_kernel");
 }
 
