@@ -17,18 +17,24 @@ from copy import deepcopy
 import torch
 import torch.nn.functional as F
 
+from . import optim
+
 
 def make_inner_optimizer(opt, netG, netE):
     m = opt['train']['maml']
     params = [p for p in netG.parameters() if p.requires_grad]
     if not opt['train']['use_real']:
         params += [p for p in netE.parameters() if p.requires_grad]
+    # same update rules as the torch.optim objects test_dynavsr.py:223-231 builds; on the GPU the 158
+    # parameter tensors are stepped by the native multi-tensor kernels (dynavsr_amd/optim.py)
+    on_gpu = all(p.is_cuda for p in params)
     if m['optimizer'] == 'Adam':
-        # same update rule as test_dynavsr.py:223-227; on the GPU the 158 parameter tensors are stepped by
-        # ONE fused kernel instead of ~12 foreach launches (1.35 -> 0.64 ms of a 10.8 ms inner step, most of the rest is host time)
-        fused = all(p.is_cuda for p in params)
-        return torch.optim.Adam(params, lr=m['lr_alpha'], betas=(m['beta1'], m['beta2']), fused=fused)
+        if on_gpu:
+            return optim.Adam(params, lr=m['lr_alpha'], betas=(m['beta1'], m['beta2']))
+        return torch.optim.Adam(params, lr=m['lr_alpha'], betas=(m['beta1'], m['beta2']))
     if m['optimizer'] == 'SGD':
+        if on_gpu:
+            return optim.SGD(params, lr=m['lr_alpha'])
         return torch.optim.SGD(params, lr=m['lr_alpha'])
     raise NotImplementedError()
 

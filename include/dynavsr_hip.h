@@ -232,6 +232,18 @@ int dvsr_charbonnier_forward(const float* x, const float* y, float* loss, long l
 int dvsr_charbonnier_backward(const float* x, const float* y, const float* grad_loss, float* gx, long long n,
                               float eps, dvsr_stream_t stream);
 
+/* ---- inner-loop optimiser steps over lists of parameter tensors ------------------------------------
+ * test_dynavsr.py:223-231 steps torch.optim.Adam(lr_alpha, betas) / torch.optim.SGD(lr_alpha) over the
+ * ~158 tensors of netG + netE once per inner iteration; these entry points do one such step (same
+ * single-tensor formulas, no amsgrad / momentum) with one launch per 48 tensors.  All arrays are HOST
+ * arrays of length n_tensors; a NULL gradient or numel <= 0 skips that tensor (torch.optim skips
+ * parameters whose .grad is None).  `step` is the 1-based step count of the Adam bias correction. */
+int dvsr_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const long long* numel, int n_tensors, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, dvsr_stream_t stream);
+int dvsr_sgd_step(float* const* params, const float* const* grads, const long long* numel, int n_tensors,
+                  float lr, float weight_decay, dvsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

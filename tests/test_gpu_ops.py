@@ -253,3 +253,28 @@ def test_charbonnier(ops):
     got = ops.charbonnier(xg, dev(y))
     (gg,) = torch.autograd.grad(got * 3.0, xg)
     assert abs(float(got) - float(ref)) < 1e-6 * float(ref) and relerr(gg, rg) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd"])
+def test_native_optimizer_matches_torch(kind):
+    """dvsr_adam_step / dvsr_sgd_step against torch.optim over several steps, ragged tensor list (one
+    parameter without a gradient, > 48 tensors so that the launch is split)."""
+    from dynavsr_amd import optim
+    torch.manual_seed(0)
+    shapes = [(64, 64, 3, 3), (64,), (3, 64, 3, 3), (216, 64, 3, 3), (1,)] + [(5, 7)] * 50
+    a = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    if kind == "adam":
+        oa, ob = optim.Adam(a, lr=1e-2, betas=(0.9, 0.99)), torch.optim.Adam(b, lr=1e-2, betas=(0.9, 0.99))
+    else:
+        oa, ob = optim.SGD(a, lr=1e-2), torch.optim.SGD(b, lr=1e-2)
+    for step in range(4):
+        for i, (p, q) in enumerate(zip(a, b)):
+            g = torch.randn_like(p) * (10.0 ** (step - 2))
+            p.grad, q.grad = (None, None) if i == 4 else (g.clone(), g.clone())
+        oa.step(); ob.step()
+        for p, q in zip(a, b):
+            assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max() + 1e-3), (kind, step)
+    assert float((a[4] - b[4]).abs().max()) == 0.0
+    if kind == "adam":
+        assert oa.state[a[0]]['step'] == 4 and relerr(oa.state[a[0]]['exp_avg'], ob.state[b[0]]['exp_avg']) < 1e-6
