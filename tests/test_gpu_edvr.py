@@ -307,3 +307,44 @@ def test_edvr_bf16_mfma_path():
     errs = sorted(relerr(a.grad, b.grad) for a, b in zip(net.parameters(), ref.parameters()))
     # (a random-weight 40-layer network amplifies the 4e-3 per-layer operand rounding; measured median 0.12)
     assert errs[len(errs) // 2] < 0.25 and errs[-1] < 0.6, (errs[len(errs) // 2], errs[-1])
+
+
+def test_config2_full_size_forward_parity():
+    """BASELINE configs[1] at its full size (1x5x3x180x320 -> 3x720x1280): SURVEY 8d's parity line, output vs the
+    CPU oracle max-abs <= 1e-3 on [0,1] data and PSNR(GPU, CPU) >= 60 dB.  (The oracle forward takes a few
+    seconds on the GPU box's host cores.)"""
+    from oracle import edvr as oedvr
+    P = synth.edvr_state_dict(0)
+    x = synth.clip(1, 1, 5, 180, 320, smooth=False)
+    net = make_net(0)
+    with torch.no_grad():
+        y = net(x.cuda()).cpu()
+        yo = oedvr.edvr_forward(P, x)
+    assert y.shape == (1, 3, 720, 1280)
+    d = (y - yo).abs()
+    assert float(d.max()) <= 1e-3, float(d.max())
+    assert relerr(y, yo) < 2e-4
+    assert 10 * np.log10(1.0 / float(((y - yo) ** 2).mean())) >= 60.0
+
+
+def test_inner_step_size_forward_backward_vs_oracle():
+    """EDVR on the inner-step clip of the north_star (SLR 44x80 of an LR 176x320 clip): loss and the gradient
+    w.r.t. the input clip (which feeds the estimator's backward) against the oracle, and the parameter
+    gradients by norm (isolated ReLU / floor kink flips allow ~1e-3 per tensor)."""
+    from oracle import edvr as oedvr
+    from dynavsr_amd import hipops
+    P = synth.edvr_state_dict(0)
+    x = synth.clip(3, 1, 5, 44, 80)
+    tgt = synth.clip(4, 1, 1, 176, 320)[:, 0]
+    net = make_net(0)
+    xg = x.cuda().requires_grad_(True)
+    loss = hipops.charbonnier(net(xg), tgt.cuda())
+    loss.backward()
+    PO = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in P.items())
+    xo = x.clone().requires_grad_(True)
+    lo = oedvr.charbonnier(oedvr.edvr_forward(PO, xo), tgt)
+    lo.backward()
+    assert abs(float(loss.detach()) - float(lo.detach())) / float(lo.detach()) < 1e-5
+    assert relerr(xg.grad, xo.grad) < 5e-3
+    gn = lambda ps: float(torch.sqrt(sum((p.grad.detach().double().cpu() ** 2).sum() for p in ps)))
+    assert abs(gn(net.parameters()) - gn(PO.values())) / gn(PO.values()) < 5e-3
