@@ -23,9 +23,10 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak 
 HBM_PEAK_GBS = 8000.0           # same guide, HBM3E peak
 
 
-def cpu_baseline(cfg, h, w, seed):
+def cpu_baseline(cfg, h, w, seed, y_gpu=None):
     """The CPU oracle (torch CPU convs + C restatement of the DCN) timed on this box's host cores
-    on ONE clip of the same workload.  A reported baseline, not the target."""
+    on ONE clip of the same workload.  A reported baseline, not the target.  The same clip was run by the
+    timed loop on rank 0, so the oracle's output doubles as the full-size parity check (`y_gpu`)."""
     from dynavsr_amd import synth
     from oracle import dcn as odcn, edvr as oedvr
     odcn.lib()
@@ -34,11 +35,16 @@ def cpu_baseline(cfg, h, w, seed):
     threads = torch.get_num_threads()
     with torch.no_grad():
         t0 = time.time()
-        oedvr.edvr_forward(P, x)
+        ref = oedvr.edvr_forward(P, x)
         dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "1 clip forward (EDVR-M x4, 1x5x3x%dx%d), fp32, oracle/edvr.py on %d torch/OpenMP "
-                      "threads of %d host cpus, no warm-up" % (h, w, threads, os.cpu_count())}
+    out = {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": "1 clip forward (EDVR-M x4, 1x5x3x%dx%d), fp32, oracle/edvr.py on %d torch/OpenMP "
+                     "threads of %d host cpus, no warm-up" % (h, w, threads, os.cpu_count())}
+    if y_gpu is not None:
+        d = (y_gpu.detach().cpu().double() - ref.double())
+        out["parity_vs_this_run"] = {"rel_l2": float(d.norm() / ref.double().norm()), "max_abs": float(d.abs().max()),
+                                     "psnr_db": float(10 * torch.log10(1.0 / (d ** 2).mean()))}
+    return out
 
 
 def inner_step_rate(dev, steps=8):
@@ -204,7 +210,7 @@ def main():
         if world == 1 and not args.no_inner_step:
             line["inner_step"] = inner_step_rate(dev)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, h, w, 0)
+            line["cpu_baseline"] = cpu_baseline(cfg, h, w, 0, y)   # same clip (seed 1 + rank 0), same weights
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
