@@ -67,6 +67,13 @@ struct TileOut {
   int gmask_act = 0;
 };
 
+// Raw buffer view of one image of an NCHW tensor: loads / stores whose byte offset is >= num_records are
+// dropped (loads return 0) by the hardware, so edge tiles need no predication at all.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const float* base, size_t floats) {
+  const size_t bytes = floats * 4;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes < 0xFFFFFFFFull ? (int)bytes : -1, 0x00020000);
+}
+
 template <bool FULL, int MT, int NT>
 __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT], const TileOut& t, int n,
                                                      int co_block, int hi, int oy_first, int ox) {
@@ -87,65 +94,97 @@ __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT]
         bv[mt][r] = t.bias[(FULL || co < t.Cout) ? co : t.Cout - 1];
       }
   }
+  const float neg = t.gmask_act == ACT_LRELU ? 0.1f : (t.gmask_act == ACT_RELU ? 0.f : 1.f);
+  if (FULL) {
+    // Full tiles: address = wave-uniform channel plane (scalar registers) + one per-lane 32-bit byte offset
+    // shared by all 16 registers, i.e. no vector address arithmetic per store.
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int oy = oy_first + nt;
+        if (t.ps == 0) {
+          const unsigned voff = (unsigned)(((size_t)(4 * hi) * HWo + (size_t)oy * t.Wo + ox) * 4);
+          auto addr = [&](const float* base, int r) -> const float* {
+            const int cu = co_block + mt * 32 + (r & 3) + 8 * (r >> 2);  // uniform part of the channel
+            return reinterpret_cast<const float*>(
+                reinterpret_cast<const char*>(base + ((size_t)n * t.Cout + cu) * HWo) + voff);
+          };
+          float extra[16], gm[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { extra[r] = 0.f; gm[r] = 1.f; }
+          if (t.res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) extra[r] = *addr(t.res, r);
+          }
+          if (t.accum) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) extra[r] += *addr(t.y, r);
+          }
+          if (t.gmask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gm[r] = *addr(t.gmask, r) > 0.f ? 1.f : neg;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[mt][nt][r] + bv[mt][r];
+            v = (fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)) + extra[r]) * gm[r];  // act: v > 0 ? v : slope * v
+            *const_cast<float*>(addr(t.y, r)) = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+            float v = acc[mt][nt][r] + bv[mt][r];
+            v = fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f));
+            const int cq = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
+            t.y[(((size_t)n * (t.Cout >> 2) + cq) * (2 * t.Ho) + (2 * oy + dy)) * (size_t)(2 * t.Wo) +
+                (2 * ox + dx)] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+  // Edge tiles (common on the small inner-step clips: 44x80 is 2.5 tiles wide): every access goes through
+  // a bounds-checked raw buffer of this image with the byte offset forced out of range for invalid
+  // (row, column, channel) combinations -- still straight-line code, no store waits for another store.
+  const size_t img = (size_t)t.Cout * HWo;
+  const __amdgpu_buffer_rsrc_t ry = image_rsrc(t.y + (size_t)n * img, img);
+  const __amdgpu_buffer_rsrc_t rr = image_rsrc(t.res ? t.res + (size_t)n * img : t.y, t.res ? img : 0);
+  const __amdgpu_buffer_rsrc_t rg = image_rsrc(t.gmask ? t.gmask + (size_t)n * img : t.y, t.gmask ? img : 0);
+  const __amdgpu_buffer_rsrc_t ra = image_rsrc(t.y + (size_t)n * img, t.accum ? img : 0);
+  const bool col_ok = ox < t.Wo;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int oy = oy_first + nt;
-      const bool row_ok = FULL || oy < t.Ho;
-      const int oyc = row_ok ? oy : t.Ho - 1;
-      if (t.ps == 0) {
-        // Full tiles: address = wave-uniform channel plane (scalar registers) + one per-lane 32-bit byte
-        // offset shared by all 16 registers, i.e. no vector address arithmetic per store.  Edge tiles
-        // compute (and clamp) the channel per lane.
-        const unsigned voff = (unsigned)(((size_t)(4 * hi) * HWo + (size_t)oyc * t.Wo + ox) * 4);
-        const size_t pix = (size_t)n * t.Cout * HWo + (size_t)oyc * t.Wo + ox;  // channel 0 of this pixel
-        auto addr = [&](const float* base, int r) -> const float* {
-          if (FULL) {
-            const int cu = co_block + mt * 32 + (r & 3) + 8 * (r >> 2);  // uniform part of the channel
-            return reinterpret_cast<const float*>(
-                reinterpret_cast<const char*>(base + ((size_t)n * t.Cout + cu) * HWo) + voff);
-          }
-          const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
-          return base + pix + (size_t)(co < t.Cout ? co : t.Cout - 1) * HWo;
-        };
-        float extra[16];
+      const bool px_ok = col_ok && oy < t.Ho;
+      unsigned off[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) extra[r] = 0.f;
-        if (t.res) {
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+        size_t o;
+        if (t.ps == 0) o = (size_t)co * HWo + (size_t)oy * t.Wo + ox;
+        else o = ((size_t)(co >> 2) * (2 * t.Ho) + (2 * oy + ((co >> 1) & 1))) * (size_t)(2 * t.Wo) + (2 * ox + (co & 1));
+        off[r] = (px_ok && co < t.Cout) ? (unsigned)(o * 4) : 0xFFFFFFFFu;
+      }
+      float extra[16], gm[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) extra[r] = *addr(t.res, r);
-        }
-        if (t.accum) {
+      for (int r = 0; r < 16; ++r)
+        extra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off[r], 0, 0));
 #pragma unroll
-          for (int r = 0; r < 16; ++r) extra[r] += *addr(t.y, r);
-        }
-        float gm[16];
+      for (int r = 0; r < 16; ++r)
+        extra[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, off[r], 0, 0));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gm[r] = 1.f;
-        if (t.gmask) {
-          const float neg = t.gmask_act == ACT_LRELU ? 0.1f : (t.gmask_act == ACT_RELU ? 0.f : 1.f);
+      for (int r = 0; r < 16; ++r)
+        gm[r] = (t.gmask && __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, off[r], 0, 0)) <= 0.f) ? neg : 1.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) gm[r] = *addr(t.gmask, r) > 0.f ? 1.f : neg;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
-          float v = acc[mt][nt][r] + bv[mt][r];
-          v = (fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)) + extra[r]) * gm[r];  // act: v > 0 ? v : slope * v
-          if (FULL || (row_ok && co < t.Cout)) *const_cast<float*>(addr(t.y, r)) = v;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
-          float v = acc[mt][nt][r] + bv[mt][r];
-          v = fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f));
-          const int cq = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
-          if (FULL || (row_ok && co < t.Cout))
-            t.y[(((size_t)n * (t.Cout >> 2) + cq) * (2 * t.Ho) + (2 * oy + dy)) * (size_t)(2 * t.Wo) +
-                (2 * ox + dx)] = v;
-        }
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[mt][nt][r] + bv[mt][r];
+        v = (fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)) + extra[r]) * gm[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, off[r], 0, 0);
       }
     }
   }
@@ -161,7 +200,7 @@ __device__ __forceinline__ void store_mfma_tile(const f32x16 (&acc)[MT][NT], con
   const int ox = ox0 + lo;
   if (full) {
     store_mfma_tile_impl<true, MT, NT>(acc, t, n, co_block, hi, oy_first, ox);
-  } else if (ox < t.Wo) {
+  } else {
     store_mfma_tile_impl<false, MT, NT>(acc, t, n, co_block, hi, oy_first, ox);
   }
 }

@@ -420,7 +420,6 @@ static double conv2_pipe_cost(int TH, int MT, int KK, int CC, int N, int Ho, int
 }
 
 ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ctot) {
-  (void)Ctot;
   static int force = -2;  // DVSR_CONV_TILE=0|1|2 pins (8,2)/(4,2)/(4,1) tiles (A/B aid); default: model
   if (force == -2) {
     const char* v = getenv("DVSR_CONV_TILE");
@@ -440,7 +439,20 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
   if (force == 2) return ConvGeo{cc, 4, 1};
   const double c42 = conv2_pipe_cost(4, 2, ks * ks, cc, N, Ho, Wo, Cout);
   const double c41 = conv2_pipe_cost(4, 1, ks * ks, cc, N, Ho, Wo, Cout);
-  return c41 < 0.97 * c42 ? ConvGeo{cc, 4, 1} : ConvGeo{cc, 4, 2};
+  ConvGeo g = c41 < 0.97 * c42 ? ConvGeo{cc, 4, 1} : ConvGeo{cc, 4, 2};
+  // Small grids (every workgroup resident at once) are bound by one memory latency per chunk, not by the
+  // matrix pipe: 16-channel chunks halve the number of exposed latencies.  DVSR_CONV_CC16_BELOW=<workgroups>
+  // moves the threshold (0 disables).
+  static int cc16_below = -1;
+  if (cc16_below < 0) {
+    const char* v = getenv("DVSR_CONV_CC16_BELOW");
+    cc16_below = v ? atoi(v) : 0;
+  }
+  if (ks == 3 && stride == 1 && Ctot >= 32) {
+    const long long wgs = (long long)ceil_div(Wo, 32) * ceil_div(Ho, 4) * N * ceil_div(Cout, 32 * g.mt);
+    if (wgs <= cc16_below) g.cc = 16;
+  }
+  return g;
 }
 
 int conv2_pch_cc(int ks, int cc, int bf) { return 2 * ks * ks * (bf ? cc / 16 : cc / 8) * 2 * 32 * 4; }
@@ -500,6 +512,8 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
       case 882: return launch_conv2<3, 1, 8, 8, 2>(k, st);
       case 842: return launch_conv2<3, 1, 8, 4, 2>(k, st);
       case 841: return launch_conv2<3, 1, 8, 4, 1>(k, st);
+      case 1642: return launch_conv2<3, 1, 16, 4, 2>(k, st);
+      case 1641: return launch_conv2<3, 1, 16, 4, 1>(k, st);
     }
   } else if (d.ks == 2) {  // the estimator's 4x4 stride-2 convs, re-expressed over a space-to-depth input
     switch (code) {
