@@ -662,7 +662,8 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
       return pool3s2_bwd(bs.arena + o->x0.off, bs.at(b.b), bs.at(b.c), bs.at(b.a), o->planes, o->H, o->W, b.accum, st);
     case B_GATE:
       return tsa_gate_bwd(bs.arena + o->x0.off, bs.arena + o->x1.off, bs.arena + o->res.off, bs.arena + o->y.off,
-                          bs.at(b.b), bs.at(b.a), bs.at(b.c), bs.at(b.d), o->gB, o->gN, o->gC, o->gHW, st);
+                          bs.at(b.b), bs.at(b.a), bs.at(b.c), bs.at(b.d), o->gB, o->gN, o->gC, o->gHW, st,
+                          bs.garena + o->y.off);  // cor's (otherwise unused) gradient slot holds g_dot
     case B_BLEND:
       return tsa_blend_bwd(bs.arena + o->x0.off, bs.arena + o->x1.off, bs.at(b.b), bs.at(b.a), bs.at(b.c),
                            o->y.numel, b.accum, st);

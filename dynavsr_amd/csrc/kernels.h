@@ -85,7 +85,7 @@ int tsa_gate_fwd(const float* emb, const float* emb_ref, const float* aligned, f
                  float* gated, int B, int N, int C, size_t HW, hipStream_t st);
 int tsa_gate_bwd(const float* emb, const float* emb_ref, const float* aligned, const float* cor,
                  const float* g_gated, float* g_emb, float* g_emb_ref, float* g_aligned, int B,
-                 int N, int C, size_t HW, hipStream_t st);
+                 int N, int C, size_t HW, hipStream_t st, float* gdot_scratch = nullptr);
 int tsa_blend_fwd(const float* fea, const float* att, const float* add, float* out, size_t n,
                   hipStream_t st);
 int tsa_blend_bwd(const float* fea, const float* att, const float* g, float* g_fea, float* g_att_io,

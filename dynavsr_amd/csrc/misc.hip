@@ -336,6 +336,47 @@ __global__ void tsa_gate_bwd_kernel(const float* __restrict__ emb, const float* 
   }
 }
 
+// Two-pass variant with N x more threads (the one above runs B*HW threads, 3520 on the inner-step clip:
+// 190 us).  Pass 1, thread = (b, n, pixel): g_aligned, g_emb and the per-frame scalar g_dot (kept in
+// `gdot`, [B][N][HW]).  Pass 2, thread = (b, c, pixel): g_emb_ref = sum_n g_dot * emb, same order of
+// summation over n as the single-pass kernel.
+__global__ void tsa_gate_bwd1_kernel(const float* __restrict__ emb_ref, const float* __restrict__ aligned,
+                                     const float* __restrict__ cor, const float* __restrict__ g_gated,
+                                     float* __restrict__ g_emb, float* __restrict__ g_aligned,
+                                     float* __restrict__ gdot, int B, int N, int C, size_t HW) {
+  const size_t total = (size_t)B * N * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i % HW, bn = i / HW, b = bn / N;
+    const float s = cor[i];
+    const float* gg = g_gated + bn * C * HW + p;
+    const float* al = aligned + bn * C * HW + p;
+    float* ga = g_aligned + bn * C * HW + p;
+    float gcor = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+      const float g = gg[c * HW];
+      gcor += g * al[c * HW];
+      ga[c * HW] = g * s;
+    }
+    const float gd = gcor * s * (1.f - s);
+    gdot[i] = gd;
+    const float* r = emb_ref + b * C * HW + p;
+    float* ge = g_emb + bn * C * HW + p;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) ge[c * HW] = gd * r[c * HW];
+  }
+}
+__global__ void tsa_gate_bwd2_kernel(const float* __restrict__ emb, const float* __restrict__ gdot,
+                                     float* __restrict__ g_emb_ref, int B, int N, int C, size_t HW) {
+  const size_t total = (size_t)B * C * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i % HW, bc = i / HW, c = bc % C, b = bc / C;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += gdot[(b * N + n) * HW + p] * emb[((b * N + n) * C + c) * HW + p];
+    g_emb_ref[i] = s;
+  }
+}
+
 // ---- TSA blend: out = fea * sigmoid(att) * 2 + att_add (EDVR_arch.py:200-202) ---------------
 __global__ void tsa_blend_fwd_kernel(const float* __restrict__ fea, const float* __restrict__ att,
                                      const float* __restrict__ add, float* __restrict__ out,
@@ -518,9 +559,17 @@ int tsa_gate_fwd(const float* emb, const float* emb_ref, const float* aligned, f
 }
 int tsa_gate_bwd(const float* emb, const float* emb_ref, const float* aligned, const float* cor,
                  const float* g_gated, float* g_emb, float* g_emb_ref, float* g_aligned, int B,
-                 int N, int C, size_t HW, hipStream_t st) {
+                 int N, int C, size_t HW, hipStream_t st, float* gdot_scratch) {
   DVSR_REQUIRE(emb && emb_ref && aligned && cor && g_gated && g_emb && g_emb_ref && g_aligned,
                DVSR_ERR_INVALID, "tsa_gate_bwd: null pointer");
+  if (gdot_scratch) {  // [B][N][HW] floats of scratch: the two-pass, N x more parallel variant
+    LAUNCH(tsa_gate_bwd1_kernel, (size_t)B * N * HW, st, emb_ref, aligned, cor, g_gated, g_emb, g_aligned, gdot_scratch,
+           B, N, C, HW);
+    int rc = check_launch("tsa_gate_bwd1_kernel");
+    if (rc) return rc;
+    LAUNCH(tsa_gate_bwd2_kernel, (size_t)B * C * HW, st, emb, gdot_scratch, g_emb_ref, B, N, C, HW);
+    return check_launch("tsa_gate_bwd2_kernel");
+  }
   LAUNCH(tsa_gate_bwd_kernel, (size_t)B * HW, st, emb, emb_ref, aligned, cor, g_gated, g_emb,
          g_emb_ref, g_aligned, B, N, C, HW);
   return check_launch("tsa_gate_bwd_kernel");
