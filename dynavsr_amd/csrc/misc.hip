@@ -518,10 +518,53 @@ int upsample_bilinear_fwd(const float* x, float* y, size_t planes, int H, int W,
   LAUNCH(upsample_bilinear_fwd_kernel, nout, st, x, y, planes, H, W, S, mul);
   return check_launch("upsample_bilinear_fwd_kernel");
 }
+// S = 2 backward: input pixel (iy, ix) is read by output rows 2iy-1 .. 2iy+2 with the fixed weights
+// (0.25, 0.75, 0.75, 0.25) -- at the borders output 0 reads in[0] with weight 1 and output 2H-1 reads
+// in[H-1] with 0.75 + 0.25 -- and likewise along x: a 4x4 gather with separable constant weights instead of
+// the generic kernel's search over candidate outputs.
+__device__ __forceinline__ void up2_bwd_weights(int i, int n, float (&w)[4]) {
+  w[0] = i > 0 ? 0.25f : 0.f;                  // output 2i-1 (odd, of input i-1): lambda 0.25 on i
+  w[1] = i > 0 ? 0.75f : 1.f;                  // output 2i (even): 0.75 on i, or exactly in[0]
+  w[2] = i < n - 1 ? 0.75f : 1.f;              // output 2i+1 (odd): 0.75 on i (+0.25 when i+1 clamps to i)
+  w[3] = i < n - 1 ? 0.25f : 0.f;              // output 2i+2 (even, of input i+1): 0.25 on i
+}
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, unsigned planes, int H,
+                                      int W, float mul, int accumulate) {
+  const unsigned total = planes * (unsigned)H * (unsigned)W;
+  const int Wo = 2 * W;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int ix = (int)(i % (unsigned)W);
+    const unsigned t = i / (unsigned)W;
+    const int iy = (int)(t % (unsigned)H);
+    const unsigned p = t / (unsigned)H;
+    float wy[4], wx[4];
+    up2_bwd_weights(iy, H, wy);
+    up2_bwd_weights(ix, W, wx);
+    const float* g = gy + (size_t)p * 4 * H * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int oy = 2 * iy - 1 + a;
+      if (wy[a] == 0.f) continue;
+      float row = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (wx[b] != 0.f) row += wx[b] * g[(size_t)oy * Wo + 2 * ix - 1 + b];
+      acc += wy[a] * row;
+    }
+    acc *= mul;
+    gx[i] = accumulate ? gx[i] + acc : acc;
+  }
+}
+
 int upsample_bilinear_bwd(const float* gy, float* gx, size_t planes, int H, int W, int S, float mul,
                           int accumulate, hipStream_t st) {
   DVSR_REQUIRE(gy && gx && planes > 0 && H > 0 && W > 0 && S >= 1, DVSR_ERR_INVALID,
                "upsample_bilinear_bwd: bad argument");
+  if (S == 2 && H >= 2 && W >= 2 && planes * H * W < (1ull << 32)) {
+    LAUNCH(upsample2x_bwd_kernel, planes * H * W, st, gy, gx, (unsigned)planes, H, W, mul, accumulate);
+    return check_launch("upsample2x_bwd_kernel");
+  }
   LAUNCH(upsample_bilinear_bwd_kernel, planes * H * W, st, gy, gx, planes, H, W, S, mul, accumulate);
   return check_launch("upsample_bilinear_bwd_kernel");
 }
