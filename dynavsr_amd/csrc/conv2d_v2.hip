@@ -31,7 +31,7 @@ struct ConvK2 {
   const float* x0; const float* x1; const float* wp; const float* bias; const float* res; float* y;
   int N, c0, c1, H, W, Cout, Ho, Wo, pad, act, ps, x1_bdiv;
   long long x0_bs, x1_bs;
-  int tiles_x, tiles_y, ntiles, ncb, nchunks;
+  int tiles_x, tiles_y, ntiles, ncb, nchunks, nitems;
   int in_ps, in_dil, Hs, Ws, accum;
   const float* gmask; int gmask_act;
 #ifdef DVSR_CONV_TRACE
@@ -154,17 +154,16 @@ int pack_weights_run(const PackTable& t, hipStream_t st) {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int KS, int S, int CC, int TH, int MT, bool BF = false>
-__global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
+// One work item = one (pixel tile, 32*MT-cout block).
+template <int KS, int S, int CC, int TH, int MT, bool BF>
+__device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, float* const smem) {
   using Sh = Conv2Shape<KS, S, CC, TH, MT, BF>;
   constexpr int KK = Sh::KK, IH = Sh::IH, IW = Sh::IW, PLANE = Sh::PLANE, E = Sh::E, KQ4 = Sh::KQ4,
                 NT = Sh::NT;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const s_in0 = smem;
   float* const s_w0 = smem + Sh::IN_FLOATS;
 
   // XCD-aware order: the ncb cout blocks of one pixel tile get ids that differ by 8 (same XCD/L2)
-  const int id = blockIdx.x;
   const int tile = (id / (8 * a.ncb)) * 8 + (id & 7);
   const int cbi = (id >> 3) % a.ncb;  // block of 32*MT output channels
   if (tile >= a.ntiles) return;
@@ -385,6 +384,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
 #endif
 }
 
+// The kernel walks work items with a grid stride; the default launch has one workgroup per item (see
+// launch_conv2 for the persistent variant and why it is not the default).  tools/conv_trace.py reports the
+// per-CU occupancy of a launch: 2.6-2.7 of 3 workgroup slots on average, ~13 k cycles of slot turnover.
+template <int KS, int S, int CC, int TH, int MT, bool BF = false>
+__global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  for (int id = blockIdx.x; id < a.nitems; id += gridDim.x) {
+    conv2d_pipe_item<KS, S, CC, TH, MT, BF>(a, id, smem);
+    __syncthreads();  // every wave is done with both LDS buffers before the next item's prologue writes them
+  }
+}
+
 template <int KS, int S, int CC, int TH, int MT, bool BF = false>
 static int launch_conv2(ConvK2 k, hipStream_t st) {
   using Sh = Conv2Shape<KS, S, CC, TH, MT, BF>;
@@ -401,7 +412,18 @@ static int launch_conv2(ConvK2 k, hipStream_t st) {
   }
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 32 * MT);
-  const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
+  k.nitems = ceil_div(k.ntiles, 8) * 8 * k.ncb;
+  // Default: one workgroup per item.  DVSR_CONV_PERSIST=1 (A/B aid) launches only the workgroups the chip can
+  // hold (256 CUs x floor(160 KB / LDS per workgroup), capped at 3 by the registers; a multiple of 8 so that an
+  // item keeps its XCD) and lets them walk the items with a grid stride.  Measured 2-3 % SLOWER on every big
+  // layer (fe_rb_a 199.9 vs 192.6 us, HRconv 612.9 vs 596.8): the ~13 k-cycle slot turnover of the plain
+  // launch is not idle matrix-pipe time -- the two resident workgroups absorb it.
+  static int persist = -1;
+  if (persist < 0) { const char* v = getenv("DVSR_CONV_PERSIST"); persist = (v && v[0] == '1') ? 1 : 0; }
+  int per_cu = (int)(160 * 1024 / lds);
+  per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
+  const int slots = 256 * per_cu;
+  const int grid = (persist && k.nitems > slots) ? slots : k.nitems;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, k);
   return check_launch("conv2d_pipe_kernel");
 }

@@ -94,6 +94,38 @@ stat("sum wait+LDS write / wg", wr.sum(1))
 stat("sum MFMA part 2 + barrier / wg", m2.sum(1))
 stat("epilogue issue", t[:, 41] - t[:, 40])
 stat("epilogue store ack", t[:, 42] - t[:, 41])
+# occupancy per CU: workgroups that ran on the same CU (HW_ID se/sh/cu; the 8 XCDs have unrelated s_memtime
+# bases, so a CU group is additionally split where start times jump by more than 1e8 ticks)
+key = ((hw >> 8) & 0xFF).astype(np.int64)  # cu_id, sh_id, se_id
+groups = {}
+for i in range(len(t)):
+    groups.setdefault(int(key[i]), []).append(i)
+conc, gaps = [], []
+for k, idxs in groups.items():
+    idxs.sort(key=lambda i: t[i, 0])
+    run = [idxs[0]]
+    runs = []
+    for a, b in zip(idxs[:-1], idxs[1:]):
+        if t[b, 0] - t[a, 0] > 1e8:
+            runs.append(run); run = []
+        run.append(b)
+    runs.append(run)
+    for r in runs:
+        if len(r) < 4:
+            continue
+        st, en = t[r, 0], t[r, 42]
+        span = float(en.max() - st.min())
+        busy = float((en - st).sum())
+        conc.append(busy / span)
+        # per-slot turnover: time from the k-th end to the (k+3)-th start when 3 workgroups share a CU
+        ends = np.sort(en); starts = np.sort(st)
+        if len(starts) > 3:
+            gaps.extend(list(starts[3:] - ends[:len(starts) - 3]))
+if conc:
+    print("per-CU occupancy (sum of workgroup lifetimes / CU active span): median %.2f  p10 %.2f  p90 %.2f  (3 = always full)" %
+          (np.median(conc), np.percentile(conc, 10), np.percentile(conc, 90)))
+    print("slot turnover (next workgroup's start - a finished one's end, 3 slots per CU): median %.0f cycles  p90 %.0f" %
+          (np.median(gaps), np.percentile(gaps, 90)))
 # start-time histogram: how many rounds of workgroups
 order = np.argsort(start)
 print("start times (cycles) deciles:", np.percentile(start, [0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100]).astype(int))
