@@ -99,8 +99,8 @@ def inner_step_rate(dev, steps=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--height", type=int, default=180)
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--no-cpu-baseline", action="store_true")
