@@ -55,15 +55,22 @@ struct ConvK2 {
 // BF = bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): a 16-byte LDS operand then holds 8
 // consecutive channels (k = 8*hi .. 8*hi+7 of a 16-channel block) instead of the 4 of the fp32 layout
 // (k = 2kk + hi), everything else -- tiles, double buffering, DMA pieces, epilogue -- is shared.
-template <int KS, int S, int CC, int TH, int MT, bool BF = false>
+// BF = 2 ("split3", experimental): both operands are split into three bf16 pieces (hi / mid / lo) and the six
+// largest partial products are issued, small terms first -- as accurate as the exact-fp32 MFMA against a
+// double reference (profiles/r01_bf16_split_probe.txt) for 6 x 32 instead of 8 x 64 pipe cycles per tap and
+// 16 channels.  Three LDS images of everything: 150 KB double-buffered, one workgroup per CU.
+template <int KS, int S, int CC, int TH, int MT, int BF = 0>
 struct Conv2Shape {
   static constexpr int TW = 32, KK = KS * KS, NT = TH / 4;  // NT pixel rows per wave
   static constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
   static constexpr int PLANE = IH * IW, E = (PLANE + 255) / 256;
   static constexpr int KQ4 = BF ? CC / 16 : CC / 8;   // 16-byte operand groups (x 2 lane halves) per chunk
-  static constexpr int IN_FLOATS = KQ4 * PLANE * 8;   // = KQ4 * IH * 2 * IW float4
-  static constexpr int HALF = KK * KQ4 * 2 * 32 * 4;  // packed floats of one 32-cout half
-  static constexpr int W_FLOATS = MT * HALF;
+  static constexpr int PIECES = BF == 2 ? 3 : 1;      // bf16 pieces per operand
+  static constexpr int IN1 = KQ4 * PLANE * 8;         // one piece of the halo image = KQ4 * IH * 2 * IW float4
+  static constexpr int IN_FLOATS = PIECES * IN1;
+  static constexpr int HALF = KK * KQ4 * 2 * 32 * 4;  // packed floats of one 32-cout half (of one piece)
+  static constexpr int W1 = MT * HALF;                // one piece of the weight image
+  static constexpr int W_FLOATS = PIECES * W1;
   static constexpr int NPIECE = W_FLOATS / 256;       // 1-KiB DMA pieces (one wave-instruction each)
   static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
   static constexpr size_t LDS_BYTES = (size_t)2 * BUF_FLOATS * sizeof(float);
@@ -124,15 +131,22 @@ __global__ void pack_weights_bf16_kernel(PackTable t) {
     const int lo = r & 31; r >>= 5;
     const int hi = r & 1; r >>= 1;
     const int q = r % kb; r /= kb;
-    const int tap = r % e.KK;
-    const int mt = r / e.KK;
+    const int tap = r % e.KK; r /= e.KK;
+    const int mt = r & 1;
+    const int piece = r >> 1;  // 0 (the only one for bf = 1) | hi / mid / lo of the 3-way split (bf = 2)
     const int co = cb * 64 + mt * 32 + lo, ci = k * e.CC + 16 * q + 8 * hi + j;
     float v = 0.f;
     if (co < e.Cout && ci < e.Ctot) {
       if (!e.wt) v = e.w[((size_t)co * e.Ctot + ci) * e.KK + tap];
       else v = e.w[((size_t)ci * e.w_ctot + e.w_coff + co) * e.KK + (e.KK - 1 - tap)];
     }
-    P16[i] = (__bf16)v;
+    __bf16 out = (__bf16)v;
+    if (piece > 0) {
+      const float r1 = v - (float)out;
+      const __bf16 m = (__bf16)r1;
+      out = piece == 1 ? m : (__bf16)(r1 - (float)m);
+    }
+    P16[i] = out;
   }
 }
 
@@ -155,7 +169,7 @@ int pack_weights_run(const PackTable& t, hipStream_t st) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // One work item = one (pixel tile, 32*MT-cout block).
-template <int KS, int S, int CC, int TH, int MT, bool BF>
+template <int KS, int S, int CC, int TH, int MT, int BF>
 __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, float* const smem) {
   using Sh = Conv2Shape<KS, S, CC, TH, MT, BF>;
   constexpr int KK = Sh::KK, IH = Sh::IH, IW = Sh::IW, PLANE = Sh::PLANE, E = Sh::E, KQ4 = Sh::KQ4,
@@ -214,7 +228,9 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
 
   float rin[CC][E];
   // packed weights of this workgroup's cout block: 64-cout block (cbi*MT)/2, starting half (cbi*MT)%2
-  const float* wp_cb = a.wp + ((size_t)((cbi * MT) >> 1) * a.nchunks * 2 + ((cbi * MT) & 1)) * Sh::HALF;
+  // global image: [64-cout block][chunk][piece][half][HALF]
+  constexpr int PIECES = Sh::PIECES;
+  const float* wp_cb = a.wp + ((size_t)((cbi * MT) >> 1) * a.nchunks * PIECES * 2 + ((cbi * MT) & 1)) * Sh::HALF;
 
   // Halo loads of chunk k into registers (raw; masked when they are written to LDS).  All address
   // math is wave-uniform scalar work: one base pointer per chunk (a chunk never straddles the two
@@ -245,15 +261,17 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
   // issues the same number of DMAs (the last piece is re-sent when NPIECE % 4 != 0), so the loop body
   // stays one basic block and the compiler's vmcnt bookkeeping stays exact.
   auto issue_dma = [&](int k, int buf) {
-    const float* wsrc = wp_cb + (size_t)k * (2 * Sh::HALF);
+    const float* wsrc = wp_cb + (size_t)k * (PIECES * 2 * Sh::HALF);
     float* wdst = s_w0 + buf * Sh::BUF_FLOATS;
+    constexpr int NP1 = Sh::W1 / 256;  // 1-KiB DMA pieces of one operand piece
 #pragma unroll
     for (int j = 0; j < (Sh::NPIECE + 3) / 4; ++j) {
       int piece = j * 4 + wave;
       piece = piece < Sh::NPIECE ? piece : Sh::NPIECE - 1;
+      const int op = piece / NP1, within = piece - op * NP1;  // operand piece (hi / mid / lo), 1-KiB block inside it
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(wsrc + piece * 256 + lane * 4),
-          (__attribute__((address_space(3))) void*)(wdst + piece * 256), 16, 0, 0);
+          (const __attribute__((address_space(1))) void*)(wsrc + op * (2 * Sh::HALF) + within * 256 + lane * 4),
+          (__attribute__((address_space(3))) void*)(wdst + op * Sh::W1 + within * 256), 16, 0, 0);
     }
   };
   // halo registers of chunk k -> LDS buffer, transposed to [q][row][hi][x] x float4(kk): one
@@ -269,7 +287,22 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
           for (int h2 = 0; h2 < 2; ++h2) {
             const bool ev = evalid[e];
             f32x4 v;
-            if (BF) {  // 8 consecutive channels, rounded to bf16 (RNE)
+            if (BF == 2) {  // 8 consecutive channels, each split into three bf16 pieces: x = hi + mid + lo (+ 2^-24)
+              const int cb0 = k * CC + 16 * q + 8 * h2;
+              bf16x8 p0, p1, p2;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const float x = (ev && cb0 + i < Ctot) ? rin[16 * q + 8 * h2 + i][e] : 0.f;
+                const __bf16 h = (__bf16)x;
+                const float r1 = x - (float)h;
+                const __bf16 m = (__bf16)r1;
+                p0[i] = h; p1[i] = m; p2[i] = (__bf16)(r1 - (float)m);
+              }
+              float* dst = s_in + ((size_t)(q * IH * 2 * IW) + elds[e] + h2 * IW) * 4;
+              *reinterpret_cast<f32x4*>(dst + Sh::IN1) = __builtin_bit_cast(f32x4, p1);
+              *reinterpret_cast<f32x4*>(dst + 2 * Sh::IN1) = __builtin_bit_cast(f32x4, p2);
+              v = __builtin_bit_cast(f32x4, p0);
+            } else if (BF) {  // 8 consecutive channels, rounded to bf16 (RNE)
               const int cb0 = k * CC + 16 * q + 8 * h2;
               bf16x8 hv;
 #pragma unroll
@@ -312,18 +345,21 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
     }
     if (k < 8) DVSR_STAMP(3 + 4 * k);
     // MFMA over (tap, q): operands of step i+1 are read before the MFMAs of step i
-    f32x4 A[2][MT], Bv[2][NT];
+    f32x4 A[2][MT][PIECES], Bv[2][NT][PIECES];
     auto load_ops = [&](int step, int rb) {
       const int tap = step / KQ4, q = step - tap * KQ4;
       const int ty = tap / KS, tx = tap - ty * KS;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        A[rb][mt] = *reinterpret_cast<const f32x4*>(
-            s_w + ((size_t)((((mt * KK + tap) * KQ4 + q) * 2 + hi) * 32 + lo)) * 4);
+      for (int op = 0; op < PIECES; ++op) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        Bv[rb][nt] = *reinterpret_cast<const f32x4*>(
-            s_in + ((size_t)(((q * IH + (NT * wave + nt) * S + ty) * 2 + hi) * IW + lo * S + tx)) * 4);
+        for (int mt = 0; mt < MT; ++mt)
+          A[rb][mt][op] = *reinterpret_cast<const f32x4*>(
+              s_w + op * Sh::W1 + ((size_t)((((mt * KK + tap) * KQ4 + q) * 2 + hi) * 32 + lo)) * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          Bv[rb][nt][op] = *reinterpret_cast<const f32x4*>(
+              s_in + op * Sh::IN1 + ((size_t)(((q * IH + (NT * wave + nt) * S + ty) * 2 + hi) * IW + lo * S + tx)) * 4);
+      }
     };
     load_ops(0, 0);
 #pragma unroll
@@ -337,13 +373,24 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
         __builtin_amdgcn_sched_barrier(0);
         if (k < 8) DVSR_STAMP(5 + 4 * k);
       }
-      if (BF) {
+      if (BF == 2) {  // six partial products, small terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, A[rb][mt][PA[t6] < PIECES ? PA[t6] : 0]),
+                  __builtin_bit_cast(bf16x8, Bv[rb][nt][PB[t6] < PIECES ? PB[t6] : 0]), acc[mt][nt], 0, 0, 0);
+      } else if (BF) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[rb][mt]),
-                                                                  __builtin_bit_cast(bf16x8, Bv[rb][nt]), acc[mt][nt],
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[rb][mt][0]),
+                                                                  __builtin_bit_cast(bf16x8, Bv[rb][nt][0]), acc[mt][nt],
                                                                   0, 0, 0);
       } else {
 #pragma unroll
@@ -352,7 +399,7 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][mt][j], Bv[rb][nt][j], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][mt][0][j], Bv[rb][nt][0][j], acc[mt][nt], 0, 0, 0);
       }
     }
     if (HAS_NEXT) __syncthreads();  // next buffers complete (the barrier's vmcnt(0) covers the DMA)
@@ -387,8 +434,8 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
 // The kernel walks work items with a grid stride; the default launch has one workgroup per item (see
 // launch_conv2 for the persistent variant and why it is not the default).  tools/conv_trace.py reports the
 // per-CU occupancy of a launch: 2.6-2.7 of 3 workgroup slots on average, ~13 k cycles of slot turnover.
-template <int KS, int S, int CC, int TH, int MT, bool BF = false>
-__global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
+template <int KS, int S, int CC, int TH, int MT, int BF = 0>
+__global__ __launch_bounds__(256, BF == 2 ? 1 : 2) void conv2d_pipe_kernel(ConvK2 a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   for (int id = blockIdx.x; id < a.nitems; id += gridDim.x) {
     conv2d_pipe_item<KS, S, CC, TH, MT, BF>(a, id, smem);
@@ -396,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_pipe_kernel(ConvK2 a) {
   }
 }
 
-template <int KS, int S, int CC, int TH, int MT, bool BF = false>
+template <int KS, int S, int CC, int TH, int MT, int BF = 0>
 static int launch_conv2(ConvK2 k, hipStream_t st) {
   using Sh = Conv2Shape<KS, S, CC, TH, MT, BF>;
   auto kern = conv2d_pipe_kernel<KS, S, CC, TH, MT, BF>;
@@ -477,7 +524,7 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
   return g;
 }
 
-int conv2_pch_cc(int ks, int cc, int bf) { return 2 * ks * ks * (bf ? cc / 16 : cc / 8) * 2 * 32 * 4; }
+int conv2_pch_cc(int ks, int cc, int bf) { return (bf == 2 ? 3 : 1) * 2 * ks * ks * (bf ? cc / 16 : cc / 8) * 2 * 32 * 4; }
 
 // `wp` = weights packed by pack_weights_kernel for this (ks, wt, geo.cc) combination.
 #ifdef DVSR_CONV_TRACE
@@ -519,8 +566,12 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
   if (geo.bf) {
     DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && geo.cc == 16 && geo.th == 4, DVSR_ERR_UNSUPPORTED,
                  "conv2d_packed: the bf16 kernel exists for 3x3 stride-1 convs with 16-channel chunks");
-    if (geo.mt == 2) return launch_conv2<3, 1, 16, 4, 2, true>(k, st);
-    return launch_conv2<3, 1, 16, 4, 1, true>(k, st);
+    if (geo.bf == 2) {
+      if (geo.mt == 2) return launch_conv2<3, 1, 16, 4, 2, 2>(k, st);
+      return launch_conv2<3, 1, 16, 4, 1, 2>(k, st);
+    }
+    if (geo.mt == 2) return launch_conv2<3, 1, 16, 4, 2, 1>(k, st);
+    return launch_conv2<3, 1, 16, 4, 1, 1>(k, st);
   }
   if (d.ks == 3 && d.stride == 2) {
     switch (code) {

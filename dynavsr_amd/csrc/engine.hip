@@ -150,7 +150,7 @@ struct Builder {
     if (wmap) o.w2_off = alloc("", (size_t)Cout * (c0 + c1) * ks * ks).off;
     {
       const bool bf = p.cfg.bf16_mfma && ks == 3 && stride == 1 && pad < 0 && (c1 == 0 || c0 % 16 == 0);
-      auto as_bf = [&](ConvGeo g) { if (bf) { g.cc = 16; g.th = 4; g.bf = 1; } return g; };
+      auto as_bf = [&](ConvGeo g) { if (bf) { g.cc = 16; g.th = 4; g.bf = p.cfg.bf16_mfma == 2 ? 2 : 1; } return g; };
       o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1));
       o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, o.geo.bf);
       o.wp_off = alloc("", o.wp_floats).off;

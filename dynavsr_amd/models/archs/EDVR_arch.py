@@ -62,7 +62,7 @@ class EDVR(nn.Module):
         """bf16_mfma (not a reference option): run the 3x3 stride-1 convolutions on the bf16 MFMA with fp32
         accumulation (network_G.bf16_mfma in the YAML; BASELINE configs[4])."""
         super().__init__()
-        self.bf16_mfma = bool(bf16_mfma)
+        self.bf16_mfma = int(bf16_mfma)  # 0 fp32 MFMA | 1 bf16 operands | 2 three-way bf16 split (experimental)
         if predeblur or HR_in or not w_TSA:
             raise NotImplementedError("dynavsr_amd EDVR supports predeblur=False, HR_in=False, "
                                       "w_TSA=True (the only configuration DynaVSR ships)")

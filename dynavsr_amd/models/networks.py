@@ -13,7 +13,7 @@ def define_G(opt):
     return EDVR_arch.EDVR(nf=net['nf'], nframes=net['nframes'], groups=net['groups'],
                           front_RBs=net['front_RBs'], back_RBs=net['back_RBs'], center=net['center'],
                           predeblur=net['predeblur'], HR_in=net['HR_in'], w_TSA=net['w_TSA'],
-                          scale=opt['scale'], bf16_mfma=bool(net.get('bf16_mfma') or False))
+                          scale=opt['scale'], bf16_mfma=int(net.get('bf16_mfma') or 0))
 
 
 def define_E(opt):
