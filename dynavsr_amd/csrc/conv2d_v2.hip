@@ -70,7 +70,8 @@ struct Conv2Shape {
   static constexpr int IN_FLOATS = PIECES * IN1;
   static constexpr int HALF = KK * KQ4 * 2 * 32 * 4;  // packed floats of one 32-cout half (of one piece)
   static constexpr int W1 = MT * HALF;                // one piece of the weight image
-  static constexpr int W_FLOATS = PIECES * W1;
+  static constexpr bool AG = BF == 2;                 // A operands straight from global memory (L1/L2), not via LDS
+  static constexpr int W_FLOATS = AG ? 0 : PIECES * W1;
   static constexpr int NPIECE = W_FLOATS / 256;       // 1-KiB DMA pieces (one wave-instruction each)
   static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
   static constexpr size_t LDS_BYTES = (size_t)2 * BUF_FLOATS * sizeof(float);
@@ -261,6 +262,7 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
   // issues the same number of DMAs (the last piece is re-sent when NPIECE % 4 != 0), so the loop body
   // stays one basic block and the compiler's vmcnt bookkeeping stays exact.
   auto issue_dma = [&](int k, int buf) {
+    if constexpr (Sh::AG) return;
     const float* wsrc = wp_cb + (size_t)k * (PIECES * 2 * Sh::HALF);
     float* wdst = s_w0 + buf * Sh::BUF_FLOATS;
     constexpr int NP1 = Sh::W1 / 256;  // 1-KiB DMA pieces of one operand piece
@@ -268,7 +270,7 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
     for (int j = 0; j < (Sh::NPIECE + 3) / 4; ++j) {
       int piece = j * 4 + wave;
       piece = piece < Sh::NPIECE ? piece : Sh::NPIECE - 1;
-      const int op = piece / NP1, within = piece - op * NP1;  // operand piece (hi / mid / lo), 1-KiB block inside it
+      const int op = piece / (NP1 > 0 ? NP1 : 1), within = piece - op * NP1;  // operand piece (hi / mid / lo), 1-KiB block inside it
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(wsrc + op * (2 * Sh::HALF) + within * 256 + lane * 4),
           (__attribute__((address_space(3))) void*)(wdst + op * Sh::W1 + within * 256), 16, 0, 0);
@@ -330,13 +332,28 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
   //   end              : one barrier
   constexpr int NSTEP = KK * KQ4;
   constexpr int SPLIT = (3 * NSTEP) / 4;
+  static_assert(!Sh::AG || (NSTEP % 3 == 0 && KQ4 == 1), "the register ring of the global-A path needs NSTEP % 3 == 0");
+  // BF == 2: the weight operands never touch LDS.  Every lane reads its 16 B of each (piece, 32-cout half) of
+  // one tap straight from the packed image (1 KiB per wave instruction, the four waves of a workgroup read the
+  // same lines: L1 hits), two steps ahead of their use.  LDS then holds only the three halo pieces, which
+  // leaves room for two workgroups per CU, and its read port only serves the B operands.
+  constexpr int AD = 1;  // prefetch distance in steps
+  f32x4 Ag[Sh::AG ? 3 : 1][MT][PIECES];
+  auto load_a = [&](int k, int tap, int slot) {
+    const float* b = wp_cb + (size_t)k * (PIECES * 2 * Sh::HALF) + tap * 256 + lane * 4;
+#pragma unroll
+    for (int op = 0; op < PIECES; ++op)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        Ag[slot][mt][op] = *reinterpret_cast<const f32x4*>(b + (op * 2 + mt) * Sh::HALF);
+  };
   auto block = [&](int k, auto has_next_tag) {
     constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
     const int buf = k & 1;
     const float* s_in = s_in0 + buf * Sh::BUF_FLOATS;
     const float* s_w = s_w0 + buf * Sh::BUF_FLOATS;
     if (k < 8) DVSR_STAMP(2 + 4 * k);
-    if (HAS_NEXT) {
+    if (HAS_NEXT && !Sh::AG) {
       issue_dma(k + 1, buf ^ 1);
       issue_halo(k + 1);
       // keep the loads up here: the scheduler would sink them to their use (a sched_group_barrier pattern
@@ -345,27 +362,47 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
     }
     if (k < 8) DVSR_STAMP(3 + 4 * k);
     // MFMA over (tap, q): operands of step i+1 are read before the MFMAs of step i
-    f32x4 A[2][MT][PIECES], Bv[2][NT][PIECES];
+    f32x4 A[2][Sh::AG ? 1 : MT][PIECES], Bv[Sh::AG ? 1 : 2][NT][PIECES];
     auto load_ops = [&](int step, int rb) {
       const int tap = step / KQ4, q = step - tap * KQ4;
       const int ty = tap / KS, tx = tap - ty * KS;
 #pragma unroll
       for (int op = 0; op < PIECES; ++op) {
+        if constexpr (!Sh::AG) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          A[rb][mt][op] = *reinterpret_cast<const f32x4*>(
-              s_w + op * Sh::W1 + ((size_t)((((mt * KK + tap) * KQ4 + q) * 2 + hi) * 32 + lo)) * 4);
+          for (int mt = 0; mt < MT; ++mt)
+            A[rb][mt][op] = *reinterpret_cast<const f32x4*>(
+                s_w + op * Sh::W1 + ((size_t)((((mt * KK + tap) * KQ4 + q) * 2 + hi) * 32 + lo)) * 4);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           Bv[rb][nt][op] = *reinterpret_cast<const f32x4*>(
               s_in + op * Sh::IN1 + ((size_t)(((q * IH + (NT * wave + nt) * S + ty) * 2 + hi) * IW + lo * S + tx)) * 4);
       }
     };
-    load_ops(0, 0);
+    auto load_b = [&](int step, int op) {  // one piece of the B operands of a step (BF == 2)
+      const int ty = step / KS, tx = step - ty * KS;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        Bv[0][nt][op] = *reinterpret_cast<const f32x4*>(
+            s_in + op * Sh::IN1 + ((size_t)((((NT * wave + nt) * S + ty) * 2 + hi) * IW + lo * S + tx)) * 4);
+    };
+    if constexpr (Sh::AG) { load_b(0, 2); load_b(0, 1); load_b(0, 0); }
+    else load_ops(0, 0);
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
       const int rb = step & 1;
-      if (step + 1 < NSTEP) load_ops(step + 1, rb ^ 1);
+      if constexpr (Sh::AG) {
+        // weights of step + 2 (ring of three register sets; NSTEP % 3 == 0 keeps the slot index static across
+        // chunks).  The halo loads of the next chunk go out right behind the first one: vmcnt retires in
+        // order, so the weights of steps 1 and 2 (issued earlier) never wait for them, and by step 3 the halo
+        // has had three steps of MFMAs to arrive.
+        if (step + AD < NSTEP) load_a(k, step + AD, (step + AD) % 3);
+        else if (HAS_NEXT) load_a(k + 1, step + AD - NSTEP, (step + AD) % 3);
+        if (HAS_NEXT && step == 0) issue_halo(k + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!Sh::AG && step + 1 < NSTEP) load_ops(step + 1, rb ^ 1);
       if (HAS_NEXT && step == SPLIT) {
         if (k < 8) DVSR_STAMP(4 + 4 * k);
         __builtin_amdgcn_sched_barrier(0);
@@ -373,17 +410,29 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
         __builtin_amdgcn_sched_barrier(0);
         if (k < 8) DVSR_STAMP(5 + 4 * k);
       }
-      if (BF == 2) {  // six partial products, small terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-        for (int t6 = 0; t6 < 6; ++t6)
+      if constexpr (BF == 2) {
+        // Six partial products per k-step (the three below 2^-24 are dropped).  The B pieces live in ONE
+        // register set: the order retires the lo piece after the first product, the mid piece after the third,
+        // and each is re-read from LDS for the next step right behind its last use -- the 4..12 MFMAs that
+        // follow cover the LDS latency.  (Two sets plus the weight ring spilled at two pixel rows per wave.)
+        auto mm = [&](int pa, int pb) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                  __builtin_bit_cast(bf16x8, A[rb][mt][PA[t6] < PIECES ? PA[t6] : 0]),
-                  __builtin_bit_cast(bf16x8, Bv[rb][nt][PB[t6] < PIECES ? PB[t6] : 0]), acc[mt][nt], 0, 0, 0);
+                  __builtin_bit_cast(bf16x8, Ag[step % 3][mt][pa]), __builtin_bit_cast(bf16x8, Bv[0][nt][pb]),
+                  acc[mt][nt], 0, 0, 0);
+        };
+        mm(0, 2);
+        if (step + 1 < NSTEP) { load_b(step + 1, 2); __builtin_amdgcn_sched_barrier(0); }
+        mm(1, 1);
+        mm(0, 1);
+        if (step + 1 < NSTEP) { load_b(step + 1, 1); __builtin_amdgcn_sched_barrier(0); }
+        mm(2, 0);
+        mm(1, 0);
+        mm(0, 0);
+        if (step + 1 < NSTEP) { load_b(step + 1, 0); __builtin_amdgcn_sched_barrier(0); }
       } else if (BF) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -410,6 +459,10 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
   if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + 60] = __builtin_amdgcn_s_memrealtime();
 #endif
   issue_dma(0, 0);
+  if constexpr (Sh::AG) {
+#pragma unroll
+    for (int i = 0; i < AD; ++i) load_a(0, i, i);
+  }
   issue_halo(0);
   write_halo(0, 0);
   DVSR_STAMP(1);
@@ -435,7 +488,7 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
 // launch_conv2 for the persistent variant and why it is not the default).  tools/conv_trace.py reports the
 // per-CU occupancy of a launch: 2.6-2.7 of 3 workgroup slots on average, ~13 k cycles of slot turnover.
 template <int KS, int S, int CC, int TH, int MT, int BF = 0>
-__global__ __launch_bounds__(256, BF == 2 ? 1 : 2) void conv2d_pipe_kernel(ConvK2 a) {
+__global__ __launch_bounds__(256, (BF == 2 && TH == 4) ? 3 : 2) void conv2d_pipe_kernel(ConvK2 a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   for (int id = blockIdx.x; id < a.nitems; id += gridDim.x) {
     conv2d_pipe_item<KS, S, CC, TH, MT, BF>(a, id, smem);
@@ -564,9 +617,14 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
 #endif
   const int code = geo.cc * 100 + geo.th * 10 + geo.mt;
   if (geo.bf) {
-    DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && geo.cc == 16 && geo.th == 4, DVSR_ERR_UNSUPPORTED,
+    DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && geo.cc == 16 && (geo.th == 4 || (geo.bf == 2 && geo.th == 8)),
+                 DVSR_ERR_UNSUPPORTED,
                  "conv2d_packed: the bf16 kernel exists for 3x3 stride-1 convs with 16-channel chunks");
     if (geo.bf == 2) {
+      if (geo.th == 8) {
+        if (geo.mt == 2) return launch_conv2<3, 1, 16, 8, 2, 2>(k, st);
+        return launch_conv2<3, 1, 16, 8, 1, 2>(k, st);
+      }
       if (geo.mt == 2) return launch_conv2<3, 1, 16, 4, 2, 2>(k, st);
       return launch_conv2<3, 1, 16, 4, 1, 2>(k, st);
     }

@@ -150,15 +150,23 @@ struct Builder {
     if (wmap) o.w2_off = alloc("", (size_t)Cout * (c0 + c1) * ks * ks).off;
     {
       const bool bf = p.cfg.bf16_mfma && ks == 3 && stride == 1 && pad < 0 && (c1 == 0 || c0 % 16 == 0);
-      auto as_bf = [&](ConvGeo g) { if (bf) { g.cc = 16; g.th = 4; g.bf = p.cfg.bf16_mfma == 2 ? 2 : 1; } return g; };
-      o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1));
+      // bf16_mfma = 2: 8-row tiles (two 32-pixel rows per wave) once they still give ~a workgroup per CU
+      static const int split_th8_from = getenv("DVSR_SPLIT_TH8_FROM") ? atoi(getenv("DVSR_SPLIT_TH8_FROM")) : 200;
+      auto as_bf = [&](ConvGeo g, int ho, int wo, int cout) {
+        if (!bf) return g;
+        g.cc = 16; g.th = 4; g.bf = p.cfg.bf16_mfma == 2 ? 2 : 1;
+        if (g.bf == 2 && (long long)ceil_div(wo, 32) * ceil_div(ho, 8) * N * ceil_div(cout, 32 * g.mt) >= split_th8_from)
+          g.th = 8;
+        return g;
+      };
+      o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1), Ho, Wo, Cout);
       o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, o.geo.bf);
       o.wp_off = alloc("", o.wp_floats).off;
       for (int which = 0; which < 2; ++which) {
         const int ci = which ? c1 : c0;
         if (!ci) continue;
         // dgrad = stride-1 conv over the input grid with Cout' = ci, Ctot' = Cout
-        o.dgeo[which] = as_bf(conv2_choose(ks, 1, N, H, W, ci, Cout));
+        o.dgeo[which] = as_bf(conv2_choose(ks, 1, N, H, W, ci, Cout), H, W, ci);
         o.dpk_floats[which] = (size_t)ceil_div(ci, 64) * ceil_div(Cout, o.dgeo[which].cc) *
                               conv2_pch_cc(ks, o.dgeo[which].cc, o.dgeo[which].bf);
         o.dpk_off[which] = p.dpack_floats;

@@ -23,7 +23,7 @@ from dynavsr_amd.models.archs.EDVR_arch import EDVR  # noqa: E402
 sel = sys.argv[1] if len(sys.argv) > 1 else "1"  # launch index among the packed convs, or an op name
 h = int(sys.argv[2]) if len(sys.argv) > 3 else 180
 w = int(sys.argv[3]) if len(sys.argv) > 3 else 320
-net = EDVR()
+net = EDVR(bf16_mfma=int(os.environ.get("DVSR_TRACE_MFMA_MODE", "0")))   # 2: the 3-way bf16 split kernel
 net.load_state_dict(synth.edvr_state_dict(0))
 net = net.cuda()
 x = synth.clip(1, 1, 5, h, w, smooth=False).cuda()

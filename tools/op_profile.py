@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch profile of the EDVR forward tape (hipEvents around every launch).
-usage (GPU box): python tools/op_profile.py [H W [reps]]"""
+usage (GPU box): python tools/op_profile.py [H W [reps [bf16_mfma]]]"""
 import os
 import sys
 
@@ -13,7 +13,8 @@ from dynavsr_amd.models.archs.EDVR_arch import EDVR  # noqa: E402
 h = int(sys.argv[1]) if len(sys.argv) > 2 else 180
 w = int(sys.argv[2]) if len(sys.argv) > 2 else 320
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-net = EDVR()
+mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+net = EDVR(bf16_mfma=mode)
 net.load_state_dict(synth.edvr_state_dict(0))
 net = net.cuda()
 x = synth.clip(1, 1, 5, h, w, smooth=False).cuda()
