@@ -56,9 +56,10 @@ struct ConvK2 {
 // consecutive channels (k = 8*hi .. 8*hi+7 of a 16-channel block) instead of the 4 of the fp32 layout
 // (k = 2kk + hi), everything else -- tiles, double buffering, DMA pieces, epilogue -- is shared.
 // BF = 2 ("split3", experimental): both operands are split into three bf16 pieces (hi / mid / lo) and the six
-// largest partial products are issued, small terms first -- as accurate as the exact-fp32 MFMA against a
-// double reference (profiles/r01_bf16_split_probe.txt) for 6 x 32 instead of 8 x 64 pipe cycles per tap and
-// 16 channels.  Three LDS images of everything: 150 KB double-buffered, one workgroup per CU.
+// largest partial products are issued -- as accurate as the exact-fp32 MFMA against a double reference
+// (profiles/r01_bf16_split_probe.txt) for 6 x 32 instead of 8 x 64 pipe cycles per tap and 16 channels.
+// LDS holds the three halo pieces only (double-buffered 65 KB at 8x32 pixels: two workgroups per CU); the
+// weight pieces are read per k-step straight from the packed image in global memory (Sh::AG).
 template <int KS, int S, int CC, int TH, int MT, int BF = 0>
 struct Conv2Shape {
   static constexpr int TW = 32, KK = KS * KS, NT = TH / 4;  // NT pixel rows per wave
@@ -484,16 +485,12 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
 #endif
 }
 
-// The kernel walks work items with a grid stride; the default launch has one workgroup per item (see
-// launch_conv2 for the persistent variant and why it is not the default).  tools/conv_trace.py reports the
-// per-CU occupancy of a launch: 2.6-2.7 of 3 workgroup slots on average, ~13 k cycles of slot turnover.
+// tools/conv_trace.py reports the per-CU occupancy of a launch: 2.6-2.7 of 3 workgroup slots on average, ~13 k
+// cycles of slot turnover.
 template <int KS, int S, int CC, int TH, int MT, int BF = 0>
 __global__ __launch_bounds__(256, (BF == 2 && TH == 4) ? 3 : 2) void conv2d_pipe_kernel(ConvK2 a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  for (int id = blockIdx.x; id < a.nitems; id += gridDim.x) {
-    conv2d_pipe_item<KS, S, CC, TH, MT, BF>(a, id, smem);
-    __syncthreads();  // every wave is done with both LDS buffers before the next item's prologue writes them
-  }
+  conv2d_pipe_item<KS, S, CC, TH, MT, BF>(a, blockIdx.x, smem);
 }
 
 template <int KS, int S, int CC, int TH, int MT, int BF = 0>
@@ -513,17 +510,11 @@ static int launch_conv2(ConvK2 k, hipStream_t st) {
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 32 * MT);
   k.nitems = ceil_div(k.ntiles, 8) * 8 * k.ncb;
-  // Default: one workgroup per item.  DVSR_CONV_PERSIST=1 (A/B aid) launches only the workgroups the chip can
-  // hold (256 CUs x floor(160 KB / LDS per workgroup), capped at 3 by the registers; a multiple of 8 so that an
-  // item keeps its XCD) and lets them walk the items with a grid stride.  Measured 2-3 % SLOWER on every big
-  // layer (fe_rb_a 199.9 vs 192.6 us, HRconv 612.9 vs 596.8): the ~13 k-cycle slot turnover of the plain
-  // launch is not idle matrix-pipe time -- the two resident workgroups absorb it.
-  static int persist = -1;
-  if (persist < 0) { const char* v = getenv("DVSR_CONV_PERSIST"); persist = (v && v[0] == '1') ? 1 : 0; }
-  int per_cu = (int)(160 * 1024 / lds);
-  per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
-  const int slots = 256 * per_cu;
-  const int grid = (persist && k.nitems > slots) ? slots : k.nitems;
+  // One workgroup per item.  A persistent launch (256 CUs x resident workgroups walking the items with a grid
+  // stride) was measured 2-3 % slower on every big layer, and the grid-stride loop alone costs 19 VGPRs, i.e.
+  // the third workgroup per CU (152 -> 171); a chunk stream across a workgroup's items with cross-item
+  // prefetch and deferred stores was no faster either.
+  const int grid = k.nitems;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, k);
   return check_launch("conv2d_pipe_kernel");
 }

@@ -154,7 +154,11 @@ typedef struct dvsr_edvr_config {
   /* 0: every contraction on the exact-fp32 MFMA (default; the parity configuration).
    * 1: the 3x3 stride-1 convolutions (forward and data gradient) round their operands to bf16 and run on
    *    v_mfma_f32_32x32x16_bf16 with fp32 accumulation; activations, weights, gradients, the DCN, the 1x1 /
-   *    stride-2 convs and all weight gradients stay fp32 (BASELINE configs[4], "EDVR-L, bf16 MFMA path"). */
+   *    stride-2 convs and all weight gradients stay fp32 (BASELINE configs[4], "EDVR-L, bf16 MFMA path").
+   * 2: experimental.  The same convolutions with every fp32 operand split exactly into three bf16 pieces
+   *    (8 + 8 + 8 mantissa bits) and the six partial products above 2^-24 accumulated in fp32 on the bf16
+   *    MFMA: fp32-level results (held to the fp32 parity bars by the tests), 6 x 32 instead of 8 x 64
+   *    matrix-pipe cycles per 16 channels.  Not the default and not what bench.py's `value` is measured on. */
   int bf16_mfma;
 } dvsr_edvr_config;
 typedef struct dvsr_edvr_plan dvsr_edvr_plan;
