@@ -248,6 +248,25 @@ int dvsr_adam_step(float* const* params, const float* const* grads, float* const
 int dvsr_sgd_step(float* const* params, const float* const* grads, const long long* numel, int n_tensors,
                   float lr, float weight_decay, dvsr_stream_t stream);
 
+/* ---- per-frame image metrics on the device ------------------------------------------
+ * Replaces, per super-resolved frame of test_dynavsr.py:285-292 (and of the validation loops of
+ * train_dynavsr.py), the device->host copy of the fp32 frame plus
+ *   util.tensor2img(rlt, mode='rgb')      codes/utils/util.py:112-142   clamp to [lo,hi], rescale, x255,
+ *                                                                       round half to even, uint8 HWC
+ *   util.calculate_psnr(img, hr_image)    codes/utils/util.py:262-269   20 log10(255 / sqrt(mse)) over uint8
+ *   util.calculate_ssim(img, hr_image)    codes/utils/util.py:271-313   11x11 Gaussian (sigma 1.5) window in
+ *                                                                       float64, "valid" region, mean over
+ *                                                                       pixels and channels
+ * sr, gt: [C,H,W] fp32 device tensors in the network's value range (both are quantised the tensor2img way:
+ * the reference's hr_image is tensor2img(GT)).  out (DEVICE, 2 doubles): out[0] = mean squared difference of
+ * the two uint8 frames (exact integer sum / (C*H*W); the caller forms the PSNR, inf when 0), out[1] = mean
+ * SSIM (NaN when H or W <= 10: the reference's mean of an empty map).  sr_hwc_u8 (nullable): the uint8
+ * [H,W,C] image of sr for the PNG writer.  Deterministic (integer atomics + fixed-order sums). */
+size_t dvsr_frame_metrics_workspace_bytes(int C, int H, int W);
+int dvsr_frame_metrics(const float* sr, const float* gt, int C, int H, int W, float lo, float hi,
+                       unsigned char* sr_hwc_u8, double* out, void* workspace, size_t workspace_bytes,
+                       dvsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,4 +18,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_traffic.py $out/db_FETCH_SIZE/p_results.db $out/db_WRITE_SIZE/p_results.db $out/${tag}_pmc_hbm_traffic.txt $out/pmc_traffic.json
 rm -rf $out/db_FETCH_SIZE $out/db_WRITE_SIZE
+python tools/metrics_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_metrics_720x1280.txt
+rocprofv3 --kernel-trace --stats -d $out/db3 -o m -- python tools/metrics_bench.py > /dev/null 2>&1
+python tools/rocprof_summary.py $out/db3/m_results.db | head -8 >> $out/${tag}_metrics_720x1280.txt; rm -rf $out/db3
 du -sh gpurun_out
