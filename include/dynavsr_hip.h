@@ -267,6 +267,17 @@ int dvsr_frame_metrics(const float* sr, const float* gt, int C, int H, int W, fl
                        unsigned char* sr_hwc_u8, double* out, void* workspace, size_t workspace_bytes,
                        dvsr_stream_t stream);
 
+/* ---- synthetic degradation on the device -------------------------------------------
+ * Replaces the tensor part of Degradation.apply (codes/data/random_kernel_generator.py:84-130):
+ *   img = ReflectionPad2d(K // 2)(img);  lr = conv2d(img, kernel.repeat(3,1,1,1), groups=3, stride=scale)
+ * for a clip img [N,C,H,W] (N frames) -> out [N,C,Ho,Wo], Ho = (H + 2 (K//2) - K) / scale + 1.
+ * kernels: [n_kernels,K,K] fp32 on the device, already centre-of-mass shifted (kernel_shift :51-76 stays on
+ * the host: a 27 x 27 spline shift).  n_kernels = 1: one kernel for every frame (:91-103); otherwise frame i
+ * uses kernel (i + kernel_offset) mod n_kernels (:104-122: offset 0 for N = n_kernels, -1 for N = n_kernels + 2).
+ * quantise != 0 fuses vsrbase.py:185 `mul(255).clamp(0, 255).round().div(255)` into the store. */
+int dvsr_degrade_apply(const float* img, const float* kernels, float* out, int N, int C, int H, int W, int K,
+                       int scale, int n_kernels, int kernel_offset, int quantise, dvsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -287,14 +287,68 @@ def inner_step(models, U):
             save("psnr", gtseed=9, img=a, psnr=p)
 
 
+def degradation_cases():
+    """Degradation (codes/data/random_kernel_generator.py) run as shipped, on CPU.  Its kernel_shift calls
+    np.int (:72), removed in numpy 1.24: for this run only the name is restored as the alias of int it was.
+    Cases: scale 4 and 2, an isotropic / two anisotropic kernels / the delta kernel, a single image, the
+    per-frame kernel array with T and T + 2 frames, and vsrbase.py:184-186's HR -> LR -> (8-bit) -> SLR chain."""
+    from oracle import degradation as od
+    if not hasattr(np, "int"):
+        np.int = int
+    import data.random_kernel_generator as rkg
+    out = {}
+    seed = [770]
+
+    def frames(*shape):          # inputs are regenerated from the seed by the tests: fixtures hold outputs only
+        seed[0] += 1
+        return np.random.RandomState(seed[0]).rand(*shape).astype(np.float32), seed[0]
+    cases = [("s4_aniso", 21, 4, 0.7, [2.0, 0.8], (5, 3, 64, 80)), ("s2_aniso", 21, 2, -1.9, [0.4, 3.1], (5, 3, 40, 48)),
+             ("s4_iso", 21, 4, 0.0, [1.0, 1.0], (2, 3, 36, 36)), ("s4_delta", 21, 4, 0.0, [0, 0], (2, 3, 32, 40)),
+             ("s2_k11", 11, 2, 0.3, [1.5, 0.6], (3, 3, 24, 28))]
+    for tag, ks, scale, theta, sigma, shape in cases:
+        img, sd = frames(*shape)
+        d = rkg.Degradation(ks, scale, theta=theta, sigma=sigma)
+        lr = d.apply(torch.from_numpy(img)).numpy()
+        assert np.allclose(d.kernel, od.build_kernel(ks, theta, sigma), rtol=0, atol=1e-15)
+        assert np.allclose(d.kernel_shift(d.kernel), od.kernel_shift(d.kernel, scale), rtol=0, atol=1e-15)
+        e = np.abs(lr - od.apply(img, d.kernel, scale)).max()
+        assert e < 2e-6, (tag, e)
+        out.update({tag + "__seed_shape": np.array((sd,) + shape), tag + "__params": np.array([ks, scale, theta, sigma[0], sigma[1]]),
+                    tag + "__kernel": d.kernel, tag + "__shifted": d.kernel_shift(d.kernel), tag + "__lr": lr})
+    # single image C H W
+    img, sd = frames(3, 32, 32)
+    d = rkg.Degradation(21, 4, theta=1.1, sigma=[3.0, 1.2])
+    out.update({"single__seed_shape": np.array((sd, 3, 32, 32)), "single__params": np.array([21, 4, 1.1, 3.0, 1.2]),
+                "single__lr": d.apply(torch.from_numpy(img)).numpy()})
+    # one kernel per frame (T = 5), clips of T and T + 2 frames
+    kset = np.stack([rkg.Degradation(21, 4, theta=-3 + i, sigma=[0.5 + i, 4.0 - 0.7 * i]).kernel for i in range(5)], 0)
+    d = rkg.Degradation(21, 4)
+    d.set_kernel_directly(kset)
+    for n in (5, 7):
+        img, sd = frames(n, 3, 32, 36)
+        lr = d.apply(torch.from_numpy(img)).numpy()
+        assert np.abs(lr - od.apply(img, kset, 4)).max() < 2e-6
+        out.update({"perframe%d__seed_shape" % n: np.array((sd, n, 3, 32, 36)), "perframe%d__lr" % n: lr})
+    out["perframe__kernels"] = kset
+    # the dataset's chain (vsrbase.py:184-186)
+    img, sd = frames(5, 3, 128, 128)
+    d = rkg.Degradation(21, 4, theta=0.4, sigma=[1.7, 2.9])
+    lr = d.apply(torch.from_numpy(img)).mul(255).clamp(0, 255).round().div(255)
+    slr = d.apply(lr)
+    out.update({"chain__seed_shape": np.array((sd, 5, 3, 128, 128)), "chain__params": np.array([21, 4, 0.4, 1.7, 2.9]), "chain__lr": lr.numpy(),
+                "chain__slr": slr.numpy()})
+    save("degradation", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     E, L, models, U = import_reference()
-    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "estimators", "inner"]
+    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "estimators", "inner", "degradation"]
     if "dcn" in which: dcn_cases()
     if "pcd" in which: pcd_tsa(E)
     if "edvr" in which: edvr_full(E)
     if "mfdn" in which: mfdn_full(L)
     if "estimators" in which: estimator_variants(L)
     if "inner" in which: inner_step(models, U)
+    if "degradation" in which: degradation_cases()

@@ -21,4 +21,5 @@ rm -rf $out/db_FETCH_SIZE $out/db_WRITE_SIZE
 python tools/metrics_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_metrics_720x1280.txt
 rocprofv3 --kernel-trace --stats -d $out/db3 -o m -- python tools/metrics_bench.py > /dev/null 2>&1
 python tools/rocprof_summary.py $out/db3/m_results.db | head -8 >> $out/${tag}_metrics_720x1280.txt; rm -rf $out/db3
+python tools/degrade_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_degradation.txt
 du -sh gpurun_out
