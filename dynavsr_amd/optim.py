@@ -48,9 +48,18 @@ class Adam(_Native):
             k = p.numel()
             m.append(flat[off:off + k]); v.append(flat[off + k:off + 2 * k]); off += 2 * k
             self.state[p] = {'step': 0, 'exp_avg': m[-1].view_as(p), 'exp_avg_sq': v[-1].view_as(p)}
+        self._flat = flat
         self._marr = (ctypes.c_void_p * self._n)(*[t.data_ptr() for t in m])
         self._varr = (ctypes.c_void_p * self._n)(*[t.data_ptr() for t in v])
         self._step = 0
+
+    def reset(self):
+        """Back to the state of a freshly constructed optimiser (moments zero, step 0): the per-frame adaptation
+        builds a new Adam for every frame (test_dynavsr.py:223-231); this is the same thing without 316 views."""
+        self._flat.zero_()
+        self._step = 0
+        for p in self._ps:
+            self.state[p]['step'] = 0
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -71,6 +80,9 @@ class Adam(_Native):
 class SGD(_Native):
     def __init__(self, params, lr=1e-3, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, weight_decay=weight_decay))
+
+    def reset(self):
+        pass  # stateless
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -201,6 +201,35 @@ def test_inner_step_golden(optimizer):
     assert torch.equal(model.netG.state_dict()["conv_first.weight"].cpu(), PG["conv_first.weight"])
 
 
+@pytest.mark.parametrize("optimizer", ["SGD", "Adam"])
+def test_adapt_frame_reuses_copies_like_a_fresh_deepcopy(optimizer):
+    """test_dynavsr.py:208 deep-copies netG / netE and builds a new optimiser for EVERY frame.  adapt_frame
+    refreshes the previous frame's copies in place and resets the native optimiser; the second frame must come
+    out as if everything had been rebuilt (same clip -> same result), and the meta-parameters stay untouched."""
+    from dynavsr_amd.adapt import adapt_frame
+    from dynavsr_amd.models import create_model
+    opt = _gpu_opt(optimizer)
+    opt["train"]["maml"]["adapt_iter"] = 2
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    PG, PE = synth.edvr_state_dict(0), synth.mfdn_state_dict(0)
+    model.netG.load_state_dict(PG); est.netE.load_state_dict(PE); est_fixed.netE.load_state_dict(synth.mfdn_state_dict(1))
+    a, b = {"LQs": synth.clip(1, 1, 5, 32, 48).cuda()}, {"LQs": synth.clip(2, 1, 5, 32, 48).cuda()}
+    r1 = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, a)
+    sr1, l1 = r1["sr"].clone(), [float(v) for v in r1["losses"]]
+    g_first, e_first = modelcp.netG, estcp.netE
+    adapt_frame(opt, model, est, modelcp, estcp, est_fixed, b)          # another clip in between
+    r3 = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, a)
+    assert modelcp.netG is g_first and estcp.netE is e_first            # refreshed in place, not re-created
+    assert all(abs(x - float(y)) <= 1e-5 * abs(x) for x, y in zip(l1, r3["losses"]))
+    assert relerr(r3["sr"], sr1) < 1e-5
+    for k, v in model.netG.state_dict().items():
+        assert torch.equal(v.cpu(), PG[k]), k
+    for k, v in est.netE.state_dict().items():
+        assert torch.equal(v.cpu(), PE[k]), k
+
+
 def test_dcn_dropin_module_matches_engine_and_oracle():
     """Op-level drop-in (models/archs/dcn) forward+backward vs the C oracle."""
     from dynavsr_amd.models.archs.dcn import ModulatedDeformConvPack

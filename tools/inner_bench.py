@@ -83,8 +83,47 @@ def full_frame():
     adapt_frame(opt, model, est, modelcp, estcp, est_fixed, data)   # deepcopy + inner step + adapted forward
 
 
+gt = synth.clip(7, 1, 1, 4 * h, 4 * w, smooth=False)[0, 0].cuda()
+from dynavsr_amd.utils import util  # noqa: E402
+
+
+def full_frame_with_metrics():   # test_dynavsr.py:197-305 per frame: both super-resolved frames are scored
+    modelcp.feed_data(data, need_GT=False); modelcp.test()
+    m0 = util.frame_metrics(modelcp.fake_H, gt, need_img=True)
+    r = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, data)
+    m1 = util.frame_metrics(r["sr"], gt, need_img=True)
+    return m0, m1
+
+
+def host_metrics():              # the reference's way: fp32 frame to the host, tensor2img, calculate_psnr
+    img = util.tensor2img(modelcp.fake_H, mode="rgb")
+    return util.calculate_psnr(img, util.tensor2img(gt, mode="rgb"))
+
+
 print("LR %dx%d (SLR %dx%d), EDVR-M x4 + MFDN, fp32" % (h, w, h // 4, w // 4))
 t = timeit(inner_step, steps); print("inner step            %8.2f ms  -> %6.1f clips/s" % (t, 1e3 / t))
 t = timeit(edvr_fwd_bwd, steps); print("  EDVR fwd+bwd on SLR   %8.2f ms" % t)
 t = timeit(mfdn_fwd, steps); print("  MFDN fwd (no grad)    %8.2f ms" % t)
 t = timeit(full_frame, max(2, steps // 3)); print("full per-frame pipeline %8.2f ms -> %6.1f frames/s" % (t, 1e3 / t))
+t = timeit(full_frame_with_metrics, max(2, steps // 3)); print("  + PSNR/SSIM + uint8 image of both frames on the GPU %8.2f ms -> %6.1f frames/s" % (t, 1e3 / t))
+t = timeit(host_metrics, 3); print("  (host path of ONE frame's tensor2img x2 + PSNR, no SSIM: %8.2f ms)" % t)
+
+
+def t_deepcopy():
+    modelcp.netG, estcp.netE = deepcopy(model.netG), deepcopy(est.netE)
+
+
+def t_optim():
+    make_inner_optimizer(opt, modelcp.netG, estcp.netE)
+
+
+def t_fixed():
+    est_fixed.feed_data(data); est_fixed.test()
+
+
+def t_test():
+    modelcp.feed_data(data, need_GT=False); modelcp.test()
+
+
+print("per-frame pipeline pieces: deepcopy(netG, netE) %.2f ms | inner optimizer construction %.2f ms | frozen estimator %.2f ms | "
+      "EDVR test() at LR size %.2f ms" % (timeit(t_deepcopy, 5), timeit(t_optim, 5), timeit(t_fixed, 5), timeit(t_test, 5)))
