@@ -93,12 +93,25 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const unsigned char* __r
   const int ox0 = blockIdx.x * ST_W, oy0 = blockIdx.y * ST_H;  // first valid-output pixel of the tile = input origin
   const unsigned char* px = qx + (size_t)c * H * W;
   const unsigned char* py = qy + (size_t)c * H * W;
-  for (int i = threadIdx.x; i < ST_IH * ST_IW; i += 256) {
-    const int r = i / ST_IW, col = i - r * ST_IW;
-    const int gy = oy0 + r, gx = ox0 + col;
-    const bool ok = gy < H && gx < W;
-    s_x[r][col] = ok ? px[(size_t)gy * W + gx] : 0;
-    s_y[r][col] = ok ? py[(size_t)gy * W + gx] : 0;
+  {  // all 2 x 5 byte loads of a thread are issued before the first LDS write (one latency, not five)
+    constexpr int NL = (ST_IH * ST_IW + 255) / 256;
+    unsigned char vx[NL], vy[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int r = i / ST_IW, col = i - r * ST_IW;
+      const int gy = oy0 + r, gx = ox0 + col;
+      const bool ok = i < ST_IH * ST_IW && gy < H && gx < W;
+      const size_t off = ok ? (size_t)gy * W + gx : 0;
+      vx[k] = px[off]; vy[k] = py[off];
+      if (!ok) { vx[k] = 0; vy[k] = 0; }
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int r = i / ST_IW, col = i - r * ST_IW;
+      if (i < ST_IH * ST_IW) { s_x[r][col] = vx[k]; s_y[r][col] = vy[k]; }
+    }
   }
   __syncthreads();
   // horizontal pass: one thread = 4 consecutive columns of a row (14 bytes of each frame converted once)
