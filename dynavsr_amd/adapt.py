@@ -103,3 +103,87 @@ def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, va
     modelcp.feed_data({'LQs': lqs}, need_GT=False)
     modelcp.test()
     return {'sr': modelcp.fake_H, 'losses': losses, 'slr': slr.detach()}
+
+
+def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, optimizer, inner='reference',
+                    group=None):
+    """One outer (meta) iteration of the DynaVSR training driver, codes/train_dynavsr.py:265-438, over the
+    wrapper API: the tasks of the batch are looped one clip at a time (:300), every task contributes its
+    meta-gradient to ``model.netG`` / ``est_model.netE``'s ``.grad``, and the meta optimiser steps once (:438).
+
+    train_data: {'LQs': [B,N,3,h,w], 'SuperLQs': [B,N,3,h/s,w/s], 'GT': [B,N,3,s*h,s*w]} on the GPU.
+
+    inner='reference' (default) reproduces the driver as shipped, quirk Q1 of SURVEY 8a included: the inner losses
+    are computed with ``model`` / ``est_model`` (:360-385) while the inner optimiser holds the parameters of the
+    deep copies (:326-351), so its step is a no-op and ``loss_train.backward()`` (:397) accumulates straight into
+    the meta-gradient; loss_q (:403) and loss_e (:418) are evaluated at the un-adapted weights:
+        dθ = Σ_tasks [ Σ_k ∇θ loss_train + ∇θ loss_q / B ],   dφ = Σ_tasks [ Σ_k ∇φ loss_train + ∇φ loss_e / (10 B) ]
+    inner='copies' is the first-order MAML the validation / test loops implement (:660-677, test_dynavsr.py:260-277):
+    the copies are adapted for adapt_iter steps and loss_q / loss_e are evaluated with the ADAPTED weights, their
+    gradients added to the meta-parameters' ``.grad``.
+
+    Multi-GPU: each rank runs this on its shard of the tasks; with ``group`` given (or a default
+    process group initialised) the accumulated gradients are all-reduced ONCE (mean over ranks) before the meta
+    step -- the reference instead lets DDP hooks fire on every inner backward and leaves loss_q un-reduced; at
+    world_size 1 the two coincide.  Returns {'loss_q': Σ loss_q / B, 'loss_train': [...], 'loss_e': [...]}."""
+    from . import dist as D
+    m = opt['train']['maml']
+    steps = m['adapt_iter']
+    lqs_all = train_data['LQs']
+    B, center = lqs_all.size(0), lqs_all.size(1) // 2
+    use_real = bool(opt['train']['use_real'])
+    if m['use_patch']:
+        raise NotImplementedError("train.maml.use_patch (train_dynavsr.py:208-243 random patch crops) is not built")
+    optimizer.zero_grad()
+    g_params = [p for p in model.netG.parameters()]
+    e_params = [p for p in est_model.netE.parameters()]
+
+    def add_grads(params, grads):
+        for p, g in zip(params, grads):
+            p.grad = g if p.grad is None else p.grad + g       # train_dynavsr.py:414-415 `param.grad += grads[j]`
+
+    total_q, log_train, log_e = 0.0, [], []
+    for b in range(B):
+        task = {k: train_data[k][b:b + 1] for k in ('LQs', 'GT', 'SuperLQs')}
+        lr_target = task['LQs'][:, center]                      # meta-train target: the LR centre frame (:288)
+        hr_target = task['GT'][:, center]                       # meta-test target (:290)
+        modelcp.netG, est_modelcp.netE = _fresh_copy(modelcp.netG, model.netG), _fresh_copy(est_modelcp.netE, est_model.netE)
+        inner_model, inner_est = (model, est_model) if inner == 'reference' else (modelcp, est_modelcp)
+        groups = [{'params': [p for p in modelcp.netG.parameters() if p.requires_grad], 'lr': m['lr_alpha']},
+                  {'params': [p for p in est_modelcp.netE.parameters() if p.requires_grad],
+                   'lr': m['lr_alpha_est'] if m['lr_alpha_est'] is not None else m['lr_alpha']}]
+        if m['optimizer'] == 'Adam':
+            inner_opt = torch.optim.Adam(groups, lr=m['lr_alpha'], betas=(m['beta1'], m['beta2']))
+        elif m['optimizer'] == 'SGD':
+            inner_opt = torch.optim.SGD(groups, lr=m['lr_alpha'])
+        else:
+            raise NotImplementedError()
+        for _ in range(steps):
+            inner_opt.zero_grad()
+            if not use_real:
+                inner_est.feed_data(task)
+                inner_est.forward_without_optim()
+                slr = inner_est.fake_L
+            else:
+                slr = task['SuperLQs']
+            inner_model.feed_data({'LQs': slr, 'GT': lr_target})
+            loss_train = inner_model.calculate_loss()
+            loss_train = loss_train + F.l1_loss(slr, task['SuperLQs'].to(slr.device))      # :393
+            loss_train.backward()
+            inner_opt.step()
+            log_train.append(loss_train.detach())
+        # meta test: loss_q at the weights `model` holds ('reference') or at the adapted copy ('copies')
+        q_model, q_est = (model, est_model) if inner == 'reference' else (modelcp, est_modelcp)
+        q_model.feed_data({'LQs': task['LQs'], 'GT': hr_target})
+        loss_q = q_model.calculate_loss()
+        add_grads(g_params, torch.autograd.grad(loss_q / B, list(q_model.netG.parameters())))
+        q_est.feed_data(task)
+        q_est.forward_without_optim()
+        loss_e = est_model.MyLoss(q_est.fake_L, q_est.real_L)
+        add_grads(e_params, torch.autograd.grad(loss_e / (B * 10), list(q_est.netE.parameters())))
+        total_q += float(loss_q.detach()) / B
+        log_e.append(loss_e.detach())
+    if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        D.allreduce_meta_gradients([model.netG, est_model.netE], average=True, group=group)
+    optimizer.step()
+    return {'loss_q': total_q, 'loss_train': log_train, 'loss_e': log_e}

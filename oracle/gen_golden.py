@@ -287,6 +287,86 @@ def inner_step(models, U):
             save("psnr", gtseed=9, img=a, psnr=p)
 
 
+def meta_step(models):
+    """One outer iteration of codes/train_dynavsr.py:265-438 (EDVR branch, use_real / use_patch off) driven through
+    the reference's wrappers on CPU, statement by statement -- the loop lives inside main() and cannot be imported.
+    B = 2 tasks, adapt_iter = 2, inner Adam, meta SGD (so the parameter update is -lr_G * meta-gradient).
+    LR 32x32 -> SLR 8x8, GT 128x128."""
+    from copy import deepcopy
+    import torch.nn.functional as F
+    PG, PE = synth.edvr_state_dict(0), synth.mfdn_state_dict(0)
+    opt = make_opt("Adam")
+    opt["train"]["maml"]["adapt_iter"] = 2
+    lr_G = 1e-3
+    model, est_model = models.create_model(opt)
+    modelcp, est_modelcp = models.create_model(opt)
+    load_sd(model.netG.module, PG); load_sd(est_model.netE.module, PE)
+    optim_params = [v for _, v in model.netG.named_parameters() if v.requires_grad] + \
+                   [v for _, v in est_model.netE.named_parameters() if v.requires_grad]
+    optimizer = torch.optim.SGD(optim_params, lr=lr_G)
+    train_data = {"LQs": synth.clip(31, 2, 5, 32, 32), "SuperLQs": synth.clip(32, 2, 5, 8, 8),
+                  "GT": synth.clip(33, 2, 5, 128, 128)}
+    center_idx, lr_alpha, update_step = 2, opt["train"]["maml"]["lr_alpha"], 2
+    optimizer.zero_grad()
+    meta_train_data, meta_test_data = {}, {}
+    meta_train_data["GT"] = train_data["LQs"][:, center_idx]
+    meta_test_data["LQs"] = train_data["LQs"]
+    meta_test_data["GT"] = train_data["GT"][:, center_idx]
+    total_loss_q = 0
+    batch_size = train_data["LQs"].size(0)
+    l_train = []
+    for batch in range(batch_size):
+        train_data_i = {k: train_data[k][batch:batch + 1] for k in ("LQs", "GT", "SuperLQs")}
+        meta_train_data_i = {"GT": meta_train_data["GT"][batch:batch + 1]}
+        meta_test_data_i = {"LQs": meta_test_data["LQs"][batch:batch + 1], "GT": meta_test_data["GT"][batch:batch + 1]}
+        modelcp.netG, est_modelcp.netE = deepcopy(model.netG), deepcopy(est_model.netE)
+        sr_params = [v for _, v in modelcp.netG.named_parameters() if v.requires_grad]
+        est_params = [v for _, v in est_modelcp.netE.named_parameters() if v.requires_grad]
+        inner_optimizer = torch.optim.Adam([{"params": sr_params, "lr": lr_alpha}, {"params": est_params, "lr": lr_alpha}],
+                                           lr=lr_alpha, betas=(opt["train"]["maml"]["beta1"], opt["train"]["maml"]["beta2"]))
+        for k in range(update_step):
+            inner_optimizer.zero_grad()
+            est_model.feed_data(train_data_i)
+            est_model.forward_without_optim()
+            meta_train_data_i["LQs"] = est_model.fake_L
+            model.feed_data(meta_train_data_i)
+            loss_train = model.calculate_loss()
+            loss_train += F.l1_loss(meta_train_data_i["LQs"], train_data_i["SuperLQs"])
+            loss_train.backward()
+            inner_optimizer.step()
+            l_train.append(float(loss_train))
+        model.feed_data(meta_test_data_i)
+        loss_q = model.calculate_loss()
+        for param, base_param in zip(model.netG.parameters(), modelcp.netG.parameters()):
+            param.data = base_param.data
+        grads = torch.autograd.grad(loss_q / batch_size, model.netG.parameters())
+        for j, param in enumerate(model.netG.parameters()):
+            param.grad += grads[j]
+        est_model.feed_data(train_data_i)
+        est_model.forward_without_optim()
+        loss_e = est_model.MyLoss(est_model.fake_L, est_model.real_L)
+        for param, base_param in zip(est_model.netE.parameters(), est_modelcp.netE.parameters()):
+            param.data = base_param.data
+        gradsE = torch.autograd.grad(loss_e / (batch_size * 10), est_model.netE.parameters())
+        for j, param in enumerate(est_model.netE.parameters()):
+            param.grad += gradsE[j]
+        total_loss_q += loss_q.item() / batch_size
+        del modelcp.netG, est_modelcp.netE
+    gG = OrderedDict((k, p.grad.detach().clone()) for k, p in model.netG.module.named_parameters())
+    gE = OrderedDict((k, p.grad.detach().clone()) for k, p in est_model.netE.module.named_parameters())
+    optimizer.step()
+    newG = dict(model.netG.module.named_parameters())
+    arrs = {"loss_q": total_loss_q, "loss_train": np.array(l_train), "lr_G": lr_G,
+            "gradG_norms": np.array([float(g.norm()) for g in gG.values()]),
+            "gradE_norms": np.array([float(g.norm()) for g in gE.values()])}
+    for k in TRACK:
+        arrs["gG__" + k.replace(".", "__")] = gG[k]
+        assert relerr(newG[k].detach().double() - PG[k].double(), -lr_G * gG[k].double()) < 1e-3   # rounding of p - lr*g in fp32
+    for k in TRACK_E:
+        arrs["gE__" + k.replace(".", "__")] = gE[k]
+    save("meta_step", **arrs)
+
+
 def degradation_cases():
     """Degradation (codes/data/random_kernel_generator.py) run as shipped, on CPU.  Its kernel_shift calls
     np.int (:72), removed in numpy 1.24: for this run only the name is restored as the alias of int it was.
@@ -344,7 +424,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     E, L, models, U = import_reference()
-    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "estimators", "inner", "degradation"]
+    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "estimators", "inner", "degradation", "meta"]
     if "dcn" in which: dcn_cases()
     if "pcd" in which: pcd_tsa(E)
     if "edvr" in which: edvr_full(E)
@@ -352,3 +432,4 @@ if __name__ == "__main__":
     if "estimators" in which: estimator_variants(L)
     if "inner" in which: inner_step(models, U)
     if "degradation" in which: degradation_cases()
+    if "meta" in which: meta_step(models)

@@ -230,6 +230,66 @@ def test_adapt_frame_reuses_copies_like_a_fresh_deepcopy(optimizer):
         assert torch.equal(v.cpu(), PE[k]), k
 
 
+def _meta_setup(adapt_iter=2):
+    from dynavsr_amd.models import create_model
+    opt = _gpu_opt("Adam")
+    opt["train"]["maml"]["adapt_iter"] = adapt_iter
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    PG, PE = synth.edvr_state_dict(0), synth.mfdn_state_dict(0)
+    model.netG.load_state_dict(PG); est.netE.load_state_dict(PE)
+    params = [p for p in model.netG.parameters() if p.requires_grad] + [p for p in est.netE.parameters() if p.requires_grad]
+    data = {"LQs": synth.clip(31, 2, 5, 32, 32).cuda(), "SuperLQs": synth.clip(32, 2, 5, 8, 8).cuda(),
+            "GT": synth.clip(33, 2, 5, 128, 128).cuda()}
+    return opt, model, est, modelcp, estcp, params, data, PG, PE
+
+
+def test_meta_train_step_golden():
+    """One outer iteration of train_dynavsr.py:265-438 (B = 2 tasks, adapt_iter = 2, inner Adam, meta SGD) against
+    the golden produced by driving the reference's wrappers through the same statements on CPU: loss_q, the inner
+    losses, every meta-gradient norm, five full gradient tensors, and the SGD update of the meta-parameters."""
+    from dynavsr_amd.adapt import meta_train_step
+    g = load_golden("meta_step")
+    opt, model, est, modelcp, estcp, params, data, PG, PE = _meta_setup()
+    lr_G = float(g["lr_G"])
+    optimizer = torch.optim.SGD(params, lr=lr_G)
+    r = meta_train_step(opt, model, est, modelcp, estcp, data, optimizer, inner="reference")
+    assert abs(r["loss_q"] - float(g["loss_q"])) < 2e-5 * abs(float(g["loss_q"]))
+    lt = np.array([float(v) for v in r["loss_train"]])
+    assert np.abs(lt - g["loss_train"]).max() < 2e-5 * np.abs(g["loss_train"]).max()
+    gn = np.array([float(p.grad.norm()) for p in model.netG.parameters()])
+    ge = np.array([float(p.grad.norm()) for p in est.netE.parameters()])
+    assert np.abs(gn - g["gradG_norms"]).max() < 2e-3 * g["gradG_norms"].max() and np.allclose(gn, g["gradG_norms"], rtol=2e-2, atol=1e-6)
+    assert np.allclose(ge, g["gradE_norms"], rtol=2e-2, atol=1e-6)
+    byG, byE = dict(model.netG.named_parameters()), dict(est.netE.named_parameters())
+    for key in g:
+        if key.startswith("gG__") or key.startswith("gE__"):
+            name = key[4:].replace("__", ".")
+            p = (byG if key.startswith("gG__") else byE)[name]
+            assert relerr(p.grad, g[key]) < 1e-2, name          # kink-flip envelope, see test_edvr_backward_golden
+            src = (PG if key.startswith("gG__") else PE)[name]
+            assert relerr(p.detach().cpu().double() - src.double(), -lr_G * torch.from_numpy(g[key]).double()) < 1e-2
+
+
+def test_meta_train_step_first_order_maml_mode():
+    """inner='copies': the copies are really adapted (the meta-parameters are not touched by the inner steps), loss_q
+    is taken at the adapted weights and only its first-order gradient reaches the meta-parameters."""
+    from dynavsr_amd.adapt import meta_train_step
+    opt, model, est, modelcp, estcp, params, data, PG, PE = _meta_setup(adapt_iter=1)
+    opt["train"]["maml"]["lr_alpha"] = 1e-4
+    optimizer = torch.optim.SGD(params, lr=0.0)                 # lr 0: the meta step must leave the parameters alone
+    r = meta_train_step(opt, model, est, modelcp, estcp, data, optimizer, inner="copies")
+    for k, v in model.netG.state_dict().items():
+        assert torch.equal(v.cpu(), PG[k]), k                   # inner steps ran on the copies only
+    moved = sum(float((a.detach() - b.detach()).abs().max()) > 0 for a, b in zip(modelcp.netG.parameters(), model.netG.parameters()))
+    assert moved > 100                                          # ... and the copies did move (Adam, lr_alpha)
+    # meta-gradient of netG = sum over tasks of d loss_q(adapted) / B only (no inner-loss terms as in 'reference')
+    ref = meta_train_step(opt, model, est, modelcp, estcp, data, torch.optim.SGD(params, lr=0.0), inner="reference")
+    gq = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.netG.parameters())))
+    assert np.isfinite(gq) and gq > 0 and np.isfinite(r["loss_q"])
+    assert r["loss_q"] != ref["loss_q"]                         # loss_q was taken at the ADAPTED weights
+
+
 def test_dcn_dropin_module_matches_engine_and_oracle():
     """Op-level drop-in (models/archs/dcn) forward+backward vs the C oracle."""
     from dynavsr_amd.models.archs.dcn import ModulatedDeformConvPack

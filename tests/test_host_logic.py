@@ -180,3 +180,88 @@ def test_shard_indices_cover_everything():
         for world in (1, 2, 8):
             got = sorted(i for r in range(world) for i in shard_indices(n, r, world))
             assert got == list(range(n))
+
+
+class _StubG:
+    """The slice of VideoBaseModel that adapt.meta_train_step touches, over a CPU toy network."""
+    def __init__(self):
+        torch.manual_seed(1)
+        self.netG = torch.nn.Sequential(torch.nn.Flatten(2), torch.nn.Linear(16, 16))
+
+    def feed_data(self, data, need_GT=True):
+        self.var_L, self.real_H = data["LQs"], data.get("GT")
+
+    def calculate_loss(self):
+        self.fake_H = self.netG(self.var_L).mean(1)
+        return ((self.fake_H - self.real_H.flatten(1)[:, :16]) ** 2 + 1e-6).sqrt().mean()
+
+
+class _StubE:
+    """... and of LRimgestimator_Model."""
+    def __init__(self):
+        torch.manual_seed(2)
+        self.netE = torch.nn.Linear(16, 16)
+        self.MyLoss = torch.nn.L1Loss()
+
+    def feed_data(self, data):
+        self.real_H, self.real_L = data["LQs"], data.get("SuperLQs")
+
+    def forward_without_optim(self):
+        b, n = self.real_H.shape[:2]
+        self.fake_L = self.netE(self.real_H.flatten(2)).reshape(b, n, 1, 4, 4)
+
+
+def _meta_opt():
+    from dynavsr_amd.options.options import dict_to_nonedict
+    return dict_to_nonedict({"train": {"use_real": False, "maml": {"adapt_iter": 2, "optimizer": "SGD", "lr_alpha": 1e-2,
+                                                                      "use_patch": False}}})
+
+
+def _meta_data():
+    g = torch.Generator().manual_seed(7)
+    return {"LQs": torch.rand(2, 3, 1, 4, 4, generator=g), "SuperLQs": torch.rand(2, 3, 1, 4, 4, generator=g),
+            "GT": torch.rand(2, 3, 1, 4, 4, generator=g)}
+
+
+def _meta_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from dynavsr_amd import dist as ddist
+    from dynavsr_amd.adapt import meta_train_step
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ddist.init_dist(backend="gloo")
+    model, est, modelcp, estcp = _StubG(), _StubE(), _StubG(), _StubE()
+    params = list(model.netG.parameters()) + list(est.netE.parameters())
+    data = _meta_data()
+    shard = {k: v[rank:rank + 1] for k, v in data.items()}          # one task per rank (range(rank, B, world))
+    meta_train_step(_meta_opt(), model, est, modelcp, estcp, shard, torch.optim.SGD(params, lr=0.5))
+    if rank == 0:
+        out.put([p.detach().numpy().copy() for p in params])    # plain arrays: nothing to share after exit
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_meta_train_step_data_parallel_gloo():
+    """world_size 2 on CPU (stub wrappers with the surface meta_train_step touches): every rank runs its shard of the
+    tasks, ONE all-reduce averages the accumulated meta-gradients, the meta step then moves every rank's
+    parameters by the mean of the per-rank gradients."""
+    from dynavsr_amd.adapt import meta_train_step
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_meta_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    grads = []
+    for r in range(world):                                           # the same shards, one process, no collective
+        model, est, modelcp, estcp = _StubG(), _StubE(), _StubG(), _StubE()
+        params = list(model.netG.parameters()) + list(est.netE.parameters())
+        shard = {k: v[r:r + 1] for k, v in _meta_data().items()}
+        meta_train_step(_meta_opt(), model, est, modelcp, estcp, shard, torch.optim.SGD(params, lr=0.0))
+        grads.append([p.grad.clone() for p in params])
+        start = [p.detach().clone() for p in params]
+    for p_new, p0, g0, g1 in zip(got, start, grads[0], grads[1]):
+        assert torch.allclose(torch.from_numpy(p_new), p0 - 0.5 * 0.5 * (g0 + g1), atol=1e-6)
