@@ -22,4 +22,5 @@ python tools/metrics_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_metrics_720x12
 rocprofv3 --kernel-trace --stats -d $out/db3 -o m -- python tools/metrics_bench.py > /dev/null 2>&1
 python tools/rocprof_summary.py $out/db3/m_results.db | head -8 >> $out/${tag}_metrics_720x1280.txt; rm -rf $out/db3
 python tools/degrade_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_degradation.txt
+python tools/meta_bench.py 4 1 2>&1 | grep -v amdgpu > $out/${tag}_meta_train_step.txt
 du -sh gpurun_out
