@@ -68,9 +68,21 @@ __global__ __launch_bounds__(256) void frame_quant_kernel(const float* __restric
       }
     }
     if (x_hwc) {
+      if (VEC && C == 3) {  // 4 RGB pixels = 12 contiguous, 4-byte aligned bytes: three dword stores
+        unsigned char b[12];
 #pragma unroll
-      for (int i = 0; i < V; ++i)
-        for (int c = 0; c < C; ++c) x_hwc[(V * p + i) * C + c] = hwc[i * 4 + c];
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) b[i * 3 + c] = hwc[i * 4 + c];
+        unsigned* dst = reinterpret_cast<unsigned*>(x_hwc + 12 * p);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          dst[q] = (unsigned)b[4 * q] | ((unsigned)b[4 * q + 1] << 8) | ((unsigned)b[4 * q + 2] << 16) | ((unsigned)b[4 * q + 3] << 24);
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+          for (int c = 0; c < C; ++c) x_hwc[(V * p + i) * C + c] = hwc[i * 4 + c];
+      }
     }
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
