@@ -187,3 +187,43 @@ def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, opt
         D.allreduce_meta_gradients([model.netG, est_model.netE], average=True, group=group)
     optimizer.step()
     return {'loss_q': total_q, 'loss_train': log_train, 'loss_e': log_e}
+
+
+def adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, clips, overlap=True):
+    """The frame loop of test_dynavsr.py:197-283 as a generator: for every clip {'LQs': [1,N,3,H,W]} yields
+    (baseline SR, adapt_frame's result dict).
+
+    The baseline forward of clip i+1 (``model.test()``: the un-adapted network, test_dynavsr.py:200-204) does not
+    depend on the adaptation of clip i, and the inner step works on a 16x smaller grid whose launches fill a
+    fraction of the 256 CUs -- so with ``overlap`` the next clip's baseline runs on a second HIP stream underneath
+    the current clip's adaptation.  Results are identical to the sequential loop (same kernels, same inputs)."""
+    clips = iter(clips)
+    cur = next(clips, None)
+    if cur is None:
+        return
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream() if overlap else main
+
+    def baseline(data):
+        lqs = data['LQs'].cuda() if not data['LQs'].is_cuda else data['LQs']
+        side.wait_stream(main)                      # the clip may have been produced on the main stream
+        with torch.cuda.stream(side), torch.no_grad():
+            was_training = model.netG.training
+            model.netG.eval()
+            sr = model.netG(lqs)
+            model.netG.train(was_training)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return sr, ev
+
+    pending = baseline(cur)
+    while cur is not None:
+        nxt = next(clips, None)
+        sr0, ev = pending
+        if nxt is not None:
+            pending = baseline(nxt)                 # enqueued before the adaptation's launches: runs underneath them
+        r = adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, cur)
+        main.wait_event(ev)
+        sr0.record_stream(main)
+        yield sr0, r
+        cur = nxt

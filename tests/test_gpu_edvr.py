@@ -230,6 +230,31 @@ def test_adapt_frame_reuses_copies_like_a_fresh_deepcopy(optimizer):
         assert torch.equal(v.cpu(), PE[k]), k
 
 
+def test_adapt_video_overlap_equals_sequential_loop():
+    """adapt_video runs the next clip's baseline forward on a second stream underneath the current clip's
+    adaptation; the per-clip results must be those of the plain loop (baseline test() + adapt_frame)."""
+    from dynavsr_amd.adapt import adapt_frame, adapt_video
+    from dynavsr_amd.models import create_model
+    opt = _gpu_opt("Adam")
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    model.netG.load_state_dict(synth.edvr_state_dict(0)); est.netE.load_state_dict(synth.mfdn_state_dict(0))
+    est_fixed.netE.load_state_dict(synth.mfdn_state_dict(1))
+    clips = [{"LQs": synth.clip(40 + i, 1, 5, 32, 48).cuda()} for i in range(4)]
+    want = []
+    for c in clips:
+        model.feed_data(c, need_GT=False); model.test()
+        base = model.fake_H.clone()
+        want.append((base, adapt_frame(opt, model, est, modelcp, estcp, est_fixed, c)["sr"].clone()))
+    got = [(a.clone(), r["sr"].clone()) for a, r in adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips)]
+    assert len(got) == len(want)
+    for (a, b), (c, d) in zip(got, want):
+        assert torch.equal(a, c)                       # forward only: bit-identical
+        assert relerr(b, d) < 1e-5                     # through a backward with fp32 atomics in the weight gradients
+    assert list(adapt_video(opt, model, est, modelcp, estcp, est_fixed, [])) == []
+
+
 def _meta_setup(adapt_iter=2):
     from dynavsr_amd.models import create_model
     opt = _gpu_opt("Adam")

@@ -127,3 +127,21 @@ def t_test():
 
 print("per-frame pipeline pieces: deepcopy(netG, netE) %.2f ms | inner optimizer construction %.2f ms | frozen estimator %.2f ms | "
       "EDVR test() at LR size %.2f ms" % (timeit(t_deepcopy, 5), timeit(t_optim, 5), timeit(t_fixed, 5), timeit(t_test, 5)))
+
+from dynavsr_amd.adapt import adapt_video  # noqa: E402
+clips = [{"LQs": synth.clip(10 + i, 1, 5, h, w, smooth=False).cuda()} for i in range(12)]
+for ov in (False, True):
+    for _ in adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips[:3], overlap=ov):
+        pass
+    sync()
+    t0 = time.perf_counter()
+    outs = [(a, r["sr"]) for a, r in adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips, overlap=ov)]
+    sync()
+    t = (time.perf_counter() - t0) / len(clips) * 1e3
+    print("adapt_video over %d clips, baseline of clip i+1 %s: %6.2f ms per frame -> %5.1f frames/s"
+          % (len(clips), "on a second stream under the adaptation of clip i" if ov else "sequential", t, 1e3 / t))
+    if ov:
+        print("  overlapped == sequential results: max |diff| baseline %.1e adapted %.1e"
+              % (max(float((a - b).abs().max()) for (a, _), (b, _) in zip(outs, ref)),
+                 max(float((a - b).abs().max()) for (_, a), (_, b) in zip(outs, ref))))
+    ref = outs
