@@ -58,7 +58,8 @@ def _fresh_copy(dst, src):
     return deepcopy(src)
 
 
-def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, val_data, slr_weight=10.0):
+def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, val_data, slr_weight=10.0,
+                final_test=True):
     """Adapt copies of (model.netG, est_model.netE) on one LR clip and super-resolve it.
 
     val_data: {'LQs': [1,N,3,H,W] (+ 'SuperLQs' when train.use_real)}.  Returns a dict with the
@@ -73,8 +74,11 @@ def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, va
     # a new inner optimiser per frame, like the reference; when the copies were refreshed in place the previous
     # frame's native optimiser holds the very same parameters and is reset instead of rebuilt
     m = opt['train']['maml']
-    sig = (m['optimizer'], m['lr_alpha'], m.get('beta1'), m.get('beta2'), bool(opt['train']['use_real']))
+    sig = (m['optimizer'], m['lr_alpha'], m.get('beta1'), m.get('beta2'), bool(opt['train']['use_real']),
+           tuple(id(p) for p in modelcp.netG.parameters()), tuple(id(p) for p in est_modelcp.netE.parameters()))
     cached = getattr(modelcp, '_inner_opt', None)
+    # (the signature holds the identity of every parameter: a cached optimiser is only reused for the very tensors
+    # it was built on -- a caller may have swapped modelcp.netG for another copy in between)
     if cached is not None and cached[0] == sig and prev == (modelcp.netG, est_modelcp.netE) and hasattr(cached[1], 'reset'):
         inner = cached[1]
         inner.reset()
@@ -100,6 +104,8 @@ def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, va
         loss.backward()
         inner.step()
         losses.append(loss.detach())
+    if not final_test:      # adapt_video runs the adapted forward itself (on another stream)
+        return {'sr': None, 'losses': losses, 'slr': slr.detach()}
     modelcp.feed_data({'LQs': lqs}, need_GT=False)
     modelcp.test()
     return {'sr': modelcp.fake_H, 'losses': losses, 'slr': slr.detach()}
@@ -189,41 +195,85 @@ def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, opt
     return {'loss_q': total_q, 'loss_train': log_train, 'loss_e': log_e}
 
 
+_STREAMS = {}
+
+
+def _side_streams(lqs_device):
+    """Two side streams per device, created once: the caching allocator keeps one block pool per stream, and the
+    3 GB workspaces of the full-size forwards must come back from the pool, not from hipMalloc, on every call."""
+    key = torch.device(lqs_device).index if torch.device(lqs_device).index is not None else torch.cuda.current_device()
+    if key not in _STREAMS:
+        _STREAMS[key] = (torch.cuda.Stream(device=key), torch.cuda.Stream(device=key))
+    return _STREAMS[key]
+
+
 def adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, clips, overlap=True):
     """The frame loop of test_dynavsr.py:197-283 as a generator: for every clip {'LQs': [1,N,3,H,W]} yields
-    (baseline SR, adapt_frame's result dict).
+    (baseline SR, adapt_frame's result dict with the adapted 'sr').
 
-    The baseline forward of clip i+1 (``model.test()``: the un-adapted network, test_dynavsr.py:200-204) does not
-    depend on the adaptation of clip i, and the inner step works on a 16x smaller grid whose launches fill a
-    fraction of the 256 CUs -- so with ``overlap`` the next clip's baseline runs on a second HIP stream underneath
-    the current clip's adaptation.  Results are identical to the sequential loop (same kernels, same inputs)."""
+    Per clip the loop is baseline forward (un-adapted network, :200-204) -> inner steps on copies -> adapted
+    forward.  The two full-size forwards do not depend on the NEXT clip's adaptation, and the inner step works on a
+    16x smaller grid whose launches fill a fraction of the 256 CUs -- so with ``overlap`` the next clip's baseline
+    and the current clip's adapted forward run on two further HIP streams underneath the following adaptation
+    (two alternating sets of copies, so a forward never reads weights that are being refreshed).  Results are
+    those of the sequential loop (same kernels, same inputs).  A yielded result stays valid until the generator
+    is advanced twice."""
     clips = iter(clips)
     cur = next(clips, None)
     if cur is None:
         return
     main = torch.cuda.current_stream()
-    side = torch.cuda.Stream() if overlap else main
+    if not overlap:
+        while cur is not None:
+            lqs = cur['LQs'] if cur['LQs'].is_cuda else cur['LQs'].cuda()
+            model.feed_data({'LQs': lqs}, need_GT=False)
+            model.test()
+            yield model.fake_H, adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, cur)
+            cur = next(clips, None)
+        return
+    s_base, s_test = _side_streams(lqs_device=cur['LQs'].device if cur['LQs'].is_cuda else torch.device('cuda'))
+    sets = [[modelcp.netG, est_modelcp.netE, getattr(modelcp, '_inner_opt', None), None],
+            [None, None, None, None]]                # [netG copy, netE copy, cached inner optimiser, last-use event]
 
-    def baseline(data):
-        lqs = data['LQs'].cuda() if not data['LQs'].is_cuda else data['LQs']
-        side.wait_stream(main)                      # the clip may have been produced on the main stream
-        with torch.cuda.stream(side), torch.no_grad():
-            was_training = model.netG.training
-            model.netG.eval()
-            sr = model.netG(lqs)
-            model.netG.train(was_training)
+    def forward_on(stream, net, lqs):
+        stream.wait_stream(main)                     # weights / clip were produced on the main stream
+        with torch.cuda.stream(stream), torch.no_grad():
+            was_training = net.training
+            net.eval()
+            sr = net(lqs)
+            net.train(was_training)
             ev = torch.cuda.Event()
-            ev.record(side)
+            ev.record(stream)
         return sr, ev
 
-    pending = baseline(cur)
+    def on_gpu(data):
+        return data['LQs'] if data['LQs'].is_cuda else data['LQs'].cuda()
+
+    pending, i, prev_out = forward_on(s_base, model.netG, on_gpu(cur)), 0, None
     while cur is not None:
         nxt = next(clips, None)
-        sr0, ev = pending
+        lqs = on_gpu(cur)
+        sr0, ev0 = pending
         if nxt is not None:
-            pending = baseline(nxt)                 # enqueued before the adaptation's launches: runs underneath them
-        r = adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, cur)
-        main.wait_event(ev)
-        sr0.record_stream(main)
-        yield sr0, r
-        cur = nxt
+            pending = forward_on(s_base, model.netG, on_gpu(nxt))   # enqueued first: runs underneath the adaptation
+        st = sets[i & 1]
+        if st[3] is not None:
+            main.wait_event(st[3])                   # this set's previous adapted forward has read its weights
+        modelcp.netG, est_modelcp.netE, modelcp._inner_opt = st[0], st[1], st[2]
+        r = adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, {'LQs': lqs}, final_test=False)
+        st[0], st[1], st[2] = modelcp.netG, est_modelcp.netE, getattr(modelcp, '_inner_opt', None)
+        sr1, ev1 = forward_on(s_test, modelcp.netG, lqs)
+        st[3] = ev1
+        if prev_out is not None:                     # hand out clip i-1 now that clip i's work is enqueued
+            (p0, pe0), (p1, pe1), pr = prev_out
+            main.wait_event(pe0); main.wait_event(pe1)
+            p0.record_stream(main); p1.record_stream(main)
+            pr['sr'] = p1
+            yield p0, pr
+        prev_out = ((sr0, ev0), (sr1, ev1), r)
+        cur, i = nxt, i + 1
+    (p0, pe0), (p1, pe1), pr = prev_out
+    main.wait_event(pe0); main.wait_event(pe1)
+    p0.record_stream(main); p1.record_stream(main)
+    pr['sr'] = p1
+    yield p0, pr

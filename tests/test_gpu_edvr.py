@@ -222,6 +222,10 @@ def test_adapt_frame_reuses_copies_like_a_fresh_deepcopy(optimizer):
     adapt_frame(opt, model, est, modelcp, estcp, est_fixed, b)          # another clip in between
     r3 = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, a)
     assert modelcp.netG is g_first and estcp.netE is e_first            # refreshed in place, not re-created
+    from copy import deepcopy
+    modelcp.netG, estcp.netE = deepcopy(model.netG), deepcopy(est.netE)  # a caller swaps the copies: the cached
+    r4 = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, a)      # optimiser must not be reused for them
+    assert relerr(r4["sr"], sr1) < 1e-5
     assert all(abs(x - float(y)) <= 1e-5 * abs(x) for x, y in zip(l1, r3["losses"]))
     assert relerr(r3["sr"], sr1) < 1e-5
     for k, v in model.netG.state_dict().items():

@@ -139,7 +139,7 @@ for ov in (False, True):
     sync()
     t = (time.perf_counter() - t0) / len(clips) * 1e3
     print("adapt_video over %d clips, baseline of clip i+1 %s: %6.2f ms per frame -> %5.1f frames/s"
-          % (len(clips), "on a second stream under the adaptation of clip i" if ov else "sequential", t, 1e3 / t))
+          % (len(clips), "and adapted forward of clip i on side streams under the next adaptation" if ov else "sequential", t, 1e3 / t))
     if ov:
         print("  overlapped == sequential results: max |diff| baseline %.1e adapted %.1e"
               % (max(float((a - b).abs().max()) for (a, _), (b, _) in zip(outs, ref)),
