@@ -157,6 +157,29 @@ def edvr_full(E):
              **{"grad__" + k.replace(".", "__"): ref_g[k] for k in FULL_GRADS})
 
 
+def edvr_x2(E):
+    """EDVR-M x2 (the shipped x2 YAMLs, e.g. options/test/EDVR/EDVR_V.yml: nf 64, back_RBs 10, scale 2): one
+    pixel-shuffle stage less (EDVR_arch.py:244-245,303-304) and a x2 bilinear base."""
+    cfg = dict(nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, scale=2)
+    P = synth.edvr_state_dict(6, **cfg)
+    net = load_sd(E.EDVR(**cfg), P)
+    h, w, seed = 24, 32, 7
+    x = synth.clip(seed, 1, 5, h, w)
+    tgt = synth.clip(seed + 100, 1, 1, 2 * h, 2 * w)[:, 0]
+    y = net(x.clone())
+    loss = oedvr.charbonnier(y, tgt)
+    loss.backward()
+    ref_g = OrderedDict((k, p.grad.detach()) for k, p in net.named_parameters())
+    PO = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in P.items())
+    yo = oedvr.edvr_forward(PO, x, scale=2)
+    og = torch.autograd.grad(oedvr.charbonnier(yo, tgt), list(PO.values()))
+    assert relerr(yo, y) < 1e-5, relerr(yo, y)
+    assert max(relerr(a, ref_g[k]) for k, a in zip(PO, og)) < 1e-4
+    save("edvr_x2_24x32", wseed=6, xseed=seed, tseed=seed + 100, h=h, w=w, out=y, loss=float(loss),
+         grad_norms=np.array([float(g.norm()) for g in ref_g.values()]),
+         **{"grad__" + k.replace(".", "__"): ref_g[k] for k in FULL_GRADS if k in ref_g})
+
+
 def mfdn_full(L):
     """G5: MFDN x4 forward/backward on 1x5x3x32x32 through the reference module."""
     M = synth.mfdn_state_dict(0)
@@ -428,6 +451,7 @@ if __name__ == "__main__":
     if "dcn" in which: dcn_cases()
     if "pcd" in which: pcd_tsa(E)
     if "edvr" in which: edvr_full(E)
+    if "edvr" in which or "edvr_x2" in which: edvr_x2(E)
     if "mfdn" in which: mfdn_full(L)
     if "estimators" in which: estimator_variants(L)
     if "inner" in which: inner_step(models, U)

@@ -33,6 +33,33 @@ def test_edvr_forward_golden(tag):
     assert float((y.cpu() - torch.from_numpy(g["out"])).abs().max()) < 1e-3
 
 
+def test_edvr_x2_forward_backward_golden():
+    """EDVR-M x2 -- the configuration of the shipped x2 YAMLs (options/test/EDVR/EDVR_V.yml: nf 64, back_RBs 10,
+    scale 2; EDVR_arch.py:244-245,303-304 drop upconv1) -- against the reference's output and gradients."""
+    from dynavsr_amd import hipops
+    g = load_golden("edvr_x2_24x32")
+    h, w = int(g["h"]), int(g["w"])
+    cfg = dict(nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, scale=2)
+    net = make_net(int(g["wseed"]), **cfg)
+    assert len(list(net.parameters())) == 142
+    x = synth.clip(int(g["xseed"]), 1, 5, h, w).cuda()
+    tgt = synth.clip(int(g["tseed"]), 1, 1, 2 * h, 2 * w)[:, 0].cuda()
+    y = net(x)
+    assert tuple(y.shape) == (1, 3, 2 * h, 2 * w)
+    assert relerr(y, g["out"]) < 2e-4 and float((y.detach().cpu() - torch.from_numpy(g["out"])).abs().max()) < 1e-3
+    loss = hipops.charbonnier(y, tgt)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    norms = np.array([float(p.grad.norm()) for p in net.ordered_parameters()])
+    bad = [(n, a, b) for n, a, b in zip(net._names, norms, g["grad_norms"]) if abs(a - b) > 1e-3 * abs(b) + 1e-9]
+    assert not bad, bad[:8]
+    by_name = dict(zip(net._names, net.ordered_parameters()))
+    for key in g:
+        if key.startswith("grad__"):
+            name = key[len("grad__"):].replace("__", ".")
+            assert relerr(by_name[name].grad, g[key]) < 1e-2, name
+
+
 def test_edvr_forward_layerwise_vs_oracle():
     """Every named intermediate of the engine against the oracle's taps (B=2 exercises batching)."""
     from oracle import edvr as oedvr

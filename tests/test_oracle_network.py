@@ -53,6 +53,22 @@ def test_edvr_forward_backward_golden(tag):
             assert relerr(by_name[name], g[key]) < 2e-4, name
 
 
+def test_edvr_x2_forward_backward_golden():
+    """EDVR-M x2 (the shipped x2 YAMLs): one pixel-shuffle stage less, x2 bilinear base."""
+    g = load_golden("edvr_x2_24x32")
+    h, w = int(g["h"]), int(g["w"])
+    cfg = dict(nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, scale=2)
+    P = OrderedDict((k, v.requires_grad_(True)) for k, v in synth.edvr_state_dict(int(g["wseed"]), **cfg).items())
+    assert "upconv1.weight" not in P and len(P) == 142
+    x = synth.clip(int(g["xseed"]), 1, 5, h, w)
+    tgt = synth.clip(int(g["tseed"]), 1, 1, 2 * h, 2 * w)[:, 0]
+    y = edvr.edvr_forward(P, x, scale=2)
+    loss = edvr.charbonnier(y, tgt)
+    assert tuple(y.shape) == (1, 3, 2 * h, 2 * w) and relerr(y, g["out"]) < 1e-5
+    grads = torch.autograd.grad(loss, list(P.values()))
+    assert np.allclose(np.array([float(v.norm()) for v in grads]), g["grad_norms"], rtol=2e-4, atol=1e-9)
+
+
 def test_mfdn_golden():
     g = load_golden("mfdn_32x32")
     M = OrderedDict((k, v.requires_grad_(True)) for k, v in synth.mfdn_state_dict(int(g["wseed"])).items())
