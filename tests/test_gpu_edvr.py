@@ -48,7 +48,7 @@ def test_edvr_x2_forward_backward_golden():
     assert tuple(y.shape) == (1, 3, 2 * h, 2 * w)
     assert relerr(y, g["out"]) < 2e-4 and float((y.detach().cpu() - torch.from_numpy(g["out"])).abs().max()) < 1e-3
     loss = hipops.charbonnier(y, tgt)
-    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
     loss.backward()
     norms = np.array([float(p.grad.norm()) for p in net.ordered_parameters()])
     bad = [(n, a, b) for n, a, b in zip(net._names, norms, g["grad_norms"]) if abs(a - b) > 1e-3 * abs(b) + 1e-9]
@@ -259,6 +259,36 @@ def test_adapt_frame_reuses_copies_like_a_fresh_deepcopy(optimizer):
         assert torch.equal(v.cpu(), PG[k]), k
     for k, v in est.netE.state_dict().items():
         assert torch.equal(v.cpu(), PE[k]), k
+
+
+def test_inner_step_x2_wrapper_path_vs_oracle():
+    """The x2 family (options/test/EDVR/EDVR_M.yml = the geometry of the reference's EDVR_V.yml: EDVR-M x2 + MFDN
+    x2): one inner step through create_model / adapt_frame against the functional oracle."""
+    import os
+    from conftest import ROOT
+    from dynavsr_amd.adapt import adapt_frame
+    from dynavsr_amd.models import create_model
+    from dynavsr_amd.options import options as option
+    from oracle import inner as oinner
+    opt = option.dict_to_nonedict(option.parse(os.path.join(ROOT, "dynavsr_amd", "options", "test", "EDVR", "EDVR_M.yml"),
+                                               is_train=False))
+    opt["dist"] = False
+    for k in ("pretrain_model_G", "pretrain_model_E"):
+        opt["path"][k] = None
+    opt["train"]["maml"]["optimizer"] = "SGD"
+    assert opt["scale"] == 2
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    cfg = dict(nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, scale=2)
+    PG, PE, PEF = synth.edvr_state_dict(0, **cfg), synth.mfdn_state_dict(0, scale=2), synth.mfdn_state_dict(1, scale=2)
+    model.netG.load_state_dict(PG); est.netE.load_state_dict(PE); est_fixed.netE.load_state_dict(PEF)
+    lqs = synth.clip(1, 1, 5, 32, 48)
+    r = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, {"LQs": lqs.cuda()})
+    assert tuple(r["slr"].shape) == (1, 5, 3, 16, 24) and tuple(r["sr"].shape) == (1, 3, 64, 96)
+    losses, _, _, sro = oinner.inner_adapt(PG, PE, PEF, lqs, 1, "SGD", 1e-5, (0.9, 0.99), scale=2)
+    assert abs(float(r["losses"][0]) - losses[0]) < 2e-5 * abs(losses[0])
+    assert relerr(r["sr"], sro) < 2e-4
 
 
 def test_adapt_video_overlap_equals_sequential_loop():
