@@ -291,6 +291,50 @@ def test_inner_step_x2_wrapper_path_vs_oracle():
     assert relerr(r["sr"], sro) < 2e-4
 
 
+def test_inner_step_x2_sfdn_image_mode_vs_oracle():
+    """EDVR-M x2 + SFDN (network_E: which_model_E SFDN, mode image -- the single-frame estimator of
+    options/train/MAML/EDVR/EDVR_REDS_SFDN.yml, frames folded into the batch by LRestimator_model.feed_data :99-101):
+    one inner SGD step through the wrappers, loss and adapted output against the functional oracle."""
+    import os
+    import torch.nn.functional as F
+    from conftest import ROOT
+    from dynavsr_amd.adapt import adapt_frame
+    from dynavsr_amd.models import create_model
+    from dynavsr_amd.options import options as option
+    from oracle import edvr as oedvr, mfdn as omfdn
+    opt = option.dict_to_nonedict(option.parse(os.path.join(ROOT, "dynavsr_amd", "options", "test", "EDVR", "EDVR_M.yml"),
+                                               is_train=False))
+    opt["dist"] = False
+    for k in ("pretrain_model_G", "pretrain_model_E"):
+        opt["path"][k] = None
+    opt["train"]["maml"]["optimizer"] = "SGD"
+    opt["network_E"] = option.dict_to_nonedict({"which_model_E": "SFDN", "mode": "image", "nf": 64})
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    cfg = dict(nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, scale=2)
+    PG, PE, PEF = synth.edvr_state_dict(0, **cfg), synth.sfdn_state_dict(0), synth.sfdn_state_dict(1)
+    model.netG.load_state_dict(PG); est.netE.load_state_dict(PE); est_fixed.netE.load_state_dict(PEF)
+    lqs = synth.clip(3, 1, 5, 32, 48)
+    lr = opt["train"]["maml"]["lr_alpha"]
+    r = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, {"LQs": lqs.cuda()})
+    # oracle: the same step with plain autograd
+    OG = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in PG.items())
+    OE = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in PE.items())
+    slr = omfdn.sfdn_forward(OE, lqs[0]).unsqueeze(0)                       # [1,5,3,16,24]
+    with torch.no_grad():
+        slr_fixed = omfdn.sfdn_forward(PEF, lqs[0]).unsqueeze(0)
+    loss = oedvr.charbonnier(oedvr.edvr_forward(OG, slr, scale=2), lqs[:, 2]) + 10 * F.l1_loss(slr, slr_fixed)
+    grads = torch.autograd.grad(loss, list(OG.values()) + list(OE.values()))
+    with torch.no_grad():
+        for p, g in zip(list(OG.values()) + list(OE.values()), grads):
+            p -= lr * g
+        sro = oedvr.edvr_forward(OG, lqs, scale=2)
+    assert relerr(r["slr"], slr) < 1e-5
+    assert abs(float(r["losses"][0]) - float(loss.detach())) < 2e-5 * abs(float(loss.detach()))
+    assert relerr(r["sr"], sro) < 2e-4
+
+
 def test_adapt_video_overlap_equals_sequential_loop():
     """adapt_video runs the next clip's baseline forward on a second stream underneath the current clip's
     adaptation; the per-clip results must be those of the plain loop (baseline test() + adapt_frame)."""
