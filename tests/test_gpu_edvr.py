@@ -335,6 +335,37 @@ def test_inner_step_x2_sfdn_image_mode_vs_oracle():
     assert relerr(r["sr"], sro) < 2e-4
 
 
+def test_inner_step_use_real_vs_oracle():
+    """train.use_real = True (test_dynavsr.py:242-243, 225-226): the SLR clip comes from the data ('SuperLQs'), the
+    estimator is neither run nor optimised; one SGD step of netG against plain autograd on the oracle."""
+    import torch.nn.functional as F
+    from dynavsr_amd.adapt import adapt_frame
+    from dynavsr_amd.models import create_model
+    from oracle import edvr as oedvr, mfdn as omfdn
+    opt = _gpu_opt("SGD")
+    opt["train"]["use_real"] = True
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    PG, PE, PEF = synth.edvr_state_dict(0), synth.mfdn_state_dict(0), synth.mfdn_state_dict(1)
+    model.netG.load_state_dict(PG); est.netE.load_state_dict(PE); est_fixed.netE.load_state_dict(PEF)
+    lqs, slr = synth.clip(1, 1, 5, 64, 64), synth.clip(2, 1, 5, 16, 16)
+    r = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, {"LQs": lqs.cuda(), "SuperLQs": slr.cuda()})
+    OG = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in PG.items())
+    with torch.no_grad():
+        slr_fixed = omfdn.mfdn_forward(PEF, lqs)
+    loss = oedvr.charbonnier(oedvr.edvr_forward(OG, slr), lqs[:, 2]) + 10 * F.l1_loss(slr, slr_fixed)
+    grads = torch.autograd.grad(loss, list(OG.values()))
+    with torch.no_grad():
+        for p, g in zip(OG.values(), grads):
+            p -= opt["train"]["maml"]["lr_alpha"] * g
+        sro = oedvr.edvr_forward(OG, lqs)
+    assert abs(float(r["losses"][0]) - float(loss.detach())) < 2e-5 * abs(float(loss.detach()))
+    assert relerr(r["sr"], sro) < 2e-4
+    for k, v in estcp.netE.state_dict().items():
+        assert torch.equal(v.cpu(), PE[k]), k            # the estimator copy was not stepped
+
+
 def test_adapt_video_overlap_equals_sequential_loop():
     """adapt_video runs the next clip's baseline forward on a second stream underneath the current clip's
     adaptation; the per-clip results must be those of the plain loop (baseline test() + adapt_frame)."""
