@@ -31,7 +31,7 @@ struct ConvK2 {
   const float* x0; const float* x1; const float* wp; const float* bias; const float* res; float* y;
   int N, c0, c1, H, W, Cout, Ho, Wo, pad, act, ps, x1_bdiv;
   long long x0_bs, x1_bs;
-  int tiles_x, tiles_y, ntiles, ncb, nchunks, nitems;
+  int tiles_x, tiles_y, ntiles, ncb, nchunks, nitems, tiles_per_xcd;
   int in_ps, in_dil, Hs, Ws, accum;
   const float* gmask; int gmask_act;
 #ifdef DVSR_CONV_TRACE
@@ -179,10 +179,16 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
   float* const s_in0 = smem;
   float* const s_w0 = smem + Sh::IN_FLOATS;
 
-  // XCD-aware order: the ncb cout blocks of one pixel tile get ids that differ by 8 (same XCD/L2)
-  const int tile = (id / (8 * a.ncb)) * 8 + (id & 7);
-  const int cbi = (id >> 3) % a.ncb;  // block of 32*MT output channels
-  if (tile >= a.ntiles) return;
+  // XCD-aware order.  Workgroup ids are dealt round-robin to the 8 XCDs (id & 7), each with its own L2.  An XCD
+  // owns a contiguous range of tiles in (frame, row, column) order, i.e. a band of tile rows, walked top-down:
+  // the two halo rows a tile shares with its vertical neighbours are then L2 hits (with tiles dealt round-robin,
+  // vertical neighbours sat on different XCDs and every halo row crossed the fabric twice: 87 MB fetched per
+  // launch against 51 MB of input).  The ncb cout blocks of a tile follow each other on the same XCD.
+  const int q_ = id >> 3;
+  const int cbi = q_ % a.ncb;  // block of 32*MT output channels
+  const int j_ = q_ / a.ncb;
+  const int tile = (id & 7) * a.tiles_per_xcd + j_;
+  if (j_ >= a.tiles_per_xcd || tile >= a.ntiles) return;
   const int tx_ = tile % a.tiles_x;
   const int t2 = tile / a.tiles_x;
   const int ty_ = t2 % a.tiles_y;
@@ -509,7 +515,8 @@ static int launch_conv2(ConvK2 k, hipStream_t st) {
   }
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 32 * MT);
-  k.nitems = ceil_div(k.ntiles, 8) * 8 * k.ncb;
+  k.tiles_per_xcd = ceil_div(k.ntiles, 8);
+  k.nitems = k.tiles_per_xcd * 8 * k.ncb;
   // One workgroup per item.  A persistent launch (256 CUs x resident workgroups walking the items with a grid
   // stride) was measured 2-3 % slower on every big layer, and the grid-stride loop alone costs 19 VGPRs, i.e.
   // the third workgroup per CU (152 -> 171); a chunk stream across a workgroup's items with cross-item
