@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(SmallK a) {
   constexpr int WPC = ((9 * COUT + 3) / 4) * 4;
   __shared__ __attribute__((aligned(16))) float s_in[2][CC * PLANE];
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [ceil(C/8)*8][WPC]
-  const int tile = blockIdx.x;
+  // an XCD (blockIdx.x & 7: workgroups are dealt round-robin) owns a band of tile rows, so the two halo rows a
+  // tile shares with its vertical neighbours are L2 hits
+  const int tpx = (a.ntiles + 7) >> 3;
+  const int tile = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= tpx || tile >= a.ntiles) return;
   const int tx_ = tile % a.tiles_x;
   const int t2 = tile / a.tiles_x;
   const int ty_ = t2 % a.tiles_y;
@@ -131,10 +135,10 @@ int conv3x3_small_cout_run(const float* x, const float* w, const float* bias, co
   k.tiles_x = ceil_div(W, 64); k.tiles_y = ceil_div(H, 8); k.ntiles = k.tiles_x * k.tiles_y * N;
   auto wbytes = [&](int cout) { return (size_t)ceil_div(C, 8) * 8 * (((9 * cout + 3) / 4) * 4) * sizeof(float); };
   switch (Cout) {  // exact channel count: no wasted accumulators
-    case 1: hipLaunchKernelGGL(conv3x3_small_cout_kernel<1>, dim3(k.ntiles), dim3(256), wbytes(1), st, k); break;
-    case 2: hipLaunchKernelGGL(conv3x3_small_cout_kernel<2>, dim3(k.ntiles), dim3(256), wbytes(2), st, k); break;
-    case 3: hipLaunchKernelGGL(conv3x3_small_cout_kernel<3>, dim3(k.ntiles), dim3(256), wbytes(3), st, k); break;
-    default: hipLaunchKernelGGL(conv3x3_small_cout_kernel<4>, dim3(k.ntiles), dim3(256), wbytes(4), st, k); break;
+    case 1: hipLaunchKernelGGL(conv3x3_small_cout_kernel<1>, dim3(8 * ceil_div(k.ntiles, 8)), dim3(256), wbytes(1), st, k); break;
+    case 2: hipLaunchKernelGGL(conv3x3_small_cout_kernel<2>, dim3(8 * ceil_div(k.ntiles, 8)), dim3(256), wbytes(2), st, k); break;
+    case 3: hipLaunchKernelGGL(conv3x3_small_cout_kernel<3>, dim3(8 * ceil_div(k.ntiles, 8)), dim3(256), wbytes(3), st, k); break;
+    default: hipLaunchKernelGGL(conv3x3_small_cout_kernel<4>, dim3(8 * ceil_div(k.ntiles, 8)), dim3(256), wbytes(4), st, k); break;
   }
   return check_launch("conv3x3_small_cout_kernel");
 }

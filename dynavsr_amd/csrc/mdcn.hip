@@ -416,10 +416,14 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_reg_kernel(DcnK2 a) {
   __shared__ __attribute__((aligned(16))) float s_x[XPX * 8];
   __shared__ __attribute__((aligned(16))) float s_w[WF];
 
+  // an XCD (id & 7) owns a band of tile rows (same mapping as conv2d_pipe_kernel): the 16 x 40 sampling windows of
+  // vertically adjacent 8 x 32 tiles overlap by half and now meet in one L2
   const int id = blockIdx.x;
-  const int tile = (id / (8 * a.ncb)) * 8 + (id & 7);
-  const int cb = (id >> 3) % a.ncb;
-  if (tile >= a.ntiles) return;
+  const int tpx = (a.ntiles + 7) >> 3;
+  const int q_ = id >> 3;
+  const int cb = q_ % a.ncb;
+  const int tile = (id & 7) * tpx + q_ / a.ncb;
+  if (q_ / a.ncb >= tpx || tile >= a.ntiles) return;
   const int tx_ = tile % a.tiles_x;
   const int t2 = tile / a.tiles_x;
   const int ty_ = t2 % a.tiles_y;
