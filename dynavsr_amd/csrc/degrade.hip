@@ -209,8 +209,8 @@ extern "C" int dvsr_degrade_apply(const float* img, const float* kernels, float*
   DVSR_REQUIRE(img && kernels && out, DVSR_ERR_INVALID, "degrade_apply: null img/kernels/out");
   DVSR_REQUIRE(N >= 1 && C >= 1 && H >= 1 && W >= 1 && n_kernels >= 1, DVSR_ERR_INVALID,
                "degrade_apply: N=%d C=%d H=%d W=%d n_kernels=%d", N, C, H, W, n_kernels);
-  DVSR_REQUIRE(K >= 1 && K <= DG_MAXK && (K & 1) && scale >= 1 && scale <= DG_MAXS, DVSR_ERR_UNSUPPORTED,
-               "degrade_apply: kernel edge %d (odd, <= %d) / scale %d (<= %d)", K, DG_MAXK, scale, DG_MAXS);
+  DVSR_REQUIRE(K >= 1 && K <= DG_MAXK && scale >= 1 && scale <= DG_MAXS, DVSR_ERR_UNSUPPORTED,
+               "degrade_apply: kernel edge %d (<= %d) / scale %d (<= %d)", K, DG_MAXK, scale, DG_MAXS);
   // ReflectionPad2d's own contract: padding must be smaller than the input
   DVSR_REQUIRE(K / 2 < H && K / 2 < W, DVSR_ERR_INVALID, "degrade_apply: reflection pad %d needs H, W > %d (got %dx%d)",
                K / 2, K / 2, H, W);

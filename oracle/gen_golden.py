@@ -407,7 +407,8 @@ def degradation_cases():
         return np.random.RandomState(seed[0]).rand(*shape).astype(np.float32), seed[0]
     cases = [("s4_aniso", 21, 4, 0.7, [2.0, 0.8], (5, 3, 64, 80)), ("s2_aniso", 21, 2, -1.9, [0.4, 3.1], (5, 3, 40, 48)),
              ("s4_iso", 21, 4, 0.0, [1.0, 1.0], (2, 3, 36, 36)), ("s4_delta", 21, 4, 0.0, [0, 0], (2, 3, 32, 40)),
-             ("s2_k11", 11, 2, 0.3, [1.5, 0.6], (3, 3, 24, 28))]
+             ("s2_k11", 11, 2, 0.3, [1.5, 0.6], (3, 3, 24, 28)),
+             ("s2_k10_even", 10, 2, 0.5, [1.2, 0.7], (2, 3, 22, 26))]    # even kernel_size: K stays even after the shift pad
     for tag, ks, scale, theta, sigma, shape in cases:
         img, sd = frames(*shape)
         d = rkg.Degradation(ks, scale, theta=theta, sigma=sigma)

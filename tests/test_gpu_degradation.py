@@ -10,7 +10,7 @@ from dynavsr_amd.data.random_kernel_generator import Degradation
 from oracle import degradation as od
 
 pytestmark = pytest.mark.gpu
-CASES = ["s4_aniso", "s2_aniso", "s4_iso", "s4_delta", "s2_k11"]
+CASES = ["s4_aniso", "s2_aniso", "s4_iso", "s4_delta", "s2_k11", "s2_k10_even"]
 
 
 def frames(seed_shape):

@@ -6,7 +6,7 @@ import pytest
 from conftest import load_golden
 from oracle import degradation as od
 
-CASES = ["s4_aniso", "s2_aniso", "s4_iso", "s4_delta", "s2_k11"]
+CASES = ["s4_aniso", "s2_aniso", "s4_iso", "s4_delta", "s2_k11", "s2_k10_even"]
 
 
 def frames(seed_shape):
