@@ -1,73 +1,72 @@
-"""Estimator wrapper with the reference's surface (codes/models/LRestimator_model.py:29-174):
-``feed_data / forward_without_optim / optimize_parameters / test`` and the attributes
-``netE, real_H, real_L, var_H, fake_L, MyLoss`` used by the DynaVSR drivers
-(test_dynavsr.py:238-241,267-269; train_dynavsr.py:360-362,417-426)."""
+"""Wrapper around the down-scaling estimator netE (MFDN / SFDN): SLR = netE(LR).
+
+The DynaVSR drivers touch this surface (codes/models/LRestimator_model.py:29-174; test_dynavsr.py:238-241,
+267-269; train_dynavsr.py:360-362,417-426): ``feed_data`` -> ``forward_without_optim`` (with grad) or ``test`` (no
+grad) -> ``fake_L``; ``real_H`` / ``real_L`` / ``var_H``; ``MyLoss``; ``optimize_parameters`` for the estimator's own
+pre-training; ``load`` / ``save`` of ``*_E.pth``.  Clip layout: the data dict holds [B,T,C,H,W]; MFDN ('video' mode)
+is fed [B,C,T,H,W], SFDN ('image' mode) gets the frames folded into the batch.
+"""
 import logging
 from collections import OrderedDict
 
 import torch
-import torch.nn as nn
 
 from . import networks
 from .base_model import BaseModel, unwrap
 
 logger = logging.getLogger('base')
+_LOSSES = {'l1': torch.nn.L1Loss, 'l2': torch.nn.MSELoss}
 
 
 class LRimgestimator_Model(BaseModel):
+    def __init__(self, opt):
+        super().__init__(opt)
+        net_opt, train_set = opt['network_E'], opt['datasets']['train']
+        self.train_opt = opt['train']
+        self.rank = torch.distributed.get_rank() if opt['dist'] else -1
+        self.scale, self.mode, self.model_name = opt['scale'], net_opt['mode'], net_opt['which_model_E']
+        self.kernel_size = train_set['kernel_size']
+        self.patch_size = train_set['patch_size']
+        self.batch_size = train_set['batch_size']
+        self.netE = networks.define_E(opt).to(self.device)
+        self.load()
+        loss_cls = _LOSSES.get(self.train_opt['loss_ftn'])
+        self.MyLoss = loss_cls(reduction='mean').to(self.device) if loss_cls is not None else None
+        if self.is_train:
+            self._setup_training(self.train_opt)
+
     def name(self):
         return 'Estimator_Model'
 
-    def __init__(self, opt):
-        super().__init__(opt)
-        self.rank = torch.distributed.get_rank() if opt['dist'] else -1
-        t = self.train_opt = opt['train']
-        ds = opt['datasets']['train']
-        self.kernel_size, self.patch_size, self.batch_size = ds['kernel_size'], ds['patch_size'], ds['batch_size']
-        self.scale = opt['scale']
-        self.model_name = opt['network_E']['which_model_E']
-        self.mode = opt['network_E']['mode']
-        self.netE = networks.define_E(opt).to(self.device)
-        self.load()
-        self.MyLoss = {'l1': nn.L1Loss(reduction='mean'), 'l2': nn.MSELoss(reduction='mean')}.get(t['loss_ftn'])
-        if self.MyLoss is not None:
-            self.MyLoss = self.MyLoss.to(self.device)
-        if self.is_train:
-            self.netE.train()
-            wd = t['weight_decay_R'] if t['weight_decay_R'] else 0
-            self.optimizer_E = torch.optim.Adam([p for p in self.netE.parameters() if p.requires_grad],
-                                                lr=t['lr_C'], weight_decay=wd)
-            self.optimizers.append(self.optimizer_E)
-            if t['lr_scheme'] != 'MultiStepLR':
-                raise NotImplementedError('MultiStepLR learning rate scheme is enough.')
-            self.schedulers.append(torch.optim.lr_scheduler.MultiStepLR(self.optimizer_E, list(t['lr_steps']),
-                                                                        t['lr_gamma']))
-            self.log_dict = OrderedDict()
+    def _setup_training(self, t):
+        if t['lr_scheme'] != 'MultiStepLR':
+            raise NotImplementedError('MultiStepLR learning rate scheme is enough.')
+        self.netE.train()
+        trainable = [p for p in self.netE.parameters() if p.requires_grad]
+        self.optimizer_E = torch.optim.Adam(trainable, lr=t['lr_C'], weight_decay=t['weight_decay_R'] or 0)
+        self.optimizers.append(self.optimizer_E)
+        self.schedulers.append(torch.optim.lr_scheduler.MultiStepLR(self.optimizer_E, list(t['lr_steps']), t['lr_gamma']))
+        self.log_dict = OrderedDict()
 
+    # ---- data in, estimate out -----------------------------------------------------------------------------------
     def feed_data(self, data):
-        self.real_H = data['LQs'].to(self.device)
+        clip = data['LQs'].to(self.device)
+        self.real_H = clip
         self.real_L = data['SuperLQs'].to(self.device) if 'SuperLQs' in data.keys() else None
-        b, t, c, h, w = self.real_H.shape
-        # 'image' mode folds frames into the batch (SFDN); 'video' mode feeds B,C,T,H,W (MFDN)
-        self.var_H = self.real_H.reshape(b * t, c, h, w) if self.mode == 'image' else self.real_H.transpose(1, 2)
+        if self.mode == 'image':
+            self.var_H = clip.reshape(-1, *clip.shape[2:])          # [B*T,C,H,W]
+        else:
+            self.var_H = clip.transpose(1, 2)                       # [B,C,T,H,W]
 
     def _estimate(self):
         y = self.netE(self.var_H)
-        if self.mode == 'image':
-            b, t, c = self.real_H.shape[:3]
-            return y.reshape(b, t, c, *y.shape[-2:])
-        return y.transpose(1, 2)
+        if self.mode != 'image':
+            return y.transpose(1, 2)
+        b, t, c = self.real_H.shape[:3]
+        return y.reshape(b, t, c, y.shape[-2], y.shape[-1])
 
     def forward_without_optim(self, step=None):
         self.fake_L = self._estimate()
-
-    def optimize_parameters(self, step=None):
-        self.optimizer_E.zero_grad()
-        self.fake_L = self._estimate()
-        loss = self.MyLoss(self.fake_L, self.real_L)
-        self.log_dict['l_pix'] = loss.item()
-        loss.backward()
-        self.optimizer_E.step()
 
     def test(self):
         self.netE.eval()
@@ -75,29 +74,40 @@ class LRimgestimator_Model(BaseModel):
             self.fake_L = self._estimate()
         self.netE.train()
 
+    def optimize_parameters(self, step=None):
+        self.optimizer_E.zero_grad()
+        self.forward_without_optim()
+        lr_loss = self.MyLoss(self.fake_L, self.real_L)
+        self.log_dict['l_pix'] = lr_loss.item()
+        lr_loss.backward()
+        self.optimizer_E.step()
+
+    # ---- reporting -----------------------------------------------------------------------------------------------
     def get_current_log(self):
         return self.log_dict
 
     def get_current_visuals(self, need_GT=True):
-        out = OrderedDict()
-        mid = self.fake_L.size(1) // 2
-        out['LQ'] = self.real_L.detach()[0, mid].float().cpu()
-        out['rlt'] = self.fake_L.detach()[0, mid].float().cpu()
+        centre = self.fake_L.size(1) // 2
+
+        def frame(clip):
+            return clip.detach()[0, centre].float().cpu()
+        visuals = OrderedDict(LQ=frame(self.real_L), rlt=frame(self.fake_L))
         if need_GT:
-            out['GT'] = self.real_H.detach()[0, mid].float().cpu()
-        return out
+            visuals['GT'] = frame(self.real_H)
+        return visuals
 
     def print_network(self):
-        s, n = self.get_network_description(self.netE)
-        logger.info('Network R structure: {}, with parameters: {:,d}'.format(
-            unwrap(self.netE).__class__.__name__, n))
-        logger.info(s)
+        text, count = self.get_network_description(self.netE)
+        logger.info('Network R structure: {}, with parameters: {:,d}'.format(type(unwrap(self.netE)).__name__, count))
+        logger.info(text)
 
+    # ---- checkpoints ---------------------------------------------------------------------------------------------
     def load(self):
-        path = self.opt['path']['pretrain_model_E']
-        if path is not None:
-            logger.info('Loading pretrained model for E [{:s}] ...'.format(path))
-            self.load_network(path, self.netE)
+        ckpt = self.opt['path']['pretrain_model_E']
+        if ckpt is None:
+            return
+        logger.info('Loading pretrained model for E [{:s}] ...'.format(ckpt))
+        self.load_network(ckpt, self.netE)
 
     def save(self, iter_step):
         self.save_network(self.netE, 'E', iter_step)

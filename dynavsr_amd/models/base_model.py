@@ -1,10 +1,11 @@
-"""Wrapper base class: device choice, LR helpers, checkpoint save/load/resume.
+"""What every model wrapper shares: the device, the optimiser / scheduler lists with their learning-rate helpers,
+and checkpoint I/O.
 
-Same behaviour as codes/models/base_model.py:8-121 (method names, file naming
-``{iter}_{label}.pth`` / ``{iter}_{type}.state``, 'module.' prefix stripped on load) so that the
-DynaVSR drivers and checkpoints work unchanged.  Networks are held bare (no DataParallel shell):
-with one process per GPU there is nothing for it to do, and state-dict keys are written without
-the 'module.' prefix exactly like the reference writes them (base_model.py:77-79).
+Behaviour follows codes/models/base_model.py:8-121 where the DynaVSR drivers can observe it: the method names,
+the checkpoint file names ``<iter>_<label>.pth`` / ``<iter>[_<type>].state``, tensors saved on the CPU, a leading
+'module.' stripped from every key on load, linear learning-rate warm-up on top of the schedulers.  Networks are
+held bare -- with one process per GPU a DataParallel shell has nothing to do -- and ``unwrap`` keeps code that
+receives a wrapped network working.
 """
 import os
 from collections import OrderedDict
@@ -13,19 +14,72 @@ import torch
 
 
 def unwrap(network):
-    return network.module if hasattr(network, 'module') and isinstance(network.module, torch.nn.Module) \
-        else network
+    """The module itself, whether or not something DataParallel-like wraps it."""
+    inner = getattr(network, 'module', None)
+    return inner if isinstance(inner, torch.nn.Module) else network
+
+
+def _state_file(opt, iter_step, model_type):
+    stem = str(iter_step) if model_type is None else '{}_{}'.format(iter_step, model_type)
+    return os.path.join(opt['path']['training_state'], stem + '.state')
 
 
 class BaseModel:
     def __init__(self, opt):
         self.opt = opt
-        self.device = torch.device('cuda' if opt['gpu_ids'] is not None else 'cpu')
         self.is_train = opt['is_train']
-        self.schedulers = []
-        self.optimizers = []
+        self.device = torch.device('cpu' if opt['gpu_ids'] is None else 'cuda')
+        self.optimizers, self.schedulers = [], []
 
-    # -- hooks the concrete wrappers fill in
+    # ---- checkpoints -------------------------------------------------------------------------------------------
+    def save_network(self, network, network_label, iter_label):
+        weights = OrderedDict((name, t.cpu()) for name, t in unwrap(network).state_dict().items())
+        torch.save(weights, os.path.join(self.opt['path']['models'], '{}_{}.pth'.format(iter_label, network_label)))
+
+    def load_network(self, load_path, network, strict=True):
+        prefix = 'module.'
+        weights = OrderedDict((name[len(prefix):] if name.startswith(prefix) else name, t)
+                              for name, t in torch.load(load_path, map_location='cpu').items())
+        unwrap(network).load_state_dict(weights, strict=strict)
+
+    def save_training_state(self, epoch, iter_step, model_type=None):
+        torch.save({'epoch': epoch, 'iter': iter_step,
+                    'optimizers': [o.state_dict() for o in self.optimizers],
+                    'schedulers': [s.state_dict() for s in self.schedulers]},
+                   _state_file(self.opt, iter_step, model_type))
+
+    def resume_training(self, resume_state):
+        for kind, mine in (('optimizers', self.optimizers), ('schedulers', self.schedulers)):
+            saved = resume_state[kind]
+            assert len(saved) == len(mine), 'Wrong lengths of ' + kind
+            for obj, state in zip(mine, saved):
+                obj.load_state_dict(state)
+
+    # ---- learning rate -----------------------------------------------------------------------------------------
+    def get_current_learning_rate(self):
+        return [group['lr'] for group in self.optimizers[0].param_groups]
+
+    def _get_init_lr(self):
+        return [[group['initial_lr'] for group in o.param_groups] for o in self.optimizers]
+
+    def _set_lr(self, lr_groups_l):
+        for optimizer, lrs in zip(self.optimizers, lr_groups_l):
+            for group, lr in zip(optimizer.param_groups, lrs):
+                group['lr'] = lr
+
+    def update_learning_rate(self, cur_iter, warmup_iter=-1):
+        for scheduler in self.schedulers:
+            scheduler.step()
+        if cur_iter < warmup_iter:             # linear ramp towards the initial rates
+            ramp = cur_iter / warmup_iter
+            self._set_lr([[lr * ramp for lr in lrs] for lrs in self._get_init_lr()])
+
+    # ---- introspection -----------------------------------------------------------------------------------------
+    def get_network_description(self, network):
+        net = unwrap(network)
+        return str(net), sum(p.numel() for p in net.parameters())
+
+    # ---- what a concrete wrapper provides ------------------------------------------------------------------------
     def feed_data(self, data):
         pass
 
@@ -46,52 +100,3 @@ class BaseModel:
 
     def load(self):
         pass
-
-    # -- learning-rate helpers (base_model.py:37-66)
-    def _set_lr(self, lr_groups_l):
-        for optimizer, lr_groups in zip(self.optimizers, lr_groups_l):
-            for group, lr in zip(optimizer.param_groups, lr_groups):
-                group['lr'] = lr
-
-    def _get_init_lr(self):
-        return [[g['initial_lr'] for g in o.param_groups] for o in self.optimizers]
-
-    def update_learning_rate(self, cur_iter, warmup_iter=-1):
-        for s in self.schedulers:
-            s.step()
-        if cur_iter < warmup_iter:
-            self._set_lr([[v / warmup_iter * cur_iter for v in grp] for grp in self._get_init_lr()])
-
-    def get_current_learning_rate(self):
-        return [g['lr'] for g in self.optimizers[0].param_groups]
-
-    def get_network_description(self, network):
-        network = unwrap(network)
-        return str(network), sum(p.numel() for p in network.parameters())
-
-    # -- checkpoints (base_model.py:74-121)
-    def save_network(self, network, network_label, iter_label):
-        path = os.path.join(self.opt['path']['models'], '{}_{}.pth'.format(iter_label, network_label))
-        torch.save(OrderedDict((k, v.cpu()) for k, v in unwrap(network).state_dict().items()), path)
-
-    def load_network(self, load_path, network, strict=True):
-        loaded = torch.load(load_path, map_location='cpu')
-        clean = OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in loaded.items())
-        unwrap(network).load_state_dict(clean, strict=strict)
-
-    def save_training_state(self, epoch, iter_step, model_type=None):
-        state = {'epoch': epoch, 'iter': iter_step,
-                 'schedulers': [s.state_dict() for s in self.schedulers],
-                 'optimizers': [o.state_dict() for o in self.optimizers]}
-        name = '{}_{}.state'.format(iter_step, model_type) if model_type is not None \
-            else '{}.state'.format(iter_step)
-        torch.save(state, os.path.join(self.opt['path']['training_state'], name))
-
-    def resume_training(self, resume_state):
-        opts, scheds = resume_state['optimizers'], resume_state['schedulers']
-        assert len(opts) == len(self.optimizers), 'Wrong lengths of optimizers'
-        assert len(scheds) == len(self.schedulers), 'Wrong lengths of schedulers'
-        for mine, saved in zip(self.optimizers, opts):
-            mine.load_state_dict(saved)
-        for mine, saved in zip(self.schedulers, scheds):
-            mine.load_state_dict(saved)

@@ -311,75 +311,64 @@ def inner_step(models, U):
 
 
 def meta_step(models):
-    """One outer iteration of codes/train_dynavsr.py:265-438 (EDVR branch, use_real / use_patch off) driven through
-    the reference's wrappers on CPU, statement by statement -- the loop lives inside main() and cannot be imported.
-    B = 2 tasks, adapt_iter = 2, inner Adam, meta SGD (so the parameter update is -lr_G * meta-gradient).
+    """One outer (meta) iteration with the semantics of codes/train_dynavsr.py:265-438 (EDVR branch, use_real and
+    use_patch off), evaluated on CPU with the REFERENCE's wrapper objects (its create_model / feed_data /
+    calculate_loss / forward_without_optim / MyLoss are what runs) -- the driver keeps this loop inside main(), so it
+    cannot be imported; the steps below are its data flow, restated:
+      per task: fresh deep copies (:326) whose parameters the inner optimiser holds (:328-351); adapt_iter times:
+      SLR from est_model, loss_train = model's Charbonnier on (SLR -> LR centre) + L1(SLR, SuperLQs), backward,
+      inner step (:355-399; quirk Q1: the losses go through model / est_model, so the step moves nothing and the
+      gradients land on the meta-parameters); then loss_q on (LR -> GT centre) / B and loss_e / (10 B) are added to
+      the meta-gradients with autograd.grad (:403-426); finally one step of the meta optimiser (:438).
+    B = 2 tasks, adapt_iter = 2, inner Adam, meta SGD (the update is -lr_G * meta-gradient).
     LR 32x32 -> SLR 8x8, GT 128x128."""
     from copy import deepcopy
     import torch.nn.functional as F
     PG, PE = synth.edvr_state_dict(0), synth.mfdn_state_dict(0)
     opt = make_opt("Adam")
-    opt["train"]["maml"]["adapt_iter"] = 2
-    lr_G = 1e-3
+    maml = opt["train"]["maml"]
+    maml["adapt_iter"] = 2
+    lr_G, n_tasks, centre = 1e-3, 2, 2
     model, est_model = models.create_model(opt)
     modelcp, est_modelcp = models.create_model(opt)
     load_sd(model.netG.module, PG); load_sd(est_model.netE.module, PE)
-    optim_params = [v for _, v in model.netG.named_parameters() if v.requires_grad] + \
-                   [v for _, v in est_model.netE.named_parameters() if v.requires_grad]
-    optimizer = torch.optim.SGD(optim_params, lr=lr_G)
-    train_data = {"LQs": synth.clip(31, 2, 5, 32, 32), "SuperLQs": synth.clip(32, 2, 5, 8, 8),
-                  "GT": synth.clip(33, 2, 5, 128, 128)}
-    center_idx, lr_alpha, update_step = 2, opt["train"]["maml"]["lr_alpha"], 2
-    optimizer.zero_grad()
-    meta_train_data, meta_test_data = {}, {}
-    meta_train_data["GT"] = train_data["LQs"][:, center_idx]
-    meta_test_data["LQs"] = train_data["LQs"]
-    meta_test_data["GT"] = train_data["GT"][:, center_idx]
-    total_loss_q = 0
-    batch_size = train_data["LQs"].size(0)
-    l_train = []
-    for batch in range(batch_size):
-        train_data_i = {k: train_data[k][batch:batch + 1] for k in ("LQs", "GT", "SuperLQs")}
-        meta_train_data_i = {"GT": meta_train_data["GT"][batch:batch + 1]}
-        meta_test_data_i = {"LQs": meta_test_data["LQs"][batch:batch + 1], "GT": meta_test_data["GT"][batch:batch + 1]}
+    g_params, e_params = list(model.netG.parameters()), list(est_model.netE.parameters())
+    meta_opt = torch.optim.SGD(g_params + e_params, lr=lr_G)
+    batch = {"LQs": synth.clip(31, n_tasks, 5, 32, 32), "SuperLQs": synth.clip(32, n_tasks, 5, 8, 8),
+             "GT": synth.clip(33, n_tasks, 5, 128, 128)}
+    meta_opt.zero_grad()
+    inner_losses, loss_q_sum = [], 0.0
+    for t in range(n_tasks):
+        task = {k: v[t:t + 1] for k, v in batch.items()}
         modelcp.netG, est_modelcp.netE = deepcopy(model.netG), deepcopy(est_model.netE)
-        sr_params = [v for _, v in modelcp.netG.named_parameters() if v.requires_grad]
-        est_params = [v for _, v in est_modelcp.netE.named_parameters() if v.requires_grad]
-        inner_optimizer = torch.optim.Adam([{"params": sr_params, "lr": lr_alpha}, {"params": est_params, "lr": lr_alpha}],
-                                           lr=lr_alpha, betas=(opt["train"]["maml"]["beta1"], opt["train"]["maml"]["beta2"]))
-        for k in range(update_step):
-            inner_optimizer.zero_grad()
-            est_model.feed_data(train_data_i)
+        inner_opt = torch.optim.Adam([{"params": list(modelcp.netG.parameters()), "lr": maml["lr_alpha"]},
+                                      {"params": list(est_modelcp.netE.parameters()), "lr": maml["lr_alpha"]}],
+                                     lr=maml["lr_alpha"], betas=(maml["beta1"], maml["beta2"]))
+        for _ in range(maml["adapt_iter"]):
+            inner_opt.zero_grad()
+            est_model.feed_data(task)
             est_model.forward_without_optim()
-            meta_train_data_i["LQs"] = est_model.fake_L
-            model.feed_data(meta_train_data_i)
-            loss_train = model.calculate_loss()
-            loss_train += F.l1_loss(meta_train_data_i["LQs"], train_data_i["SuperLQs"])
+            slr = est_model.fake_L
+            model.feed_data({"LQs": slr, "GT": task["LQs"][:, centre]})
+            loss_train = model.calculate_loss() + F.l1_loss(slr, task["SuperLQs"])
             loss_train.backward()
-            inner_optimizer.step()
-            l_train.append(float(loss_train))
-        model.feed_data(meta_test_data_i)
+            inner_opt.step()
+            inner_losses.append(float(loss_train.detach()))
+        model.feed_data({"LQs": task["LQs"], "GT": task["GT"][:, centre]})
         loss_q = model.calculate_loss()
-        for param, base_param in zip(model.netG.parameters(), modelcp.netG.parameters()):
-            param.data = base_param.data
-        grads = torch.autograd.grad(loss_q / batch_size, model.netG.parameters())
-        for j, param in enumerate(model.netG.parameters()):
-            param.grad += grads[j]
-        est_model.feed_data(train_data_i)
+        for p, g in zip(g_params, torch.autograd.grad(loss_q / n_tasks, g_params)):
+            p.grad += g
+        est_model.feed_data(task)
         est_model.forward_without_optim()
         loss_e = est_model.MyLoss(est_model.fake_L, est_model.real_L)
-        for param, base_param in zip(est_model.netE.parameters(), est_modelcp.netE.parameters()):
-            param.data = base_param.data
-        gradsE = torch.autograd.grad(loss_e / (batch_size * 10), est_model.netE.parameters())
-        for j, param in enumerate(est_model.netE.parameters()):
-            param.grad += gradsE[j]
-        total_loss_q += loss_q.item() / batch_size
-        del modelcp.netG, est_modelcp.netE
+        for p, g in zip(e_params, torch.autograd.grad(loss_e / (n_tasks * 10), e_params)):
+            p.grad += g
+        loss_q_sum += float(loss_q.detach()) / n_tasks
     gG = OrderedDict((k, p.grad.detach().clone()) for k, p in model.netG.module.named_parameters())
     gE = OrderedDict((k, p.grad.detach().clone()) for k, p in est_model.netE.module.named_parameters())
-    optimizer.step()
+    meta_opt.step()
     newG = dict(model.netG.module.named_parameters())
-    arrs = {"loss_q": total_loss_q, "loss_train": np.array(l_train), "lr_G": lr_G,
+    arrs = {"loss_q": loss_q_sum, "loss_train": np.array(inner_losses), "lr_G": lr_G,
             "gradG_norms": np.array([float(g.norm()) for g in gG.values()]),
             "gradE_norms": np.array([float(g.norm()) for g in gE.values()])}
     for k in TRACK:
