@@ -181,8 +181,8 @@ struct Builder {
     o.type = OP_DCN; o.name = name; o.pw = pw; o.pb = pb; o.x0 = x; o.x1 = om;
     o.N = N; o.c0 = C; o.H = H; o.W = W; o.Cout = C; o.dg = dg; o.act = act;
     o.y = alloc(name, (size_t)N * C * H * W);
-    if (C == dg * 8) {  // LDS-sampler kernel: weights packed like a conv with 8-channel chunks
-      o.wp_floats = (size_t)ceil_div(C, 64) * dg * conv2_pch(3, 1);
+    if (C % (dg * 8) == 0) {  // LDS-sampler kernel: weights packed like a conv with 8-channel chunks
+      o.wp_floats = (size_t)ceil_div(C, 64) * (C / 8) * conv2_pch(3, 1);
       o.wp_off = alloc("", o.wp_floats).off;
     }
     p.ops.push_back(o);
@@ -699,7 +699,7 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
     if (o.type == OP_DCN && fwd_base && o.wp_floats) {
       PackEntry& e = t.e[t.n++];
       e.w = P[o.pw]; e.P = fwd_base + o.wp_off; e.Cout = o.Cout; e.Ctot = o.c0; e.KK = 9; e.CC = 8; e.wt = 0;
-      e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64); e.nchunks = o.dg; e.pch = conv2_pch(3, 1); e.bf = 0;
+      e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64); e.nchunks = o.c0 / 8; e.pch = conv2_pch(3, 1); e.bf = 0;
       if (t.n == 48) { int rc = flush(); if (rc) return rc; }
     }
     if (o.type != OP_CONV) continue;

@@ -491,12 +491,16 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_reg_kernel(DcnK2 a) {
 
   const float* wp_cb = a.wp + (size_t)cb * a.nchunks * WF;
   DCN_STAMP(0);
-  for (int g = 0; g < a.dg; ++g) {
-    if (g < 2) DCN_STAMP(1 + 30 * g);
-    prefetch_x(g);    // no cross-group register prefetch: 24 fewer VGPRs buy the third wave per SIMD
+  // One pass per 8-channel chunk; a deformable group spans a.nchunks / a.dg of them (1 for EDVR-M's 64
+  // channels, 2 for EDVR-L's 128) which share the group's offsets and masks.
+  const int sub = a.nchunks / a.dg;
+  for (int kc = 0; kc < a.nchunks; ++kc) {
+    const int g = kc / sub;
+    if (kc < 2) DCN_STAMP(1 + 30 * kc);
+    prefetch_x(kc);   // no cross-group register prefetch: 24 fewer VGPRs buy the third wave per SIMD
     __syncthreads();  // previous group's taps are done with s_x / s_w
     {
-      const float* wsrc = wp_cb + (size_t)g * WF;
+      const float* wsrc = wp_cb + (size_t)kc * WF;
 #pragma unroll
       for (int j = 0; j < (NPIECE + 3) / 4; ++j) {
         const int piece = j * 4 + wave;
@@ -519,10 +523,10 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_reg_kernel(DcnK2 a) {
       }
     }
     load_off(g);
-    if (g < 2) DCN_STAMP(2 + 30 * g);
+    if (kc < 2) DCN_STAMP(2 + 30 * kc);
     __syncthreads();  // window visible, weight DMA drained
-    if (g < 2) DCN_STAMP(3 + 30 * g);
-    const float* xg = a.x + ((size_t)n * a.C + g * CPG) * HW;
+    if (kc < 2) DCN_STAMP(3 + 30 * kc);
+    const float* xg = a.x + ((size_t)n * a.C + kc * CPG) * HW;
     // Fast sampler of one tap, BRANCH-FREE: window coordinates are clamped (always a legal LDS read), lanes
     // whose footprint leaves the window get 0 and are flagged; the exact global-gather path for them runs
     // in a rare fix-up below.  Being straight-line code, the sampler of tap t+1 shares a basic block with
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_reg_kernel(DcnK2 a) {
     if (fix) fixup(0, Bc);
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) {
-      if (g < 2) DCN_STAMP(4 + 30 * g + 2 * tap);
+      if (kc < 2) DCN_STAMP(4 + 30 * kc + 2 * tap);
       f32x4 A[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_reg_kernel(DcnK2 a) {
           __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
         }
       }
-      if (g < 2) DCN_STAMP(5 + 30 * g + 2 * tap);
+      if (kc < 2) DCN_STAMP(5 + 30 * kc + 2 * tap);
       if (tap + 1 < KK) {
         if (fix) fixup(tap + 1, Bn);
         Bc[0] = Bn[0]; Bc[1] = Bn[1];
@@ -632,13 +636,14 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
                             long long msk_bs, int mask_logit, const float* wp, const float* b, float* out,
                             int N, int C, int H, int W, int Cout, int dg, int act, hipStream_t st) {
   DVSR_REQUIRE(x && off && msk && wp && out, DVSR_ERR_INVALID, "mdcn_forward_packed: null pointer");
-  DVSR_REQUIRE(C == dg * 8, DVSR_ERR_UNSUPPORTED, "mdcn_forward_packed: needs C/dg == 8 (got %d/%d)", C, dg);
+  DVSR_REQUIRE(dg > 0 && C % (dg * 8) == 0, DVSR_ERR_UNSUPPORTED,
+               "mdcn_forward_packed: needs C/dg to be a multiple of 8 (got %d/%d)", C, dg);
   DcnK2 k;
   k.x = x; k.off = off; k.msk = msk; k.wp = wp; k.bias = b; k.out = out;
   k.off_bstride = off_bs; k.msk_bstride = msk_bs; k.mask_logit = mask_logit;
   k.N = N; k.C = C; k.H = H; k.W = W; k.Cout = Cout; k.dg = dg; k.act = act;
   k.tiles_x = ceil_div(W, 32); k.tiles_y = ceil_div(H, 8); k.ntiles = k.tiles_x * k.tiles_y * N;
-  k.ncb = ceil_div(Cout, 64); k.nchunks = dg;
+  k.ncb = ceil_div(Cout, 64); k.nchunks = C / 8;
 #ifdef DVSR_CONV_TRACE
   k.trace = (g_dcn_countdown == 0) ? g_dcn_trace : nullptr;
   if (g_dcn_countdown >= 0) --g_dcn_countdown;
@@ -646,7 +651,7 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
   const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
   static int variant = -1;  // DVSR_DCN_FWD=lds selects the LDS-column-tile kernel (A/B aid)
   if (variant < 0) { const char* v = getenv("DVSR_DCN_FWD"); variant = (v && v[0] == 'l') ? 1 : 0; }
-  if (variant == 1) {
+  if (variant == 1 && C == dg * 8) {
     hipLaunchKernelGGL(mdcn_fwd_lds_kernel<4>, dim3(grid), dim3(256), 0, st, k);
     return check_launch("mdcn_fwd_lds_kernel");
   }
@@ -662,7 +667,8 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
 // Op-level entry to the LDS-sampler kernel: packs `w` into the caller's workspace first.
 // Same contract as dvsr_mdcn_forward restricted to stride = pad = dil = 1, C/dg = 8.
 extern "C" size_t dvsr_mdcn_forward_fast_workspace_bytes(int C, int Cout, int dg) {
-  return (size_t)dvsr::ceil_div(Cout, 64) * dg * dvsr::conv2_pch(3, 1) * sizeof(float) + (size_t)C * 0;
+  (void)dg;
+  return (size_t)dvsr::ceil_div(Cout, 64) * dvsr::ceil_div(C, 8) * dvsr::conv2_pch(3, 1) * sizeof(float);
 }
 
 extern "C" int dvsr_mdcn_forward_fast(const float* x, const float* offset, const float* mask, const float* w,
@@ -670,14 +676,14 @@ extern "C" int dvsr_mdcn_forward_fast(const float* x, const float* offset, const
                                       int act, void* workspace, size_t workspace_bytes, dvsr_stream_t stream) {
   using namespace dvsr;
   DVSR_REQUIRE(x && offset && mask && w && out && workspace, DVSR_ERR_INVALID, "mdcn_forward_fast: null pointer");
-  DVSR_REQUIRE(dg > 0 && C == dg * 8, DVSR_ERR_UNSUPPORTED, "mdcn_forward_fast: needs C/dg == 8");
+  DVSR_REQUIRE(dg > 0 && C % (dg * 8) == 0, DVSR_ERR_UNSUPPORTED, "mdcn_forward_fast: needs C/dg to be a multiple of 8");
   DVSR_REQUIRE(workspace_bytes >= dvsr_mdcn_forward_fast_workspace_bytes(C, Cout, dg), DVSR_ERR_WORKSPACE,
                "mdcn_forward_fast: workspace too small");
   PackTable t;
   t.n = 1;
   PackEntry& e = t.e[0];
   e.w = w; e.P = (float*)workspace; e.Cout = Cout; e.Ctot = C; e.KK = 9; e.CC = 8; e.wt = 0; e.w_ctot = 0;
-  e.w_coff = 0; e.ncb = ceil_div(Cout, 64); e.nchunks = dg; e.pch = conv2_pch(3, 1); e.bf = 0;
+  e.w_coff = 0; e.ncb = ceil_div(Cout, 64); e.nchunks = C / 8; e.pch = conv2_pch(3, 1); e.bf = 0;
   int rc = pack_weights_run(t, (hipStream_t)stream);
   if (rc) return rc;
   const long long P = (long long)H * W;

@@ -56,7 +56,8 @@ int dvsr_mdcn_forward(const float* x, const float* offset, const float* mask, co
                       dvsr_stream_t stream);
 
 /* Fast path of dvsr_mdcn_forward for the EDVR configuration (3x3, stride = pad = dil = 1, groups = 1,
- * C/dg = 8): the deformable group's input planes are staged in LDS and sampled from there (8 LDS
+ * C/dg a multiple of 8 -- EDVR-M 64/8, EDVR-L 128/8): 8-channel slices of a deformable group's input planes
+ * are staged in LDS and sampled from there (8 LDS
  * reads per (pixel, tap) instead of 32 global gathers); samples that leave the staged window
  * (|offset| > 4 px) fall back to exact global gathers.  The workspace receives the packed weights. */
 size_t dvsr_mdcn_forward_fast_workspace_bytes(int C, int Cout, int dg);
