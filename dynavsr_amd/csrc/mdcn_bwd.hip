@@ -143,6 +143,7 @@ struct DcnF {
   float* gx; float* goff; float* gmsk; float* col;
   long long off_bs, msk_bs, goff_bs, gmsk_bs;
   int mask_logit, N, C, H, W, Cout, dg, tiles_x, tiles_y;
+  int sub;  // 8-channel chunks per deformable group (1: EDVR-M, 2: EDVR-L); blockIdx.y walks the C/8 chunks
 };
 
 template <int HALO>
@@ -155,14 +156,18 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   __shared__ float s_max[4];
   const int KST = a.Cout >> 1;
 
-  const int tile = blockIdx.x, g = blockIdx.y, n = blockIdx.z;
+  // blockIdx.y = 8-channel chunk kc of the input; its deformable group g supplies offsets / masks.  With more
+  // than one chunk per group the offset / mask gradients of the chunks are summed with atomics into buffers the
+  // host zeroed (two commutative adds per element: still deterministic).
+  const int tile = blockIdx.x, kc = blockIdx.y, n = blockIdx.z;
+  const int g = kc / a.sub;
   const int tx_ = tile % a.tiles_x, ty_ = tile / a.tiles_x;
   const int oy0 = ty_ * TH, ox0 = tx_ * TW;
   const int wy0 = oy0 - 1 - HALO, wx0 = ox0 - 1 - HALO;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo = lane & 31, hi = lane >> 5;
   const size_t HW = (size_t)a.H * a.W;
-  const float* xg = a.x + ((size_t)n * a.C + g * 8) * HW;
+  const float* xg = a.x + ((size_t)n * a.C + kc * 8) * HW;
 
   // ---- stage the input window (zero outside the image), clear the gradient window, stage W^T.
   // All global loads of a stage are issued before the first LDS write (a load per loop iteration would
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       const int idx = base + tid + 256 * e;
       const int l = idx & 63, kk = (idx >> 6) % KST, mt = idx / (64 * KST);
       const int m = mt * 32 + (l & 31), o = 2 * kk + (l >> 5);
-      rw[e] = (idx < 3 * KST * 64 && m < 72) ? a.w[((size_t)o * a.C + g * 8 + (m & 7)) * 9 + (m >> 3)] : 0.f;
+      rw[e] = (idx < 3 * KST * 64 && m < 72) ? a.w[((size_t)o * a.C + kc * 8 + (m & 7)) * 9 + (m >> 3)] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   float* goffn = a.goff + (size_t)n * a.goff_bs;
   float* gmskn = a.gmsk + (size_t)n * a.gmsk_bs;
   float* coln = a.col + (size_t)n * a.C * 9 * HW;
-  float* gxg = a.gx ? a.gx + ((size_t)n * a.C + g * 8) * HW : nullptr;
+  float* gxg = a.gx ? a.gx + ((size_t)n * a.C + kc * 8) * HW : nullptr;
 #pragma unroll
   for (int mt = 0; mt < 3; ++mt) {
 #pragma unroll
@@ -365,13 +370,18 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
         gw += __shfl_xor(gw, 32, 64);
         if (pv[nt]) {
           if (hi == 0) {
-            goffn[(size_t)(g * 18 + 2 * tap) * HW + pofs[nt]] = gh;
-            goffn[(size_t)(g * 18 + 2 * tap + 1) * HW + pofs[nt]] = gw;
-            gmskn[(size_t)(g * 9 + tap) * HW + pofs[nt]] = a.mask_logit ? gm * m * (1.f - m) : gm;
+            float* ph = goffn + (size_t)(g * 18 + 2 * tap) * HW + pofs[nt];
+            float* pm = gmskn + (size_t)(g * 9 + tap) * HW + pofs[nt];
+            const float gmv = a.mask_logit ? gm * m * (1.f - m) : gm;
+            if (a.sub == 1) {
+              ph[0] = gh; ph[HW] = gw; pm[0] = gmv;
+            } else {
+              unsafeAtomicAdd(ph, gh); unsafeAtomicAdd(ph + HW, gw); unsafeAtomicAdd(pm, gmv);
+            }
           }
 #pragma unroll
           for (int cq = 0; cq < 4; ++cq)
-            coln[((size_t)(g * 8 + 4 * hi + cq) * 9 + tap) * HW + pofs[nt]] = colv[cq];
+            coln[((size_t)(kc * 8 + 4 * hi + cq) * 9 + tap) * HW + pofs[nt]] = colv[cq];
         }
       }
     }
@@ -427,13 +437,21 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
     const char* v = getenv("DVSR_DCN_BWD");
     use_fused = (v && v[0] == 'u') ? 0 : 1;
   }
-  if (use_fused && a.cpg == 8 && stride == 1 && pad == 1 && dil == 1 && Cout % 32 == 0 && Cout <= 128) {
+  if (use_fused && a.cpg % 8 == 0 && stride == 1 && pad == 1 && dil == 1 && Cout % 32 == 0 && Cout <= 128) {
     constexpr int HALO = 4, XPX = (8 + 2 + 2 * HALO) * (32 + 2 + 2 * HALO);
     DcnF f;
     f.x = x; f.off = off; f.msk = msk; f.w = w; f.gout = gout; f.gx = gx; f.goff = goff; f.gmsk = gmsk; f.col = col;
     f.off_bs = a.off_bs; f.msk_bs = a.msk_bs; f.goff_bs = goff_bs; f.gmsk_bs = gmsk_bs;
     f.mask_logit = mask_logit; f.N = N; f.C = C; f.H = H; f.W = W; f.Cout = Cout; f.dg = dg;
     f.tiles_x = ceil_div(W, 32); f.tiles_y = ceil_div(H, 8);
+    f.sub = a.cpg / 8;
+    if (f.sub > 1) {  // the chunks of a group add their offset / mask gradients into zeroed buffers
+      for (int n = 0; n < N; ++n) {
+        hipError_t e1 = hipMemsetAsync(goff + (size_t)n * goff_bs, 0, (size_t)dg * 18 * P * sizeof(float), st);
+        hipError_t e2 = hipMemsetAsync(gmsk + (size_t)n * gmsk_bs, 0, (size_t)dg * 9 * P * sizeof(float), st);
+        DVSR_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, DVSR_ERR_HIP, "mdcn_backward: memset of goff/gmsk failed");
+      }
+    }
     const size_t lds = (size_t)(8 * XPX + std::max(16 * XPX, 3 * (Cout / 2) * 64)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -441,7 +459,7 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
                           (int)((8 * XPX + std::max(16 * XPX, 3 * 64 * 64)) * sizeof(float)));
       attr_done = true;
     }
-    hipLaunchKernelGGL(mdcn_bwd_fused_kernel<HALO>, dim3(f.tiles_x * f.tiles_y, dg, N), dim3(256), lds, st, f);
+    hipLaunchKernelGGL(mdcn_bwd_fused_kernel<HALO>, dim3(f.tiles_x * f.tiles_y, C / 8, N), dim3(256), lds, st, f);
     int rc = check_launch("mdcn_bwd_fused_kernel");
     if (rc) return rc;
     if (gw)  // dW = gout . col^T, db = gout . 1 (the kernel above wrote the modulated samples to col)
