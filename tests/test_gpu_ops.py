@@ -245,6 +245,27 @@ def test_mdcn_backward_vs_oracle(ops, std, h, w):
         assert relerr(a, b_) < TOL, name
 
 
+@pytest.mark.parametrize("std", [1.5, 8.0])
+def test_mdcn_16_channels_per_group_vs_oracle(ops, std):
+    """EDVR-L's DCN: C = 128, dg = 8 -> 16 channels per deformable group.  The LDS-sampler forward and the fused
+    backward walk such a group as two 8-channel chunks that share offsets and masks (the chunks' offset / mask
+    gradients are added); both against the C oracle, with offsets that leave the staged window too."""
+    from oracle import dcn as odcn
+    n, c, dg, cout, h, w = 2, 128, 8, 128, 12, 36
+    x, off = rnd(n, c, h, w, seed=11), rnd(n, dg * 18, h, w, seed=12, scale=std)
+    m = torch.from_numpy(np.random.RandomState(13).random_sample((n, dg * 9, h, w)))
+    wt, b, go = rnd(cout, c, 3, 3, seed=14, scale=0.03), rnd(cout, seed=15), rnd(n, cout, h, w, seed=16)
+    yo = odcn.forward(x.float().double(), off.float().double(), m.float().double(), wt.float().double(),
+                      b.float().double(), 1, 1, 1, 1, dg)
+    y = ops.mdcn_forward_fast(dev(x), dev(off), dev(m), dev(wt), dev(b), dg)
+    assert relerr(y, yo) < TOL
+    ref = odcn.backward(x.float().double(), off.float().double(), m.float().double(), wt.float().double(), True,
+                        go.float().double(), 1, 1, 1, 1, dg)
+    got = ops.mdcn_backward(dev(x), dev(off), dev(m), dev(wt), dev(go), 1, 1, 1, 1, dg)
+    for a_, b_, name in zip(got, ref, ("gx", "goffset", "gmask", "gw", "gb")):
+        assert relerr(a_, b_) < TOL, name
+
+
 def test_charbonnier(ops):
     x, y = rnd(2, 3, 40, 52, seed=1).requires_grad_(), rnd(2, 3, 40, 52, seed=2)
     ref = torch.mean(torch.sqrt((x - y) ** 2 + 1e-6))
