@@ -445,7 +445,11 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
     f.mask_logit = mask_logit; f.N = N; f.C = C; f.H = H; f.W = W; f.Cout = Cout; f.dg = dg;
     f.tiles_x = ceil_div(W, 32); f.tiles_y = ceil_div(H, 8);
     f.sub = a.cpg / 8;
-    if (f.sub > 1) {  // the chunks of a group add their offset / mask gradients into zeroed buffers
+    if (f.sub > 1 && gmsk == goff + (size_t)dg * 18 * P && goff_bs == gmsk_bs && goff_bs == (long long)dg * 27 * P) {
+      // offsets and masks are the two parts of one [N, 27 dg, H, W] tensor (the engine's layout): one memset
+      DVSR_REQUIRE(hipMemsetAsync(goff, 0, (size_t)N * goff_bs * sizeof(float), st) == hipSuccess, DVSR_ERR_HIP,
+                   "mdcn_backward: memset of goff/gmsk failed");
+    } else if (f.sub > 1) {  // the chunks of a group add their offset / mask gradients into zeroed buffers
       for (int n = 0; n < N; ++n) {
         hipError_t e1 = hipMemsetAsync(goff + (size_t)n * goff_bs, 0, (size_t)dg * 18 * P * sizeof(float), st);
         hipError_t e2 = hipMemsetAsync(gmsk + (size_t)n * gmsk_bs, 0, (size_t)dg * 9 * P * sizeof(float), st);
