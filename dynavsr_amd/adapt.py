@@ -244,6 +244,10 @@ def adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, cl
             net.train(was_training)
             ev = torch.cuda.Event()
             ev.record(stream)
+        # the clip was allocated on the main stream and is read here until the END of the tape (base_up reads the
+        # centre frame last): tell the caching allocator, or a transient clip (a `.cuda()` copy of a CPU clip, a
+        # generator's temporary) is handed out again on the main stream while this forward is still in flight
+        lqs.record_stream(stream)
         return sr, ev
 
     def on_gpu(data):

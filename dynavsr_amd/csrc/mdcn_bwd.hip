@@ -4,13 +4,17 @@
 //   dcol = W^T . gout (addmm, :617-620) -> col2im_coord kernel (kernel.cu:694-766: grad offset/mask)
 //   -> col2im kernel (kernel.cu:634-692: grad input, atomicAdd) -> im2col again (:569-632)
 //   -> grad_weight += gout . col^T, grad_bias += gout . 1 (:653-665).
-// Round-1 structure (correctness first): the two contractions run on the MFMA conv kernels
-// (dcol = 1x1 "dgrad" conv over the flattened [Cout][C*9] weight; dW/db = 1x1 wgrad over the
-// column buffer), the two sampler kernels below are fused per (pixel, tap) over the CPG channels
-// of a deformable group: one thread computes the tap geometry once and produces the offset
-// gradient pair, the mask gradient and the 4*CPG input-gradient atomics.  Unlike the forward,
-// the [C*9, P] column / dcol buffers DO round-trip HBM here (as in the reference); fusing them
-// into LDS is the planned next step (DESIGN.md "DCN backward").
+// Two paths:
+//  * EDVR's configuration (3x3, stride/pad/dilation 1, C/dg a multiple of 8): ONE fused kernel,
+//    mdcn_bwd_fused_kernel -- dcol = W^T . gout on the MFMA stays in registers (never in HBM), the per-(pixel,
+//    tap) sampler produces the offset / mask gradients in registers, the input gradient is accumulated in an
+//    LDS window with 64-bit fixed-point ds_add_u64 and leaves as one fp32 atomic per touched element; only the
+//    column buffer of the weight gradient round-trips HBM (1x1 wgrad over it).  Groups of 16 channels are walked
+//    as two 8-channel chunks.
+//  * every other configuration (C/dg = 4, other strides / dilations; DVSR_DCN_BWD=unfused forces it): the
+//    three-kernel form of the reference -- the two contractions on the MFMA conv kernels (dcol = 1x1 "dgrad"
+//    over the flattened [Cout][C*9] weight, dW/db = 1x1 wgrad over the column buffer) around the fused
+//    col2im / col2im_coord sampler kernels below; the [C*9, P] buffers do round-trip HBM there.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <algorithm>

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from scipy import ndimage
 
-from .. import _lib as L
+from dynavsr_amd import _lib as L
 
 
 class Degradation:

@@ -80,12 +80,34 @@ class Plan:
             pass
 
 
-def get_plan(cfg, b, h, w):
-    key = (tuple(cfg), b, h, w)
+def get_plan(cfg, b, h, w, device=None):
+    """One plan per (config, shape, device): a plan owns a side stream and events of the device it was first
+    used on.  A plan is single-threaded: two host threads must not drive the same plan concurrently."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = (tuple(cfg), b, h, w, dev)
     p = _plans.get(key)
     if p is None:
         p = _plans[key] = Plan(tuple(cfg), b, h, w)
     return p
+
+
+def _stash(ctx, plan, ws, x, params):
+    """What backward needs.  The parameters are detached aliases of the live leaves (the tape re-packs the weights
+    from them), so autograd's own saved-tensor check does not see an in-place update between forward and
+    backward: the version counters -- an alias shares its base's -- are recorded here and compared in backward."""
+    ctx.plan, ctx.ws, ctx.x, ctx.params = plan, ws, x, params
+    ctx.versions = [p._version for p in params]
+
+
+def _check_stash(ctx, what):
+    if ctx.ws is None:
+        raise RuntimeError("%s: backward called a second time -- the activation arena was released after the "
+                           "first one (the tape is first-order and single-use, like once_differentiable in "
+                           "deform_conv.py:123)" % what)
+    for i, (p, v) in enumerate(zip(ctx.params, ctx.versions)):
+        if p._version != v:
+            raise RuntimeError("%s: parameter %d was modified in place between forward and backward (version %d -> "
+                               "%d); the gradient would be taken at the wrong weights" % (what, i, v, p._version))
 
 
 def _prep(t):
@@ -104,7 +126,7 @@ class EdvrFunction(torch.autograd.Function):
         b, n, c, h, w = x.shape
         if n != cfg[1] or c != 3:
             raise RuntimeError("EDVR expects [B,%d,3,H,W], got %s" % (cfg[1], tuple(x.shape)))
-        plan = get_plan(cfg, b, h, w)
+        plan = get_plan(cfg, b, h, w, x.device)
         if len(params) != plan.n_params:
             raise RuntimeError("EDVR engine expects %d parameter tensors, got %d"
                                % (plan.n_params, len(params)))
@@ -114,7 +136,7 @@ class EdvrFunction(torch.autograd.Function):
         out = x.new_empty((b, 3, cfg[5] * h, cfg[5] * w))
         plan.forward(params, x, out, ws)
         if need_grad:
-            ctx.plan, ctx.ws, ctx.x, ctx.params = plan, ws, x, params
+            _stash(ctx, plan, ws, x, params)
         if keep_ws is not None:
             keep_ws.append((plan, ws))
         return out
@@ -122,6 +144,7 @@ class EdvrFunction(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gout):
+        _check_stash(ctx, "EDVR")
         gout = _prep(gout)
         gparams = [torch.empty_like(p) for p in ctx.params]
         gx = torch.empty_like(ctx.x) if ctx.needs_input_grad[0] else None
@@ -170,8 +193,9 @@ class EstimatorPlan:
             pass
 
 
-def get_estimator_plan(cfg, b, h, w):
-    key = (tuple(cfg), b, h, w)
+def get_estimator_plan(cfg, b, h, w, device=None):
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = (tuple(cfg), b, h, w, dev)
     p = _eplans.get(key)
     if p is None:
         p = _eplans[key] = EstimatorPlan(tuple(cfg), b, h, w)
@@ -199,7 +223,7 @@ class EstimatorFunction(torch.autograd.Function):
         else:
             b, c, h, w = x.shape
             oshape = (b, c, h // scale, w // scale)
-        plan = get_estimator_plan(cfg, b, h, w)
+        plan = get_estimator_plan(cfg, b, h, w, x.device)
         if len(params) != plan.n_params:
             raise RuntimeError("estimator engine expects %d parameter tensors, got %d" % (plan.n_params, len(params)))
         params = [_prep(p.detach()) for p in params]
@@ -208,12 +232,13 @@ class EstimatorFunction(torch.autograd.Function):
         out = x.new_empty(oshape)
         plan.forward(params, x, out, ws)
         if need_grad:
-            ctx.plan, ctx.ws, ctx.x, ctx.params = plan, ws, x, params
+            _stash(ctx, plan, ws, x, params)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gout):
+        _check_stash(ctx, "estimator")
         gout = _prep(gout)
         gparams = [torch.empty_like(p) for p in ctx.params]
         ctx.plan.backward(ctx.params, ctx.x, gout, gparams, ctx.ws)

@@ -170,6 +170,8 @@ def mdcn_backward(x, offset, mask, weight, gout, stride=1, padding=0, dilation=1
 class _Charbonnier(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, eps):
+        if x.shape != y.shape:      # the kernel walks both with one element count; torch would broadcast or raise
+            raise RuntimeError("charbonnier: prediction %s and target %s differ in shape" % (tuple(x.shape), tuple(y.shape)))
         x, y = x.contiguous(), y.contiguous()
         ws = torch.empty(int(L.lib().dvsr_charbonnier_workspace_bytes()), dtype=torch.uint8, device=x.device)
         loss = x.new_empty(())

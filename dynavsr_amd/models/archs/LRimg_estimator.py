@@ -8,7 +8,7 @@ path: a CPU input raises.
 """
 import torch.nn as nn
 
-from ... import engine
+from dynavsr_amd import engine
 
 
 class DirectKernelEstimatorVideo(nn.Module):

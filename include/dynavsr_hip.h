@@ -9,7 +9,11 @@
  *     internal synchronisation, no allocation: scratch comes from a caller workspace;
  *   - returns 0 on success or a negative DVSR_ERR_* code and never throws; the message of the
  *     last failure on the calling thread is dvsr_last_error();
- *   - re-entrant; the only global mutable state is that thread-local error string.
+ *   - the stateless entry points are re-entrant (the only global mutable state is that thread-local error
+ *     string).  PLAN objects (dvsr_edvr_plan, dvsr_estimator_plan) are NOT: a plan owns a side stream and
+ *     fork/join events that its backward records on, so one plan must be driven by one host thread at a time
+ *     (the reference's caller is single-threaded too: the autograd engine thread).  Different plans
+ *     may be used from different threads concurrently.
  *
  * Each declaration cites the reference interface it replaces (paths under codes/ of
  * esw0116/DynaVSR).  The reference's only native boundary is the pybind11 module

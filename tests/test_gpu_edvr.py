@@ -391,6 +391,57 @@ def test_adapt_video_overlap_equals_sequential_loop():
     assert list(adapt_video(opt, model, est, modelcp, estcp, est_fixed, [])) == []
 
 
+def test_adapt_video_transient_clips_are_not_reused_under_the_side_streams():
+    """The DataLoader case: clips arrive on the CPU (adapt_video copies them to the GPU itself) or as GPU
+    temporaries nobody else holds.  The side-stream forwards read the clip until the end of their tape, so the
+    caching allocator must not hand its block out on the main stream meanwhile: the consumer below allocates and
+    overwrites same-sized blocks between the yields, and the results must still be those of the plain loop."""
+    from dynavsr_amd.adapt import adapt_frame, adapt_video
+    from dynavsr_amd.models import create_model
+    opt = _gpu_opt("Adam")
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    model.netG.load_state_dict(synth.edvr_state_dict(0)); est.netE.load_state_dict(synth.mfdn_state_dict(0))
+    est_fixed.netE.load_state_dict(synth.mfdn_state_dict(1))
+    host = [synth.clip(60 + i, 1, 5, 32, 48) for i in range(5)]
+    want = []
+    for c in host:
+        d = {"LQs": c.cuda()}
+        model.feed_data(d, need_GT=False); model.test()
+        want.append((model.fake_H.clone(), adapt_frame(opt, model, est, modelcp, estcp, est_fixed, d)["sr"].clone()))
+    for make in (lambda c: {"LQs": c},                          # CPU clips
+                 lambda c: {"LQs": c.cuda()}):                  # GPU temporaries owned by the generator only
+        got = []
+        for a, r in adapt_video(opt, model, est, modelcp, estcp, est_fixed, (make(c) for c in host)):
+            got.append((a.clone(), r["sr"].clone()))
+            junk = [torch.full_like(host[0], float(k + 7), device="cuda") for k in range(6)]   # same-size blocks
+            del junk
+        assert len(got) == len(want)
+        for (a, b), (c, d) in zip(got, want):
+            assert torch.equal(a, c)
+            assert relerr(b, d) < 1e-5
+
+
+def test_engine_refuses_stale_weights_and_second_backward():
+    """The tape keeps detached aliases of the parameters and releases its arena after one backward: an in-place
+    update between forward and backward, or a second backward, must raise instead of returning wrong numbers."""
+    from dynavsr_amd import hipops
+    net = make_net(0)
+    x = synth.clip(5, 1, 5, 16, 16).cuda()
+    y = net(x)
+    with torch.no_grad():
+        next(net.parameters()).add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        y.sum().backward()
+    y = net(x)
+    y.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        y.sum().backward()
+    with pytest.raises(RuntimeError, match="differ in shape"):
+        hipops.charbonnier(y.detach(), y.detach()[:, :2])
+
+
 def _meta_setup(adapt_iter=2):
     from dynavsr_amd.models import create_model
     opt = _gpu_opt("Adam")
