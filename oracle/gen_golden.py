@@ -180,6 +180,35 @@ def edvr_x2(E):
          **{"grad__" + k.replace(".", "__"): ref_g[k] for k in FULL_GRADS if k in ref_g})
 
 
+def edvr_l(E):
+    """BASELINE.json configs[4] / SURVEY 8d config 5: EDVR-L x4 (nf 128, 7 frames, 40 reconstruction blocks,
+    options/test/EDVR/EDVR_V_S4.yml:52-58) on a 1x7x3x64x64 clip (256x256 HR tile), forward + d(charbonnier)/d(all
+    parameters) through the reference module.  The 3x256x256 output is stored sub-sampled (every 4th pixel) with
+    its norm and sum -- the -m gpu test compares the full tensor against the oracle, which is pinned here."""
+    cfg = dict(nf=128, nframes=7, groups=8, front_RBs=5, back_RBs=40, scale=4)
+    P = synth.edvr_state_dict(8, **cfg)
+    net = load_sd(E.EDVR(**cfg), P)
+    h, w, seed = 64, 64, 9
+    x = synth.clip(seed, 1, 7, h, w)
+    tgt = synth.clip(seed + 100, 1, 1, 4 * h, 4 * w)[:, 0]
+    y = net(x.clone())
+    loss = oedvr.charbonnier(y, tgt)
+    loss.backward()
+    ref_g = OrderedDict((k, p.grad.detach()) for k, p in net.named_parameters())
+    PO = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in P.items())
+    yo = oedvr.edvr_forward(PO, x, **cfg)
+    og = torch.autograd.grad(oedvr.charbonnier(yo, tgt), list(PO.values()))
+    assert relerr(yo, y) < 1e-5, relerr(yo, y)
+    worst = max(relerr(a, ref_g[k]) for k, a in zip(PO, og))
+    assert worst < 1e-4, worst
+    save("edvr_l_64x64", wseed=8, xseed=seed, tseed=seed + 100, h=h, w=w, out_sub=y[:, :, ::4, ::4],
+         out_norm=float(y.double().norm()), out_sum=float(y.double().sum()), loss=float(loss),
+         grad_norms=np.array([float(g.norm()) for g in ref_g.values()]),
+         **{"grad__" + k.replace(".", "__"): ref_g[k] for k in
+            ("conv_first.weight", "pcd_align.L1_dcnpack.conv_offset_mask.bias", "tsa_fusion.tAtt_1.bias",
+             "recon_trunk.39.conv2.bias", "conv_last.weight")})
+
+
 def mfdn_full(L):
     """G5: MFDN x4 forward/backward on 1x5x3x32x32 through the reference module."""
     M = synth.mfdn_state_dict(0)
@@ -442,6 +471,7 @@ if __name__ == "__main__":
     if "pcd" in which: pcd_tsa(E)
     if "edvr" in which: edvr_full(E)
     if "edvr" in which or "edvr_x2" in which: edvr_x2(E)
+    if "edvr_l" in which: edvr_l(E)      # several minutes on 8 cores; not part of the default set
     if "mfdn" in which: mfdn_full(L)
     if "estimators" in which: estimator_variants(L)
     if "inner" in which: inner_step(models, U)
