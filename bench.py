@@ -1,16 +1,27 @@
 #!/usr/bin/env python3
-"""Benchmark of the EDVR hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+"""Benchmark of the EDVR hot path on MI355X (contract: see the task statement / DESIGN.md §5).
 
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-One step = one pass of the hot path over one synthetic clip per GPU:
-EDVR-M x4 forward, 1x5x3x180x320 -> 3x720x1280, fp32 (BASELINE.json configs[1]).  Clips are
-independent work items, so ranks shard clips with no data-path collective:
-"scaling": "weak".  Rank 0 prints ONE JSON line.
+`value` -- one step = one pass of the hot path over one synthetic clip per GPU: EDVR-M x4 forward,
+1x5x3x180x320 -> 3x720x1280, fp32 (BASELINE.json configs[1], the configuration the metric is quoted on).
+Clips are independent work items, so ranks shard clips with no data-path collective:
+"scaling": "weak".  Rank 0 prints ONE JSON line.  Beside the headline the line carries:
+  roofline           dominant kernel of the headline forward, hipEvents around every launch
+  inner_step         (ii) one inner MAML step at LR 176x320 (MFDN fwd+bwd, EDVR fwd+bwd on the SLR clip, losses,
+                     Adam) over >= 50 steps, with its own roofline object and the launches per step
+  per_frame_pipeline (iii) baseline forward + inner step + adapted forward per frame (adapt_video)
+  meta_step          configs[3]: every rank runs one outer meta-training iteration on its shard of the tasks and
+                     the meta-gradient is all-reduced over RCCL (the one real exchange step of the method)
+  edvr_l_bf16        configs[4]: EDVR-L x4 1x7x3x64x64 on the three MFMA modes
+  cpu_baseline       the CPU oracle on this box's host cores (a reported baseline, not the target)
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
 import sys
 import time
 
@@ -20,48 +31,137 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, dense bf16
 HBM_PEAK_GBS = 8000.0           # same guide, HBM3E peak
 
-
-def cpu_baseline(cfg, h, w, seed, y_gpu=None):
-    """The CPU oracle (torch CPU convs + C restatement of the DCN) timed on this box's host cores
-    on ONE clip of the same workload.  A reported baseline, not the target.  The same clip was run by the
-    timed loop on rank 0, so the oracle's output doubles as the full-size parity check (`y_gpu`)."""
-    from dynavsr_amd import synth
-    from oracle import dcn as odcn, edvr as oedvr
-    odcn.lib()
-    P = synth.edvr_state_dict(seed)
-    x = synth.clip(1, 1, cfg["nframes"], h, w, smooth=False)
-    threads = torch.get_num_threads()
-    with torch.no_grad():
-        t0 = time.time()
-        ref = oedvr.edvr_forward(P, x)
-        dt = time.time() - t0
-    out = {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-           "sample": "1 clip forward (EDVR-M x4, 1x5x3x%dx%d), fp32, oracle/edvr.py on %d torch/OpenMP "
-                     "threads of %d host cpus, no warm-up" % (h, w, threads, os.cpu_count())}
-    if y_gpu is not None:
-        d = (y_gpu.detach().cpu().double() - ref.double())
-        out["parity_vs_this_run"] = {"rel_l2": float(d.norm() / ref.double().norm()), "max_abs": float(d.abs().max()),
-                                     "psnr_db": float(10 * torch.log10(1.0 / (d ** 2).mean()))}
-    return out
+# Algorithmic work (probe-derived; scales linearly in H*W)
+F_EDVR_M_180 = 973.6e9          # EDVR-M x4 forward, 1x5x3x180x320
+F_MFDN_180 = 53.1e9             # MFDN x4 forward, 5 frames of 180x320
+F_EDVR_L_64 = 373.4e9           # EDVR-L x4 forward, 1x7x3x64x64
 
 
-def inner_step_rate(dev, steps=8):
-    """Secondary figure (north_star target >= 50 clips/s): one inner MAML step through the wrapper
-    API at LR 176x320 -> SLR 44x80: MFDN forward with grad, EDVR forward+backward on the SLR clip,
-    Charbonnier + 10*L1 losses, Adam step over G u E parameters (test_dynavsr.py:235-277)."""
-    from copy import deepcopy
-    import torch.nn.functional as F
-    from dynavsr_amd import synth
-    from dynavsr_amd.adapt import make_inner_optimizer
-    from dynavsr_amd.models import create_model
+def f_edvr(h, w):
+    return F_EDVR_M_180 * (h * w) / (180.0 * 320.0)
+
+
+def f_mfdn(h, w):
+    return F_MFDN_180 * (h * w) / (180.0 * 320.0)
+
+
+def f_inner(h, w):
+    """3 x EDVR(SLR) (forward, data gradient, weight gradient) + 3 x MFDN(LR) + the frozen MFDN: 386 GFLOP @176x320."""
+    return 3 * f_edvr(h // 4, w // 4) + 4 * f_mfdn(h, w)
+
+
+def _opt():
     from dynavsr_amd.options import options as option
     opt = option.dict_to_nonedict(option.parse(os.path.join(
         ROOT, "dynavsr_amd", "options", "test", "EDVR", "EDVR_M_S4.yml"), is_train=False))
     opt["dist"] = False
     for k in ("pretrain_model_G", "pretrain_model_E"):
         opt["path"][k] = None
+    return opt
+
+
+def _sources_digest():
+    """Identity of the conv kernel sources the committed PMC traffic figure was collected on."""
+    h = hashlib.sha256()
+    for f in ("conv2d_v2.hip", "small_grid.h", "common.h"):
+        with open(os.path.join(ROOT, "dynavsr_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+# ---- CPU baseline ---------------------------------------------------------------------------------
+def cpu_baseline(cfg, h, w, seed, y_gpu=None):
+    """The CPU oracle (torch CPU convs + C restatement of the DCN) timed on this box's host cores on a bounded
+    sample of the same workloads: forward @HxW on all cores (1 warm-up + median of 3), forward
+    @64x64 on ONE core and on all cores (1 warm-up + median of 3 each), one inner step @176x320 on all cores
+    (1 warm-up + median of 3).  The headline clip was run by the timed GPU loop on rank 0, so the oracle's
+    output doubles as the full-size parity check (`y_gpu`)."""
+    from collections import OrderedDict
+    import torch.nn.functional as F
+    from dynavsr_amd import synth
+    from oracle import dcn as odcn, edvr as oedvr, mfdn as omfdn
+    odcn.lib()
+    P = synth.edvr_state_dict(seed)
+    all_threads = torch.get_num_threads()
+
+    def med(fn, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    ref = [None]
+    x = synth.clip(1, 1, cfg["nframes"], h, w, smooth=False)
+
+    def fwd_big():
+        with torch.no_grad():
+            ref[0] = oedvr.edvr_forward(P, x)
+    t_all = med(fwd_big)
+    x64 = synth.clip(1, 1, cfg["nframes"], 64, 64, smooth=False)
+
+    def fwd64():
+        with torch.no_grad():
+            oedvr.edvr_forward(P, x64)
+    t64_all = med(fwd64)
+    def omp_threads(n):   # the C DCN oracle is plain OpenMP (libgomp); torch may run its own pool
+        torch.set_num_threads(n)
+        try:
+            import ctypes
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(n)
+        except OSError:
+            pass
+    omp_threads(1)
+    try:
+        t64_one = med(fwd64)
+    finally:
+        omp_threads(all_threads)
+    # one inner MAML step (test_dynavsr.py:235-277) at LR 176x320 through the oracle's functions
+    PG = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in P.items())
+    PE = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in synth.mfdn_state_dict(0).items())
+    lqs = synth.clip(3, 1, 5, 176, 320, smooth=False)
+    with torch.no_grad():
+        slr_fixed = omfdn.mfdn_forward(synth.mfdn_state_dict(1), lqs)
+    adam = torch.optim.Adam(list(PG.values()) + list(PE.values()), lr=1e-5, betas=(0.9, 0.99))
+
+    def inner():
+        adam.zero_grad()
+        slr = omfdn.mfdn_forward(PE, lqs)
+        loss = oedvr.charbonnier(oedvr.edvr_forward(PG, slr), lqs[:, 2]) + 10 * F.l1_loss(slr, slr_fixed)
+        loss.backward()
+        adam.step()
+    t_inner = med(inner)
+    out = {"value": 1.0 / t_all, "unit": "frames/s", "cores": all_threads, "kind": "port",
+           "sample": "EDVR-M x4 forward, 1 clip 1x5x3x%dx%d, fp32, oracle/edvr.py (torch CPU convs + the C DCN oracle) on "
+                     "%d torch/OpenMP threads of %d host cpus; 1 warm-up, median of 3" % (h, w, all_threads, os.cpu_count()),
+           "forward_64x64": {"all_cores": {"value": 1.0 / t64_all, "unit": "frames/s", "cores": all_threads},
+                             "single_core": {"value": 1.0 / t64_one, "unit": "frames/s", "cores": 1},
+                             "sample": "1x5x3x64x64 (BASELINE configs[0] size), 1 warm-up, median of 3"},
+           "inner_step_176x320": {"value": 1.0 / t_inner, "unit": "clips/s", "cores": all_threads,
+                                  "sample": "MFDN fwd+bwd @176x320, EDVR fwd+bwd @44x80, Charbonnier + 10 L1, Adam; "
+                                            "frozen MFDN hoisted like the GPU path; 1 warm-up, median of 3"}}
+    if y_gpu is not None:
+        d = (y_gpu.detach().cpu().double() - ref[0].double())
+        out["parity_vs_this_run"] = {"rel_l2": float(d.norm() / ref[0].double().norm()), "max_abs": float(d.abs().max()),
+                                     "psnr_db": float(10 * torch.log10(1.0 / (d ** 2).mean()))}
+    return out
+
+
+# ---- inner MAML step (SURVEY §8d ii) --------------------------------------------------------------
+def inner_step_rate(dev, steps=60, h=176, w=320):
+    """One inner MAML step through the wrapper API at LR 176x320 -> SLR 44x80: MFDN forward with grad, EDVR
+    forward+backward on the SLR clip, Charbonnier + 10*L1 losses, Adam step over G u E parameters
+    (test_dynavsr.py:235-277).  north_star target: >= 50 clips/s."""
+    from copy import deepcopy
+    from dynavsr_amd import engine, hipops, synth
+    from dynavsr_amd.adapt import make_inner_optimizer
+    from dynavsr_amd.models import create_model
+    opt = _opt()
     model, est = create_model(opt)
     _, est_fixed = create_model(opt)
     model.netG.load_state_dict(synth.edvr_state_dict(0))
@@ -70,7 +170,7 @@ def inner_step_rate(dev, steps=8):
     netG, netE = deepcopy(model.netG), deepcopy(est.netE)
     model.netG, est.netE = netG, netE
     inner = make_inner_optimizer(opt, netG, netE)
-    lqs = synth.clip(3, 1, 5, 176, 320, smooth=False).to(dev)
+    lqs = synth.clip(3, 1, 5, h, w, smooth=False).to(dev)
     data = {"LQs": lqs}
     est_fixed.feed_data(data); est_fixed.test()
     slr_fixed = est_fixed.fake_L
@@ -79,11 +179,11 @@ def inner_step_rate(dev, steps=8):
         est.feed_data(data); est.forward_without_optim()
         inner.zero_grad()
         model.feed_data({"LQs": est.fake_L, "GT": lqs[:, 2]})
-        loss = model.calculate_loss() + 10 * F.l1_loss(est.fake_L, slr_fixed)
+        loss = hipops.inner_loss(model.calculate_loss(), est.fake_L, slr_fixed, 10.0)
         loss.backward()
         inner.step()
 
-    for _ in range(3):
+    for _ in range(5):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -91,15 +191,175 @@ def inner_step_rate(dev, steps=8):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    fl = f_inner(h, w)
+    ach = fl / (ms * 1e-3) / 1e12
+    gp = engine.get_plan(netG._cfg(), 1, h // 4, w // 4)
+    ep = engine.get_estimator_plan((engine.MFDN, netE.nf, netE.in_nc, netE.scale, lqs.shape[1]), 1, h, w)
+    launches = {"edvr_forward": gp.n_launches, "edvr_backward": gp.n_backward_launches,
+                "estimator_forward": ep.n_launches, "estimator_backward": ep.n_backward_launches}
     return {"value": 1e3 / ms, "unit": "clips/s", "ms_per_step": ms, "steps": steps,
-            "workload": "1 inner MAML step, EDVR-M x4 + MFDN, LR 1x5x3x176x320 -> SLR 44x80, fp32, Adam; "
-                        "MFDN runs on the native estimator tape (dvsr_estimator_*)"}
+            "workload": "1 inner MAML step, EDVR-M x4 + MFDN, LR 1x5x3x%dx%d -> SLR %dx%d, fp32, Adam; both networks "
+                        "on their native tapes; the frozen estimator's output is computed once per frame, outside "
+                        "the step loop (SURVEY 8f-1)" % (h, w, h // 4, w // 4),
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_gflop_per_step": fl / 1e9,
+                         "note": "whole step (not one kernel): SURVEY 8d's 386 GFLOP x H*W scaling / step time / fp32 MFMA peak"},
+            "tape_ops_per_step": launches,
+            "target_clips_per_s": 50}
+
+
+# ---- per-frame pipeline (SURVEY §8d iii) ----------------------------------------------------------
+def per_frame_pipeline_rate(dev, clips=10, h=176, w=320):
+    """test_dynavsr.py:197-283 per frame: un-adapted baseline forward, copies refreshed, one inner step, adapted
+    forward -- adapt_video with the two full-size forwards on side streams under the next clip's adaptation."""
+    from dynavsr_amd import synth
+    from dynavsr_amd.adapt import adapt_video
+    from dynavsr_amd.models import create_model
+    opt = _opt()
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    model.netG.load_state_dict(synth.edvr_state_dict(0)); est.netE.load_state_dict(synth.mfdn_state_dict(0))
+    est_fixed.netE.load_state_dict(synth.mfdn_state_dict(1))
+    data = [{"LQs": synth.clip(10 + i, 1, 5, h, w, smooth=False).to(dev)} for i in range(clips)]
+    out = {}
+    for name, ov in (("sequential", False), ("overlapped", True)):
+        for _ in adapt_video(opt, model, est, modelcp, estcp, est_fixed, data[:3], overlap=ov):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in adapt_video(opt, model, est, modelcp, estcp, est_fixed, data, overlap=ov):
+            pass
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / clips * 1e3
+    ms = out["overlapped"]
+    fl = 2 * f_edvr(h, w) + f_inner(h, w)
+    ach = fl / (ms * 1e-3) / 1e12
+    return {"value": 1e3 / ms, "unit": "frames/s", "ms_per_frame": ms, "ms_per_frame_sequential": out["sequential"],
+            "clips": clips,
+            "workload": "per frame: baseline EDVR-M x4 forward @%dx%d + 1 inner MAML step + adapted forward @%dx%d "
+                        "(the baseline forward is report-only in the reference and is measured here too)" % (h, w, h, w),
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_gflop_per_frame": fl / 1e9}}
+
+
+# ---- configs[3]: one outer meta-training iteration with the RCCL exchange -----------------------------
+def meta_step_rate(dev, world, dist, tasks_per_rank=2, iters=4):
+    """Every rank: adapt.meta_train_step on its own `tasks_per_rank` tasks at the training YAML's shapes (LR 5x3x64x64,
+    SLR 16x16, HR 256x256; train_dynavsr.py:265-438), with the meta-gradient all-reduce over the process group.
+    The collective alone is timed separately on the same flat buffer."""
+    from dynavsr_amd import dist as D, synth
+    from dynavsr_amd.adapt import meta_train_step
+    from dynavsr_amd.models import create_model
+    rank = dist.get_rank() if dist is not None else 0
+    opt = _opt()
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    model.netG.load_state_dict(synth.edvr_state_dict(0)); est.netE.load_state_dict(synth.mfdn_state_dict(0))
+    params = list(model.netG.parameters()) + list(est.netE.parameters())
+    optimizer = torch.optim.Adam(params, lr=1e-5, betas=(0.9, 0.99))
+    B = tasks_per_rank
+    data = {"LQs": synth.clip(100 + rank, B, 5, 64, 64, smooth=False).to(dev),
+            "SuperLQs": synth.clip(200 + rank, B, 5, 16, 16, smooth=False).to(dev),
+            "GT": synth.clip(300 + rank, B, 5, 256, 256, smooth=False).to(dev)}
+    force = dist is not None
+
+    def it():
+        return meta_train_step(opt, model, est, modelcp, estcp, data, optimizer, inner="reference",
+                               force_collective=force)
+    for _ in range(2):
+        it()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        r = it()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / iters
+    # the exchange step alone
+    nbytes, ar_ms = None, None
+    if dist is not None:
+        for _ in range(2):
+            nbytes = D.allreduce_meta_gradients([model.netG, est.netE], average=True, force=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            D.allreduce_meta_gradients([model.netG, est.netE], average=True, force=True)
+        torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - t0) / 10 * 1e3
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return {"value": world * B / dt, "unit": "tasks/s (all ranks)", "tasks_per_s_per_gpu": B / dt,
+            "ms_per_outer_iteration": dt * 1e3, "tasks_per_rank": B, "ranks": world,
+            "allreduce": {"backend": "nccl (RCCL)" if dist is not None else None, "bytes": nbytes, "ms": ar_ms,
+                          "includes": "pack of the .grad tensors into one flat fp32 buffer, ONE all-reduce, unpack",
+                          "executed": dist is not None},
+            "loss_q": r["loss_q"],
+            "workload": "train_dynavsr.py outer iteration (inner='reference'), EDVR-M x4 + MFDN, per rank %d tasks of LR "
+                        "5x3x64x64 / SLR 16x16 / HR 256x256, 1 inner Adam step, meta Adam; weak scaling over ranks" % B}
+
+
+# ---- configs[4]: EDVR-L on the three MFMA modes -----------------------------------------------------
+def edvr_l_rates(dev, steps=10):
+    from dynavsr_amd import hipops, synth
+    from dynavsr_amd.models.archs.EDVR_arch import EDVR
+    cfg = dict(nf=128, nframes=7, groups=8, front_RBs=5, back_RBs=40, scale=4)
+    x = synth.clip(9, 1, 7, 64, 64, smooth=False).to(dev)
+    tgt = synth.clip(109, 1, 1, 256, 256, smooth=False)[:, 0].to(dev)
+    out, y0 = {}, None
+    for mode, name in ((0, "fp32_mfma"), (1, "bf16_operands"), (2, "bf16_split3")):
+        net = EDVR(bf16_mfma=mode, **cfg)
+        net.load_state_dict(synth.edvr_state_dict(8, **cfg), strict=True)
+        net = net.to(dev)
+
+        def fwd():
+            with torch.no_grad():
+                return net(x)
+
+        def fwd_bwd():
+            for p in net.parameters():
+                p.grad = None
+            hipops.charbonnier(net(x), tgt).backward()
+        res = {}
+        for key, fn, mult in (("forward", fwd, 1.0), ("forward_backward", fwd_bwd, 3.0)):
+            for _ in range(3):
+                y = fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                y = fn()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            res[key] = {"ms": ms, "tflops": mult * F_EDVR_L_64 / (ms * 1e-3) / 1e12}
+            if key == "forward":
+                yf = y
+        if mode == 0:
+            y0 = yf
+        else:
+            d = (yf - y0).double()
+            res["rel_l2_vs_fp32_mfma"] = float(d.norm() / y0.double().norm())
+            res["psnr_db_vs_fp32_mfma"] = float(10 * torch.log10(1.0 / (d ** 2).mean()))
+        peak = FP32_MFMA_PEAK_TFLOPS if mode == 0 else BF16_MFMA_PEAK_TFLOPS / (6.0 if mode == 2 else 1.0)
+        res["roofline"] = {"bound": "mfma", "achieved": res["forward"]["tflops"], "peak": peak, "unit": "TFLOP/s",
+                           "frac": res["forward"]["tflops"] / peak, "traffic": None}
+        out[name] = res
+        del net
+    out["workload"] = ("EDVR-L x4 (nf 128, 7 frames, 40 blocks) 1x7x3x64x64 -> 3x256x256 (BASELINE configs[4] tile), "
+                       "373.4 GFLOP forward; bf16 modes: 3x3 stride-1 convolutions (forward + data gradient) on "
+                       "v_mfma_f32_32x32x16_bf16 with fp32 accumulate, everything else fp32; peak for bf16_split3 = "
+                       "2500/6 TFLOP/s of fp32-equivalent work (six bf16 products per fp32 product)")
+    return out
 
 
 def split_mode_rate(cfg, h, w, x, y_fp32, steps, warmup):
-    """The same forward with network_G.bf16_mfma = 2: every fp32 operand of the 3x3 convs split
-    into three bf16 pieces, six products on the bf16 MFMA, fp32 accumulation.  Reported BESIDE the headline,
-    never as it: `value` above is the exact-fp32 MFMA path."""
+    """The headline forward with network_G.bf16_mfma = 2: reported BESIDE the headline, never as it."""
     from dynavsr_amd import synth
     from dynavsr_amd.models.archs.EDVR_arch import EDVR
     net = EDVR(bf16_mfma=2, **cfg)
@@ -123,6 +383,11 @@ def split_mode_rate(cfg, h, w, x, y_fp32, steps, warmup):
 
 
 def main():
+    # The ONE JSON line must be the only thing on stdout: RCCL prints a version banner there (from C, flushed at exit),
+    # so file descriptor 1 is pointed at stderr for the whole run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -130,8 +395,9 @@ def main():
     ap.add_argument("--height", type=int, default=180)
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-inner-step", action="store_true")
-    ap.add_argument("--no-split", action="store_true", help="skip the experimental bf16-split timing")
+    ap.add_argument("--no-inner-step", action="store_true", help="skip the inner-step and per-frame-pipeline legs")
+    ap.add_argument("--no-split", action="store_true", help="skip the bf16 legs (split-mode forward, EDVR-L)")
+    ap.add_argument("--no-meta", action="store_true", help="skip the meta-training iteration with the RCCL all-reduce")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -144,12 +410,23 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with 1 rank)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dist, dist_err = None, None
+    try:
+        import torch.distributed as tdist
+        if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with 1 rank)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        elif not args.no_meta:                  # plain `python bench.py`: a one-rank RCCL group for the meta_step leg
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                     device_id=dev)
+        if tdist.is_initialized():
+            dist = tdist
+    except Exception as e:   # only the optional one-rank group may fail softly
+        if world > 1:
+            raise
+        dist_err = "%s: %s" % (type(e).__name__, e)
 
     from dynavsr_amd import engine, synth
     from dynavsr_amd.models.archs.EDVR_arch import EDVR
@@ -182,11 +459,23 @@ def main():
         elapsed = float(t)
     assert torch.isfinite(y).all()
 
+    meta = None
+    if not args.no_meta:   # every rank takes part (the collective)
+        try:
+            meta = meta_step_rate(dev, world, dist)
+        except Exception as e:
+            if world > 1:
+                raise
+            meta = {"error": "%s: %s" % (type(e).__name__, e)}
+        if dist_err:
+            meta["process_group_error"] = dist_err
+
     line = None
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         line = {
-            "metric": "inner-loop frames/sec/GPU (EDVR-M x4, 5x3x180x320)",
+            "metric": "inner-loop frames/sec/GPU (EDVR-M x4, 5x3x180x320): forward leg = BASELINE.json configs[1]; "
+                      "the inner MAML step and the per-frame pipeline are `inner_step` / `per_frame_pipeline`",
             "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -218,33 +507,47 @@ def main():
             ach = by / (t_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS}
-        traffic, traffic_src = None, None
-        try:   # HBM bytes per launch from the committed PMC passes (cannot be collected inside this process)
+        # HBM bytes per launch from the committed PMC passes (counters cannot be collected inside this process).
+        # The file names the kernel sources it was collected on; a figure from other sources is NOT reported.
+        traffic, traffic_src, traffic_err = None, None, None
+        try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                t = json.load(f).get(dom)
+                tj = json.load(f)
+            t = tj.get(dom)
             if t and (h, w) == (180, 320):
-                traffic, traffic_src = t["bytes_per_launch"], t["source"]
-        except (OSError, ValueError):
-            pass
+                if tj.get("sources_sha256_16") == _sources_digest():
+                    traffic, traffic_src = t["bytes_per_launch"], t["source"]
+                else:
+                    traffic_err = ("profiles/pmc_traffic.json was collected on other kernel sources (%s, now %s): re-run "
+                                   "tools/collect_profiles.sh" % (tj.get("sources_sha256_16"), _sources_digest()))
+                    print("bench.py: STALE PMC TRAFFIC -- " + traffic_err, file=sys.stderr, flush=True)
+        except (OSError, ValueError) as e:
+            traffic_err = "profiles/pmc_traffic.json unreadable: %s" % e
         roof.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": dom, "launches_per_step": cnt // reps,
                      "avg_launch_ms": t_ms / cnt, "share_of_step": t_ms / total_ms,
                      "method": "hipEvent pair around every launch on the launch stream, %d instrumented "
                                "passes after the timed region" % reps})
+        if traffic_err:
+            roof["traffic_error"] = traffic_err
         line["roofline"] = roof
         line["kernel_breakdown_ms_per_step"] = {k: round(a[0] / reps, 4) for k, a in
                                                 sorted(acc.items(), key=lambda kv: -kv[1][0])}
         line["end_to_end_tflops"] = sum(a[1] for a in acc.values()) / reps / (ms * 1e-3) / 1e12
-        if world == 1 and not args.no_split:
-            line["experimental_bf16_split"] = split_mode_rate(cfg, h, w, x, y, args.steps, args.warmup)
+        if meta is not None:
+            line["meta_step"] = meta
         if world == 1 and not args.no_inner_step:
             line["inner_step"] = inner_step_rate(dev)
+            line["per_frame_pipeline"] = per_frame_pipeline_rate(dev)
+        if world == 1 and not args.no_split:
+            line["experimental_bf16_split"] = split_mode_rate(cfg, h, w, x, y, args.steps, args.warmup)
+            line["edvr_l_bf16"] = edvr_l_rates(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, h, w, 0, y)   # same clip (seed 1 + rank 0), same weights
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if line is not None:
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
 
 if __name__ == "__main__":

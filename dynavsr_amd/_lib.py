@@ -64,6 +64,7 @@ def _declare(lib):
         "dvsr_estimator_plan_create": (I, [POINTER(EstimatorConfig), I, I, I, POINTER(c_void_p)]),
         "dvsr_estimator_plan_destroy": (None, [P]),
         "dvsr_estimator_num_params": (I, [P]),
+        "dvsr_estimator_num_launches": (I, [P, I]),
         "dvsr_estimator_workspace_bytes": (c_size_t, [P, I]),
         "dvsr_estimator_forward": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P]),
         "dvsr_estimator_backward": (I, [P, POINTER(c_void_p), P, P, POINTER(c_void_p), P, c_size_t, P]),
@@ -78,6 +79,8 @@ def _declare(lib):
         "dvsr_frame_metrics": (I, [P, P, I, I, I, F, F, P, P, P, c_size_t, P]),
         "dvsr_charbonnier_workspace_bytes": (c_size_t, []),
         "dvsr_charbonnier_forward": (I, [P, P, P, LL, F, P, c_size_t, P]),
+        "dvsr_l1_tail_forward": (I, [P, P, P, F, P, LL, P, c_size_t, P]),
+        "dvsr_l1_tail_backward": (I, [P, P, P, F, P, LL, P]),
         "dvsr_charbonnier_backward": (I, [P, P, P, P, LL, F, P]),
         "dvsr_edvr_op_info": (I, [P, I, c_char_p, I, c_char_p, I, POINTER(ctypes.c_double),
                                   POINTER(ctypes.c_double)]),

@@ -17,7 +17,7 @@ from copy import deepcopy
 import torch
 import torch.nn.functional as F
 
-from . import optim
+from . import hipops, optim
 
 
 def make_inner_optimizer(opt, netG, netE):
@@ -100,7 +100,10 @@ def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, va
         inner.zero_grad()
         modelcp.feed_data({'LQs': slr, 'GT': target})
         loss = modelcp.calculate_loss()
-        loss = loss + slr_weight * F.l1_loss(slr.to(slr_fixed.device), slr_fixed)
+        if slr.is_cuda and loss.is_cuda:       # one native reduction for the L1 tail (hipops.inner_loss)
+            loss = hipops.inner_loss(loss, slr, slr_fixed, slr_weight)
+        else:
+            loss = loss + slr_weight * F.l1_loss(slr.to(slr_fixed.device), slr_fixed)
         loss.backward()
         inner.step()
         losses.append(loss.detach())
@@ -112,7 +115,7 @@ def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, va
 
 
 def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, optimizer, inner='reference',
-                    group=None):
+                    group=None, force_collective=False):
     """One outer (meta) iteration of the DynaVSR training driver, codes/train_dynavsr.py:265-438, over the
     wrapper API: the tasks of the batch are looped one clip at a time (:300), every task contributes its
     meta-gradient to ``model.netG`` / ``est_model.netE``'s ``.grad``, and the meta optimiser steps once (:438).
@@ -190,7 +193,7 @@ def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, opt
         total_q += float(loss_q.detach()) / B
         log_e.append(loss_e.detach())
     if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-        D.allreduce_meta_gradients([model.netG, est_model.netE], average=True, group=group)
+        D.allreduce_meta_gradients([model.netG, est_model.netE], average=True, group=group, force=force_collective)
     optimizer.step()
     return {'loss_q': total_q, 'loss_train': log_train, 'loss_e': log_e}
 

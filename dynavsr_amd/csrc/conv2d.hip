@@ -172,7 +172,8 @@ int conv2d_run(const dvsr_conv2d_desc& d, const ConvExtra& ex, hipStream_t st) {
   DVSR_REQUIRE(d.N > 0 && d.c0 > 0 && d.c1 >= 0 && d.H > 0 && d.W > 0 && d.Cout > 0,
                DVSR_ERR_INVALID, "conv2d: non-positive dimension");
   DVSR_REQUIRE(d.c1 == 0 || d.x1, DVSR_ERR_INVALID, "conv2d: c1 > 0 but x1 is null");
-  DVSR_REQUIRE(d.ks == 1 || d.ks == 3, DVSR_ERR_UNSUPPORTED, "conv2d: ks=%d (supported: 1, 3)", d.ks);
+  DVSR_REQUIRE(d.ks == 1 || d.ks == 3 || d.ks == 7 || d.ks == 9, DVSR_ERR_UNSUPPORTED,
+               "conv2d: ks=%d (supported: 1, 3, and the 7 / 9 of TOFlow)", d.ks);
   DVSR_REQUIRE(d.stride == 1 || (d.stride == 2 && d.ks == 3), DVSR_ERR_UNSUPPORTED,
                "conv2d: stride=%d with ks=%d unsupported", d.stride, d.ks);
   DVSR_REQUIRE(d.pad == d.ks / 2, DVSR_ERR_UNSUPPORTED, "conv2d: pad=%d must be ks/2", d.pad);
@@ -200,6 +201,10 @@ int conv2d_run(const dvsr_conv2d_desc& d, const ConvExtra& ex, hipStream_t st) {
   if (k.in_dil) k.x0_bs = (long long)d.c0 * ex.Hs * ex.Ws;
   if (d.ks == 3 && d.stride == 1) return launch_conv<3, 1, 8>(k, st);
   if (d.ks == 3 && d.stride == 2) return launch_conv<3, 2, 8>(k, st);
+  // SpyNet's 7x7 and TOFlow's 9x9 (TOF_arch.py:32-42, 107-108): chunks sized so that the 64 x CC x ks^2 weight
+  // image fits LDS next to the halo tile (119 KB / 94 KB: one workgroup per CU)
+  if (d.ks == 7) return launch_conv<7, 1, 8>(k, st);
+  if (d.ks == 9) return launch_conv<9, 1, 4>(k, st);
   return launch_conv<1, 1, 32>(k, st);
 }
 

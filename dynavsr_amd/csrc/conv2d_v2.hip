@@ -24,20 +24,9 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "small_grid.h"
 
 namespace dvsr {
-
-struct ConvK2 {
-  const float* x0; const float* x1; const float* wp; const float* bias; const float* res; float* y;
-  int N, c0, c1, H, W, Cout, Ho, Wo, pad, act, ps, x1_bdiv;
-  long long x0_bs, x1_bs;
-  int tiles_x, tiles_y, ntiles, ncb, nchunks, nitems, tiles_per_xcd;
-  int in_ps, in_dil, Hs, Ws, accum;
-  const float* gmask; int gmask_act;
-#ifdef DVSR_CONV_TRACE
-  long long* trace;  // debug build only (tools/conv_trace.py): 64 cycle stamps per workgroup
-#endif
-};
 
 // Debug timeline: thread 0 of every workgroup stamps s_memtime at the phase boundaries of the
 // pipeline.  Compiled in only with -DDVSR_CONV_TRACE (a separate library; the product build has none).
@@ -526,6 +515,25 @@ static int launch_conv2(ConvK2 k, hipStream_t st) {
   return check_launch("conv2d_pipe_kernel");
 }
 
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void conv2d_ksplit_kernel(ConvK2 a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv2d_ksplit_item<MT, NT>(a, blockIdx.x, smem);
+}
+
+template <int MT, int NT>
+static int launch_ksplit(ConvK2 k, hipStream_t st) {
+  using Sh = KsShape<MT, NT>;
+  auto kern = conv2d_ksplit_kernel<MT, NT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(k.nitems), dim3(256), Sh::LDS_BYTES, st, k);  // tiles: conv2d_packed_prepare
+  return check_launch("conv2d_ksplit_kernel");
+}
+
 // Launch geometry.  Calibrated on MI355X per-layer timings of all five candidate geometries
 // (profiles/r01_conv_geometry_sweep.txt): the 4x32-pixel tile beats 8x32 on every EDVR layer, 16-channel
 // chunks never beat 8, and between 64 (MT=2) and 32 (MT=1) output channels per workgroup the winner is
@@ -539,7 +547,26 @@ static double conv2_pipe_cost(int TH, int MT, int KK, int CC, int N, int Ho, int
   return ceil(wgs / 256.0) * 64.0 * KK * (CC / 2) * (TH / 4) * MT;
 }
 
-ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ctot) {
+ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ctot, int allow_ksplit) {
+  // Small grids: the K-split kernel (geo {32, NT, MT} with ks == 3).  DVSR_CONV_KSPLIT_BELOW=<workgroups of the
+  // 4x32x32 geometry> moves the threshold (0 disables); DVSR_CONV_KSPLIT_NT=1|2 pins the tile shape.
+  if (ks == 3 && stride == 1 && allow_ksplit && Ctot >= 32 && Cout >= 32) {
+    static int below = -1, pin_nt = -1;
+    if (below < 0) {
+      const char* v = getenv("DVSR_CONV_KSPLIT_BELOW");
+      below = v ? atoi(v) : 1400;
+      const char* n = getenv("DVSR_CONV_KSPLIT_NT");
+      pin_nt = n ? atoi(n) : 0;
+    }
+    const long long wg41 = (long long)ceil_div(Wo, 32) * ceil_div(Ho, 4) * N * ceil_div(Cout, 32);
+    if (wg41 < below) {
+      // 1 row x 64 couts (even row count not needed) or 2 rows x 32 couts: the latter halves the weight traffic
+      // per workgroup but needs an even split of the rows and Cout in 32-blocks; 64-wide blocks waste less when
+      // Cout % 64 == 0
+      const bool nt2 = pin_nt ? pin_nt == 2 : (Cout % 64 != 0 && Ho % 2 == 0);
+      return nt2 ? ConvGeo{32, 2, 1} : ConvGeo{32, 1, 2};
+    }
+  }
   static int force = -2;  // DVSR_CONV_TILE=0|1|2 pins (8,2)/(4,2)/(4,1) tiles (A/B aid); default: model
   if (force == -2) {
     const char* v = getenv("DVSR_CONV_TILE");
@@ -589,14 +616,13 @@ extern "C" int dvsr_debug_conv_trace(void* buf, int launch_index) {
 }
 #endif
 
-int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo,
-                      hipStream_t st) {
+int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo, ConvK2* out) {
   DVSR_REQUIRE(d.x0 && wp && d.y, DVSR_ERR_INVALID, "conv2d_packed: null x0/wp/y");
   DVSR_REQUIRE(((d.ks == 1 || d.ks == 2) && d.stride == 1) || (d.ks == 3 && (d.stride == 1 || d.stride == 2)),
                DVSR_ERR_UNSUPPORTED, "conv2d_packed: ks=%d stride=%d", d.ks, d.stride);
   DVSR_REQUIRE(d.c1 == 0 || (d.c0 % geo.cc == 0 && !ex.in_ps && !ex.in_dil), DVSR_ERR_UNSUPPORTED,
                "conv2d_packed: two inputs need c0 %% %d == 0 and a plain first input (c0=%d)", geo.cc, d.c0);
-  ConvK2 k;
+  ConvK2& k = *out;
   k.x0 = d.x0; k.x1 = d.x1; k.wp = wp; k.bias = d.bias; k.res = d.res; k.y = d.y;
   k.N = d.N; k.c0 = d.c0; k.c1 = d.c1; k.H = d.H; k.W = d.W; k.Cout = d.Cout;
   k.pad = d.pad; k.act = d.act; k.ps = d.pixel_shuffle; k.x1_bdiv = d.x1_bdiv > 0 ? d.x1_bdiv : 1;
@@ -613,6 +639,24 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
   k.trace = (g_trace_countdown == 0) ? g_trace_buf : nullptr;
   if (g_trace_countdown >= 0) --g_trace_countdown;
 #endif
+  if (d.ks == 3 && geo.cc == 32) {  // K-split small-grid kernel: tile bookkeeping of its launch
+    DVSR_REQUIRE(d.stride == 1 && (d.c1 == 0 || d.c0 % 32 == 0) && !ex.in_ps && !ex.in_dil && d.pad == 1 &&
+                     ((geo.th == 1 && geo.mt == 2) || (geo.th == 2 && geo.mt == 1)),
+                 DVSR_ERR_UNSUPPORTED, "conv2d_packed: the K-split kernel needs 3x3/s1/pad 1, plain inputs, c0 %% 32 == 0 "
+                 "with two inputs (th=%d mt=%d)", geo.th, geo.mt);
+    k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, geo.th); k.ntiles = k.tiles_x * k.tiles_y * k.N;
+    k.ncb = ceil_div(k.Cout, 32 * geo.mt);
+    k.tiles_per_xcd = ceil_div(k.ntiles, 8);
+    k.nitems = k.tiles_per_xcd * 8 * k.ncb;
+  }
+  return DVSR_OK;
+}
+
+int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo,
+                      hipStream_t st) {
+  ConvK2 k;
+  int rc = conv2d_packed_prepare(d, wp, ex, geo, &k);
+  if (rc) return rc;
   const int code = geo.cc * 100 + geo.th * 10 + geo.mt;
   if (geo.bf) {
     DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && geo.cc == 16 && (geo.th == 4 || (geo.bf == 2 && geo.th == 8)),
@@ -628,6 +672,10 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
     }
     if (geo.mt == 2) return launch_conv2<3, 1, 16, 4, 2, 1>(k, st);
     return launch_conv2<3, 1, 16, 4, 1, 1>(k, st);
+  }
+  if (d.ks == 3 && geo.cc == 32) {  // K-split small-grid kernel
+    if (geo.mt == 2) return launch_ksplit<2, 1>(k, st);
+    return launch_ksplit<1, 2>(k, st);
   }
   if (d.ks == 3 && d.stride == 2) {
     switch (code) {

@@ -19,16 +19,9 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "small_grid.h"
 
 namespace dvsr {
-
-struct WgradK {
-  const float* x; const float* gy; float* partial; float* dbp;
-  long long x_bs;
-  int x_bdiv;
-  int N, Cin, H, W, Cout, Ho, Wo, pad, gy_ps;
-  int tiles_x, tiles_y, ntiles, nsplit, nob, ncb, nslot;
-};
 
 template <int KS, int S>
 struct WgShape {
@@ -141,142 +134,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
 //   * the bias gradient falls out of the A operands the MFMA loop reads anyway (one v_add per k-step).
 // 2 x 51.7 KB of LDS: one workgroup per CU, which is also what the pixel split produces.
 // -------------------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(256, 1) void conv2d_wgrad_pipe_kernel(WgradK a) {
-  using Sh = WgShape<KS, 1>;
-  constexpr int KK = KS * KS, IW = Sh::IW, PLANE = Sh::PLANE, PLANEP = Sh::PLANEP, GROW = Sh::GROW, NPX = Sh::NPX;
-  constexpr int XM = (PLANE + 63) / 64;  // wave-instructions per channel plane of the x tile
-  constexpr int BUF = 64 * GROW + 64 * PLANEP;
+template <int KS, bool KYS = false>
+__global__ __launch_bounds__(256, KYS ? 2 : 1) void conv2d_wgrad_pipe_kernel(WgradK a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  const int split = blockIdx.x, ob = blockIdx.y, cbk = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lo = lane & 31, hi = lane >> 5;
-  const int ot = wave >> 1, ct = wave & 1;
-  const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
-
-  // lane-fixed parts of the staging addresses
-  const int gpy = lane >> 5, gpx = lane & 31;  // gy tile: lane = pixel
-  const unsigned g_lane = a.gy_ps ? (unsigned)((2 * gpy) * (2 * a.Wo) + 2 * gpx) : (unsigned)(gpy * a.Wo + gpx);
-  int xiy[XM], xix[XM];
-#pragma unroll
-  for (int m = 0; m < XM; ++m) {
-    const int e = lane + 64 * m;
-    xiy[m] = e / IW;
-    xix[m] = e - xiy[m] * IW;
-  }
-
-  f32x16 acc[KK];
-#pragma unroll
-  for (int t = 0; t < KK; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float db = 0.f;
-  const bool do_db = cbk == 0 && ct == 0;
-
-  float rg[16], rx[16][XM];
-  bool g_ok, x_ok[XM];
-  auto issue_loads = [&](int tile) {
-    const int tx_ = tile % a.tiles_x;
-    const int t2 = tile / a.tiles_x;
-    const int ty_ = t2 % a.tiles_y;
-    const int n = t2 / a.tiles_y;
-    const int oy0 = ty_ * Sh::TH, ox0 = tx_ * Sh::TW;
-    // gy: 16 channels per wave, one pixel per lane
-    g_ok = oy0 + gpy < a.Ho && ox0 + gpx < a.Wo;
-    const unsigned g_off = g_ok ? g_lane * 4u : 0u;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      int co = ob * 64 + wave * 16 + j;
-      co = co < a.Cout ? co : a.Cout - 1;  // clamped channels are masked at the LDS write
-      const float* base;
-      if (a.gy_ps)
-        base = a.gy + (((size_t)n * (a.Cout >> 2) + (co >> 2)) * (2 * a.Ho) + 2 * oy0 + ((co >> 1) & 1)) *
-                          (size_t)(2 * a.Wo) + 2 * ox0 + (co & 1);
-      else
-        base = a.gy + ((size_t)n * a.Cout + co) * HWo + (size_t)oy0 * a.Wo + ox0;
-      rg[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + g_off);
-    }
-    // x halo: 16 channels per wave, XM x 64 plane elements per channel
-    const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
-    unsigned x_off[XM];
-#pragma unroll
-    for (int m = 0; m < XM; ++m) {
-      const int gy_ = iy0 + xiy[m], gx_ = ix0 + xix[m];
-      x_ok[m] = lane + 64 * m < PLANE && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W;
-      x_off[m] = x_ok[m] ? (unsigned)(gy_ * a.W + gx_) * 4u : 0u;
-    }
-    const float* xn = a.x + (size_t)(n / a.x_bdiv) * a.x_bs;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      int ci = cbk * 64 + wave * 16 + j;
-      ci = ci < a.Cin ? ci : a.Cin - 1;
-      const char* base = reinterpret_cast<const char*>(xn + (size_t)ci * HW);
-#pragma unroll
-      for (int m = 0; m < XM; ++m) rx[j][m] = *reinterpret_cast<const float*>(base + x_off[m]);
-    }
-  };
-  auto write_lds = [&](int buf) {
-    float* s_g = smem + buf * BUF;
-    float* s_x = s_g + 64 * GROW;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int o = wave * 16 + j;
-      s_g[o * GROW + lane] = (g_ok && ob * 64 + o < a.Cout) ? rg[j] : 0.f;
-#pragma unroll
-      for (int m = 0; m < XM; ++m)
-        if (lane + 64 * m < PLANE) s_x[o * PLANEP + lane + 64 * m] = (x_ok[m] && cbk * 64 + o < a.Cin) ? rx[j][m] : 0.f;
-    }
-  };
-  auto mfma_steps = [&](int buf, int k0, int k1) {
-    const float* s_g = smem + buf * BUF;
-    const float* s_x = s_g + 64 * GROW;
-#pragma unroll 4
-    for (int kk = k0; kk < k1; ++kk) {
-      const int p = 2 * kk + hi;
-      const int py = p >> 5, px = p & 31;
-      const float av = s_g[(ot * 32 + lo) * GROW + p];
-      const float* bx = s_x + (ct * 32 + lo) * PLANEP + py * IW + px;
-      db += av;
-#pragma unroll
-      for (int t = 0; t < KK; ++t) {
-        const int ty = t / KS, tx = t - ty * KS;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bx[ty * IW + tx], acc[t], 0, 0, 0);
-      }
-    }
-  };
-
-  int tile = split;
-  if (tile < a.ntiles) {
-    issue_loads(tile);
-    write_lds(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (; tile < a.ntiles; tile += a.nsplit) {
-    const bool has_next = tile + a.nsplit < a.ntiles;
-    if (has_next) issue_loads(tile + a.nsplit);
-    mfma_steps(buf, 0, 3 * NPX / 8);
-    if (has_next) write_lds(buf ^ 1);
-    mfma_steps(buf, 3 * NPX / 8, NPX / 2);
-    __syncthreads();
-    buf ^= 1;
-  }
-
-  // ---- partial[slot][tap][o][c]  (o, c padded to the 64-blocks of the grid), slot = split % nslot
-  const int OP = a.nob * 64, CP = a.ncb * 64;
-  const int slot = split % a.nslot;
-#pragma unroll
-  for (int t = 0; t < KK; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = ob * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const int c = cbk * 64 + ct * 32 + lo;
-      unsafeAtomicAdd(a.partial + (((size_t)slot * KK + t) * OP + o) * CP + c, acc[t][r]);
-    }
-  // lane (lo, hi) summed gy[o = ot*32 + lo] over the pixels of parity hi
-  if (do_db) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + ob * 64 + ot * 32 + lo, db);
+  conv2d_wgrad_pipe_item<KS, KYS>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // dW[o][c_off + c][tap] = sum_s partial[s][tap][o][c];  db[o] = sum_s dbp[s][o]
@@ -385,20 +246,17 @@ size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int 
   return ((size_t)ns * KK * nob * 64 * ncb * 64 + (size_t)ns * nob * 64) * sizeof(float);
 }
 
-// x: one input of the conv ([N/x_bdiv][Cin][H][W], batch stride x_bs or dense), gy: gradient of the
-// conv's pre-activation output.  Writes dW[:, c_off:c_off+Cin, :, :] of a [Cout][Ctot][ks][ks]
-// gradient (and db when non-null).
-int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
-                     float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
-                     int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad,
-                     WgradReduceEntry* defer) {
+int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW, float* db,
+                         int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks, int stride, void* ws,
+                         size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad, WgradReduceEntry* defer,
+                         WgradLaunch* out) {
   DVSR_REQUIRE(x && gy && dW && ws, DVSR_ERR_INVALID, "conv2d_wgrad: null pointer");
-  DVSR_REQUIRE(((ks == 1 || ks == 2) && stride == 1) || (ks == 3 && (stride == 1 || stride == 2)),
+  DVSR_REQUIRE(((ks == 1 || ks == 2 || ks == 7 || ks == 9) && stride == 1) || (ks == 3 && (stride == 1 || stride == 2)),
                DVSR_ERR_UNSUPPORTED, "conv2d_wgrad: ks=%d stride=%d unsupported", ks, stride);
   if (pad < 0) pad = ks / 2;
   const size_t need = conv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ks, stride, pad);
   DVSR_REQUIRE(ws_bytes >= need, DVSR_ERR_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
-  WgradK k;
+  WgradK& k = out->k;
   k.x = x; k.gy = gy; k.x_bs = x_bs > 0 ? x_bs : (long long)Cin * H * W; k.x_bdiv = x_bdiv > 0 ? x_bdiv : 1;
   k.N = N; k.Cin = Cin; k.H = H; k.W = W; k.Cout = Cout; k.pad = pad; k.gy_ps = gy_ps;
   k.Ho = (H + 2 * k.pad - ks) / stride + 1;
@@ -414,39 +272,84 @@ int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy
     const size_t zbytes = ((size_t)k.nslot * KK * k.nob * 64 * k.ncb * 64 + (size_t)k.nslot * k.nob * 64) * sizeof(float);
     DVSR_REQUIRE(hipMemsetAsync(ws, 0, zbytes, st) == hipSuccess, DVSR_ERR_HIP, "conv2d_wgrad: memset failed");
   }
-  dim3 grid(k.nsplit, k.nob, k.ncb);
+  out->grid = dim3(k.nsplit, k.nob, k.ncb);
+  out->ks = ks; out->stride = stride;
+  { static const int nf = getenv("DVSR_WGRAD_NOFLUSH") ? atoi(getenv("DVSR_WGRAD_NOFLUSH")) : 0; k.noflush = nf; }
+  // small pixel grids: one kernel row per workgroup (conv2d_wgrad_pipe_kernel<3, true>); the pixel split is then
+  // sized for ~two workgroups per CU over the three rows.  DVSR_WGRAD_KYS_BELOW=<tiles x cout blocks x cin blocks>
+  // moves the threshold (0 disables).
+  static int kys_below = -1;
+  if (kys_below < 0) {
+    const char* v = getenv("DVSR_WGRAD_KYS_BELOW");
+    kys_below = v ? atoi(v) : 4096;
+  }
+  out->kys = (ks == 3 && stride == 1 && (long long)k.ntiles * k.nob * k.ncb < kys_below) || ks == 7 || ks == 9;
+  if (out->kys) {
+    static int kys_wgs = -1;   // DVSR_WGRAD_KYS_WGS=<workgroups per launch to aim for>
+    if (kys_wgs < 0) {
+      const char* v = getenv("DVSR_WGRAD_KYS_WGS");
+      kys_wgs = v ? atoi(v) : 288;
+    }
+    int s = ceil_div(ks == 3 ? kys_wgs : 512, ks * k.nob * k.ncb);
+    k.nsplit = s > k.ntiles ? k.ntiles : (s < 1 ? 1 : s);
+    if (k.nslot > k.nsplit) k.nslot = k.nsplit;   // (the slot region was sized for the un-split launch: never larger)
+    out->grid = dim3(ks * k.nsplit, k.nob, k.ncb);
+  }
+  if (defer)  // the caller reduces a batch of layers later (wgrad_reduce_batch); `ws` must stay untouched until then
+    *defer = WgradReduceEntry{k.partial, k.dbp, dW, db, k.nslot, KK, k.nob * 64, k.ncb * 64, Cout, Cin, Ctot, c_off};
+  return DVSR_OK;
+}
+
+int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st) {
+  const WgradK& k = l.k;
+  const dim3 grid = l.grid;
+  const int ks = l.ks, stride = l.stride;
   static int use_simple = -1;  // DVSR_WGRAD_SIMPLE=1: the non-pipelined kernel for every shape (A/B aid)
   if (use_simple < 0) {
     const char* v = getenv("DVSR_WGRAD_SIMPLE");
     use_simple = (v && v[0] == '1') ? 1 : 0;
   }
   if (stride == 1 && !use_simple) {
-    auto launch_pipe = [&](auto ks_tag) {
+    auto launch_pipe = [&](auto ks_tag, auto kys_tag) {
       constexpr int KS_ = decltype(ks_tag)::value;
-      using Sh = WgShape<KS_, 1>;
-      constexpr size_t lds = 2 * (size_t)(64 * Sh::GROW + 64 * Sh::PLANEP) * sizeof(float);
+      constexpr bool KYS_ = decltype(kys_tag)::value;
+      constexpr size_t lds = WgPipeShape<KS_, KYS_>::LDS_BYTES;
       static bool done = false;
       if (!done) {
-        hipFuncSetAttribute((const void*)conv2d_wgrad_pipe_kernel<KS_>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)conv2d_wgrad_pipe_kernel<KS_, KYS_>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         done = true;
       }
-      hipLaunchKernelGGL(conv2d_wgrad_pipe_kernel<KS_>, grid, dim3(256), lds, st, k);
+      hipLaunchKernelGGL((conv2d_wgrad_pipe_kernel<KS_, KYS_>), grid, dim3(256), lds, st, k);
     };
-    if (ks == 3) launch_pipe(std::integral_constant<int, 3>{});
-    else if (ks == 2) launch_pipe(std::integral_constant<int, 2>{});
-    else launch_pipe(std::integral_constant<int, 1>{});
+    if (ks == 7) launch_pipe(std::integral_constant<int, 7>{}, std::true_type{});
+    else if (ks == 9) launch_pipe(std::integral_constant<int, 9>{}, std::true_type{});
+    else if (ks == 3 && l.kys) launch_pipe(std::integral_constant<int, 3>{}, std::true_type{});
+    else if (ks == 3) launch_pipe(std::integral_constant<int, 3>{}, std::false_type{});
+    else if (ks == 2) launch_pipe(std::integral_constant<int, 2>{}, std::false_type{});
+    else launch_pipe(std::integral_constant<int, 1>{}, std::false_type{});
   } else if (ks == 3 && stride == 1) launch_wgrad<3, 1>(k, grid, st);
   else if (ks == 3) launch_wgrad<3, 2>(k, grid, st);
   else if (ks == 2) launch_wgrad<2, 1>(k, grid, st);
   else launch_wgrad<1, 1>(k, grid, st);
-  int rc = check_launch("conv2d_wgrad_kernel");
+  return check_launch("conv2d_wgrad_kernel");
+}
+
+// x: one input of the conv ([N/x_bdiv][Cin][H][W], batch stride x_bs or dense), gy: gradient of the
+// conv's pre-activation output.  Writes dW[:, c_off:c_off+Cin, :, :] of a [Cout][Ctot][ks][ks]
+// gradient (and db when non-null).
+int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
+                     float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
+                     int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad,
+                     WgradReduceEntry* defer) {
+  WgradLaunch l;
+  int rc = conv2d_wgrad_prepare(x, x_bs, x_bdiv, gy, gy_ps, dW, db, N, Cin, H, W, Cout, Ctot, c_off, ks, stride, ws,
+                                ws_bytes, st, scratch_is_zero, pad, defer, &l);
   if (rc) return rc;
-  if (defer) {  // the caller reduces a batch of layers later (wgrad_reduce_batch); `ws` must stay untouched until then
-    *defer = WgradReduceEntry{k.partial, k.dbp, dW, db, k.nslot, KK, k.nob * 64, k.ncb * 64, Cout, Cin, Ctot, c_off};
-    return DVSR_OK;
-  }
-  const int total = Cout * Cin * KK;
+  rc = conv2d_wgrad_launch(l, st);
+  if (rc || defer) return rc;
+  const WgradK& k = l.k;
+  const int KK = ks * ks, total = Cout * Cin * KK;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, k.partial, k.dbp,
                      dW, db, k.nslot, KK, k.nob * 64, k.ncb * 64, Cout, Cin, Ctot, c_off);
   return check_launch("wgrad_reduce_kernel");

@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "small_grid.h"
 
 namespace dvsr {
 
@@ -159,14 +160,17 @@ struct Builder {
           g.th = 8;
         return g;
       };
-      o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1), Ho, Wo, Cout);
+      // the K-split small-grid kernel takes plain inputs with an explicit pad of 1 and 32-channel chunks
+      const int ks_ok = pad < 0 && !wmap && (c1 == 0 || c0 % 32 == 0) && !p.cfg.bf16_mfma;
+      o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1, ks_ok), Ho, Wo, Cout);
       o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, o.geo.bf);
       o.wp_off = alloc("", o.wp_floats).off;
       for (int which = 0; which < 2; ++which) {
         const int ci = which ? c1 : c0;
         if (!ci) continue;
         // dgrad = stride-1 conv over the input grid with Cout' = ci, Ctot' = Cout
-        o.dgeo[which] = as_bf(conv2_choose(ks, 1, N, H, W, ci, Cout), H, W, ci);
+        // (data gradient: the gradient tensor is the plain input unless it is pixel-shuffled or zero-dilated)
+        o.dgeo[which] = as_bf(conv2_choose(ks, 1, N, H, W, ci, Cout, ks_ok && !ps && stride == 1), H, W, ci);
         o.dpk_floats[which] = (size_t)ceil_div(ci, 64) * ceil_div(Cout, o.dgeo[which].cc) *
                               conv2_pch_cc(ks, o.dgeo[which].cc, o.dgeo[which].bf);
         o.dpk_off[which] = p.dpack_floats;
@@ -364,9 +368,11 @@ static int build_plan(dvsr_edvr_plan& p) {
 // (DCN input gradient) first contributions zero the slot first; later ones accumulate.
 struct BackBuilder {
   dvsr_edvr_plan& p;
-  std::vector<char> written;  // per allocation
+  std::vector<char> written;  // per allocation: 0 untouched, 1 written, 2 = a whole-slot copy is PENDING (see copyadd)
+  struct Pending { Ref src; size_t n; int fwd; };
+  std::vector<Pending> pending;  // per allocation, valid while written == 2
   bool gx_zeroed = false;
-  explicit BackBuilder(dvsr_edvr_plan& plan) : p(plan), written(plan.allocs.size(), 0) {}
+  explicit BackBuilder(dvsr_edvr_plan& plan) : p(plan), written(plan.allocs.size(), 0), pending(plan.allocs.size()) {}
 
   int alloc_index(size_t off) const {
     int lo = 0, hi = (int)p.allocs.size() - 1, ans = -1;
@@ -388,11 +394,33 @@ struct BackBuilder {
     r.off = t.off;
     return r;
   }
+  // A pending copy becomes a real launch (someone is about to read or accumulate into the slot).
+  void materialize(int ai) {
+    if (ai < 0 || written[ai] != 2) return;
+    BOp o;
+    o.type = B_COPYADD; o.fwd = pending[ai].fwd; o.a.space = R_GRAD; o.a.off = p.allocs[ai].first; o.b = pending[ai].src;
+    o.n = pending[ai].n; o.accum = 0;
+    p.bops.push_back(o);
+    written[ai] = 1;
+  }
+  void materialize(const T& t) { if (t.space == SP_ARENA) materialize(alloc_index(t.off)); }
+  // A data-gradient launch that covers the whole slot takes a pending copy as its residual input instead
+  // (gx = dgrad + gy: the skip connection of a residual block costs no launch of its own).
+  bool take_pending_as_residual(const T& t, Ref* src) {
+    if (t.space != SP_ARENA) return false;
+    const int ai = alloc_index(t.off);
+    if (written[ai] != 2 || t.off != p.allocs[ai].first || t.numel != p.allocs[ai].second || pending[ai].n != t.numel)
+      return false;
+    *src = pending[ai].src;
+    written[ai] = 1;
+    return true;
+  }
   // Declares a contribution to grad(t); returns the accumulate flag for it.
   int contribute(const T& t, bool full, int fwd) {
     if (t.space == SP_INPUT) return 1;  // gx is zeroed once up front, everything accumulates
     const int ai = alloc_index(t.off);
     const bool whole = full && t.off == p.allocs[ai].first && t.numel == p.allocs[ai].second;
+    materialize(ai);
     if (written[ai]) return 1;
     written[ai] = 1;
     if (whole) return 0;
@@ -402,6 +430,15 @@ struct BackBuilder {
     return 1;
   }
   void copyadd(const T& dst, const Ref& src, size_t n, int fwd) {
+    if (dst.space == SP_ARENA) {   // first, whole-slot contribution: keep the copy pending
+      const int ai = alloc_index(dst.off);
+      static const bool defer = [] { const char* v = getenv("DVSR_FUSE_RES_BWD"); return !(v && v[0] == '0'); }();
+      if (defer && !written[ai] && dst.off == p.allocs[ai].first && dst.numel == p.allocs[ai].second && n == dst.numel) {
+        written[ai] = 2;
+        pending[ai] = Pending{src, n, fwd};
+        return;
+      }
+    }
     BOp o;
     o.type = B_COPYADD; o.fwd = fwd; o.a = grad(dst); o.b = src; o.n = n;
     o.accum = contribute(dst, true, fwd);
@@ -442,6 +479,9 @@ static void build_backward(dvsr_edvr_plan& p) {
   for (int i = (int)p.ops.size() - 1; i >= 0; --i) {
     const Op& o = p.ops[i];
     const Ref gy = BackBuilder::grad(o.y);
+    bb.materialize(o.y);    // this op reads the gradients of its outputs: pending copies into them become launches
+    bb.materialize(o.y2);
+    if (o.type == OP_GATE) bb.materialize(o.res);
     switch (o.type) {
       case OP_CONV: {
         const int Ho = conv_out(o, o.H), Wo = conv_out(o, o.W);
@@ -474,9 +514,10 @@ static void build_backward(dvsr_edvr_plan& p) {
           BOp d; d.type = B_DGRAD; d.fwd = i; d.which = which; d.b = gy;
           if (!strided) {
             T full = xin; full.numel = (size_t)o.N * ci * o.H * o.W;
-            d.accum = bb.contribute(full, true, i);
+            if (!p.use_v1 && bb.take_pending_as_residual(full, &d.e)) d.accum = 0;   // gx = dgrad + (pending copy's source)
+            else d.accum = bb.contribute(full, true, i);
             d.a = BackBuilder::grad(xin);
-            if (!d.accum && !o.c1 && fuse_act) {
+            if (!d.accum && !o.c1 && fuse_act && d.e.space == R_NONE) {
               const int prod = sole_producer_with_act(p, full, i);
               if (prod >= 0) { d.mask_op = prod; act_fused[prod] = 1; }
             }
@@ -569,6 +610,7 @@ static void build_backward(dvsr_edvr_plan& p) {
       }
     }
   }
+  for (size_t ai = 0; ai < p.allocs.size(); ++ai) bb.materialize((int)ai);
   p.tmp_floats = (tmp + 63) & ~(size_t)63;
   p.scratch_bytes = (scratch + 255) & ~(size_t)255;
   p.wscratch_bytes = (wscratch + 255) & ~(size_t)255;
@@ -590,6 +632,34 @@ struct BBases {
     }
   }
 };
+
+// Argument marshalling of the two gradient launches of a conv, shared by the separate and the fused paths.
+static int prep_wgrad(const dvsr_edvr_plan& p, const BOp& b, float* const* GP, const BBases& bs, void* scratch,
+                      size_t scratch_bytes, hipStream_t st, WgradReduceEntry* defer, WgradLaunch* out) {
+  const Op* o = &p.ops[b.fwd];
+  const int ci = b.which ? o->c1 : o->c0;
+  float* dW = o->wmap ? bs.garena + o->w2_off : GP[o->pw];
+  return conv2d_wgrad_prepare(bs.at(b.a), b.which ? o->x1_bs : o->x0_bs, b.which ? o->x1_bdiv : 1, bs.at(b.b), o->ps, dW,
+                              b.which ? nullptr : GP[o->pb], o->N, ci, o->H, o->W, o->Cout, o->c0 + o->c1,
+                              b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st, 1, conv_pad(*o), defer, out);
+}
+
+static void dgrad_desc(const dvsr_edvr_plan& p, const BOp& b, const float* const* P, const BBases& bs,
+                       dvsr_conv2d_desc* gd, ConvExtra* exd) {
+  const Op* o = &p.ops[b.fwd];
+  const int Ho = conv_out(*o, o->H), Wo = conv_out(*o, o->W);
+  dvsr_conv2d_desc g = {};
+  g.x0 = bs.at(b.b); g.w = o->wmap ? bs.arena + o->w2_off : P[o->pw]; g.y = bs.at(b.a); g.N = o->N; g.c0 = o->Cout;
+  g.Cout = b.which ? o->c1 : o->c0;
+  g.ks = o->ks; g.stride = 1; g.pad = o->ks - 1 - conv_pad(*o); g.act = ACT_NONE; g.x1_bdiv = 1;
+  g.res = bs.at(b.e);   // skip-connection gradient folded into this launch (BackBuilder::take_pending_as_residual)
+  ConvExtra ex;
+  ex.wt = 1; ex.w_ctot = o->c0 + o->c1; ex.w_coff = b.which ? o->c0 : 0; ex.accum = b.accum; ex.in_ps = o->ps ? 1 : 0;
+  if (b.mask_op >= 0 && !bs.use_v1) { ex.gmask = bs.arena + p.ops[b.mask_op].y.off; ex.gmask_act = p.ops[b.mask_op].act; }
+  if (o->stride == 2) { ex.in_dil = 2; ex.Hs = Ho; ex.Ws = Wo; g.H = o->H; g.W = o->W; }
+  else { g.H = Ho; g.W = Wo; }
+  *gd = g; *exd = ex;
+}
 
 static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* const* P, float* const* GP,
                            const BBases& bs, void* scratch, size_t scratch_bytes, hipStream_t st,
@@ -631,18 +701,10 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
     case B_ADDMEAN:
       return addmean_bwd(bs.at(b.b), bs.at(b.a), o->N / o->T, o->c0, o->T, (size_t)o->H * o->W, st);
     case B_DGRAD: {
-      float* gx = bs.at(b.a);
-      if (!gx) return DVSR_OK;
-      const int Ho = conv_out(*o, o->H), Wo = conv_out(*o, o->W);
-      dvsr_conv2d_desc g = {};
-      g.x0 = bs.at(b.b); g.w = o->wmap ? bs.arena + o->w2_off : P[o->pw]; g.y = gx; g.N = o->N; g.c0 = o->Cout;
-      g.Cout = b.which ? o->c1 : o->c0;
-      g.ks = o->ks; g.stride = 1; g.pad = o->ks - 1 - conv_pad(*o); g.act = ACT_NONE; g.x1_bdiv = 1;
+      if (!bs.at(b.a)) return DVSR_OK;
+      dvsr_conv2d_desc g;
       ConvExtra ex;
-      ex.wt = 1; ex.w_ctot = o->c0 + o->c1; ex.w_coff = b.which ? o->c0 : 0; ex.accum = b.accum; ex.in_ps = o->ps ? 1 : 0;
-      if (b.mask_op >= 0 && !bs.use_v1) { ex.gmask = bs.arena + p.ops[b.mask_op].y.off; ex.gmask_act = p.ops[b.mask_op].act; }
-      if (o->stride == 2) { ex.in_dil = 2; ex.Hs = Ho; ex.Ws = Wo; g.H = o->H; g.W = o->W; }
-      else { g.H = Ho; g.W = Wo; }
+      dgrad_desc(p, b, P, bs, &g, &ex);
       if (bs.use_v1) return conv2d_run(g, ex, st);
       return conv2d_packed_run(g, bs.dpack + o->dpk_off[b.which], ex, o->dgeo[b.which], st);
     }
@@ -879,22 +941,44 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
   std::vector<WgradReduceEntry> reduces;
   std::vector<const BOp*> unmaps;
   reduces.reserve(p->bops.size());
+  // An event recorded on the main stream delays the main stream's NEXT kernel by ~6 us (profiles/r02b timeline),
+  // which on the small inner-step clips is a third of a layer: the weight gradients of `fork_every` consecutive
+  // layers therefore share one fork (a gradient buffer is never rewritten once its layer's turn has come, so
+  // launching a weight gradient a few layers late is safe).  DVSR_BWD_FORK_EVERY=<layers> (1 = a fork per layer).
+  static const int fork_every = [] { const char* v = getenv("DVSR_BWD_FORK_EVERY"); int n = v ? atoi(v) : 3; return n < 1 ? 1 : n; }();
+  std::vector<WgradLaunch> waiting;
+  int waiting_layers = 0;
+  auto flush_waiting = [&]() -> int {
+    if (waiting.empty()) return DVSR_OK;
+    hipStream_t ws = st;
+    if (use_side) {
+      DVSR_REQUIRE(hipEventRecord(p->ev_fork, st) == hipSuccess && hipStreamWaitEvent(p->side, p->ev_fork, 0) == hipSuccess,
+                   DVSR_ERR_HIP, "edvr_backward: fork to the wgrad stream failed");
+      ws = p->side;
+      forked = true;
+    }
+    for (const WgradLaunch& l : waiting) {
+      int rc = conv2d_wgrad_launch(l, ws);
+      if (rc != DVSR_OK) return rc;
+    }
+    waiting.clear();
+    waiting_layers = 0;
+    return DVSR_OK;
+  };
   for (const BOp& b : p->bops) {
     int rc = DVSR_OK;
     if (b.type == B_WGRAD) {
-      hipStream_t ws = st;
-      if (use_side) {
-        if (b.fwd != last_fork_fwd) {  // gy of this layer is final on `st` at this point of the tape
-          DVSR_REQUIRE(hipEventRecord(p->ev_fork, st) == hipSuccess &&
-                           hipStreamWaitEvent(p->side, p->ev_fork, 0) == hipSuccess,
-                       DVSR_ERR_HIP, "edvr_backward: fork to the wgrad stream failed");
-          last_fork_fwd = b.fwd;
-        }
-        ws = p->side;
-        forked = true;
-      }
       reduces.emplace_back();
-      rc = run_backward_op(*p, b, params, grad_params, bs, (char*)wscratch + b.ws_off, b.ws_bytes, ws, 1, &reduces.back());
+      WgradLaunch l;
+      rc = prep_wgrad(*p, b, grad_params, bs, (char*)wscratch + b.ws_off, b.ws_bytes, st, &reduces.back(), &l);
+      if (rc != DVSR_OK) return rc;
+      if (b.fwd != last_fork_fwd) {   // gy of this layer is final on `st` at this point of the tape
+        if (waiting_layers >= fork_every) rc = flush_waiting();
+        last_fork_fwd = b.fwd;
+        ++waiting_layers;
+      }
+      waiting.push_back(l);
+      if (!use_side && rc == DVSR_OK) rc = flush_waiting();
     } else if (b.type == B_WUNMAP) {
       unmaps.push_back(&b);  // needs the reduced gradient: after the batched reduce below
     } else {
@@ -903,8 +987,10 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
     if (rc != DVSR_OK) return rc;
   }
   {
+    int rc = flush_waiting();
+    if (rc != DVSR_OK) return rc;
     hipStream_t ws = use_side && forked ? p->side : st;
-    int rc = wgrad_reduce_batch(reduces.data(), (int)reduces.size(), ws);
+    rc = wgrad_reduce_batch(reduces.data(), (int)reduces.size(), ws);
     if (rc != DVSR_OK) return rc;
     for (const BOp* b : unmaps) {
       rc = run_backward_op(*p, *b, params, grad_params, bs, nullptr, 0, ws);
@@ -1151,6 +1237,11 @@ extern "C" void dvsr_estimator_plan_destroy(dvsr_estimator_plan* ep) {
 }
 
 extern "C" int dvsr_estimator_num_params(const dvsr_estimator_plan* ep) { return ep ? ep->core.n_params : -1; }
+
+extern "C" int dvsr_estimator_num_launches(const dvsr_estimator_plan* ep, int backward) {
+  if (!ep) return -1;
+  return backward ? (int)ep->core.bops.size() : (int)ep->core.ops.size();
+}
 
 extern "C" size_t dvsr_estimator_workspace_bytes(const dvsr_estimator_plan* ep, int need_grad) {
   return ep ? dvsr_edvr_workspace_bytes(&ep->core, need_grad) : 0;

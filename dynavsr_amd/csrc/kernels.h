@@ -36,7 +36,7 @@ int conv2_pch(int ks, int stride);  // floats per packed (cout block, chunk)
 int conv2_cc(int ks, int stride);   // input channels per chunk
 int pack_weights_run(const PackTable& t, hipStream_t st);
 struct ConvGeo { int cc, th, mt; int bf = 0; };  // channels per chunk, tile rows (x32 px), 32-cout halves per workgroup
-ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ctot);
+ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ctot, int allow_ksplit = 1);
 int conv2_pch_cc(int ks, int cc, int bf = 0);   // fp32-sized slots per packed (64-cout block, chunk of cc channels)
 int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo,
                       hipStream_t st);

@@ -499,6 +499,45 @@ __global__ void charbonnier_bwd_kernel(const float* __restrict__ x, const float*
   }
 }
 
+// Loss tail of the inner MAML step (test_dynavsr.py:264-274): out = base + weight * mean|x - y|.  Same fixed-order
+// two-stage reduction as the Charbonnier loss; `base` is the pixel loss that is already on the device.
+__global__ void l1_partial_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ partial,
+                                  size_t n) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    s += fabsf(x[i] - y[i]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void l1_final_kernel(const float* __restrict__ partial, const float* __restrict__ base, float* __restrict__ out,
+                                int nb, float scale) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (base ? base[0] : 0.f) + red[0] * scale;
+}
+// gx = gscale * scale * sign(x - y)   (torch's l1_loss backward: sign(0) = 0)
+__global__ void l1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gscale,
+                              float* __restrict__ gx, size_t n, float scale) {
+  const float g = gscale[0] * scale;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = x[i] - y[i];
+    gx[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+  }
+}
+
 #define LAUNCH(kern, n, st, ...) \
   hipLaunchKernelGGL(kern, dim3(stream_grid(n)), dim3(256), 0, st, __VA_ARGS__)
 
@@ -705,6 +744,26 @@ extern "C" int dvsr_charbonnier_backward(const float* x, const float* y, const f
   LAUNCH(charbonnier_bwd_kernel, (size_t)n, (hipStream_t)stream, x, y, grad_loss, gx, (size_t)n, eps,
          1.f / (float)n);
   return check_launch("charbonnier_bwd_kernel");
+}
+
+extern "C" int dvsr_l1_tail_forward(const float* x, const float* y, const float* base, float weight, float* loss,
+                                    long long n, void* workspace, size_t workspace_bytes, dvsr_stream_t stream) {
+  DVSR_REQUIRE(x && y && loss && workspace && n > 0, DVSR_ERR_INVALID, "l1_tail_forward: bad argument");
+  DVSR_REQUIRE(workspace_bytes >= CHARB_BLOCKS * sizeof(float), DVSR_ERR_WORKSPACE, "l1_tail_forward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int nb = (int)(((size_t)n + 255) / 256);
+  if (nb > CHARB_BLOCKS) nb = CHARB_BLOCKS;
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, st, x, y, (float*)workspace, (size_t)n);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, base, loss, nb,
+                     weight / (float)n);
+  return check_launch("l1_tail_forward");
+}
+
+extern "C" int dvsr_l1_tail_backward(const float* x, const float* y, const float* grad_loss, float weight, float* gx,
+                                     long long n, dvsr_stream_t stream) {
+  DVSR_REQUIRE(x && y && grad_loss && gx && n > 0, DVSR_ERR_INVALID, "l1_tail_backward: bad argument");
+  LAUNCH(l1_bwd_kernel, (size_t)n, (hipStream_t)stream, x, y, grad_loss, gx, (size_t)n, weight / (float)n);
+  return check_launch("l1_bwd_kernel");
 }
 
 extern "C" int dvsr_upsample_bilinear_forward(const float* x, float* y, long long planes, int H,

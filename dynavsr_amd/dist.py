@@ -29,33 +29,29 @@ def shard_indices(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
-def allreduce_meta_gradients(modules, average=True, group=None):
+def allreduce_meta_gradients(modules, average=True, group=None, force=False):
     """Sum (or average) ``.grad`` of every parameter of ``modules`` across ranks with ONE
-    collective over a flat buffer.  Parameters without a grad contribute zeros."""
+    collective over a flat buffer.  Parameters without a grad contribute zeros.  ``force`` issues the
+    collective on a one-rank group as well (a no-op numerically; used by bench.py and the gpu test so that the
+    RCCL path is the one that runs at N = 1 too).  Returns the bytes exchanged."""
     params = [p for m in modules for p in m.parameters() if p.requires_grad]
     if not params:
         return 0
-    dev, dt = params[0].device, torch.float32
-    flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=dt)
-    off = 0
-    for p in params:
-        n = p.numel()
-        if p.grad is not None:
-            flat[off:off + n].copy_(p.grad.reshape(-1))
-        off += n
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    dev = params[0].device
+    # pack: ONE concatenation kernel (a missing .grad enters as zeros), not a copy per tensor
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32)
+                      for p in params]) if len(params) > 1 else \
+        (params[0].grad if params[0].grad is not None else torch.zeros_like(params[0])).reshape(-1).float().clone()
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:
             flat.div_(dist.get_world_size(group))
-    off = 0
+    # unpack: one multi-tensor copy back into the .grad tensors (created where missing)
+    pieces = flat.split([p.numel() for p in params])
     for p in params:
-        n = p.numel()
-        g = flat[off:off + n].view_as(p)
         if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
-        off += n
+            p.grad = torch.empty_like(p)
+    torch._foreach_copy_([p.grad for p in params], [g.view_as(p) for g, p in zip(pieces, params)])
     return flat.numel() * 4
 
 

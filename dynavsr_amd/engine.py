@@ -28,6 +28,7 @@ class Plan:
                 "dvsr_edvr_plan_create")
         self.n_params = L.lib().dvsr_edvr_num_params(self._h)
         self.n_launches = L.lib().dvsr_edvr_num_launches(self._h)
+        self.n_backward_launches = L.lib().dvsr_edvr_num_backward_launches(self._h)
 
     def workspace_bytes(self, need_grad):
         return int(L.lib().dvsr_edvr_workspace_bytes(self._h, int(need_grad)))
@@ -168,6 +169,8 @@ class EstimatorPlan:
         L.check(L.lib().dvsr_estimator_plan_create(L.EstimatorConfig(*cfg), b, h, w, ctypes.byref(self._h)),
                 "dvsr_estimator_plan_create")
         self.n_params = L.lib().dvsr_estimator_num_params(self._h)
+        self.n_launches = L.lib().dvsr_estimator_num_launches(self._h, 0)
+        self.n_backward_launches = L.lib().dvsr_estimator_num_launches(self._h, 1)
 
     def workspace_bytes(self, need_grad):
         return int(L.lib().dvsr_estimator_workspace_bytes(self._h, int(need_grad)))

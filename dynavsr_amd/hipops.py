@@ -196,3 +196,38 @@ class _Charbonnier(torch.autograd.Function):
 def charbonnier(x, y, eps=1e-6):
     """mean(sqrt((x-y)^2 + eps)) with autograd (models/loss.py:26-30)."""
     return _Charbonnier.apply(x, y, eps)
+
+
+class _InnerLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, base, x, y, weight):
+        if x.shape != y.shape:
+            raise RuntimeError("inner_loss: %s vs %s" % (tuple(x.shape), tuple(y.shape)))
+        x, y = x.contiguous(), y.contiguous()
+        b = base.detach().reshape(()).float()
+        ws = torch.empty(int(L.lib().dvsr_charbonnier_workspace_bytes()), dtype=torch.uint8, device=x.device)
+        loss = x.new_empty(())
+        L.check(L.lib().dvsr_l1_tail_forward(L.ptr(x), L.ptr(y), b.data_ptr(), float(weight), loss.data_ptr(), x.numel(),
+                                             ws.data_ptr(), ws.numel(), L.stream()), "dvsr_l1_tail_forward")
+        ctx.save_for_backward(x, y)
+        ctx.weight = float(weight)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = g.contiguous().float()
+        gx = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gx = torch.empty_like(x)
+            L.check(L.lib().dvsr_l1_tail_backward(L.ptr(x), L.ptr(y), g.data_ptr(), ctx.weight, L.ptr(gx), x.numel(),
+                                                  L.stream()), "dvsr_l1_tail_backward")
+        return (g if ctx.needs_input_grad[0] else None, gx if ctx.needs_input_grad[1] else None,
+                -gx if ctx.needs_input_grad[2] else None, None)
+
+
+def inner_loss(loss_pix, slr, slr_fixed, weight=10.0):
+    """loss_pix + weight * F.l1_loss(slr, slr_fixed) (test_dynavsr.py:264-274) as one native reduction: the pixel loss
+    stays a device scalar, its gradient passes through, the L1 gradient is one kernel."""
+    return _InnerLoss.apply(loss_pix, slr, slr_fixed, weight)

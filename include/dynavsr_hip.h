@@ -225,6 +225,9 @@ typedef struct dvsr_estimator_plan dvsr_estimator_plan;
 int dvsr_estimator_plan_create(const dvsr_estimator_config* cfg, int B, int H, int W, dvsr_estimator_plan** out);
 void dvsr_estimator_plan_destroy(dvsr_estimator_plan* plan);
 int dvsr_estimator_num_params(const dvsr_estimator_plan* plan);
+/* tape length: forward ops (backward = 0) or backward ops (backward = 1); a measurement aid like
+ * dvsr_edvr_num_launches / dvsr_edvr_num_backward_launches */
+int dvsr_estimator_num_launches(const dvsr_estimator_plan* plan, int backward);
 size_t dvsr_estimator_workspace_bytes(const dvsr_estimator_plan* plan, int need_grad);
 int dvsr_estimator_forward(const dvsr_estimator_plan* plan, const float* const* params, const float* x, float* out,
                            void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
@@ -240,6 +243,16 @@ int dvsr_charbonnier_forward(const float* x, const float* y, float* loss, long l
                              void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
 int dvsr_charbonnier_backward(const float* x, const float* y, const float* grad_loss, float* gx, long long n,
                               float eps, dvsr_stream_t stream);
+
+/* ---- loss tail of the inner MAML step (test_dynavsr.py:264-274) ------------------------------------------
+ * loss = cri_pix(netG(SLR), LR_center) + 10 * F.l1_loss(SLR, SLR_fixed): loss[0] = (base ? base[0] : 0) +
+ * weight * mean|x - y| with `base` the pixel loss already on the device (one reduction + one 1-thread kernel instead
+ * of the abs / mean / mul / add chain); backward writes gx = grad_loss[0] * weight / n * sign(x - y) (sign(0) = 0,
+ * as torch's l1_loss); the gradient w.r.t. base is grad_loss itself.  Workspace: dvsr_charbonnier_workspace_bytes(). */
+int dvsr_l1_tail_forward(const float* x, const float* y, const float* base, float weight, float* loss, long long n,
+                         void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
+int dvsr_l1_tail_backward(const float* x, const float* y, const float* grad_loss, float weight, float* gx, long long n,
+                          dvsr_stream_t stream);
 
 /* ---- inner-loop optimiser steps over lists of parameter tensors ------------------------------------
  * test_dynavsr.py:223-231 steps torch.optim.Adam(lr_alpha, betas) / torch.optim.SGD(lr_alpha) over the

@@ -276,6 +276,28 @@ def test_charbonnier(ops):
     assert abs(float(got) - float(ref)) < 1e-6 * float(ref) and relerr(gg, rg) < 1e-6
 
 
+def test_inner_loss_tail(ops):
+    """loss_pix + 10 * F.l1_loss(SLR, SLR_fixed) (test_dynavsr.py:264-274) as one native reduction: value, the
+    pass-through gradient of the pixel loss, the sign gradient of the L1 term (sign(0) = 0 like torch), ragged
+    and > 256 K element sizes."""
+    import torch.nn.functional as F
+    for shape, seed in (((1, 5, 3, 44, 80), 3), ((7, 13), 4), ((2, 5, 3, 176, 320), 5)):
+        x, y = rnd(*shape, seed=seed), rnd(*shape, seed=seed + 10)
+        x.view(-1)[::7] = y.view(-1)[::7]                      # exact ties
+        x.requires_grad_()
+        base = torch.tensor(0.37, requires_grad=True)
+        ref = base * 2.0 + 10.0 * F.l1_loss(x, y)
+        rgx, rgb = torch.autograd.grad(ref * 1.5, [x, base])
+        xg, bg = dev(x.detach()).requires_grad_(), dev(base.detach()).requires_grad_()
+        got = ops.inner_loss(bg * 2.0, xg, dev(y), 10.0)
+        ggx, ggb = torch.autograd.grad(got * 1.5, [xg, bg])
+        assert abs(float(got) - float(ref)) < 2e-6 * abs(float(ref))
+        assert relerr(ggx, rgx) < 1e-6 and abs(float(ggb) - float(rgb)) < 1e-6
+        assert float(ggx.view(-1)[::7].abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="inner_loss"):
+        ops.inner_loss(dev(torch.zeros(())), dev(torch.zeros(3, 4)), dev(torch.zeros(4, 3)))
+
+
 @pytest.mark.parametrize("kind", ["adam", "sgd"])
 def test_native_optimizer_matches_torch(kind):
     """dvsr_adam_step / dvsr_sgd_step against torch.optim over several steps, ragged tensor list (one

@@ -3,7 +3,9 @@
 and the pmc_traffic.json that bench.py reads for roofline.traffic.
 usage: pmc_traffic.py fetch.db write.db out.txt out.json"""
 import collections
+import hashlib
 import json
+import os
 import sqlite3
 import sys
 
@@ -37,7 +39,11 @@ lines.append("# dominant kernel (3x3/s1 conv, all geometries): %.1f MB HBM traff
              "vs 102.5 MB algorithmic" % (per / 1e6, tot["f"] / max(tot["n"], 1) * 1024 / 1e6,
                                           tot["w"] / max(tot["n"], 1) * 1024 / 1e6))
 open(out_txt, "w").write("\n".join(lines) + "\n")
-json.dump({"conv3x3s1": {"bytes_per_launch": per, "fetch_bytes": tot["f"] / max(tot["n"], 1) * 1024,
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dig = hashlib.sha256()
+for f in ("conv2d_v2.hip", "small_grid.h", "common.h"):   # bench.py refuses the figure when these have changed since
+    dig.update(open(os.path.join(ROOT, "dynavsr_amd", "csrc", f), "rb").read())
+json.dump({"sources_sha256_16": dig.hexdigest()[:16], "conv3x3s1": {"bytes_per_launch": per, "fetch_bytes": tot["f"] / max(tot["n"], 1) * 1024,
                          "write_bytes": tot["w"] / max(tot["n"], 1) * 1024,
                          "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
                                    % out_txt.split("/")[-1]}}, open(out_json, "w"), indent=1)
