@@ -79,6 +79,16 @@ def _declare(lib):
         "dvsr_frame_metrics": (I, [P, P, I, I, I, F, F, P, P, P, c_size_t, P]),
         "dvsr_charbonnier_workspace_bytes": (c_size_t, []),
         "dvsr_charbonnier_forward": (I, [P, P, P, LL, F, P, c_size_t, P]),
+        "dvsr_flow_warp_forward": (I, [P, P, P, I, I, I, I, LL, P]),
+        "dvsr_flow_warp_backward": (I, [P, P, P, P, P, I, I, I, I, LL, P]),
+        "dvsr_avgpool2_forward": (I, [P, P, LL, I, I, P]),
+        "dvsr_avgpool2_backward": (I, [P, P, LL, I, I, I, P]),
+        "dvsr_resize_bilinear_ac_forward": (I, [P, P, LL, I, I, I, I, F, LL, P]),
+        "dvsr_resize_bilinear_ac_backward": (I, [P, P, LL, I, I, I, I, F, LL, P]),
+        "dvsr_channel_affine": (I, [P, P, P, P, I, I, LL, LL, LL, I, P]),
+        "dvsr_batchnorm_workspace_bytes": (c_size_t, [I]),
+        "dvsr_batchnorm_forward": (I, [P] * 8 + [I, I, LL, I, F, F, I, P, c_size_t, P]),
+        "dvsr_batchnorm_backward": (I, [P] * 9 + [I, I, LL, I, I, P, c_size_t, P]),
         "dvsr_l1_tail_forward": (I, [P, P, P, F, P, LL, P, c_size_t, P]),
         "dvsr_l1_tail_backward": (I, [P, P, P, F, P, LL, P]),
         "dvsr_charbonnier_backward": (I, [P, P, P, P, LL, F, P]),

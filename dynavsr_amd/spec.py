@@ -94,3 +94,25 @@ def sfdn_param_spec(nf=64):
     _conv(s, "conv5", nf, nf * 2, 3)
     _conv(s, "conv6", 3, nf, 1)
     return s
+
+
+def tof_param_spec():
+    """OrderedDict name -> shape of the TOFlow state dict (TOF_arch.py:25-110): parameters AND BatchNorm buffers,
+    in the module's state_dict() order."""
+    s = OrderedDict()
+    chans = [(8, 32), (32, 64), (64, 32), (32, 16), (16, 2)]
+    for b in range(4):
+        for i, (ci, co) in enumerate(chans):
+            _conv(s, "SpyNet.blocks.%d.block.%d" % (b, 3 * i), co, ci, 7)
+            if i < 4:
+                pre = "SpyNet.blocks.%d.block.%d" % (b, 3 * i + 1)
+                s[pre + ".weight"] = (co,)
+                s[pre + ".bias"] = (co,)
+                s[pre + ".running_mean"] = (co,)
+                s[pre + ".running_var"] = (co,)
+                s[pre + ".num_batches_tracked"] = ()
+    _conv(s, "conv_3x7_64_9x9", 64, 21, 9)
+    _conv(s, "conv_64_64_9x9", 64, 64, 9)
+    _conv(s, "conv_64_64_1x1", 64, 64, 1)
+    _conv(s, "conv_64_3_1x1", 3, 64, 1)
+    return s

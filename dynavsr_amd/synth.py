@@ -11,7 +11,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .spec import edvr_param_spec, mfdn_param_spec, sfdn_param_spec
+from .spec import edvr_param_spec, mfdn_param_spec, sfdn_param_spec, tof_param_spec
 
 
 def _rs(seed, name):
@@ -65,6 +65,31 @@ def sfdn_state_dict(seed=0, dtype=torch.float32, **cfg):
         else:
             a = r.standard_normal(shape) * np.sqrt(2.0 / _fan_in(shape))
         sd[name] = torch.from_numpy(a).to(dtype)
+    return sd
+
+
+def tof_state_dict(seed=0, dtype=torch.float32):
+    """TOFlow weights: Kaiming-normal convolutions (the last conv of every SpyNet block x0.2, so that the flows stay
+    within a few pixels on [0,1] images), BatchNorm gamma ~ 1 +- 0.1, beta ~ +-0.05, running_mean ~ N(0, 0.1^2),
+    running_var ~ U[0.5, 1.5]: eval mode then differs from training mode (batch statistics)."""
+    sd = OrderedDict()
+    for name, shape in tof_param_spec().items():
+        r = _rs(seed + 15485863, name)
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.tensor(0, dtype=torch.long)
+            continue
+        if name.endswith("running_mean"):
+            a = r.standard_normal(shape) * 0.1
+        elif name.endswith("running_var"):
+            a = r.uniform(0.5, 1.5, shape)
+        elif len(shape) == 1 and ".block." in name and int(name.split(".block.")[1].split(".")[0]) % 3 == 1:
+            a = (1.0 + 0.1 * r.standard_normal(shape)) if name.endswith(".weight") else 0.05 * r.standard_normal(shape)
+        elif name.endswith(".bias"):
+            a = r.standard_normal(shape) * 0.01
+        else:
+            gain = 0.2 if ".block.12." in name else 1.0
+            a = r.standard_normal(shape) * (gain * np.sqrt(2.0 / _fan_in(shape)))
+        sd[name] = torch.from_numpy(np.asarray(a)).to(dtype)
     return sd
 
 

@@ -254,6 +254,46 @@ int dvsr_l1_tail_forward(const float* x, const float* y, const float* base, floa
 int dvsr_l1_tail_backward(const float* x, const float* y, const float* grad_loss, float weight, float* gx, long long n,
                           dvsr_stream_t stream);
 
+/* ---- TOFlow backbone ops (codes/models/archs/TOF_arch.py:25-140, arch_util.py:55-79) --------
+ * The convolutions of SpyNet (7x7) and of the TOFlow head (9x9, 1x1) go through dvsr_conv2d_forward / _backward
+ * (ks = 7, 9, 1); the ops below are the rest of the graph.  All fp32 NCHW, HBM-bound streaming kernels.
+ *
+ * flow_warp (arch_util.py:55-79): out[n,c,y,x] = bilinear sample of x[n,c] at (x + flow[n,0,y,x], y + flow[n,1,y,x])
+ * through F.grid_sample's align_corners=False mapping of the (size-1)-normalised grid, zeros padding.  `flow` is
+ * channel-first [N,2,H,W] (the reference permutes to NHW2 first).  out_bstride / gout_bstride (0 = dense) let the
+ * output be a channel slice of a wider tensor (torch.cat([ref, warped, flow]) is built in place).  Backward:
+ * grad_x (zeroed here, atomics) and / or grad_flow; either may be NULL. */
+int dvsr_flow_warp_forward(const float* x, const float* flow, float* out, int N, int C, int H, int W,
+                           long long out_bstride, dvsr_stream_t stream);
+int dvsr_flow_warp_backward(const float* x, const float* flow, const float* grad_out, float* grad_x, float* grad_flow,
+                            int N, int C, int H, int W, long long gout_bstride, dvsr_stream_t stream);
+/* F.avg_pool2d(x, kernel_size=2, stride=2) (TOF_arch.py:67-74); planes = N*C; output (H/2) x (W/2). */
+int dvsr_avgpool2_forward(const float* x, float* y, long long planes, int H, int W, dvsr_stream_t stream);
+int dvsr_avgpool2_backward(const float* grad_y, float* grad_x, long long planes, int H, int W, int accumulate,
+                           dvsr_stream_t stream);
+/* F.interpolate(x, size=(Ho,Wo), mode='bilinear', align_corners=True) * mul (TOF_arch.py:84-85); y_plane_stride
+ * (0 = Ho*Wo) addresses a channel slice.  Backward zeroes grad_x and scatters. */
+int dvsr_resize_bilinear_ac_forward(const float* x, float* y, long long planes, int H, int W, int Ho, int Wo, float mul,
+                                    long long y_plane_stride, dvsr_stream_t stream);
+int dvsr_resize_bilinear_ac_backward(const float* grad_y, float* grad_x, long long planes, int H, int W, int Ho, int Wo,
+                                     float mul, long long gy_plane_stride, dvsr_stream_t stream);
+/* out[n,c,:] (+)= x[n,c,:] * scale[c] + shift[c]; scale / shift may be NULL (1 / 0): normalize / denormalize
+ * (TOF_arch.py:13-22) and channel-slice copies; batch strides 0 = dense. */
+int dvsr_channel_affine(const float* x, const float* scale, const float* shift, float* out, int N, int C, long long HW,
+                        long long x_bstride, long long out_bstride, int accumulate, dvsr_stream_t stream);
+/* nn.BatchNorm2d (+ the ReLU behind it, TOF_arch.py:33-42).  training != 0: batch statistics, running estimates
+ * updated in place (momentum, unbiased variance); else the running estimates.  save_mean / save_rstd [C] feed the
+ * backward, which takes the gradient w.r.t. the (post-ReLU) output and needs y only when relu. */
+size_t dvsr_batchnorm_workspace_bytes(int C);
+int dvsr_batchnorm_forward(const float* x, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* y, float* save_mean, float* save_rstd, int N, int C, long long HW,
+                           int training, float momentum, float eps, int relu, void* workspace, size_t workspace_bytes,
+                           dvsr_stream_t stream);
+int dvsr_batchnorm_backward(const float* x, const float* grad_y, const float* y, const float* gamma,
+                            const float* save_mean, const float* save_rstd, float* grad_x, float* grad_gamma,
+                            float* grad_beta, int N, int C, long long HW, int training, int relu, void* workspace,
+                            size_t workspace_bytes, dvsr_stream_t stream);
+
 /* ---- inner-loop optimiser steps over lists of parameter tensors ------------------------------------
  * test_dynavsr.py:223-231 steps torch.optim.Adam(lr_alpha, betas) / torch.optim.SGD(lr_alpha) over the
  * ~158 tensors of netG + netE once per inner iteration; these entry points do one such step (same

@@ -209,6 +209,51 @@ def edvr_l(E):
              "recon_trunk.39.conv2.bias", "conv_last.weight")})
 
 
+def tof_cases():
+    """the reference's TOFlow module (TOF_arch.py; plain torch, runs on CPU as shipped) on 1x7x3x32x48
+    clips, adapt_official=True as networks.py:39 builds it: eval mode (running statistics) forward, and training
+    mode (batch statistics, the mode the inner MAML step runs in) forward + d(charbonnier)/d(all parameters) +
+    the updated running estimates.  oracle/tof.py is asserted against the module before anything is written."""
+    import models.archs.TOF_arch as TOF
+    from oracle import tof as otof
+    P = synth.tof_state_dict(2)
+    h, w, seed = 32, 48, 11
+    x = synth.clip(seed, 1, 7, h, w)
+    tgt = synth.clip(seed + 100, 1, 1, h, w)[:, 0]
+    net = load_sd(TOF.TOFlow(adapt_official=True), P)
+    net.eval()
+    with torch.no_grad():
+        y_eval = net(x.clone())
+        yo = otof.toflow_forward(OrderedDict((k, v.clone()) for k, v in P.items()), x, training=False)
+    assert relerr(yo, y_eval) < 1e-6, relerr(yo, y_eval)
+    net = load_sd(TOF.TOFlow(adapt_official=True), P)
+    net.train()
+    y = net(x.clone())
+    loss = oedvr.charbonnier(y, tgt)
+    loss.backward()
+    ref_g = OrderedDict((k, p.grad.detach()) for k, p in net.named_parameters())
+    PO = OrderedDict((k, (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()))
+                     for k, v in P.items())
+    taps = {}
+    yo = otof.toflow_forward(PO, x, training=True, taps=taps)
+    og = torch.autograd.grad(oedvr.charbonnier(yo, tgt), [PO[k] for k in ref_g])
+    assert relerr(yo, y) < 1e-6, relerr(yo, y)
+    worst = max(relerr(a, ref_g[k]) for k, a in zip(ref_g, og))
+    assert worst < 1e-4, worst
+    sd_after = net.state_dict()
+    for k in sd_after:
+        if "running" in k:
+            assert relerr(PO[k], sd_after[k]) < 1e-6, k
+    keep = ("SpyNet.blocks.0.block.0.weight", "SpyNet.blocks.3.block.12.bias", "SpyNet.blocks.2.block.4.weight",
+            "conv_64_64_1x1.weight", "conv_64_3_1x1.bias")
+    save("tof_32x48", wseed=2, xseed=seed, tseed=seed + 100, h=h, w=w, out_eval=y_eval, out_train=y, loss=float(loss.detach()),
+         flow_last=torch.stack(taps["flow_l3"], 1), warped=taps["warped"],
+         grad_names=np.array(list(ref_g.keys())), grad_norms=np.array([float(g.norm()) for g in ref_g.values()]),
+         running_mean_b3_1=sd_after["SpyNet.blocks.3.block.1.running_mean"],
+         running_var_b3_1=sd_after["SpyNet.blocks.3.block.1.running_var"],
+         **{"grad__" + k.replace(".", "__"): ref_g[k] for k in keep})
+
+
 def mfdn_full(L):
     """G5: MFDN x4 forward/backward on 1x5x3x32x32 through the reference module."""
     M = synth.mfdn_state_dict(0)
@@ -466,11 +511,12 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     E, L, models, U = import_reference()
-    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "estimators", "inner", "degradation", "meta"]
+    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "estimators", "inner", "degradation", "meta", "tof"]
     if "dcn" in which: dcn_cases()
     if "pcd" in which: pcd_tsa(E)
     if "edvr" in which: edvr_full(E)
     if "edvr" in which or "edvr_x2" in which: edvr_x2(E)
+    if "tof" in which: tof_cases()
     if "edvr_l" in which: edvr_l(E)      # several minutes on 8 cores; not part of the default set
     if "mfdn" in which: mfdn_full(L)
     if "estimators" in which: estimator_variants(L)

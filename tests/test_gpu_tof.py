@@ -1,0 +1,202 @@
+"""GPU parity of the TOFlow backbone: every op against a plain PyTorch fp64 CPU reference of the same
+op, and the whole module (training and eval mode, forward and backward) against the golden produced by the
+reference's own TOFlow module and against oracle/tof.py.  Tolerances: forward rel-L2 <= 2e-5 per op / 2e-4 for the
+network, gradients rel-L2 <= 2e-4 per op."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, relerr
+from dynavsr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape) * scale).float()
+
+
+@pytest.mark.parametrize("ks,cin,cout,h,w", [(7, 8, 32, 20, 37), (7, 64, 32, 16, 32), (7, 16, 2, 9, 33), (9, 21, 64, 24, 40),
+                                             (9, 64, 64, 16, 16), (1, 64, 3, 12, 20)])
+def test_tof_conv_forward_backward(ks, cin, cout, h, w):
+    """SpyNet's 7x7, the head's 9x9 / 1x1: bias + ReLU + residual fused forward, and dX / dW / db."""
+    from dynavsr_amd import _lib as L, tofops as T
+    x, wt, b = rnd(2, cin, h, w, seed=1), rnd(cout, cin, ks, ks, seed=2, scale=(cin * ks * ks) ** -0.5), rnd(cout, seed=3, scale=0.1)
+    res, go = rnd(2, cout, h, w, seed=4), rnd(2, cout, h, w, seed=5)
+    for act, use_res in ((L.ACT_NONE, True), (L.ACT_RELU, False)):
+        xd, wd, bd, rd = [t.double().requires_grad_() for t in (x, wt, b, res)]
+        y = F.conv2d(xd, wd, bd, padding=ks // 2)
+        y = (F.relu(y) if act == L.ACT_RELU else y) + (rd if use_res else 0)
+        gr = torch.autograd.grad(y, [xd, wd, bd] + ([rd] if use_res else []), go.double())
+        xg, wg, bg, rg = [t.cuda().requires_grad_() for t in (x, wt, b, res)]
+        yg = T.conv(xg, wg, bg, res=rg if use_res else None, act=act)
+        gg = torch.autograd.grad(yg, [xg, wg, bg] + ([rg] if use_res else []), go.cuda())
+        assert relerr(yg, y) < 2e-5
+        for a, r_ in zip(gg, gr):
+            assert relerr(a, r_) < 2e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24), (1, 3, 7, 9), (3, 3, 32, 48)])
+def test_flow_warp_forward_backward(shape):
+    """arch_util.flow_warp: against the reference's own formulation (grid / (size-1), grid_sample align_corners=False)
+    in fp64, with flows that leave the image, land on integer positions and on the -0.5 / W-0.5 borders."""
+    from dynavsr_amd import tofops as T
+    from oracle import tof as otof
+    n, c, h, w = shape
+    x = rnd(n, c, h, w, seed=1)
+    flow = rnd(n, 2, h, w, seed=2, scale=2.5)
+    flow[0, :, 0, :] = 0.0                      # exact grid positions
+    flow[0, 0, 1, :] = 40.0                     # far outside
+    flow[0, 1, 2, :] = -40.0
+    flow[0, 0, 3, 0] = -0.5 * (w - 1) / w       # ix == -0.5 exactly for x = 0 ... (border of the zero padding)
+    go = rnd(n, c, h, w, seed=3)
+    xd, fd = x.double().requires_grad_(), flow.double().requires_grad_()
+    y = otof.flow_warp(xd, fd.permute(0, 2, 3, 1))
+    gx, gf = torch.autograd.grad(y, [xd, fd], go.double())
+    xg, fg = x.cuda().requires_grad_(), flow.cuda().requires_grad_()
+    yg = T.flow_warp(xg, fg)
+    ggx, ggf = torch.autograd.grad(yg, [xg, fg], go.cuda())
+    assert relerr(yg, y) < 2e-5 and relerr(ggx, gx) < 2e-5
+    # d/dflow flips sign at integer sampling positions (floor kink): compare away from them, like the DCN tests
+    frac = (torch.stack([(torch.arange(w)[None, None, :] + fd[:, 0].detach()) * w / (w - 1) - 0.5,
+                         (torch.arange(h)[None, :, None] + fd[:, 1].detach()) * h / (h - 1) - 0.5], 1) % 1.0)
+    smooth = ((frac > 1e-3) & (frac < 1 - 1e-3)).all(1, keepdim=True).expand_as(gf)
+    assert float((ggf.cpu().double() - gf)[smooth].norm() / gf[smooth].norm()) < 2e-4
+    with pytest.raises(RuntimeError, match="flow must be"):
+        T.flow_warp(xg, fg[:, :, :-1])
+
+
+def test_avgpool_resize_affine_ops():
+    from dynavsr_amd import tofops as T
+    x = rnd(2, 3, 18, 28, seed=1)
+    go = rnd(2, 3, 9, 14, seed=2)
+    xd = x.double().requires_grad_()
+    y = F.avg_pool2d(xd, 2, 2, count_include_pad=False)
+    (gr,) = torch.autograd.grad(y, xd, go.double())
+    xg = x.cuda().requires_grad_()
+    yg = T.avg_pool2(xg)
+    (gg,) = torch.autograd.grad(yg, xg, go.cuda())
+    assert relerr(yg, y) < 1e-6 and relerr(gg, gr) < 1e-6
+    assert T.avg_pool2(rnd(1, 2, 7, 9).cuda()).shape == (1, 2, 3, 4)          # odd sizes: floor, last row / column dropped
+    for (h, w), (ho, wo) in (((4, 6), (8, 12)), ((2, 3), (5, 7)), ((1, 1), (2, 2)), ((3, 5), (3, 5))):
+        f = rnd(2, 2, h, w, seed=3)
+        go = rnd(2, 2, ho, wo, seed=4)
+        fd = f.double().requires_grad_()
+        y = F.interpolate(fd, size=(ho, wo), mode="bilinear", align_corners=True) * 2.0
+        (gr,) = torch.autograd.grad(y, fd, go.double())
+        fg = f.cuda().requires_grad_()
+        yg = T.resize_bilinear_ac(fg, (ho, wo), 2.0)
+        (gg,) = torch.autograd.grad(yg, fg, go.cuda())
+        assert relerr(yg, y) < 1e-6 and relerr(gg, gr) < 1e-5, ((h, w), (ho, wo))
+    s, t = torch.tensor([2.0, 0.5, -1.0]), torch.tensor([0.1, 0.2, 0.3])
+    xg = x.cuda().requires_grad_()
+    yg = T.channel_affine(xg, s.cuda(), t.cuda())
+    (gg,) = torch.autograd.grad(yg, xg, torch.ones_like(yg))
+    assert relerr(yg, x * s.view(1, 3, 1, 1) + t.view(1, 3, 1, 1)) < 1e-7 and relerr(gg, s.view(1, 3, 1, 1).expand_as(x)) < 1e-7
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("relu", [True, False])
+def test_batchnorm_forward_backward(training, relu):
+    from dynavsr_amd import tofops as T
+    n, c, h, w = 3, 32, 13, 21
+    x = rnd(n, c, h, w, seed=1) * 2.0 + 0.5
+    go = rnd(n, c, h, w, seed=2)
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * rnd(c, seed=3)); bn.bias.copy_(0.1 * rnd(c, seed=4))
+        bn.running_mean.copy_(0.3 * rnd(c, seed=5)); bn.running_var.copy_(0.5 + rnd(c, seed=6).abs())
+    ref = torch.nn.BatchNorm2d(c).double()
+    ref.load_state_dict(bn.state_dict())
+    bn, ref = bn.cuda().train(training), ref.train(training)
+    xd = x.double().requires_grad_()
+    y = ref(xd)
+    y = F.relu(y) if relu else y
+    gr = torch.autograd.grad(y, [xd, ref.weight, ref.bias], go.double())
+    xg = x.cuda().requires_grad_()
+    yg = T.batchnorm(xg, bn, relu=relu)
+    gg = torch.autograd.grad(yg, [xg, bn.weight, bn.bias], go.cuda())
+    assert relerr(yg, y) < 2e-6
+    for a, r_ in zip(gg, gr):
+        assert relerr(a, r_) < 2e-5
+    assert relerr(bn.running_mean, ref.running_mean) < 1e-6 and relerr(bn.running_var, ref.running_var) < 1e-6
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == (1 if training else 0)
+
+
+def _tof(seed):
+    from dynavsr_amd.models.archs.TOF_arch import TOFlow
+    net = TOFlow(adapt_official=True)
+    net.load_state_dict(synth.tof_state_dict(seed), strict=True)
+    return net.cuda()
+
+
+def test_toflow_eval_and_training_golden():
+    """The module against the reference's golden: eval forward; training forward, Charbonnier loss, all 80 parameter
+    gradient norms, five full gradients, and the running statistics after the six SpyNet calls."""
+    from dynavsr_amd import hipops
+    g = load_golden("tof_32x48")
+    h, w = int(g["h"]), int(g["w"])
+    x = synth.clip(int(g["xseed"]), 1, 7, h, w).cuda()
+    tgt = synth.clip(int(g["tseed"]), 1, 1, h, w)[:, 0].cuda()
+    net = _tof(int(g["wseed"]))
+    net.eval()
+    with torch.no_grad():
+        y = net(x)
+    assert relerr(y, g["out_eval"]) < 2e-4 and float((y.cpu() - torch.from_numpy(g["out_eval"])).abs().max()) < 1e-3
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    net.batch_neighbors = True                   # eval: one SpyNet pass over the 6 neighbours == the loop
+    with torch.no_grad():
+        assert relerr(net(x), y) < 1e-6
+    net.batch_neighbors = False
+    assert all(torch.equal(v, sd0[k]) for k, v in net.state_dict().items())      # eval mode leaves the buffers alone
+    net.train()
+    y = net(x)
+    assert relerr(y, g["out_train"]) < 2e-4
+    loss = hipops.charbonnier(y, tgt)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss.backward()
+    by_name = dict(net.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    assert names == list(by_name.keys())
+    bad = [(k, float(by_name[k].grad.norm()), b) for k, b in zip(names, g["grad_norms"])
+           if abs(float(by_name[k].grad.norm()) - b) > 2e-3 * b + 1e-6]
+    assert not bad, bad[:6]
+    for key in g:
+        if key.startswith("grad__"):
+            name = key[len("grad__"):].replace("__", ".")
+            assert relerr(by_name[name].grad, g[key]) < 1e-2, name
+    sd = net.state_dict()
+    assert relerr(sd["SpyNet.blocks.3.block.1.running_mean"], g["running_mean_b3_1"]) < 1e-5
+    assert relerr(sd["SpyNet.blocks.3.block.1.running_var"], g["running_var_b3_1"]) < 1e-5
+    assert int(sd["SpyNet.blocks.0.block.1.num_batches_tracked"]) == 6
+
+
+def test_toflow_batch2_vs_oracle_and_wrapper():
+    """B = 2 at another size against oracle/tof.py (flows, warped stack, output), and the wrapper API with
+    network_G.which_model_G = TOF (networks.py:37-39): feed_data / test() / calculate_loss / backward."""
+    from oracle import tof as otof
+    P = synth.tof_state_dict(5)
+    x = synth.clip(21, 2, 7, 48, 32)
+    taps = {}
+    with torch.no_grad():
+        ref = otof.toflow_forward(OrderedDict((k, v.clone()) for k, v in P.items()), x, training=False, taps=taps)
+    net = _tof(5).eval()
+    with torch.no_grad():
+        y = net(x.cuda())
+    assert relerr(y, ref) < 2e-4
+    from dynavsr_amd.models import create_model
+    from dynavsr_amd.options.options import dict_to_nonedict
+    opt = dict_to_nonedict({"name": "tof", "model": "video_base", "scale": 4, "gpu_ids": [0], "dist": False, "is_train": False,
+                            "network_G": {"which_model_G": "TOF"}, "path": {"strict_load": True},
+                            "train": {"pixel_criterion": "cb", "pixel_weight": 1.0}})
+    model = create_model(opt)
+    model.netG.load_state_dict(P)
+    model.feed_data({"LQs": x[:1], "GT": x[:1, 3]})
+    model.test()
+    assert relerr(model.fake_H, ref[:1]) < 2e-4
+    loss = model.calculate_loss()
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.netG.parameters())
