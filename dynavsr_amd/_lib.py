@@ -89,6 +89,10 @@ def _declare(lib):
         "dvsr_batchnorm_workspace_bytes": (c_size_t, [I]),
         "dvsr_batchnorm_forward": (I, [P] * 8 + [I, I, LL, I, F, F, I, P, c_size_t, P]),
         "dvsr_batchnorm_backward": (I, [P] * 9 + [I, I, LL, I, I, P, c_size_t, P]),
+        "dvsr_temporal_gather3_forward": (I, [P, P, I, I, I, LL, I, P]),
+        "dvsr_temporal_gather3_backward": (I, [P, P, I, I, I, LL, I, P]),
+        "dvsr_dynamic_filter_forward": (I, [P, P, P, P, I, I, I, I, I, P]),
+        "dvsr_dynamic_filter_backward": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
         "dvsr_l1_tail_forward": (I, [P, P, P, F, P, LL, P, c_size_t, P]),
         "dvsr_l1_tail_backward": (I, [P, P, P, F, P, LL, P]),
         "dvsr_charbonnier_backward": (I, [P, P, P, P, LL, F, P]),

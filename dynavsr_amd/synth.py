@@ -93,6 +93,34 @@ def tof_state_dict(seed=0, dtype=torch.float32):
     return sd
 
 
+def duf_state_dict(seed=0, layers=16, scale=4, dtype=torch.float32):
+    """DUF weights by the names and shapes of the module's own state dict (DUF_arch.py; 101 / 185 / 353 tensors):
+    Kaiming-normal convolutions (the two output convolutions x0.3 so that the filter logits and the residual stay
+    O(1)), BatchNorm gamma ~ 1 +- 0.1, beta ~ +-0.05, running_mean ~ N(0, 0.1^2), running_var ~ U[0.5, 1.5]."""
+    from .models.archs import DUF_arch
+    cls = {16: DUF_arch.DUF_16L, 28: DUF_arch.DUF_28L}.get(layers, DUF_arch.DUF_52L)
+    spec = OrderedDict((k, tuple(v.shape)) for k, v in cls(scale=scale, adapt_official=True).state_dict().items())
+    sd = OrderedDict()
+    for name, shape in spec.items():
+        r = _rs(seed + 32452843, name)
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.tensor(0, dtype=torch.long)
+            continue
+        if name.endswith("running_mean"):
+            a = r.standard_normal(shape) * 0.1
+        elif name.endswith("running_var"):
+            a = r.uniform(0.5, 1.5, shape)
+        elif len(shape) == 1 and (name + "@").replace(".weight@", ".running_var").replace(".bias@", ".running_var") in spec:
+            a = (1.0 + 0.1 * r.standard_normal(shape)) if name.endswith(".weight") else 0.05 * r.standard_normal(shape)
+        elif name.endswith(".bias"):
+            a = r.standard_normal(shape) * 0.01
+        else:
+            gain = 0.3 if name.startswith(("conv3d_r2", "conv3d_f2")) else 1.0
+            a = r.standard_normal(shape) * (gain * np.sqrt(2.0 / _fan_in(shape)))
+        sd[name] = torch.from_numpy(np.asarray(a)).to(dtype)
+    return sd
+
+
 def clip(seed, b, n, h, w, dtype=torch.float32, smooth=True):
     """A [b, n, 3, h, w] clip in [0,1].  ``smooth`` gives low-frequency content with a global
     per-frame shift (so alignment has something to align); otherwise i.i.d. U[0,1)."""

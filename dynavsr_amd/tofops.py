@@ -223,3 +223,73 @@ class _ChannelAffine(torch.autograd.Function):
 def channel_affine(x, scale, shift):
     """x * scale[c] + shift[c] over dim 1 (constants: no gradient to scale / shift)."""
     return _ChannelAffine.apply(x, scale, shift)
+
+
+# ---- DUF (codes/models/archs/DUF_arch.py) ----------------------------------------------------------------
+class _TemporalGather3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b, t, pad_t):
+        _chk(x)
+        x = _f(x)
+        bt, c, h, w = x.shape
+        if bt != b * t:
+            raise RuntimeError("temporal_gather3: %d frames, expected B*T = %d*%d" % (bt, b, t))
+        to = t + 2 * pad_t - 2
+        y = x.new_empty((b * to, 3 * c, h, w))
+        L.check(L.lib().dvsr_temporal_gather3_forward(L.ptr(x), L.ptr(y), b, t, c, h * w, pad_t, L.stream()),
+                "dvsr_temporal_gather3_forward")
+        ctx.geo = (b, t, c, h, w, pad_t)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        b, t, c, h, w, pad_t = ctx.geo
+        g = _f(g)
+        gx = g.new_empty((b * t, c, h, w))
+        L.check(L.lib().dvsr_temporal_gather3_backward(L.ptr(g), L.ptr(gx), b, t, c, h * w, pad_t, L.stream()),
+                "dvsr_temporal_gather3_backward")
+        return gx, None, None, None
+
+
+def temporal_gather3(x, b, t, pad_t):
+    """[B*T,C,H,W] -> [B*To,3C,H,W] (channel c*3+kt = frame t+kt-pad_t, zero outside): the input of a (3,3,3) Conv3d
+    run as a 3x3 conv2d.  pad_t 1 keeps T, 0 gives To = T - 2."""
+    return _TemporalGather3.apply(x, b, t, pad_t)
+
+
+class _DynamicFilter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xc, logits, res, scale, adapt):
+        _chk(xc, logits, res)
+        xc, logits, res = _f(xc), _f(logits), _f(res)
+        b, c, h, w = xc.shape
+        r = scale * scale
+        if c != 3 or tuple(logits.shape) != (b, 25 * r, h, w) or tuple(res.shape) != (b, 3 * r, h, w):
+            raise RuntimeError("dynamic_filter: x_center %s, logits %s, residual %s do not fit scale %d"
+                               % (tuple(xc.shape), tuple(logits.shape), tuple(res.shape), scale))
+        out = xc.new_empty((b, 3, scale * h, scale * w))
+        L.check(L.lib().dvsr_dynamic_filter_forward(L.ptr(xc), L.ptr(logits), L.ptr(res), L.ptr(out), b, h, w, scale,
+                                                    int(adapt), L.stream()), "dvsr_dynamic_filter_forward")
+        ctx.save_for_backward(xc, logits)
+        ctx.cfg = (scale, int(adapt))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        xc, logits = ctx.saved_tensors
+        scale, adapt = ctx.cfg
+        g = _f(g)
+        b, _, h, w = xc.shape
+        gl = torch.empty_like(logits)
+        gr = g.new_empty((b, 3 * scale * scale, h, w))
+        gx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+        L.check(L.lib().dvsr_dynamic_filter_backward(L.ptr(xc), L.ptr(logits), L.ptr(g), L.ptr(gl), L.ptr(gr), L.ptr(gx), b, h,
+                                                     w, scale, adapt, L.stream()), "dvsr_dynamic_filter_backward")
+        return gx, gl, gr, None, None
+
+
+def dynamic_filter(x_center, filter_logits, residual, scale, adapt_official):
+    """softmax over the 25 taps + DynamicUpsamplingFilter_3C + residual (adapt_official order) + pixel_shuffle."""
+    return _DynamicFilter.apply(x_center, filter_logits, residual, scale, adapt_official)

@@ -294,6 +294,27 @@ int dvsr_batchnorm_backward(const float* x, const float* grad_y, const float* y,
                             float* grad_beta, int N, int C, long long HW, int training, int relu, void* workspace,
                             size_t workspace_bytes, dvsr_stream_t stream);
 
+/* ---- DUF backbone ops (codes/models/archs/DUF_arch.py:32-180) ------------------------------------
+ * Frames are the batch axis ([B*T][C][H][W]).  Conv3d (1,3,3) / (1,1,1) are dvsr_conv2d_* over the frames; the (3,3,3)
+ * Conv3d of the dense blocks (:45-58) is a 3x3 conv2d over 3C channels after this gather of frames t-1, t, t+1:
+ * y[(b*To + t)][c*3 + kt] = x[(b*T + t + kt - pad_t)][c] or 0; pad_t = 1 keeps T (padding (1,1,1)), pad_t = 0 is the
+ * T-reducing block (padding (0,1,1), To = T - 2).  The Conv3d weight [Cout][C][3][3][3] is that conv's
+ * [Cout][3C][3][3] weight as it lies in memory.  BatchNorm3d = dvsr_batchnorm_* over N = B*T. */
+int dvsr_temporal_gather3_forward(const float* x, float* y, int B, int T, int C, long long HW, int pad_t,
+                                  dvsr_stream_t stream);
+int dvsr_temporal_gather3_backward(const float* grad_y, float* grad_x, int B, int T, int C, long long HW, int pad_t,
+                                   dvsr_stream_t stream);
+/* Tail of DUF.forward (:160-176) in one kernel: Fx = softmax over the 25 taps of filter_logits [B][25*R][H][W]
+ * (channel f*R + r, R = scale^2), DynamicUpsamplingFilter_3C (:86-110) of the centre frame x_center [B][3][H][W] (5x5
+ * patch, zero padded), + residual [B][3R][H][W] (channel c*R + r, or 3r + c when adapt_official reorders it, :17-29),
+ * F.pixel_shuffle(scale) -> out [B][3][scale*H][scale*W].  Backward: grad_logits and grad_residual are written in
+ * full; grad_x_center may be NULL (the clip is data in the inner loop). */
+int dvsr_dynamic_filter_forward(const float* x_center, const float* filter_logits, const float* residual, float* out,
+                                int B, int H, int W, int scale, int adapt_official, dvsr_stream_t stream);
+int dvsr_dynamic_filter_backward(const float* x_center, const float* filter_logits, const float* grad_out,
+                                 float* grad_logits, float* grad_residual, float* grad_x_center, int B, int H, int W,
+                                 int scale, int adapt_official, dvsr_stream_t stream);
+
 /* ---- inner-loop optimiser steps over lists of parameter tensors ------------------------------------
  * test_dynavsr.py:223-231 steps torch.optim.Adam(lr_alpha, betas) / torch.optim.SGD(lr_alpha) over the
  * ~158 tensors of netG + netE once per inner iteration; these entry points do one such step (same

@@ -254,6 +254,52 @@ def tof_cases():
          **{"grad__" + k.replace(".", "__"): ref_g[k] for k in keep})
 
 
+def duf_cases():
+    """the reference's DUF modules (DUF_arch.py; plain torch) on CPU, adapt_official=True as networks.py:29-36
+    builds them.  DUF_16L x4 on 1x7x3x16x24: eval forward; training-mode forward + d(charbonnier)/d(all parameters)
+    + a running estimate.  DUF_16L x2, DUF_28L x4 and DUF_52L x3 on 1x7x3x8x12: eval forward (pins the block structure
+    and the other scales)."""
+    import models.archs.DUF_arch as DUF
+    from oracle import duf as oduf
+    P = synth.duf_state_dict(3, 16, 4)
+    h, w, seed = 16, 24, 13
+    x = synth.clip(seed, 1, 7, h, w)
+    tgt = synth.clip(seed + 100, 1, 1, 4 * h, 4 * w)[:, 0]
+    net = load_sd(DUF.DUF_16L(scale=4, adapt_official=True), P).eval()
+    with torch.no_grad():
+        y_eval = net(x.clone())
+        yo = oduf.duf_forward(OrderedDict((k, v.clone()) for k, v in P.items()), x, 16, 4, True, False)
+    assert relerr(yo, y_eval) < 1e-6, relerr(yo, y_eval)
+    net = load_sd(DUF.DUF_16L(scale=4, adapt_official=True), P).train()
+    y = net(x.clone())
+    loss = oedvr.charbonnier(y, tgt)
+    loss.backward()
+    ref_g = OrderedDict((k, p.grad.detach()) for k, p in net.named_parameters())
+    PO = OrderedDict((k, (v.clone().requires_grad_(True) if k in ref_g else v.clone())) for k, v in P.items())
+    yo = oduf.duf_forward(PO, x, 16, 4, True, True)
+    og = torch.autograd.grad(oedvr.charbonnier(yo, tgt), [PO[k] for k in ref_g])
+    assert relerr(yo, y) < 1e-6, relerr(yo, y)
+    worst = max(relerr(a, ref_g[k]) for k, a in zip(ref_g, og) if float(ref_g[k].norm()) > 1e-7)
+    assert worst < 1e-4, worst
+    sd_after = net.state_dict()
+    assert relerr(PO["bn3d_2.running_var"], sd_after["bn3d_2.running_var"]) < 1e-6
+    keep = ("conv3d_1.weight", "dense_block_1.conv3d_2.weight", "dense_block_2.bn3d_5.weight", "conv3d_r2.bias", "conv3d_f2.bias")
+    out = dict(wseed=3, xseed=seed, tseed=seed + 100, h=h, w=w, out_eval=y_eval, out_train=y, loss=float(loss.detach()),
+               grad_names=np.array(list(ref_g.keys())), grad_norms=np.array([float(g.norm()) for g in ref_g.values()]),
+               running_mean_bn3d_2=sd_after["bn3d_2.running_mean"], running_var_bn3d_2=sd_after["bn3d_2.running_var"],
+               **{"grad__" + k.replace(".", "__"): ref_g[k] for k in keep})
+    for layers, scale, cls in ((16, 2, DUF.DUF_16L), (28, 4, DUF.DUF_28L), (52, 3, DUF.DUF_52L)):
+        Pv = synth.duf_state_dict(4, layers, scale)
+        xv = synth.clip(seed + layers, 1, 7, 8, 12)
+        netv = load_sd(cls(scale=scale, adapt_official=True), Pv).eval()
+        with torch.no_grad():
+            yv = netv(xv.clone())
+            yov = oduf.duf_forward(OrderedDict((k, v.clone()) for k, v in Pv.items()), xv, layers, scale, True, False)
+        assert relerr(yov, yv) < 1e-6, (layers, relerr(yov, yv))
+        out["out_eval_%dL_x%d" % (layers, scale)] = yv
+    save("duf_16x24", **out)
+
+
 def mfdn_full(L):
     """G5: MFDN x4 forward/backward on 1x5x3x32x32 through the reference module."""
     M = synth.mfdn_state_dict(0)
@@ -511,12 +557,13 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     E, L, models, U = import_reference()
-    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "estimators", "inner", "degradation", "meta", "tof"]
+    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "estimators", "inner", "degradation", "meta", "tof", "duf"]
     if "dcn" in which: dcn_cases()
     if "pcd" in which: pcd_tsa(E)
     if "edvr" in which: edvr_full(E)
     if "edvr" in which or "edvr_x2" in which: edvr_x2(E)
     if "tof" in which: tof_cases()
+    if "duf" in which: duf_cases()
     if "edvr_l" in which: edvr_l(E)      # several minutes on 8 cores; not part of the default set
     if "mfdn" in which: mfdn_full(L)
     if "estimators" in which: estimator_variants(L)

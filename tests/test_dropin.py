@@ -213,3 +213,40 @@ def test_util_duf_downsample_and_flip_forward():
     assert torch.equal(ref, net(inp).detach())
     sym = util.flipx4_forward(lambda t: (t * 2, None), inp)                   # tuple outputs: first element
     assert torch.allclose(sym, inp * 2, atol=1e-7)
+
+
+@needs_ref
+def test_backbone_state_dicts_match_the_reference_modules():
+    """networks.define_G's three video backbones expose exactly the reference modules' state-dict keys and shapes, so
+    reference checkpoints load with strict=True.  The reference modules are only constructed (CPU, plain torch; EDVR's
+    CUDA extension import is stubbed like oracle/gen_golden.py does), nothing is copied."""
+    code = r'''
+import importlib.util, json, sys, types
+sys.dont_write_bytecode = True
+repo, ref = sys.argv[1], sys.argv[2]
+sys.path.insert(0, repo)
+from dynavsr_amd.models.archs import DUF_arch, EDVR_arch, TOF_arch
+sys.path.insert(0, ref)
+sys.modules["models.archs.dcn.deform_conv_cuda"] = types.ModuleType("deform_conv_cuda")
+import models.archs.DUF_arch as RD, models.archs.EDVR_arch as RE, models.archs.TOF_arch as RT
+bad = []
+pairs = [("TOF", TOF_arch.TOFlow(adapt_official=True), RT.TOFlow(adapt_official=True))]
+for n in ("DUF_16L", "DUF_28L", "DUF_52L"):
+    for s in (2, 3, 4):
+        pairs.append((n + "x%d" % s, getattr(DUF_arch, n)(scale=s, adapt_official=True), getattr(RD, n)(scale=s, adapt_official=True)))
+for s in (2, 4):
+    cfg = dict(nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, scale=s)
+    pairs.append(("EDVR-Mx%d" % s, EDVR_arch.EDVR(**cfg), RE.EDVR(**cfg)))
+for name, a, b in pairs:
+    sa, sb = a.state_dict(), b.state_dict()
+    if list(sa) != list(sb) or any(tuple(sa[k].shape) != tuple(sb[k].shape) for k in sa):
+        bad.append(name)
+print(json.dumps({"checked": len(pairs), "bad": bad}))
+'''
+    env = dict(os.environ)
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    r = subprocess.run([sys.executable, "-c", code, ROOT, REF], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["checked"] == 12 and rep["bad"] == [], rep

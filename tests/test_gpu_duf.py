@@ -1,0 +1,131 @@
+"""GPU parity of the DUF backbone: the two DUF-specific ops against fp64 PyTorch references, and the
+modules (16L training + eval, 16L x2 / 28L x4 / 52L x3 eval) against the golden from the reference's own modules."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, relerr
+from dynavsr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape) * scale).float()
+
+
+@pytest.mark.parametrize("pad_t", [1, 0])
+def test_conv3d_333_as_gather_plus_conv2d(pad_t):
+    """temporal_gather3 + 3x3 conv2d with the Conv3d weight viewed as [Cout, 3C, 3, 3] == F.conv3d (3,3,3) with
+    padding (pad_t, 1, 1), forward and all three gradients."""
+    from dynavsr_amd import tofops as T
+    b, t, c, co, h, w = 2, 7, 12, 20, 9, 13
+    x, wt, bias = rnd(b, c, t, h, w, seed=1), rnd(co, c, 3, 3, 3, seed=2, scale=(27 * c) ** -0.5), rnd(co, seed=3, scale=0.1)
+    to = t + 2 * pad_t - 2
+    go = rnd(b, co, to, h, w, seed=4)
+    xd, wd, bd = [v.double().requires_grad_() for v in (x, wt, bias)]
+    y = F.conv3d(xd, wd, bd, padding=(pad_t, 1, 1))
+    gr = torch.autograd.grad(y, [xd, wd, bd], go.double())
+    xg = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w).cuda().requires_grad_()      # frames as the batch axis
+    wg, bg = wt.cuda().requires_grad_(), bias.cuda().requires_grad_()
+    yg = T.conv(T.temporal_gather3(xg, b, t, pad_t), wg.view(co, c * 3, 3, 3), bg)
+    gg = torch.autograd.grad(yg, [xg, wg, bg], go.permute(0, 2, 1, 3, 4).reshape(b * to, co, h, w).cuda())
+    assert relerr(yg.view(b, to, co, h, w).permute(0, 2, 1, 3, 4), y) < 2e-5
+    assert relerr(gg[0].view(b, t, c, h, w).permute(0, 2, 1, 3, 4), gr[0]) < 2e-4
+    assert relerr(gg[1], gr[1]) < 2e-4 and relerr(gg[2], gr[2]) < 2e-4
+    with pytest.raises(RuntimeError, match="expected B\\*T"):
+        T.temporal_gather3(xg, b, t + 1, pad_t)
+
+
+@pytest.mark.parametrize("scale,adapt", [(4, True), (4, False), (2, True), (3, True)])
+def test_dynamic_filter_forward_backward(scale, adapt):
+    """softmax(25 taps) + DynamicUpsamplingFilter_3C + residual (adapt_official order) + pixel_shuffle in one kernel,
+    against the reference's formulation in fp64 (oracle/duf.py), with d/d(logits), d/d(residual), d/d(x_center)."""
+    from dynavsr_amd import tofops as T
+    from oracle import duf as oduf
+    b, h, w, r = 2, 9, 14, scale * scale
+    xc, lg, rx = rnd(b, 3, h, w, seed=1), rnd(b, 25 * r, h, w, seed=2, scale=2.0), rnd(b, 3 * r, h, w, seed=3)
+    go = rnd(b, 3, scale * h, scale * w, seed=4)
+    xd, ld, rd = [v.double().requires_grad_() for v in (xc, lg, rx)]
+    fx = F.softmax(ld.view(b, 25, r, h, w), dim=1)
+    rr = torch.cat((rd[:, 0::3], rd[:, 1::3], rd[:, 2::3]), 1) if adapt else rd
+    y = F.pixel_shuffle(oduf.dynamic_filter_3c(xd, fx) + rr, scale)
+    gr = torch.autograd.grad(y, [xd, ld, rd], go.double())
+    xg, lgg, rg = [v.cuda().requires_grad_() for v in (xc, lg, rx)]
+    yg = T.dynamic_filter(xg, lgg, rg, scale, adapt)
+    gg = torch.autograd.grad(yg, [xg, lgg, rg], go.cuda())
+    assert relerr(yg, y) < 2e-6
+    for a, r_ in zip(gg, gr):
+        assert relerr(a, r_) < 2e-5
+    with pytest.raises(RuntimeError, match="do not fit scale"):
+        T.dynamic_filter(xg, lgg[:, :-1], rg, scale, adapt)
+
+
+def _duf(layers, scale, seed):
+    from dynavsr_amd.models.archs import DUF_arch
+    cls = {16: DUF_arch.DUF_16L, 28: DUF_arch.DUF_28L}.get(layers, DUF_arch.DUF_52L)
+    net = cls(scale=scale, adapt_official=True)
+    net.load_state_dict(synth.duf_state_dict(seed, layers, scale), strict=True)
+    return net.cuda()
+
+
+def test_duf16_eval_and_training_golden():
+    from dynavsr_amd import hipops
+    g = load_golden("duf_16x24")
+    h, w = int(g["h"]), int(g["w"])
+    x = synth.clip(int(g["xseed"]), 1, 7, h, w).cuda()
+    tgt = synth.clip(int(g["tseed"]), 1, 1, 4 * h, 4 * w)[:, 0].cuda()
+    net = _duf(16, 4, int(g["wseed"])).eval()
+    with torch.no_grad():
+        y = net(x)
+    assert tuple(y.shape) == (1, 3, 4 * h, 4 * w)
+    assert relerr(y, g["out_eval"]) < 2e-4 and float((y.cpu() - torch.from_numpy(g["out_eval"])).abs().max()) < 1e-3
+    net.train()
+    y = net(x)
+    assert relerr(y, g["out_train"]) < 2e-4
+    loss = hipops.charbonnier(y, tgt)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss.backward()
+    by_name = dict(net.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    assert names == list(by_name.keys())
+    bad = [(k, float(by_name[k].grad.norm()), b) for k, b in zip(names, g["grad_norms"])
+           if abs(float(by_name[k].grad.norm()) - b) > 2e-3 * b + 1e-6]
+    assert not bad, bad[:6]
+    for key in g:
+        if key.startswith("grad__"):
+            name = key[len("grad__"):].replace("__", ".")
+            assert relerr(by_name[name].grad, g[key]) < 1e-2, name
+    sd = net.state_dict()
+    assert relerr(sd["bn3d_2.running_mean"], g["running_mean_bn3d_2"]) < 1e-5
+    assert relerr(sd["bn3d_2.running_var"], g["running_var_bn3d_2"]) < 1e-5
+
+
+@pytest.mark.parametrize("layers,scale", [(16, 2), (28, 4), (52, 3)])
+def test_duf_variants_eval_golden(layers, scale):
+    g = load_golden("duf_16x24")
+    x = synth.clip(int(g["xseed"]) + layers, 1, 7, 8, 12).cuda()
+    net = _duf(layers, scale, 4).eval()
+    with torch.no_grad():
+        y = net(x)
+    ref = g["out_eval_%dL_x%d" % (layers, scale)]
+    assert tuple(y.shape) == ref.shape and relerr(y, ref) < 2e-4
+
+
+def test_duf_batch2_vs_oracle_and_module_surface():
+    from oracle import duf as oduf
+    from dynavsr_amd.models.archs.DUF_arch import DynamicUpsamplingFilter_3C
+    P = synth.duf_state_dict(6, 16, 4)
+    x = synth.clip(31, 2, 7, 12, 20)
+    with torch.no_grad():
+        ref = oduf.duf_forward(OrderedDict((k, v.clone()) for k, v in P.items()), x, 16, 4, True, False)
+    net = _duf(16, 4, 6).eval()
+    with torch.no_grad():
+        assert relerr(net(x.cuda()), ref) < 2e-4
+    # the stand-alone module of the reference's surface: already soft-maxed filters in, [B,3R,H,W] out
+    xc, fx = torch.rand(1, 3, 6, 7), torch.softmax(torch.randn(1, 25, 16, 6, 7), 1)
+    want = oduf.dynamic_filter_3c(xc.double(), fx.double())
+    assert relerr(DynamicUpsamplingFilter_3C((1, 5, 5))(xc.cuda(), fx.cuda()), want) < 1e-5
