@@ -39,6 +39,31 @@ def make_inner_optimizer(opt, netG, netE):
     raise NotImplementedError()
 
 
+def draw_patch_positions(min_h, min_w, ps, n):
+    """n x common_crop's draw (preprocessing.py:76-77): py = randrange(min_h - ps + 1), then px, per patch."""
+    import random
+    py, px = [], []
+    for _ in range(n):
+        py.append(random.randrange(0, min_h - ps + 1))
+        px.append(random.randrange(0, min_w - ps + 1))
+    return py, px
+
+
+def crop(LR_seq, HR, num_patches_for_batch=4, patch_size=44):
+    """The `crop` of test_dynavsr.py:118-145 / train_dynavsr.py:208-243: `num_patches_for_batch` random patches of the
+    SLR clip LR_seq [1,T,C,h,w] and, at the same places, of its target HR [1,C,s*h,s*w], stacked into batches
+    [P,T,C,ps,ps] / [P,C,s*ps,s*ps] with ps = patch_size // 2.  Positions come from python's `random` in the
+    reference's order (common_crop, preprocessing.py:76-77: py then px per patch), so a seeded run draws the same
+    patches; the crops themselves are one gather launch each (hipops.patch_gather), differentiable w.r.t. the clip."""
+    assert HR.size(0) == 1
+    seq, hr = LR_seq[0], HR[0]
+    min_h, min_w = min(seq.shape[-2], hr.shape[-2]), min(seq.shape[-1], hr.shape[-1])
+    ps = patch_size // 2
+    py, px = draw_patch_positions(min_h, min_w, ps, num_patches_for_batch)
+    return (hipops.patch_gather(seq, py, px, ps, int(seq.shape[-2] // min_h)),
+            hipops.patch_gather(hr, py, px, ps, int(hr.shape[-2] // min_h)))
+
+
 def _fresh_copy(dst, src):
     """dst = deepcopy(src) (test_dynavsr.py:208).  When dst already is a copy from the previous frame (same class,
     same parameter names and shapes, same device) only the values are refreshed: one multi-tensor copy instead of
@@ -98,7 +123,11 @@ def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, va
         else:
             slr = val_data['SuperLQs']
         inner.zero_grad()
-        modelcp.feed_data({'LQs': slr, 'GT': target})
+        if m['use_patch']:                                      # test_dynavsr.py:255-260
+            p_lq, p_gt = crop(slr, target, m['num_patch'], m['patch_size'])
+            modelcp.feed_data({'LQs': p_lq, 'GT': p_gt})
+        else:
+            modelcp.feed_data({'LQs': slr, 'GT': target})
         loss = modelcp.calculate_loss()
         if slr.is_cuda and loss.is_cuda:       # one native reduction for the L1 tail (hipops.inner_loss)
             loss = hipops.inner_loss(loss, slr, slr_fixed, slr_weight)
@@ -141,8 +170,6 @@ def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, opt
     lqs_all = train_data['LQs']
     B, center = lqs_all.size(0), lqs_all.size(1) // 2
     use_real = bool(opt['train']['use_real'])
-    if m['use_patch']:
-        raise NotImplementedError("train.maml.use_patch (train_dynavsr.py:208-243 random patch crops) is not built")
     optimizer.zero_grad()
     g_params = [p for p in model.netG.parameters()]
     e_params = [p for p in est_model.netE.parameters()]
@@ -175,7 +202,11 @@ def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, opt
                 slr = inner_est.fake_L
             else:
                 slr = task['SuperLQs']
-            inner_model.feed_data({'LQs': slr, 'GT': lr_target})
+            if m['use_patch']:                                  # train_dynavsr.py:377-382
+                p_lq, p_gt = crop(slr, lr_target, m['num_patch'], m['patch_size'])
+                inner_model.feed_data({'LQs': p_lq, 'GT': p_gt})
+            else:
+                inner_model.feed_data({'LQs': slr, 'GT': lr_target})
             loss_train = inner_model.calculate_loss()
             loss_train = loss_train + F.l1_loss(slr, task['SuperLQs'].to(slr.device))      # :393
             loss_train.backward()

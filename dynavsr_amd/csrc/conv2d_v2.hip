@@ -550,11 +550,14 @@ static double conv2_pipe_cost(int TH, int MT, int KK, int CC, int N, int Ho, int
 ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ctot, int allow_ksplit) {
   // Small grids: the K-split kernel (geo {32, NT, MT} with ks == 3).  DVSR_CONV_KSPLIT_BELOW=<workgroups of the
   // 4x32x32 geometry> moves the threshold (0 disables); DVSR_CONV_KSPLIT_NT=1|2 pins the tile shape.
+  // Threshold from profiles/r02_small_grid_ab.txt: below ~700 such workgroups (the 44x80 levels: 66..330) the K-split
+  // kernel wins (rc_rb 19.2 -> 14.8 us, fe_rb 30 -> 26 us); at 900 (the 180x320 trunk) and 1155 (L1_om at 5x44x80) the
+  // pipelined 4-row kernel is faster again (47.5 vs 52.6 us, 65 vs 72 us): three times the halo and unshared weights.
   if (ks == 3 && stride == 1 && allow_ksplit && Ctot >= 32 && Cout >= 32) {
     static int below = -1, pin_nt = -1;
     if (below < 0) {
       const char* v = getenv("DVSR_CONV_KSPLIT_BELOW");
-      below = v ? atoi(v) : 1400;
+      below = v ? atoi(v) : 700;
       const char* n = getenv("DVSR_CONV_KSPLIT_NT");
       pin_nt = n ? atoi(n) : 0;
     }

@@ -231,3 +231,39 @@ def inner_loss(loss_pix, slr, slr_fixed, weight=10.0):
     """loss_pix + weight * F.l1_loss(slr, slr_fixed) (test_dynavsr.py:264-274) as one native reduction: the pixel loss
     stays a device scalar, its gradient passes through, the L1 gradient is one kernel."""
     return _InnerLoss.apply(loss_pix, slr, slr_fixed, weight)
+
+
+class _PatchGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, py, px, edge, scale):
+        import ctypes
+        src = src.contiguous().float()
+        lead, (h, w) = src.shape[:-2], src.shape[-2:]
+        planes = 1
+        for d in lead:
+            planes *= d
+        n = len(py)
+        e = edge * scale
+        dst = src.new_empty((n,) + tuple(lead) + (e, e))
+        apy, apx = (ctypes.c_int * n)(*py), (ctypes.c_int * n)(*px)
+        L.check(L.lib().dvsr_patch_gather_forward(L.ptr(src), L.ptr(dst), apy, apx, n, planes, h, w, edge, scale, L.stream()),
+                "dvsr_patch_gather_forward")
+        ctx.geo = (tuple(src.shape), apy, apx, n, planes, h, w, edge, scale)
+        return dst
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        shape, apy, apx, n, planes, h, w, edge, scale = ctx.geo
+        g = g.contiguous().float()
+        gs = g.new_empty(shape)
+        L.check(L.lib().dvsr_patch_gather_backward(L.ptr(g), L.ptr(gs), apy, apx, n, planes, h, w, edge, scale, L.stream()),
+                "dvsr_patch_gather_backward")
+        return gs, None, None, None, None
+
+
+def patch_gather(src, py, px, edge, scale=1):
+    """src [..., H, W] -> [P, ..., scale*edge, scale*edge]: patch p starts at (scale*py[p], scale*px[p])."""
+    if not src.is_cuda:
+        raise RuntimeError("patch_gather runs on the GPU (libdynavsr_hip); there is no CPU fallback")
+    return _PatchGather.apply(src, [int(v) for v in py], [int(v) for v in px], int(edge), int(scale))

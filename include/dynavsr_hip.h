@@ -315,6 +315,17 @@ int dvsr_dynamic_filter_backward(const float* x_center, const float* filter_logi
                                  float* grad_logits, float* grad_residual, float* grad_x_center, int B, int H, int W,
                                  int scale, int adapt_official, dvsr_stream_t stream);
 
+/* ---- random patch crops of the inner step (train.maml.use_patch) -----------------------------------------
+ * test_dynavsr.py:118-145 (and train_dynavsr.py:208-243) crop `num_patch` random patches out of the SLR clip and its
+ * target with preprocessing.common_crop (data/meta_learner/preprocessing.py:57-85) and stack them into a batch.
+ * dst[p][n][y][x] = src[n][scale*py[p] + y][scale*px[p] + x] for n < planes, 0 <= y, x < scale*edge; py / px are HOST
+ * arrays of P <= 64 positions on the lowest-resolution grid (the host draws them, like the reference).  Backward
+ * zeroes grad_src and adds the (overlapping) patches back with atomics. */
+int dvsr_patch_gather_forward(const float* src, float* dst, const int* py, const int* px, int P, int planes, int H, int W,
+                              int edge, int scale, dvsr_stream_t stream);
+int dvsr_patch_gather_backward(const float* grad_dst, float* grad_src, const int* py, const int* px, int P, int planes,
+                               int H, int W, int edge, int scale, dvsr_stream_t stream);
+
 /* ---- inner-loop optimiser steps over lists of parameter tensors ------------------------------------
  * test_dynavsr.py:223-231 steps torch.optim.Adam(lr_alpha, betas) / torch.optim.SGD(lr_alpha) over the
  * ~158 tensors of netG + netE once per inner iteration; these entry points do one such step (same

@@ -300,6 +300,37 @@ def duf_cases():
     save("duf_16x24", **out)
 
 
+def crop_cases():
+    """train.maml.use_patch: the `crop` closure of test_dynavsr.py:118-145 cannot be imported (it lives inside main()),
+    so its body is driven here statement by statement over the reference's own preprocessing.common_crop, with a
+    seeded `random`: positions are recovered from a coordinate-ramp input, crops of a random clip are stored."""
+    import random
+    from data.meta_learner import preprocessing
+    from oracle import inner as oin
+    t, c, h, w, s, n, psz = 5, 3, 22, 30, 4, 6, 16
+    r = np.random.RandomState(91)
+    seq = torch.from_numpy(r.rand(1, t, c, h, w).astype(np.float32))
+    hr = torch.from_numpy(r.rand(1, c, s * h, s * w).astype(np.float32))
+    ramp = (torch.arange(h)[:, None] * 1000 + torch.arange(w)[None, :]).float().expand(1, 1, 1, h, w)
+    random.seed(1234)
+    lrs, hrs = [], []
+    for _ in range(n):
+        a, b = preprocessing.common_crop(seq[0], hr[0], patch_size=psz // 2)
+        lrs.append(a); hrs.append(b)
+    lr_p, hr_p = torch.stack(lrs, 0), torch.stack(hrs, 0)
+    random.seed(1234)
+    pos = []
+    for _ in range(n):
+        a, _b = preprocessing.common_crop(ramp[0], hr[0], patch_size=psz // 2)
+        v = int(a[0, 0, 0, 0])
+        pos.append((v // 1000, v % 1000))
+    random.seed(1234)
+    o_lr, o_hr = oin.crop(seq, hr, n, psz)
+    assert torch.equal(o_lr, lr_p) and torch.equal(o_hr, hr_p)
+    save("crop_patches", seed=1234, dseed=91, t=t, c=c, h=h, w=w, scale=s, n=n, patch_size=psz,
+         py=np.array([p[0] for p in pos]), px=np.array([p[1] for p in pos]), lr=lr_p, hr_sum=hr_p.double().sum(dim=(1, 2, 3)))
+
+
 def mfdn_full(L):
     """G5: MFDN x4 forward/backward on 1x5x3x32x32 through the reference module."""
     M = synth.mfdn_state_dict(0)
@@ -557,11 +588,12 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     E, L, models, U = import_reference()
-    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "estimators", "inner", "degradation", "meta", "tof", "duf"]
+    which = sys.argv[1:] or ["dcn", "pcd", "edvr", "mfdn", "estimators", "inner", "degradation", "meta", "tof", "duf", "crop"]
     if "dcn" in which: dcn_cases()
     if "pcd" in which: pcd_tsa(E)
     if "edvr" in which: edvr_full(E)
     if "edvr" in which or "edvr_x2" in which: edvr_x2(E)
+    if "crop" in which: crop_cases()
     if "tof" in which: tof_cases()
     if "duf" in which: duf_cases()
     if "edvr_l" in which: edvr_l(E)      # several minutes on 8 cores; not part of the default set

@@ -423,6 +423,52 @@ def test_adapt_video_transient_clips_are_not_reused_under_the_side_streams():
             assert relerr(b, d) < 1e-5
 
 
+def test_use_patch_crop_and_inner_step():
+    """train.maml.use_patch (test_dynavsr.py:118-145,255-260): adapt.crop against the crops the reference's common_crop
+    produced (golden; bit-exact, it is a gather), its adjoint against autograd of the slicing form (overlapping
+    patches add up), and one inner step with patches against the oracle driven by the same `random` seed."""
+    import random
+    from dynavsr_amd.adapt import adapt_frame, crop
+    from dynavsr_amd.models import create_model
+    from oracle import inner as oin
+    g = load_golden("crop_patches")
+    t, c, h, w, s, n, psz = (int(g[k]) for k in ("t", "c", "h", "w", "scale", "n", "patch_size"))
+    r = np.random.RandomState(int(g["dseed"]))
+    seq = torch.from_numpy(r.rand(1, t, c, h, w).astype(np.float32))
+    hr = torch.from_numpy(r.rand(1, c, s * h, s * w).astype(np.float32))
+    random.seed(int(g["seed"]))
+    sg = seq.cuda().requires_grad_()
+    lr_p, hr_p = crop(sg, hr.cuda(), n, psz)
+    assert torch.equal(lr_p.cpu(), torch.from_numpy(g["lr"]))
+    assert np.allclose(hr_p.double().sum(dim=(1, 2, 3)).cpu().numpy(), g["hr_sum"], rtol=0, atol=1e-9)
+    go = torch.randn(lr_p.shape, generator=torch.Generator().manual_seed(2))
+    (gs,) = torch.autograd.grad(lr_p, sg, go.cuda())
+    sd = seq.clone().requires_grad_()
+    random.seed(int(g["seed"]))
+    o_lr, _ = oin.crop(sd, hr, n, psz)
+    (gr,) = torch.autograd.grad(o_lr, sd, go)
+    assert relerr(gs, gr) < 1e-6
+    with pytest.raises(RuntimeError, match="leaves the"):
+        from dynavsr_amd import hipops
+        hipops.patch_gather(sg[0], [h], [0], psz // 2, 1)
+    # one inner step on patches (LR 64x64 -> SLR 16x16, 3 patches of 8x8) vs the oracle
+    opt = _gpu_opt("SGD")
+    opt["train"]["maml"].update({"use_patch": True, "num_patch": 3, "patch_size": 16})
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    PG, PE, PF = synth.edvr_state_dict(0), synth.mfdn_state_dict(0), synth.mfdn_state_dict(1)
+    model.netG.load_state_dict(PG); est.netE.load_state_dict(PE); est_fixed.netE.load_state_dict(PF)
+    lqs = synth.clip(77, 1, 5, 64, 64)
+    random.seed(5)
+    out = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, {"LQs": lqs.cuda()})
+    random.seed(5)
+    losses, _PGa, _PEa, sr = oin.inner_adapt(PG, PE, PF, lqs, steps=1, optimizer="SGD", lr=opt["train"]["maml"]["lr_alpha"],
+                                            use_patch=True, num_patch=3, patch_size=16)
+    assert abs(float(out["losses"][0]) - losses[0]) < 1e-5 * abs(losses[0])
+    assert relerr(out["sr"], sr) < 2e-4
+
+
 def test_meta_gradient_allreduce_over_rccl():
     """dist.py on its real backend: a one-rank `nccl` (= RCCL) process group with the collective forced, so the
     branch bench.py's `meta_step` leg and an N-rank job take is executed on the GPU here as well -- the flat-buffer

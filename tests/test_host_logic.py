@@ -265,3 +265,24 @@ def test_meta_train_step_data_parallel_gloo():
         start = [p.detach().clone() for p in params]
     for p_new, p0, g0, g1 in zip(got, start, grads[0], grads[1]):
         assert torch.allclose(torch.from_numpy(p_new), p0 - 0.5 * 0.5 * (g0 + g1), atol=1e-6)
+
+
+def test_use_patch_positions_follow_the_reference_draw():
+    """train.maml.use_patch: the patch positions come out of python's `random` in common_crop's order (py, then px,
+    per patch; preprocessing.py:76-77) -- against the positions the reference's common_crop drew for the golden, and the
+    oracle's crop against the stored crops."""
+    import random
+    from dynavsr_amd.adapt import draw_patch_positions
+    from oracle import inner as oin
+    g = load_golden("crop_patches")
+    t, c, h, w, s, n, psz = (int(g[k]) for k in ("t", "c", "h", "w", "scale", "n", "patch_size"))
+    random.seed(int(g["seed"]))
+    py, px = draw_patch_positions(h, w, psz // 2, n)
+    assert py == list(g["py"]) and px == list(g["px"])
+    r = np.random.RandomState(int(g["dseed"]))
+    seq = torch.from_numpy(r.rand(1, t, c, h, w).astype(np.float32))
+    hr = torch.from_numpy(r.rand(1, c, s * h, s * w).astype(np.float32))
+    random.seed(int(g["seed"]))
+    lr_p, hr_p = oin.crop(seq, hr, n, psz)
+    assert torch.equal(lr_p, torch.from_numpy(g["lr"])) and tuple(hr_p.shape) == (n, c, s * psz // 2, s * psz // 2)
+    assert np.allclose(hr_p.double().sum(dim=(1, 2, 3)).numpy(), g["hr_sum"], rtol=0, atol=1e-9)
