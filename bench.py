@@ -53,6 +53,19 @@ def f_inner(h, w):
     return 3 * f_edvr(h // 4, w // 4) + 4 * f_mfdn(h, w)
 
 
+def _warm(fn, seconds=0.3, at_least=3):
+    """Warm-up by TIME, not by count: after host-side set-up (building a 20 M-parameter network takes seconds) the GPU
+    has clocked down, and a few short iterations are over before it is back up -- the same forward then measures 3 ms
+    slower (seen on the EDVR-L leg: 3.1 vs 6.9 ms run to run with 3 warm-up iterations)."""
+    t0, n = time.perf_counter(), 0
+    while n < at_least or time.perf_counter() - t0 < seconds:
+        fn()
+        n += 1
+        if n % 4 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+
+
 def _opt():
     from dynavsr_amd.options import options as option
     opt = option.dict_to_nonedict(option.parse(os.path.join(
@@ -183,9 +196,7 @@ def inner_step_rate(dev, steps=60, h=176, w=320):
         loss.backward()
         inner.step()
 
-    for _ in range(5):
-        step()
-    torch.cuda.synchronize()
+    _warm(step)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -269,7 +280,7 @@ def meta_step_rate(dev, world, dist, tasks_per_rank=2, iters=4):
     def it():
         return meta_train_step(opt, model, est, modelcp, estcp, data, optimizer, inner="reference",
                                force_collective=force)
-    for _ in range(2):
+    for _ in range(6):          # (a fixed count: every rank must run the same number of collectives)
         it()
     torch.cuda.synchronize()
     if dist is not None:
@@ -329,9 +340,7 @@ def edvr_l_rates(dev, steps=10):
             hipops.charbonnier(net(x), tgt).backward()
         res = {}
         for key, fn, mult in (("forward", fwd, 1.0), ("forward_backward", fwd_bwd, 3.0)):
-            for _ in range(3):
-                y = fn()
-            torch.cuda.synchronize()
+            _warm(fn)
             t0 = time.perf_counter()
             for _ in range(steps):
                 y = fn()

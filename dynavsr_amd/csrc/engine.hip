@@ -109,6 +109,7 @@ struct dvsr_edvr_plan {
   mutable hipStream_t side = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int side_streams = 1;                           // DVSR_BWD_STREAMS=0 disables
+  int fork_every = 3;                             // weight gradients of this many layers share one fork (see backward)
 };
 
 namespace dvsr {
@@ -945,7 +946,8 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
   // which on the small inner-step clips is a third of a layer: the weight gradients of `fork_every` consecutive
   // layers therefore share one fork (a gradient buffer is never rewritten once its layer's turn has come, so
   // launching a weight gradient a few layers late is safe).  DVSR_BWD_FORK_EVERY=<layers> (1 = a fork per layer).
-  static const int fork_every = [] { const char* v = getenv("DVSR_BWD_FORK_EVERY"); int n = v ? atoi(v) : 3; return n < 1 ? 1 : n; }();
+  static const int fork_env = [] { const char* v = getenv("DVSR_BWD_FORK_EVERY"); return v ? atoi(v) : 0; }();
+  const int fork_every = fork_env > 0 ? fork_env : p->fork_every;
   std::vector<WgradLaunch> waiting;
   int waiting_layers = 0;
   auto flush_waiting = [&]() -> int {
@@ -978,7 +980,10 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
         ++waiting_layers;
       }
       waiting.push_back(l);
-      if (!use_side && rc == DVSR_OK) rc = flush_waiting();
+      // only SMALL weight gradients wait for company (the small-grid kernel was chosen for them): a large one -- the
+      // estimator's at 176x320 run 100-300 us each, longer than its data-gradient chain -- must start at once, or
+      // the side stream is still busy long after the main stream has finished (profiles/r02_g_estimator_timeline.txt)
+      if (rc == DVSR_OK && (!use_side || !l.kys)) rc = flush_waiting();
     } else if (b.type == B_WUNMAP) {
       unmaps.push_back(&b);  // needs the reduced gradient: after the batched reduce below
     } else {
@@ -1217,6 +1222,7 @@ extern "C" int dvsr_estimator_plan_create(const dvsr_estimator_config* cfg, int 
   p.cfg = dvsr_edvr_config{cfg->nf, cfg->nframes, 1, 0, 0, cfg->scale, 0, 0};
   p.B = B; p.H = H; p.W = W;
   { const char* v = getenv("DVSR_BWD_STREAMS"); p.side_streams = (v && v[0] == '0') ? 0 : 1; }
+  p.fork_every = 1;   // seven layers whose weight gradients outlast the data-gradient chain: every fork at once
   int rc = build_estimator(*ep);
   if (rc != DVSR_OK) { delete ep; return rc; }
   build_backward(p);

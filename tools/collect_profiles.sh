@@ -1,26 +1,39 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): collects the per-round profile artefacts as TEXT under gpurun_out/
+# Runs on the GPU box (gpurun): collects the per-round profile artefacts as TEXT under gpurun_out/<tag>/
 # (rocprofv3 databases are summarised in place and deleted: they exceed the 64 MiB copy-back limit).
-# usage: tools/collect_profiles.sh <tag>      e.g. r01_c
+# usage: tools/collect_profiles.sh <tag>      e.g. r02_z   -> copy what should be judged into profiles/
 set -u
 tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/$tag; rm -rf gpurun_out/*; mkdir -p $out
-python bench.py 2>&1 | tail -1 > $out/${tag}_bench_line.json
-rocprofv3 --kernel-trace --stats -d $out/db1 -o r -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-inner-step --no-split > /dev/null 2>&1
+out=gpurun_out/$tag; rm -rf "$out"; mkdir -p "$out"
+B="--no-cpu-baseline --no-inner-step --no-split --no-meta"
+# 1. the driver's bench line (all legs)
+python bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench_stderr.txt
+# 2. kernel trace of the headline forward
+rocprofv3 --kernel-trace --stats -d $out/db1 -o r -- python bench.py --steps 10 --warmup 3 $B > /dev/null 2>&1
 python tools/rocprof_summary.py $out/db1/r_results.db > $out/${tag}_kernel_trace_bench_fwd180x320.txt; rm -rf $out/db1
-rocprofv3 --kernel-trace --stats -d $out/db2 -o r -- python tools/inner_bench.py 176 320 6 2>&1 | grep -E "inner|EDVR|MFDN|full|LR" > $out/${tag}_inner_step_176x320.txt
+# 3. inner step: timings, kernel table, launch timeline of one EDVR fwd+bwd at the SLR size
+rocprofv3 --kernel-trace --stats -d $out/db2 -o r -- python tools/inner_bench.py 176 320 6 2>&1 | grep -E "inner|EDVR|MFDN|full|LR|adapt_video|overlapped" > $out/${tag}_inner_step_176x320.txt
 python tools/rocprof_summary.py $out/db2/r_results.db >> $out/${tag}_inner_step_176x320.txt; rm -rf $out/db2
+rocprofv3 --kernel-trace --stats -d $out/db2b -o r -- python tools/edvr_step_profile.py 44 80 30 2>&1 | grep EDVR > $out/${tag}_edvr_step_44x80_timeline.txt
+python tools/trace_dump.py $out/db2b/r_results.db charbonnier_partial >> $out/${tag}_edvr_step_44x80_timeline.txt; rm -rf $out/db2b
+python tools/edvr_step_profile.py 44 80 40 2>&1 | grep EDVR > $out/${tag}_edvr_step_44x80.txt
+# 4. per-launch forward tables (hipEvents), headline size and SLR size
 python tools/op_profile.py 180 320 5 2>&1 | grep -v amdgpu > $out/${tag}_per_launch_fwd180x320.txt
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $out/db_$c -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-inner-step --no-split > /dev/null 2>&1
+python tools/op_profile.py 44 80 10 2>&1 | grep -v amdgpu > $out/${tag}_per_launch_fwd44x80.txt
+# 5. PMC: HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) and matrix-pipe utilisation
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  rocprofv3 --pmc $c --kernel-trace -d $out/db_$c -o p -- python bench.py --steps 3 --warmup 1 $B > /dev/null 2>&1
 done
 python tools/pmc_traffic.py $out/db_FETCH_SIZE/p_results.db $out/db_WRITE_SIZE/p_results.db $out/${tag}_pmc_hbm_traffic.txt $out/pmc_traffic.json
-rm -rf $out/db_FETCH_SIZE $out/db_WRITE_SIZE
+python tools/pmc_mfma.py $out/db_SQ_VALU_MFMA_BUSY_CYCLES/p_results.db $out/db_GRBM_GUI_ACTIVE/p_results.db > $out/${tag}_pmc_mfma_util.txt
+rm -rf $out/db_FETCH_SIZE $out/db_WRITE_SIZE $out/db_SQ_VALU_MFMA_BUSY_CYCLES $out/db_GRBM_GUI_ACTIVE
+# 6. neighbours of the path: metrics, degradation, meta step, estimator, bf16 modes, the other backbones
 python tools/metrics_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_metrics_720x1280.txt
-rocprofv3 --kernel-trace --stats -d $out/db3 -o m -- python tools/metrics_bench.py > /dev/null 2>&1
-python tools/rocprof_summary.py $out/db3/m_results.db | head -8 >> $out/${tag}_metrics_720x1280.txt; rm -rf $out/db3
 python tools/degrade_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_degradation.txt
 python tools/meta_bench.py 4 1 2>&1 | grep -v amdgpu > $out/${tag}_meta_train_step.txt
+python tools/estimator_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_estimator.txt
+python tools/bf16_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_bf16_modes.txt
+python tools/backbone_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_backbones_tof_duf.txt
 du -sh gpurun_out
