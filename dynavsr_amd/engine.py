@@ -85,7 +85,9 @@ def get_plan(cfg, b, h, w, device=None):
     """One plan per (config, shape, device): a plan owns a side stream and events of the device it was first
     used on.  A plan is single-threaded: two host threads must not drive the same plan concurrently."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    key = (tuple(cfg), b, h, w, dev)
+    # ... and per HIP stream: the plan's side stream and fork / join events belong to ONE in-flight backward, so two
+    # clips adapted concurrently on two streams (adapt_video(concurrency=2)) must not share them
+    key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream)
     p = _plans.get(key)
     if p is None:
         p = _plans[key] = Plan(tuple(cfg), b, h, w)
@@ -198,7 +200,7 @@ class EstimatorPlan:
 
 def get_estimator_plan(cfg, b, h, w, device=None):
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    key = (tuple(cfg), b, h, w, dev)
+    key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream)
     p = _eplans.get(key)
     if p is None:
         p = _eplans[key] = EstimatorPlan(tuple(cfg), b, h, w)

@@ -12,7 +12,7 @@ from collections import OrderedDict
 import torch
 
 from . import networks
-from .base_model import BaseModel, unwrap
+from .base_model import BaseModel, LogDict, unwrap
 
 logger = logging.getLogger('base')
 _LOSSES = {'l1': torch.nn.L1Loss, 'l2': torch.nn.MSELoss}
@@ -46,7 +46,7 @@ class LRimgestimator_Model(BaseModel):
         self.optimizer_E = torch.optim.Adam(trainable, lr=t['lr_C'], weight_decay=t['weight_decay_R'] or 0)
         self.optimizers.append(self.optimizer_E)
         self.schedulers.append(torch.optim.lr_scheduler.MultiStepLR(self.optimizer_E, list(t['lr_steps']), t['lr_gamma']))
-        self.log_dict = OrderedDict()
+        self.log_dict = LogDict()
 
     # ---- data in, estimate out -----------------------------------------------------------------------------------
     def feed_data(self, data):
@@ -78,7 +78,7 @@ class LRimgestimator_Model(BaseModel):
         self.optimizer_E.zero_grad()
         self.forward_without_optim()
         lr_loss = self.MyLoss(self.fake_L, self.real_L)
-        self.log_dict['l_pix'] = lr_loss.item()
+        self.log_dict['l_pix'] = lr_loss.detach()
         lr_loss.backward()
         self.optimizer_E.step()
 

@@ -5,8 +5,9 @@ fake_H, log_dict, optimizers, schedulers`` that test_dynavsr.py / train_dynavsr.
 
 ``netG`` is the engine-backed EDVR (one native call per forward/backward); it deep-copies,
 exposes ordinary leaf nn.Parameters and can be re-assigned (``modelcp.netG = deepcopy(...)``,
-test_dynavsr.py:208).  ``log_dict['l_pix']`` keeps the reference's eager ``.item()`` contract
-(one host sync per loss evaluation, Video_base_model.py:194).
+test_dynavsr.py:208).  ``log_dict['l_pix']`` reads as the float the reference stores (Video_base_model.py:194); the host
+synchronisation its eager ``.item()`` costs happens when the entry is read, not inside the step
+(base_model.LogDict).
 """
 import logging
 import os
@@ -16,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import networks
-from .base_model import BaseModel, unwrap
+from .base_model import BaseModel, LogDict, unwrap
 from .loss import CharbonnierLoss
 
 logger = logging.getLogger('base')
@@ -39,7 +40,7 @@ class VideoBaseModel(BaseModel):
         train_opt = opt['train']
         self.netG = networks.define_G(opt).to(self.device)
         self.load()
-        self.log_dict = OrderedDict()
+        self.log_dict = LogDict()
         self.cri_pix = _pixel_criterion(train_opt['pixel_criterion']).to(self.device)
         self.l_pix_w = train_opt['pixel_weight']
         if self.is_train:
@@ -79,7 +80,7 @@ class VideoBaseModel(BaseModel):
 
     def calculate_loss(self):
         l_pix = self._pixel_loss()
-        self.log_dict['l_pix'] = l_pix.item()
+        self.log_dict['l_pix'] = l_pix.detach()
         return l_pix
 
     def optimize_parameters(self, step):
@@ -87,13 +88,13 @@ class VideoBaseModel(BaseModel):
         l_pix = self._pixel_loss()
         l_pix.backward()
         self.optimizer_G.step()
-        self.log_dict['l_pix'] = l_pix.item()
+        self.log_dict['l_pix'] = l_pix.detach()
 
     def optimize_by_loss(self, loss):
         self.optimizer_G.zero_grad()
         loss.backward()
         self.optimizer_G.step()
-        self.log_dict['l_pix'] = loss.item()
+        self.log_dict['l_pix'] = loss.detach()
 
     def test(self):
         self.netG.eval()

@@ -286,3 +286,20 @@ def test_use_patch_positions_follow_the_reference_draw():
     lr_p, hr_p = oin.crop(seq, hr, n, psz)
     assert torch.equal(lr_p, torch.from_numpy(g["lr"])) and tuple(hr_p.shape) == (n, c, s * psz // 2, s * psz // 2)
     assert np.allclose(hr_p.double().sum(dim=(1, 2, 3)).numpy(), g["hr_sum"], rtol=0, atol=1e-9)
+
+
+def test_log_dict_reads_as_floats_without_an_eager_sync():
+    """log_dict['l_pix'] is what the reference's `l_pix.item()` gives, but the conversion happens at read time."""
+    from dynavsr_amd.models.base_model import LogDict
+    d = LogDict()
+    t = torch.tensor(0.25)
+    d['l_pix'] = t
+    assert isinstance(OrderedDict.__getitem__(d, 'l_pix'), torch.Tensor)       # stored as it is: no .item() on write
+    assert d['l_pix'] == 0.25 and isinstance(d['l_pix'], float)
+    d['l_pix'] = torch.tensor(0.5)
+    d['lr'] = 1e-4
+    assert d.items() == [('l_pix', 0.5), ('lr', 1e-4)] and d.values() == [0.5, 1e-4] and d.get('none', 3) == 3
+    assert all(isinstance(v, float) for _, v in d.items())
+    from dynavsr_amd.models import create_model
+    model, est = create_model(cpu_opt())
+    assert isinstance(model.log_dict, LogDict) and model.get_current_log() is model.log_dict
