@@ -85,6 +85,8 @@ def _declare(lib):
         "dvsr_avgpool2_backward": (I, [P, P, LL, I, I, I, P]),
         "dvsr_resize_bilinear_ac_forward": (I, [P, P, LL, I, I, I, I, F, LL, P]),
         "dvsr_resize_bilinear_ac_backward": (I, [P, P, LL, I, I, I, I, F, LL, P]),
+        "dvsr_upsample_bicubic_ac_forward": (I, [P, P, LL, I, I, I, P]),
+        "dvsr_upsample_bicubic_ac_backward": (I, [P, P, LL, I, I, I, P]),
         "dvsr_channel_affine": (I, [P, P, P, P, I, I, LL, LL, LL, I, P]),
         "dvsr_batchnorm_workspace_bytes": (c_size_t, [I]),
         "dvsr_batchnorm_forward": (I, [P] * 8 + [I, I, LL, I, F, F, I, P, c_size_t, P]),

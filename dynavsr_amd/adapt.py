@@ -39,6 +39,20 @@ def make_inner_optimizer(opt, netG, netE):
     raise NotImplementedError()
 
 
+def backbone_input(opt, clip):
+    """What the drivers feed netG: the clip itself for EDVR / DUF; for TOFlow, which works at the output size, the
+    clip brought there by F.interpolate(scale_factor=scale, mode='bicubic', align_corners=True)
+    (test_dynavsr.py:188-193, 245-250) -- one native launch (tofops.upsample_bicubic_ac), differentiable."""
+    if (opt['network_G'] or {}).get('which_model_G') == 'TOF' and clip.is_cuda:
+        from . import tofops
+        return tofops.upsample_bicubic_ac(clip, opt['scale'])
+    if (opt['network_G'] or {}).get('which_model_G') == 'TOF':
+        b, t, c, h, w = clip.shape
+        up = F.interpolate(clip.reshape(b * t, c, h, w), scale_factor=opt['scale'], mode='bicubic', align_corners=True)
+        return up.reshape(b, t, c, h * opt['scale'], w * opt['scale'])
+    return clip
+
+
 def draw_patch_positions(min_h, min_w, ps, n):
     """n x common_crop's draw (preprocessing.py:76-77): py = randrange(min_h - ps + 1), then px, per patch."""
     import random
@@ -123,11 +137,12 @@ def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, va
         else:
             slr = val_data['SuperLQs']
         inner.zero_grad()
+        g_in = backbone_input(opt, slr)                         # TOF: bicubic x scale (test_dynavsr.py:245-250)
         if m['use_patch']:                                      # test_dynavsr.py:255-260
-            p_lq, p_gt = crop(slr, target, m['num_patch'], m['patch_size'])
+            p_lq, p_gt = crop(g_in, target, m['num_patch'], m['patch_size'])
             modelcp.feed_data({'LQs': p_lq, 'GT': p_gt})
         else:
-            modelcp.feed_data({'LQs': slr, 'GT': target})
+            modelcp.feed_data({'LQs': g_in, 'GT': target})
         loss = modelcp.calculate_loss()
         if slr.is_cuda and loss.is_cuda:       # one native reduction for the L1 tail (hipops.inner_loss)
             loss = hipops.inner_loss(loss, slr, slr_fixed, slr_weight)
@@ -138,7 +153,7 @@ def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, va
         losses.append(loss.detach())
     if not final_test:      # adapt_video runs the adapted forward itself (on another stream)
         return {'sr': None, 'losses': losses, 'slr': slr.detach()}
-    modelcp.feed_data({'LQs': lqs}, need_GT=False)
+    modelcp.feed_data({'LQs': backbone_input(opt, lqs)}, need_GT=False)
     modelcp.test()
     return {'sr': modelcp.fake_H, 'losses': losses, 'slr': slr.detach()}
 
@@ -202,11 +217,12 @@ def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, opt
                 slr = inner_est.fake_L
             else:
                 slr = task['SuperLQs']
+            g_in = backbone_input(opt, slr)                     # TOF: bicubic x scale (train_dynavsr.py:368-374)
             if m['use_patch']:                                  # train_dynavsr.py:377-382
-                p_lq, p_gt = crop(slr, lr_target, m['num_patch'], m['patch_size'])
+                p_lq, p_gt = crop(g_in, lr_target, m['num_patch'], m['patch_size'])
                 inner_model.feed_data({'LQs': p_lq, 'GT': p_gt})
             else:
-                inner_model.feed_data({'LQs': slr, 'GT': lr_target})
+                inner_model.feed_data({'LQs': g_in, 'GT': lr_target})
             loss_train = inner_model.calculate_loss()
             loss_train = loss_train + F.l1_loss(slr, task['SuperLQs'].to(slr.device))      # :393
             loss_train.backward()
@@ -214,7 +230,7 @@ def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, opt
             log_train.append(loss_train.detach())
         # meta test: loss_q at the weights `model` holds ('reference') or at the adapted copy ('copies')
         q_model, q_est = (model, est_model) if inner == 'reference' else (modelcp, est_modelcp)
-        q_model.feed_data({'LQs': task['LQs'], 'GT': hr_target})
+        q_model.feed_data({'LQs': backbone_input(opt, task['LQs']), 'GT': hr_target})   # (:314-320 for TOF)
         loss_q = q_model.calculate_loss()
         add_grads(g_params, torch.autograd.grad(loss_q / B, list(q_model.netG.parameters())))
         q_est.feed_data(task)
@@ -260,7 +276,7 @@ def adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, cl
     if not overlap:
         while cur is not None:
             lqs = cur['LQs'] if cur['LQs'].is_cuda else cur['LQs'].cuda()
-            model.feed_data({'LQs': lqs}, need_GT=False)
+            model.feed_data({'LQs': backbone_input(opt, lqs)}, need_GT=False)
             model.test()
             yield model.fake_H, adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, cur)
             cur = next(clips, None)
@@ -274,7 +290,7 @@ def adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, cl
         with torch.cuda.stream(stream), torch.no_grad():
             was_training = net.training
             net.eval()
-            sr = net(lqs)
+            sr = net(backbone_input(opt, lqs))
             net.train(was_training)
             ev = torch.cuda.Event()
             ev.record(stream)

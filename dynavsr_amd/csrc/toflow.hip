@@ -188,6 +188,50 @@ __global__ void resize_ac_bwd_kernel(const float* __restrict__ gy, float* __rest
   }
 }
 
+// ---- F.interpolate(x, scale_factor=S, mode='bicubic', align_corners=True) -------------------------------
+// The drivers up-sample the (S)LR clip to the output size before TOFlow (test_dynavsr.py:188-193, 245-250).  ATen's
+// upsample_bicubic2d: source = dst * (in-1)/(out-1), 4x4 taps with the cubic-convolution kernel A = -0.75, indices
+// clamped to the image.
+__device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+  c[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+  c[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+  c[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+  c[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+template <bool BWD>
+__global__ void bicubic_ac_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ gx,
+                                  const float* __restrict__ gy, size_t planes, int H, int W, int Ho, int Wo) {
+  const size_t total = planes * Ho * Wo;
+  const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo);
+    const size_t t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const size_t pl = t / Ho;
+    const float ry = sh * (float)oy, rx = sw * (float)ox;
+    const int iy = (int)floorf(ry), ix = (int)floorf(rx);
+    float cy[4], cx[4];
+    cubic_coeffs(ry - (float)iy, cy);
+    cubic_coeffs(rx - (float)ix, cx);
+    float acc = 0.f;
+    const float g = BWD ? gy[i] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int yy = min(max(iy - 1 + a, 0), H - 1);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int xx = min(max(ix - 1 + b, 0), W - 1);
+        const size_t o = pl * H * W + (size_t)yy * W + xx;
+        if (BWD) unsafeAtomicAdd(gx + o, g * cy[a] * cx[b]);
+        else acc += x[o] * cy[a] * cx[b];
+      }
+    }
+    if (!BWD) y[i] = acc;
+  }
+}
+
 // ---- out[n][c][:] = x[n][c][:] * scale[c] + shift[c]  (batch strides: channel slices of wider tensors) ------
 __global__ void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                       const float* __restrict__ shift, float* __restrict__ out, int N, int C, size_t HW,
@@ -376,6 +420,26 @@ extern "C" int dvsr_resize_bilinear_ac_backward(const float* grad_y, float* grad
   const long long ps = gy_plane_stride > 0 ? gy_plane_stride : (long long)Ho * Wo;
   TOF_LAUNCH(resize_ac_bwd_kernel, (size_t)planes * Ho * Wo, st, grad_y, grad_x, (size_t)planes, H, W, Ho, Wo, mul, ps);
   return check_launch("resize_ac_bwd_kernel");
+}
+
+extern "C" int dvsr_upsample_bicubic_ac_forward(const float* x, float* y, long long planes, int H, int W, int scale,
+                                                dvsr_stream_t stream) {
+  DVSR_REQUIRE(x && y && planes > 0 && H > 0 && W > 0 && scale >= 1, DVSR_ERR_INVALID, "upsample_bicubic_ac_forward: bad argument");
+  TOF_LAUNCH(bicubic_ac_kernel<false>, (size_t)planes * H * W * scale * scale, (hipStream_t)stream, x, y, nullptr, nullptr,
+             (size_t)planes, H, W, H * scale, W * scale);
+  return check_launch("bicubic_ac_kernel");
+}
+
+extern "C" int dvsr_upsample_bicubic_ac_backward(const float* grad_y, float* grad_x, long long planes, int H, int W,
+                                                 int scale, dvsr_stream_t stream) {
+  DVSR_REQUIRE(grad_y && grad_x && planes > 0 && H > 0 && W > 0 && scale >= 1, DVSR_ERR_INVALID,
+               "upsample_bicubic_ac_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  DVSR_REQUIRE(hipMemsetAsync(grad_x, 0, (size_t)planes * H * W * sizeof(float), st) == hipSuccess, DVSR_ERR_HIP,
+               "upsample_bicubic_ac_backward: memset failed");
+  TOF_LAUNCH(bicubic_ac_kernel<true>, (size_t)planes * H * W * scale * scale, st, nullptr, nullptr, grad_x, grad_y,
+             (size_t)planes, H, W, H * scale, W * scale);
+  return check_launch("bicubic_ac_kernel(bwd)");
 }
 
 extern "C" int dvsr_channel_affine(const float* x, const float* scale, const float* shift, float* out, int N, int C,

@@ -195,6 +195,37 @@ def resize_bilinear_ac(x, size, mul=1.0):
     return _ResizeAC.apply(x, int(size[0]), int(size[1]), mul)
 
 
+class _BicubicAC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        _chk(x)
+        x = _f(x)
+        lead, (h, w) = x.shape[:-2], x.shape[-2:]
+        planes = 1
+        for d in lead:
+            planes *= d
+        y = x.new_empty(tuple(lead) + (h * scale, w * scale))
+        L.check(L.lib().dvsr_upsample_bicubic_ac_forward(L.ptr(x), L.ptr(y), planes, h, w, scale, L.stream()),
+                "dvsr_upsample_bicubic_ac_forward")
+        ctx.geo = (tuple(x.shape), planes, h, w, scale)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        shape, planes, h, w, scale = ctx.geo
+        g = _f(g)
+        gx = g.new_empty(shape)
+        L.check(L.lib().dvsr_upsample_bicubic_ac_backward(L.ptr(g), L.ptr(gx), planes, h, w, scale, L.stream()),
+                "dvsr_upsample_bicubic_ac_backward")
+        return gx, None
+
+
+def upsample_bicubic_ac(x, scale):
+    """F.interpolate(x, scale_factor=scale, mode='bicubic', align_corners=True) over the last two dims."""
+    return _BicubicAC.apply(x, int(scale))
+
+
 class _ChannelAffine(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale, shift):

@@ -277,6 +277,13 @@ int dvsr_resize_bilinear_ac_forward(const float* x, float* y, long long planes, 
                                     long long y_plane_stride, dvsr_stream_t stream);
 int dvsr_resize_bilinear_ac_backward(const float* grad_y, float* grad_x, long long planes, int H, int W, int Ho, int Wo,
                                      float mul, long long gy_plane_stride, dvsr_stream_t stream);
+/* F.interpolate(x, scale_factor=scale, mode='bicubic', align_corners=True): the drivers bring the (S)LR clip to the
+ * output size before TOFlow (test_dynavsr.py:188-193, 245-250; train_dynavsr.py:314-320).  ATen's cubic convolution
+ * (A = -0.75), clamped taps.  Backward zeroes grad_x and scatters. */
+int dvsr_upsample_bicubic_ac_forward(const float* x, float* y, long long planes, int H, int W, int scale,
+                                     dvsr_stream_t stream);
+int dvsr_upsample_bicubic_ac_backward(const float* grad_y, float* grad_x, long long planes, int H, int W, int scale,
+                                      dvsr_stream_t stream);
 /* out[n,c,:] (+)= x[n,c,:] * scale[c] + shift[c]; scale / shift may be NULL (1 / 0): normalize / denormalize
  * (TOF_arch.py:13-22) and channel-slice copies; batch strides 0 = dense. */
 int dvsr_channel_affine(const float* x, const float* scale, const float* shift, float* out, int N, int C, long long HW,

@@ -200,3 +200,63 @@ def test_toflow_batch2_vs_oracle_and_wrapper():
     loss = model.calculate_loss()
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.netG.parameters())
+
+
+def test_bicubic_align_corners_upsample():
+    """F.interpolate(scale_factor=s, mode='bicubic', align_corners=True) -- what the drivers apply in front of TOFlow
+    (test_dynavsr.py:188-193) -- forward and adjoint against torch in fp64, 5-D clips included."""
+    from dynavsr_amd import tofops as T
+    for shape, s in (((2, 3, 9, 13), 2), ((1, 7, 3, 8, 12), 4), ((1, 1, 1, 1), 3), ((2, 2, 5, 4), 4)):
+        x = rnd(*shape, seed=1)
+        h, w = shape[-2:]
+        go = rnd(*(shape[:-2] + (h * s, w * s)), seed=2)
+        xd = x.double().requires_grad_()
+        y = F.interpolate(xd.reshape(-1, 1, h, w), scale_factor=s, mode="bicubic", align_corners=True).reshape(go.shape)
+        (gr,) = torch.autograd.grad(y, xd, go.double())
+        xg = x.cuda().requires_grad_()
+        yg = T.upsample_bicubic_ac(xg, s)
+        (gg,) = torch.autograd.grad(yg, xg, go.cuda())
+        assert relerr(yg, y) < 2e-6 and relerr(gg, gr) < 2e-6, (shape, s)
+
+
+def test_toflow_inner_step_through_adapt_frame():
+    """The TOF branch of the per-frame adaptation (test_dynavsr.py:188-193, 245-250, 271-272): the SLR clip is brought to
+    the LR size with the bicubic kernel before TOFlow, the L1 term uses the SLR clip itself; loss and adapted output
+    against the same statements in plain torch on the CPU oracle."""
+    from oracle import mfdn as omfdn, tof as otof, edvr as oedvr
+    from dynavsr_amd.adapt import adapt_frame
+    from dynavsr_amd.models import create_model
+    from dynavsr_amd.options.options import dict_to_nonedict
+    scale = 2
+    opt = dict_to_nonedict({"name": "tof", "model": "video_base+lrimgestimator", "scale": scale, "gpu_ids": [0], "dist": False,
+                            "is_train": False, "network_G": {"which_model_G": "TOF"},
+                            "network_E": {"which_model_E": "MFDN", "mode": "video", "nf": 16, "in_nc": 3},
+                            "datasets": {"train": {"kernel_size": 21, "patch_size": 128, "batch_size": 1}, "val": {"N_frames": 7}},
+                            "path": {"strict_load": True},
+                            "train": {"pixel_criterion": "cb", "pixel_weight": 1.0, "use_real": False, "loss_ftn": "l1",
+                                      "maml": {"optimizer": "SGD", "lr_alpha": 1e-4, "adapt_iter": 1, "use_patch": False}}})
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    PG, PE, PF = synth.tof_state_dict(7), synth.mfdn_state_dict(2, nf=16, scale=scale), synth.mfdn_state_dict(3, nf=16, scale=scale)
+    model.netG.load_state_dict(PG); est.netE.load_state_dict(PE); est_fixed.netE.load_state_dict(PF)
+    lqs = synth.clip(55, 1, 7, 64, 96)
+    out = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, {"LQs": lqs.cuda()})
+    # the same statements on the CPU
+    G = OrderedDict((k, (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()))
+                    for k, v in PG.items())
+    E = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in PE.items())
+    up = lambda c: F.interpolate(c.reshape(-1, 3, c.shape[-2], c.shape[-1]), scale_factor=scale, mode="bicubic",
+                                 align_corners=True).reshape(c.shape[:3] + (c.shape[-2] * scale, c.shape[-1] * scale))
+    with torch.no_grad():
+        slr_fixed = omfdn.mfdn_forward(PF, lqs, scale)
+    slr = omfdn.mfdn_forward(E, lqs, scale)
+    loss = oedvr.charbonnier(otof.toflow_forward(G, up(slr), training=True), lqs[:, 3]) + 10 * F.l1_loss(slr, slr_fixed)
+    params = [v for v in list(G.values()) + list(E.values()) if v.requires_grad]
+    grads = torch.autograd.grad(loss, params)
+    with torch.no_grad():
+        for p, g_ in zip(params, grads):
+            p -= 1e-4 * g_
+        sr = otof.toflow_forward(G, up(lqs), training=False)
+    assert abs(float(out["losses"][0]) - float(loss)) < 2e-5 * abs(float(loss))
+    assert relerr(out["sr"], sr) < 2e-4
