@@ -41,7 +41,9 @@ struct ConvShape {
   static constexpr size_t LDS_BYTES = (size_t)(IN_FLOATS + W_FLOATS) * sizeof(float);
 };
 
-template <int KS, int S, int CC>
+// MT = 32-cout halves computed per workgroup: 2, or 1 when the layer has <= 32 output channels (SpyNet's 7x7 convs
+// to 32 / 16 / 2 channels and their data gradients: the second half would multiply zero weights).
+template <int KS, int S, int CC, int MT = 2>
 __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvK a) {
   using Sh = ConvShape<KS, S, CC>;
   constexpr int KK = Sh::KK, IH = Sh::IH, IW = Sh::IW, PLANE = Sh::PLANE, WROW = Sh::WROW;
@@ -69,9 +71,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvK a) {
   const float* x0n = a.x0 + (size_t)n * a.x0_bs;
   const float* x1n = a.c1 ? a.x1 + (size_t)(n / a.x1_bdiv) * a.x1_bs : nullptr;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -135,26 +137,28 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvK a) {
       for (int kk = 0; kk < CC / 2; ++kk) {
         const int c = 2 * kk + hi;
         const float a0 = s_w[(c * KK + tap) * WROW + lo];
-        const float a1 = s_w[(c * KK + tap) * WROW + 32 + lo];
         const float b0 = pin[c * PLANE];
         const float b1 = pin[c * PLANE + S * IW];
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        if constexpr (MT == 2) {
+          const float a1 = s_w[(c * KK + tap) * WROW + 32 + lo];
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
       }
     }
   }
 
   // ---- epilogue: bias, activation, residual, (pixel-shuffled) store
   const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo};
-  store_mfma_tile<2, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
+  store_mfma_tile<MT, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
 }
 
-template <int KS, int S, int CC>
+template <int KS, int S, int CC, int MT = 2>
 static int launch_conv(const ConvK& k, hipStream_t st) {
   using Sh = ConvShape<KS, S, CC>;
-  auto kern = conv2d_mfma_kernel<KS, S, CC>;
+  auto kern = conv2d_mfma_kernel<KS, S, CC, MT>;
   static bool attr_done = false;  // benign race: idempotent
   if (!attr_done) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -203,8 +207,8 @@ int conv2d_run(const dvsr_conv2d_desc& d, const ConvExtra& ex, hipStream_t st) {
   if (d.ks == 3 && d.stride == 2) return launch_conv<3, 2, 8>(k, st);
   // SpyNet's 7x7 and TOFlow's 9x9 (TOF_arch.py:32-42, 107-108): chunks sized so that the 64 x CC x ks^2 weight
   // image fits LDS next to the halo tile (119 KB / 94 KB: one workgroup per CU)
-  if (d.ks == 7) return launch_conv<7, 1, 8>(k, st);
-  if (d.ks == 9) return launch_conv<9, 1, 4>(k, st);
+  if (d.ks == 7) return d.Cout <= 32 ? launch_conv<7, 1, 8, 1>(k, st) : launch_conv<7, 1, 8, 2>(k, st);
+  if (d.ks == 9) return d.Cout <= 32 ? launch_conv<9, 1, 4, 1>(k, st) : launch_conv<9, 1, 4, 2>(k, st);
   return launch_conv<1, 1, 32>(k, st);
 }
 

@@ -712,3 +712,72 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
 }
 
 }  // namespace dvsr
+
+// ---- op-level entries to the pipelined / K-split kernels ---------------------------------------------------
+// dvsr_conv2d_forward runs the un-packed kernel (no workspace).  These take a caller workspace for the packed weight
+// image, pack it on the stream and run the geometry the engine would choose -- used by the op-composed backbones
+// (TOFlow head, DUF) whose 3x3 / 1x1 convolutions otherwise ran on the single-buffered kernel.
+namespace {
+struct OpPack {
+  dvsr::ConvGeo geo;
+  size_t floats;
+};
+OpPack op_pack(int ks, int stride, int pad, int N, int Ho, int Wo, int Cout, int Ctot, bool plain) {
+  using namespace dvsr;
+  OpPack o;
+  o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, Ctot, ks == 3 && stride == 1 && pad == 1 && plain);
+  o.floats = (size_t)ceil_div(Cout, 64) * ceil_div(Ctot, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, 0);
+  return o;
+}
+int op_run(const dvsr_conv2d_desc& d, const dvsr::ConvExtra& ex, int Cout, int Ctot, void* ws, size_t bytes, hipStream_t st) {
+  using namespace dvsr;
+  DVSR_REQUIRE((d.ks == 1 || d.ks == 3) && d.stride == 1 && d.pad == d.ks / 2, DVSR_ERR_UNSUPPORTED,
+               "conv2d (packed): ks=%d stride=%d pad=%d (1x1 / 3x3, stride 1, pad ks/2)", d.ks, d.stride, d.pad);
+  const OpPack o = op_pack(d.ks, 1, d.pad, d.N, d.H, d.W, Cout, Ctot, d.c1 == 0 || d.c0 % 32 == 0);
+  DVSR_REQUIRE(ws && bytes >= o.floats * sizeof(float), DVSR_ERR_WORKSPACE, "conv2d (packed): workspace %zu < %zu bytes", bytes,
+               o.floats * sizeof(float));
+  PackTable t;
+  t.n = 1;
+  PackEntry& e = t.e[0];
+  e.w = d.w; e.P = (float*)ws; e.Cout = Cout; e.Ctot = Ctot; e.KK = d.ks * d.ks; e.CC = o.geo.cc; e.wt = ex.wt;
+  e.w_ctot = ex.w_ctot; e.w_coff = ex.w_coff; e.ncb = ceil_div(Cout, 64); e.nchunks = ceil_div(Ctot, e.CC); e.bf = 0;
+  e.pch = conv2_pch_cc(d.ks, e.CC, 0);
+  int rc = pack_weights_run(t, st);
+  if (rc) return rc;
+  return conv2d_packed_run(d, (const float*)ws, ex, o.geo, st);
+}
+}  // namespace
+
+extern "C" size_t dvsr_conv2d_packed_workspace_bytes(const dvsr_conv2d_desc* d) {
+  if (!d || (d->ks != 1 && d->ks != 3)) return 0;
+  // the larger of the forward pack and the data-gradient pack (roles of Cout and Ctot swapped)
+  const int ctot = d->c0 + d->c1;
+  const size_t a = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, d->Cout, ctot, true).floats;
+  const size_t b = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, ctot, d->Cout, true).floats;
+  const size_t c = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, d->Cout, ctot, false).floats;
+  return (a > b ? (a > c ? a : c) : (b > c ? b : c)) * sizeof(float);
+}
+
+extern "C" int dvsr_conv2d_forward_packed(const dvsr_conv2d_desc* d, void* workspace, size_t workspace_bytes,
+                                          dvsr_stream_t stream) {
+  DVSR_REQUIRE(d && d->x0 && d->w && d->y, DVSR_ERR_INVALID, "conv2d_forward_packed: null argument");
+  DVSR_REQUIRE(d->pixel_shuffle == 0 || (d->pixel_shuffle == 2 && d->Cout % 4 == 0 && !d->res), DVSR_ERR_INVALID,
+               "conv2d_forward_packed: pixel_shuffle needs Cout %% 4 == 0 and no residual");
+  return op_run(*d, dvsr::ConvExtra(), d->Cout, d->c0 + d->c1, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// gx0 = data gradient of a single-input conv (d->c1 == 0): a stride-1 conv of gy with the transposed, tap-mirrored
+// weights.  gy: gradient w.r.t. the pre-activation output.
+extern "C" int dvsr_conv2d_dgrad_packed(const dvsr_conv2d_desc* d, const float* gy, float* gx0, void* workspace,
+                                        size_t workspace_bytes, dvsr_stream_t stream) {
+  using namespace dvsr;
+  DVSR_REQUIRE(d && gy && gx0 && d->w, DVSR_ERR_INVALID, "conv2d_dgrad_packed: null argument");
+  DVSR_REQUIRE(d->c1 == 0 && d->pixel_shuffle == 0, DVSR_ERR_UNSUPPORTED, "conv2d_dgrad_packed: single plain input only");
+  dvsr_conv2d_desc g = {};
+  g.x0 = gy; g.w = d->w; g.y = gx0; g.N = d->N; g.c0 = d->Cout; g.Cout = d->c0; g.H = d->H; g.W = d->W; g.ks = d->ks;
+  g.stride = 1; g.pad = d->ks / 2; g.act = ACT_NONE; g.x1_bdiv = 1;
+  ConvExtra ex;
+  ex.wt = 1; ex.w_ctot = d->c0; ex.w_coff = 0;
+  return op_run(g, ex, d->c0, d->Cout, workspace, workspace_bytes, (hipStream_t)stream);
+}
+

@@ -270,12 +270,15 @@ __device__ __forceinline__ void conv2d_wgrad_pipe_item(const WgradK& a, const in
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lo = lane & 31, hi = lane >> 5;
-  // wave -> (cout half, cin half) of the 64 x 64 block.  With <= 32 input channels of the block in use (the first
-  // layers: 3 or 9 channels) the second cin half would multiply zeros: the two waves of a cout half then share cin
-  // half 0 and split the pixel reduction instead (even / odd k-steps; the flush is atomic anyway).
-  const bool cin_small = a.Cin - cbk * 64 <= 32;
-  const int ot = wave >> 1, ct = cin_small ? 0 : (wave & 1);
-  const int kpar = cin_small ? (wave & 1) : 0, kinc = cin_small ? 2 : 1;
+  // wave -> (cout half, cin half) of the 64 x 64 block.  A half that holds no channels of the layer (first / last
+  // layers: 3 or 9 inputs, 3 outputs; SpyNet: 8..32 channels) would multiply zeros: the waves that would own it
+  // share the populated half instead and split the pixel reduction among them (k-steps kpar, kpar + kinc, ...;
+  // the flush is atomic anyway).
+  const bool cin_small = a.Cin - cbk * 64 <= 32, cout_small = a.Cout - ob * 64 <= 32;
+  const int ot = cout_small ? 0 : (wave >> 1);
+  const int ct = cin_small ? 0 : (wave & 1);
+  const int kinc = (cin_small ? 2 : 1) * (cout_small ? 2 : 1);
+  const int kpar = (cin_small && cout_small) ? wave : (cin_small ? (wave & 1) : (cout_small ? (wave >> 1) : 0));
   const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
 
   // lane-fixed parts of the staging addresses
@@ -295,7 +298,7 @@ __device__ __forceinline__ void conv2d_wgrad_pipe_item(const WgradK& a, const in
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float db = 0.f;
-  const bool do_db = cbk == 0 && ct == 0 && ky == 0;  // (cin_small: both waves of a cout half, each its k-steps)
+  const bool do_db = cbk == 0 && (cin_small || ct == 0) && ky == 0;  // (every wave of cin half 0, each its own k-steps)
 
   float rg[16], rx[16][XM];
   bool g_ok, x_ok[XM];

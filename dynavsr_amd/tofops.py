@@ -36,7 +36,11 @@ class _Conv(torch.autograd.Function):
         y = x.new_empty((n, cout, h, wd))
         d = L.Conv2dDesc(L.ptr(x), None, L.ptr(w), L.ptr(b), L.ptr(res), L.ptr(y), n, c, 0, h, wd, cout, ks, 1, ks // 2,
                          act, 0, 1, 0, 0)
-        L.check(L.lib().dvsr_conv2d_forward(d, L.stream()), "dvsr_conv2d_forward")
+        if ks in (1, 3):     # pipelined / small-grid kernels over a packed weight image
+            ws = torch.empty(max(int(L.lib().dvsr_conv2d_packed_workspace_bytes(d)), 16), dtype=torch.uint8, device=x.device)
+            L.check(L.lib().dvsr_conv2d_forward_packed(d, ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_forward_packed")
+        else:
+            L.check(L.lib().dvsr_conv2d_forward(d, L.stream()), "dvsr_conv2d_forward")
         ctx.save_for_backward(x, w, y if act != L.ACT_NONE else None)
         ctx.act, ctx.has_res = act, res is not None
         return y
@@ -57,8 +61,13 @@ class _Conv(torch.autograd.Function):
         ws = torch.empty(max(int(L.lib().dvsr_conv2d_backward_workspace_bytes(d)), 16), dtype=torch.uint8, device=x.device)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gw, gb = torch.empty_like(w), w.new_empty(cout)
-        L.check(L.lib().dvsr_conv2d_backward(d, L.ptr(gy), L.ptr(gx), None, L.ptr(gw), L.ptr(gb), ws.data_ptr(), ws.numel(),
-                                             L.stream()), "dvsr_conv2d_backward")
+        packed = ks in (1, 3) and gx is not None
+        L.check(L.lib().dvsr_conv2d_backward(d, L.ptr(gy), None if packed else L.ptr(gx), None, L.ptr(gw), L.ptr(gb),
+                                             ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_backward")
+        if packed:
+            pw = torch.empty(max(int(L.lib().dvsr_conv2d_packed_workspace_bytes(d)), 16), dtype=torch.uint8, device=x.device)
+            L.check(L.lib().dvsr_conv2d_dgrad_packed(d, L.ptr(gy), L.ptr(gx), pw.data_ptr(), pw.numel(), L.stream()),
+                    "dvsr_conv2d_dgrad_packed")
         return gx, gw, gb, g_res, None
 
 

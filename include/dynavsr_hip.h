@@ -254,6 +254,16 @@ int dvsr_l1_tail_forward(const float* x, const float* y, const float* base, floa
 int dvsr_l1_tail_backward(const float* x, const float* y, const float* grad_loss, float weight, float* gx, long long n,
                           dvsr_stream_t stream);
 
+/* ---- op-level entries to the pipelined / small-grid conv kernels ---------------------------------------------------
+ * dvsr_conv2d_forward needs no workspace and runs the un-packed kernel.  These pack the weights into a caller
+ * workspace on the stream and run the geometry the whole-network plan would pick for the shape (pipelined 4-row tiles,
+ * or the K-split kernel on small grids): 1x1 and 3x3, stride 1, pad ks/2; same descriptor and epilogues.  The data
+ * gradient is the same kernel over the transposed, tap-mirrored pack (single plain input). */
+size_t dvsr_conv2d_packed_workspace_bytes(const dvsr_conv2d_desc* d);
+int dvsr_conv2d_forward_packed(const dvsr_conv2d_desc* d, void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
+int dvsr_conv2d_dgrad_packed(const dvsr_conv2d_desc* d, const float* gy, float* gx0, void* workspace,
+                             size_t workspace_bytes, dvsr_stream_t stream);
+
 /* ---- TOFlow backbone ops (codes/models/archs/TOF_arch.py:25-140, arch_util.py:55-79) --------
  * The convolutions of SpyNet (7x7) and of the TOFlow head (9x9, 1x1) go through dvsr_conv2d_forward / _backward
  * (ks = 7, 9, 1); the ops below are the rest of the graph.  All fp32 NCHW, HBM-bound streaming kernels.
