@@ -249,7 +249,7 @@ size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int 
 int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW, float* db,
                          int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks, int stride, void* ws,
                          size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad, WgradReduceEntry* defer,
-                         WgradLaunch* out) {
+                         WgradLaunch* out, int bf16) {
   DVSR_REQUIRE(x && gy && dW && ws, DVSR_ERR_INVALID, "conv2d_wgrad: null pointer");
   DVSR_REQUIRE(((ks == 1 || ks == 2 || ks == 7 || ks == 9) && stride == 1) || (ks == 3 && (stride == 1 || stride == 2)),
                DVSR_ERR_UNSUPPORTED, "conv2d_wgrad: ks=%d stride=%d unsupported", ks, stride);
@@ -283,7 +283,8 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
     const char* v = getenv("DVSR_WGRAD_KYS_BELOW");
     kys_below = v ? atoi(v) : 4096;
   }
-  out->kys = (ks == 3 && stride == 1 && (long long)k.ntiles * k.nob * k.ncb < kys_below) || ks == 7 || ks == 9;
+  out->bf = bf16 && ks == 3 && stride == 1;
+  out->kys = !out->bf && ((ks == 3 && stride == 1 && (long long)k.ntiles * k.nob * k.ncb < kys_below) || ks == 7 || ks == 9);
   if (out->kys) {
     static int kys_wgs = -1;   // DVSR_WGRAD_KYS_WGS=<workgroups per launch to aim for>
     if (kys_wgs < 0) {
@@ -301,6 +302,7 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
 }
 
 int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st) {
+  if (l.bf) return conv2d_wgrad_bf16_launch(l, st);
   const WgradK& k = l.k;
   const dim3 grid = l.grid;
   const int ks = l.ks, stride = l.stride;
@@ -404,3 +406,27 @@ extern "C" int dvsr_conv2d_backward(const dvsr_conv2d_desc* d, const float* gy, 
   }
   return DVSR_OK;
 }
+
+// Weight / bias gradient of a single-input 3x3 stride-1 conv with bf16 operands on the bf16 MFMA (fp32 accumulate):
+// the op-level face of conv2d_wgrad_bf16.hip (the EDVR plan uses it when network_G.bf16_mfma = 1).  Workspace:
+// dvsr_conv2d_backward_workspace_bytes.
+extern "C" int dvsr_conv2d_wgrad_bf16(const dvsr_conv2d_desc* d, const float* gy, float* gw, float* gb, void* workspace,
+                                      size_t workspace_bytes, dvsr_stream_t stream) {
+  using namespace dvsr;
+  DVSR_REQUIRE(d && gy && gw && d->x0, DVSR_ERR_INVALID, "conv2d_wgrad_bf16: null argument");
+  DVSR_REQUIRE(d->ks == 3 && d->stride == 1 && d->c1 == 0 && d->pixel_shuffle == 0, DVSR_ERR_UNSUPPORTED,
+               "conv2d_wgrad_bf16: 3x3 stride-1 single-input convolutions only");
+  hipStream_t st = (hipStream_t)stream;
+  WgradLaunch l;
+  int rc = conv2d_wgrad_prepare(d->x0, d->x0_bstride, 1, gy, 0, gw, gb, d->N, d->c0, d->H, d->W, d->Cout, d->c0, 0, 3, 1,
+                                workspace, workspace_bytes, st, 0, d->pad, nullptr, &l, 1);
+  if (rc) return rc;
+  rc = conv2d_wgrad_launch(l, st);
+  if (rc) return rc;
+  const WgradK& k = l.k;
+  const int total = d->Cout * d->c0 * 9;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, k.partial, k.dbp, gw, gb, k.nslot, 9,
+                     k.nob * 64, k.ncb * 64, d->Cout, d->c0, d->c0, 0);
+  return check_launch("wgrad_reduce_kernel");
+}
+

@@ -642,7 +642,8 @@ static int prep_wgrad(const dvsr_edvr_plan& p, const BOp& b, float* const* GP, c
   float* dW = o->wmap ? bs.garena + o->w2_off : GP[o->pw];
   return conv2d_wgrad_prepare(bs.at(b.a), b.which ? o->x1_bs : o->x0_bs, b.which ? o->x1_bdiv : 1, bs.at(b.b), o->ps, dW,
                               b.which ? nullptr : GP[o->pb], o->N, ci, o->H, o->W, o->Cout, o->c0 + o->c1,
-                              b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st, 1, conv_pad(*o), defer, out);
+                              b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st, 1, conv_pad(*o), defer, out,
+                              p.cfg.bf16_mfma == 1 && !o->wmap);
 }
 
 static void dgrad_desc(const dvsr_edvr_plan& p, const BOp& b, const float* const* P, const BBases& bs,

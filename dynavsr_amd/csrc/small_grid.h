@@ -42,12 +42,14 @@ struct WgradLaunch {
   WgradK k;
   dim3 grid;
   int ks, stride, kys;
+  int bf = 0;  // 1: bf16 operands on v_mfma_f32_32x32x16_bf16 (conv2d_wgrad_bf16.hip; 3x3 stride 1 only)
 };
 int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW, float* db,
                          int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks, int stride, void* ws,
                          size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad, WgradReduceEntry* defer,
-                         WgradLaunch* out);
+                         WgradLaunch* out, int bf16 = 0);
 int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st);
+int conv2d_wgrad_bf16_launch(const WgradLaunch& l, hipStream_t st);
 
 // -------------------------------------------------------------------------------------------------
 // K-split variant for SMALL grids (the 44x80 / 22x40 / 11x20 levels of the inner MAML step).

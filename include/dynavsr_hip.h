@@ -264,6 +264,13 @@ int dvsr_conv2d_forward_packed(const dvsr_conv2d_desc* d, void* workspace, size_
 int dvsr_conv2d_dgrad_packed(const dvsr_conv2d_desc* d, const float* gy, float* gx0, void* workspace,
                              size_t workspace_bytes, dvsr_stream_t stream);
 
+/* Weight / bias gradient of a single-input 3x3 stride-1 convolution with both operands rounded to bf16 on
+ * v_mfma_f32_32x32x16_bf16 (fp32 accumulation and flush): what the EDVR plan runs for its weight gradients when
+ * network_G.bf16_mfma = 1 (BASELINE configs[4]).  gy = gradient w.r.t. the pre-activation output; gb may be NULL.
+ * Workspace: dvsr_conv2d_backward_workspace_bytes(d). */
+int dvsr_conv2d_wgrad_bf16(const dvsr_conv2d_desc* d, const float* gy, float* gw, float* gb, void* workspace,
+                           size_t workspace_bytes, dvsr_stream_t stream);
+
 /* ---- TOFlow backbone ops (codes/models/archs/TOF_arch.py:25-140, arch_util.py:55-79) --------
  * The convolutions of SpyNet (7x7) and of the TOFlow head (9x9, 1x1) go through dvsr_conv2d_forward / _backward
  * (ks = 7, 9, 1); the ops below are the rest of the graph.  All fp32 NCHW, HBM-bound streaming kernels.

@@ -276,6 +276,32 @@ def test_charbonnier(ops):
     assert abs(float(got) - float(ref)) < 1e-6 * float(ref) and relerr(gg, rg) < 1e-6
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 12, 40), (1, 128, 128, 9, 33), (3, 24, 72, 7, 20), (1, 64, 216, 16, 32)])
+def test_conv3x3_wgrad_bf16(ops, n, cin, cout, h, w):
+    """Weight / bias gradient with bf16 operands (conv2d_wgrad_bf16.hip): against the fp64 gradient of the SAME
+    bf16-rounded operands (only fp32 accumulation order differs: 2e-5), and against the unrounded fp64 gradient within
+    bf16's reach (2^-9 per operand: 1e-2); ragged tiles, channel counts off the 64-blocks, the bias gradient exact-ish."""
+    import torch.nn.functional as F
+    from dynavsr_amd import _lib as L
+    x, gy = rnd(n, cin, h, w, seed=1), rnd(n, cout, h, w, seed=2)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+
+    def ref(xx, gg):
+        (gw,) = torch.autograd.grad(F.conv2d(xx.double(), wt, padding=1), wt, gg.double())
+        return gw
+    gw_exact = ref(x, gy)
+    gw_round = ref(x.bfloat16().float(), gy.bfloat16().float())
+    xg, gg = dev(x), dev(gy)
+    gw, gb = torch.empty(cout, cin, 3, 3, device="cuda"), torch.empty(cout, device="cuda")
+    d = L.Conv2dDesc(L.ptr(xg), None, None, None, None, None, n, cin, 0, h, w, cout, 3, 1, 1, 0, 0, 1, 0, 0)
+    ws = torch.empty(max(int(L.lib().dvsr_conv2d_backward_workspace_bytes(d)), 16), dtype=torch.uint8, device="cuda")
+    L.check(L.lib().dvsr_conv2d_wgrad_bf16(d, L.ptr(gg), L.ptr(gw), L.ptr(gb), ws.data_ptr(), ws.numel(), L.stream()),
+            "dvsr_conv2d_wgrad_bf16")
+    assert relerr(gw, gw_round) < 2e-5, relerr(gw, gw_round)
+    assert 1e-5 < relerr(gw, gw_exact) < 1e-2
+    assert relerr(gb, gy.double().sum(dim=(0, 2, 3))) < 1e-5
+
+
 def test_inner_loss_tail(ops):
     """loss_pix + 10 * F.l1_loss(SLR, SLR_fixed) (test_dynavsr.py:264-274) as one native reduction: value, the
     pass-through gradient of the pixel loss, the sign gradient of the L1 term (sign(0) = 0 like torch), ragged
