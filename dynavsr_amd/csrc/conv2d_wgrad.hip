@@ -284,6 +284,26 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
     kys_below = v ? atoi(v) : 4096;
   }
   out->bf = bf16 && ks == 3 && stride == 1;
+  if (out->bf) {
+    // the bf16 kernel is staging- and flush-bound (36 MFMAs per tile): fewer workgroups, each with more tiles, keep the
+    // 147 KB-per-workgroup atomic flush small.  DVSR_WGRAD_BF_WGS=<workgroups per launch to aim for>.
+    static int bf_wgs = -1;
+    if (bf_wgs < 0) {
+      const char* v = getenv("DVSR_WGRAD_BF_WGS");
+      bf_wgs = v ? atoi(v) : 128;
+    }
+    // (128 at the 64x64 tiles of configs[4] -- sweep in profiles/r02_z_bf16_wgrad.txt -- growing with the pixel grid:
+    // about eight tiles per workgroup, at most 512 workgroups)
+    int target = k.ntiles / 8;
+    target = target < bf_wgs ? bf_wgs : (target > 512 ? 512 : target);
+    int s2 = ceil_div(target, k.nob * k.ncb);
+    s2 = s2 > k.ntiles ? k.ntiles : (s2 < 1 ? 1 : s2);
+    if (s2 < k.nsplit) {
+      k.nsplit = s2;
+      if (k.nslot > k.nsplit) k.nslot = k.nsplit;
+      out->grid = dim3(k.nsplit, k.nob, k.ncb);
+    }
+  }
   out->kys = !out->bf && ((ks == 3 && stride == 1 && (long long)k.ntiles * k.nob * k.ncb < kys_below) || ks == 7 || ks == 9);
   if (out->kys) {
     static int kys_wgs = -1;   // DVSR_WGRAD_KYS_WGS=<workgroups per launch to aim for>

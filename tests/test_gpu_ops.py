@@ -299,7 +299,8 @@ def test_conv3x3_wgrad_bf16(ops, n, cin, cout, h, w):
             "dvsr_conv2d_wgrad_bf16")
     assert relerr(gw, gw_round) < 2e-5, relerr(gw, gw_round)
     assert 1e-5 < relerr(gw, gw_exact) < 1e-2
-    assert relerr(gb, gy.double().sum(dim=(0, 2, 3))) < 1e-5
+    assert relerr(gb, gy.bfloat16().double().sum(dim=(0, 2, 3))) < 1e-5        # fp32 sum of the bf16-rounded operand
+    assert relerr(gb, gy.double().sum(dim=(0, 2, 3))) < 5e-3
 
 
 def test_inner_loss_tail(ops):
