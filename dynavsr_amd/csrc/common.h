@@ -8,6 +8,7 @@ namespace dvsr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Error codes returned by every C-ABI entry point (0 = success).
 enum : int {
@@ -132,14 +133,17 @@ __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT]
             *const_cast<float*>(addr(t.y, r)) = v;
           }
         } else {
+          // pixel shuffle: channels co and co + 1 (registers r, r + 1) are the horizontal neighbours 2 ox, 2 ox + 1
+          // of one output row -> one 8-byte store per pair, 256 contiguous bytes per 32 lanes
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
+          for (int r = 0; r < 16; r += 2) {
             const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
-            float v = acc[mt][nt][r] + bv[mt][r];
-            v = fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f));
-            const int cq = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
-            t.y[(((size_t)n * (t.Cout >> 2) + cq) * (2 * t.Ho) + (2 * oy + dy)) * (size_t)(2 * t.Wo) +
-                (2 * ox + dx)] = v;
+            float v0 = acc[mt][nt][r] + bv[mt][r], v1 = acc[mt][nt][r + 1] + bv[mt][r + 1];
+            v0 = fmaf(slope, fminf(v0, 0.f), fmaxf(v0, 0.f));
+            v1 = fmaf(slope, fminf(v1, 0.f), fmaxf(v1, 0.f));
+            const int cq = co >> 2, dy = (co >> 1) & 1;
+            *reinterpret_cast<f32x2*>(&t.y[(((size_t)n * (t.Cout >> 2) + cq) * (2 * t.Ho) + (2 * oy + dy)) * (size_t)(2 * t.Wo) +
+                                         2 * ox]) = f32x2{v0, v1};
           }
         }
       }

@@ -94,7 +94,9 @@ __global__ void pack_weights_kernel(PackTable t) {
     const int q = r % kq4; r /= kq4;
     const int tap = r % e.KK;
     const int mt = r / e.KK;
-    const int co = cb * 64 + mt * 32 + lo, ci = k * e.CC + 2 * (4 * q + j) + hi;
+    // channel of (operand group q, lane half hi, k-step j): interleaved for the register-staged halo image,
+    // 4 consecutive channels per lane half for the DMA-staged planar one (conv2d_dma_item)
+    const int co = cb * 64 + mt * 32 + lo, ci = k * e.CC + (e.perm ? 8 * q + 4 * hi + j : 2 * (4 * q + j) + hi);
     float v = 0.f;
     if (co < e.Cout && ci < e.Ctot) {
       if (!e.wt) v = e.w[((size_t)co * e.Ctot + ci) * e.KK + tap];
@@ -515,6 +517,189 @@ static int launch_conv2(ConvK2 k, hipStream_t st) {
   return check_launch("conv2d_pipe_kernel");
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Halo-by-DMA variant of the pipelined kernel (fp32, 3x3 / stride 1 / pad 1, plain inputs, W % 4 == 0,
+// channel counts % 8 == 0): the big layers of the 180x320 forward.
+//
+// conv2d_pipe_item spends ~75 cycles of its MFMA stream on every vector-memory instruction it issues (ablations in
+// profiles/r01_mfma_ceiling.txt: the 8 halo loads per wave and chunk cost 12 % of the kernel, the weight DMA
+// 7 %), then masks and transposes the halo through VGPRs.  Here the halo goes global -> LDS by DMA as well, in
+// 16-byte pieces: the tile's input window is widened to the aligned columns [ox0 - 4, ox0 + 36), ten float4
+// groups per (channel, row), so one global_load_lds_dwordx4 moves 64 groups = 1 KiB and a chunk
+// (8 channels x 6 rows x 10 groups = 480 groups) is TWO instructions per wave instead of eight, with no staging
+// registers, no masking and no ds_write.  The LDS image is planar, [channel][row][40 columns]; a B operand is four
+// ds_read_b32 (channels 4*hi + j, the order pack_weights_kernel uses with perm = 1), conflict-free: the 32 lanes
+// of a half read 32 consecutive dwords.
+// Groups outside the image are never written by the DMA (their lanes are masked off); the prologue zeroes them
+// once in both buffers -- validity depends on the position only, not on the chunk.
+// -------------------------------------------------------------------------------------------------
+template <int TH, int MT>
+struct DmaShape {
+  static constexpr int KK = 9, CC = 8, NT = TH / 4, IH = TH + 2, RP = 40, GR = RP / 4;
+  static constexpr int NG = CC * IH * GR;                 // 16-byte groups of one chunk's halo image
+  static constexpr int NI = (NG + 255) / 256;             // halo DMA instructions per wave and chunk
+  static constexpr int IN_FLOATS = NG * 4;
+  static constexpr int HALF = KK * 2 * 32 * 4;            // packed floats of one 32-cout half
+  static constexpr int W_FLOATS = MT * HALF;
+  static constexpr int NPIECE = W_FLOATS / 256;
+  static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
+  static constexpr size_t LDS_BYTES = (size_t)2 * BUF_FLOATS * sizeof(float);
+};
+
+template <int TH, int MT>
+__device__ __forceinline__ void conv2d_dma_item(const ConvK2& a, const int id, float* const smem) {
+  using Sh = DmaShape<TH, MT>;
+  constexpr int KK = Sh::KK, CC = Sh::CC, IH = Sh::IH, NT = Sh::NT, RP = Sh::RP, GR = Sh::GR, NI = Sh::NI;
+  float* const s_in0 = smem;
+  float* const s_w0 = smem + Sh::IN_FLOATS;
+
+  const int q_ = id >> 3;  // XCD-aware order, as conv2d_pipe_item
+  const int cbi = q_ % a.ncb;
+  const int j_ = q_ / a.ncb;
+  const int tile = (id & 7) * a.tiles_per_xcd + j_;
+  if (j_ >= a.tiles_per_xcd || tile >= a.ntiles) return;
+  const int tx_ = tile % a.tiles_x;
+  const int t2 = tile / a.tiles_x;
+  const int ty_ = t2 % a.tiles_y;
+  const int n = t2 / a.tiles_y;
+  const int oy0 = ty_ * TH, ox0 = tx_ * 32;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const size_t HW = (size_t)a.H * a.W;
+  const float* x0n = a.x0 + (size_t)n * a.x0_bs;
+  const float* x1n = a.c1 ? a.x1 + (size_t)(n / a.x1_bdiv) * a.x1_bs : x0n;
+
+  // the groups this lane moves: group L = 64 * (wave + 4 jj) + lane = (channel, row, column group)
+  unsigned hoff[NI];
+  bool hval[NI];
+#pragma unroll
+  for (int jj = 0; jj < NI; ++jj) {
+    const int L = 64 * (wave + 4 * jj) + lane;
+    const int c = L / (IH * GR), r = L - c * (IH * GR);
+    const int iy = r / GR, g = r - iy * GR;
+    const int gy = oy0 - 1 + iy, gx = ox0 - 4 + 4 * g;
+    const bool ok = L < Sh::NG && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    hoff[jj] = ok ? (unsigned)(((size_t)c * HW + (size_t)gy * a.W + gx) * 4) : 0u;
+    hval[jj] = ok;
+    if (L < Sh::NG && !ok) {
+      *reinterpret_cast<f32x4*>(s_in0 + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(s_in0 + Sh::BUF_FLOATS + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* wp_cb = a.wp + ((size_t)((cbi * MT) >> 1) * a.nchunks * 2 + ((cbi * MT) & 1)) * Sh::HALF;
+
+  auto issue_halo = [&](int k, int buf) {
+    const int cbase = k * CC;
+    const bool second = cbase >= a.c0;  // only possible when c1 > 0; a chunk never straddles the two inputs
+    const float* b = second ? x1n : x0n;
+    const int ci = second ? cbase - a.c0 : cbase;
+    const char* p = reinterpret_cast<const char*>(b + (size_t)ci * HW);
+    float* dst = s_in0 + buf * Sh::BUF_FLOATS;
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+      if (hval[jj])
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + hoff[jj]),
+                                         (__attribute__((address_space(3))) void*)(dst + 256 * (wave + 4 * jj)), 16, 0, 0);
+    }
+  };
+  auto issue_w = [&](int k, int buf) {
+    const float* wsrc = wp_cb + (size_t)k * (2 * Sh::HALF);
+    float* wdst = s_w0 + buf * Sh::BUF_FLOATS;
+#pragma unroll
+    for (int j = 0; j < (Sh::NPIECE + 3) / 4; ++j) {
+      int piece = j * 4 + wave;
+      piece = piece < Sh::NPIECE ? piece : Sh::NPIECE - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + piece * 256 + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(wdst + piece * 256), 16, 0, 0);
+    }
+  };
+
+  // B operand of (row nt of this wave, tap (ty, tx), k-step j): channel 4 hi + j, row NT wave + nt + ty, column lo + tx + 3
+  const int bbase = (4 * hi * IH + NT * wave) * RP + lo + 3;
+  auto block = [&](int k, auto has_next_tag) {
+    constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
+    const int buf = k & 1;
+    const float* s_in = s_in0 + buf * Sh::BUF_FLOATS + bbase;
+    const float* s_w = s_w0 + buf * Sh::BUF_FLOATS;
+    if (HAS_NEXT) {
+      if (!(a.ablate & 4)) issue_w(k + 1, buf ^ 1);
+      if (!(a.ablate & 2)) issue_halo(k + 1, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 A[2][MT];
+    float Bv[2][NT][4];
+    auto load_ops = [&](int tap, int rb) {
+      const int ty = tap / 3, tx = tap - ty * 3;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        A[rb][mt] = *reinterpret_cast<const f32x4*>(s_w + ((size_t)(((mt * KK + tap) * 2 + hi) * 32 + lo)) * 4);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bv[rb][nt][j] = s_in[(j * IH + nt + ty) * RP + tx];
+    };
+    load_ops(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) {
+      const int rb = tap & 1;
+      if (tap + 1 < KK) load_ops(tap + 1, rb ^ 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][mt][j], Bv[rb][nt][j], acc[mt][nt], 0, 0, 0);
+    }
+    if (HAS_NEXT && !(a.ablate & 8)) __syncthreads();  // next buffers complete (the barrier's vmcnt(0) covers both DMAs)
+  };
+
+  issue_w(0, 0);
+  issue_halo(0, 0);
+  __syncthreads();
+  for (int k = 0; k + 1 < a.nchunks; ++k) block(k, std::true_type{});
+  block(a.nchunks - 1, std::false_type{});
+
+  if ((a.ablate & 1) && acc[0][0][0] != 12345.f) return;
+  const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
+  store_mfma_tile<MT, NT>(acc, t, n, cbi * MT * 32, oy0, TH, ox0, oy0 + NT * wave, lo, hi);
+}
+
+template <int TH, int MT>
+__global__ __launch_bounds__(256, 2) void conv2d_dma_kernel(ConvK2 a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv2d_dma_item<TH, MT>(a, blockIdx.x, smem);
+}
+
+template <int TH, int MT>
+static int launch_dma(ConvK2 k, hipStream_t st) {
+  using Sh = DmaShape<TH, MT>;
+  auto kern = conv2d_dma_kernel<TH, MT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
+    attr_done = true;
+  }
+  k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
+  k.ncb = ceil_div(k.Cout, 32 * MT);
+  k.tiles_per_xcd = ceil_div(k.ntiles, 8);
+  k.nitems = k.tiles_per_xcd * 8 * k.ncb;
+  hipLaunchKernelGGL(kern, dim3(k.nitems), dim3(256), Sh::LDS_BYTES, st, k);
+  return check_launch("conv2d_dma_kernel");
+}
+
 template <int MT, int NT>
 __global__ __launch_bounds__(256, 2) void conv2d_ksplit_kernel(ConvK2 a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -553,7 +738,7 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
   // Threshold from profiles/r02_small_grid_ab.txt: below ~700 such workgroups (the 44x80 levels: 66..330) the K-split
   // kernel wins (rc_rb 19.2 -> 14.8 us, fe_rb 30 -> 26 us); at 900 (the 180x320 trunk) and 1155 (L1_om at 5x44x80) the
   // pipelined 4-row kernel is faster again (47.5 vs 52.6 us, 65 vs 72 us): three times the halo and unshared weights.
-  if (ks == 3 && stride == 1 && allow_ksplit && Ctot >= 32 && Cout >= 32) {
+  if (ks == 3 && stride == 1 && (allow_ksplit & 1) && Ctot >= 32 && Cout >= 32) {
     static int below = -1, pin_nt = -1;
     if (below < 0) {
       const char* v = getenv("DVSR_CONV_KSPLIT_BELOW");
@@ -584,12 +769,21 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
     if (force == 2 || (force < 0 && c41 < 0.97 * c42)) return ConvGeo{cc, 4, 1};
     return ConvGeo{cc, 4, 2};
   }
-  if (force == 0 && ks != 2) return ConvGeo{cc, 8, 2};
-  if (force == 1) return ConvGeo{cc, 4, 2};
-  if (force == 2) return ConvGeo{cc, 4, 1};
   const double c42 = conv2_pipe_cost(4, 2, ks * ks, cc, N, Ho, Wo, Cout);
   const double c41 = conv2_pipe_cost(4, 1, ks * ks, cc, N, Ho, Wo, Cout);
   ConvGeo g = c41 < 0.97 * c42 ? ConvGeo{cc, 4, 1} : ConvGeo{cc, 4, 2};
+  if (force == 0 && ks != 2) g = ConvGeo{cc, 8, 2};
+  if (force == 1) g = ConvGeo{cc, 4, 2};
+  if (force == 2) g = ConvGeo{cc, 4, 1};
+  // halo by DMA (conv2d_dma_item): plain pad-1 inputs on a 16-byte column grid, whole 8-channel chunks.
+  // DVSR_CONV_DMA=0 keeps the register-staged kernel (A/B aid).
+  static int dma_on = -1;
+  if (dma_on < 0) {
+    const char* v = getenv("DVSR_CONV_DMA");
+    dma_on = v ? atoi(v) : 1;
+  }
+  if (dma_on && (allow_ksplit & 2) && ks == 3 && stride == 1 && Wo % 4 == 0 && Ctot % 8 == 0) g.dma = 1;
+  if (force >= 0) return g;
   // Small grids (every workgroup resident at once) are bound by one memory latency per chunk, not by the
   // matrix pipe: 16-channel chunks halve the number of exposed latencies.  DVSR_CONV_CC16_BELOW=<workgroups>
   // moves the threshold (0 disables).
@@ -636,12 +830,29 @@ int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const Conv
   k.nchunks = ceil_div(d.c0 + d.c1, geo.cc);
   k.in_ps = ex.in_ps; k.in_dil = ex.in_dil; k.Hs = ex.Hs; k.Ws = ex.Ws; k.accum = ex.accum;
   k.gmask = ex.gmask; k.gmask_act = ex.gmask_act;
+  {
+    // measurement aid, results are WRONG when set (profiles/r02_z_conv_dma_ablation.txt): bit 0 no stores,
+    // bit 1 no halo DMA, bit 2 no weight DMA, bit 3 no chunk barriers (conv2d_dma_kernel only)
+    static int ablate = -1;
+    if (ablate < 0) {
+      const char* v = getenv("DVSR_CONV_ABLATE");
+      ablate = v ? atoi(v) : 0;
+    }
+    k.ablate = ablate;
+  }
   if (k.in_ps) k.x0_bs = (long long)d.c0 * d.H * d.W;
   if (k.in_dil) k.x0_bs = (long long)d.c0 * ex.Hs * ex.Ws;
 #ifdef DVSR_CONV_TRACE
   k.trace = (g_trace_countdown == 0) ? g_trace_buf : nullptr;
   if (g_trace_countdown >= 0) --g_trace_countdown;
 #endif
+  if (geo.dma) {
+    DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && d.pad == 1 && !ex.in_ps && !ex.in_dil && geo.cc == 8 && (geo.th == 4 || geo.th == 8) &&
+                     d.W % 4 == 0 && d.c0 % 8 == 0 && d.c1 % 8 == 0 && k.x0_bs % 4 == 0 && k.x1_bs % 4 == 0 &&
+                     ((uintptr_t)d.x0 & 15) == 0 && ((uintptr_t)d.x1 & 15) == 0,
+                 DVSR_ERR_UNSUPPORTED, "conv2d_packed: the DMA-halo kernel needs 3x3/s1/pad 1, plain 16-byte aligned inputs, "
+                 "W %% 4 == 0 and channel counts %% 8 == 0 (W=%d c0=%d c1=%d)", d.W, d.c0, d.c1);
+  }
   if (d.ks == 3 && geo.cc == 32) {  // K-split small-grid kernel: tile bookkeeping of its launch
     DVSR_REQUIRE(d.stride == 1 && (d.c1 == 0 || d.c0 % 32 == 0) && !ex.in_ps && !ex.in_dil && d.pad == 1 &&
                      ((geo.th == 1 && geo.mt == 2) || (geo.th == 2 && geo.mt == 1)),
@@ -675,6 +886,10 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
     }
     if (geo.mt == 2) return launch_conv2<3, 1, 16, 4, 2, 1>(k, st);
     return launch_conv2<3, 1, 16, 4, 1, 1>(k, st);
+  }
+  if (geo.dma) {
+    if (geo.th == 8) return geo.mt == 2 ? launch_dma<8, 2>(k, st) : launch_dma<8, 1>(k, st);
+    return geo.mt == 2 ? launch_dma<4, 2>(k, st) : launch_dma<4, 1>(k, st);
   }
   if (d.ks == 3 && geo.cc == 32) {  // K-split small-grid kernel
     if (geo.mt == 2) return launch_ksplit<2, 1>(k, st);
@@ -722,18 +937,24 @@ struct OpPack {
   dvsr::ConvGeo geo;
   size_t floats;
 };
-OpPack op_pack(int ks, int stride, int pad, int N, int Ho, int Wo, int Cout, int Ctot, bool plain) {
+OpPack op_pack(int ks, int stride, int pad, int N, int Ho, int Wo, int Cout, int Ctot, bool plain, bool aligned = false) {
   using namespace dvsr;
   OpPack o;
-  o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, Ctot, ks == 3 && stride == 1 && pad == 1 && plain);
+  const bool k3 = ks == 3 && stride == 1 && pad == 1;
+  o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, Ctot, (k3 && plain ? 1 : 0) | (k3 && aligned ? 2 : 0));
   o.floats = (size_t)ceil_div(Cout, 64) * ceil_div(Ctot, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, 0);
   return o;
+}
+OpPack op_pack_for(const dvsr_conv2d_desc& d, int Cout, int Ctot) {
+  const bool aligned = (((uintptr_t)d.x0 | (uintptr_t)d.x1) & 15) == 0 && d.c0 % 8 == 0 && d.c1 % 8 == 0 &&
+                       d.x0_bstride % 4 == 0 && d.x1_bstride % 4 == 0;
+  return op_pack(d.ks, 1, d.pad, d.N, d.H, d.W, Cout, Ctot, d.c1 == 0 || d.c0 % 32 == 0, aligned);
 }
 int op_run(const dvsr_conv2d_desc& d, const dvsr::ConvExtra& ex, int Cout, int Ctot, void* ws, size_t bytes, hipStream_t st) {
   using namespace dvsr;
   DVSR_REQUIRE((d.ks == 1 || d.ks == 3) && d.stride == 1 && d.pad == d.ks / 2, DVSR_ERR_UNSUPPORTED,
                "conv2d (packed): ks=%d stride=%d pad=%d (1x1 / 3x3, stride 1, pad ks/2)", d.ks, d.stride, d.pad);
-  const OpPack o = op_pack(d.ks, 1, d.pad, d.N, d.H, d.W, Cout, Ctot, d.c1 == 0 || d.c0 % 32 == 0);
+  const OpPack o = op_pack_for(d, Cout, Ctot);
   DVSR_REQUIRE(ws && bytes >= o.floats * sizeof(float), DVSR_ERR_WORKSPACE, "conv2d (packed): workspace %zu < %zu bytes", bytes,
                o.floats * sizeof(float));
   PackTable t;
@@ -741,6 +962,7 @@ int op_run(const dvsr_conv2d_desc& d, const dvsr::ConvExtra& ex, int Cout, int C
   PackEntry& e = t.e[0];
   e.w = d.w; e.P = (float*)ws; e.Cout = Cout; e.Ctot = Ctot; e.KK = d.ks * d.ks; e.CC = o.geo.cc; e.wt = ex.wt;
   e.w_ctot = ex.w_ctot; e.w_coff = ex.w_coff; e.ncb = ceil_div(Cout, 64); e.nchunks = ceil_div(Ctot, e.CC); e.bf = 0;
+  e.perm = o.geo.dma;
   e.pch = conv2_pch_cc(d.ks, e.CC, 0);
   int rc = pack_weights_run(t, st);
   if (rc) return rc;
@@ -756,6 +978,14 @@ extern "C" size_t dvsr_conv2d_packed_workspace_bytes(const dvsr_conv2d_desc* d) 
   const size_t b = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, ctot, d->Cout, true).floats;
   const size_t c = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, d->Cout, ctot, false).floats;
   return (a > b ? (a > c ? a : c) : (b > c ? b : c)) * sizeof(float);
+}
+
+extern "C" int dvsr_conv2d_packed_geometry(const dvsr_conv2d_desc* d, int geo[4]) {
+  DVSR_REQUIRE(d && geo && (d->ks == 1 || d->ks == 3) && d->stride == 1 && d->pad == d->ks / 2, DVSR_ERR_INVALID,
+               "conv2d_packed_geometry: 1x1 / 3x3 stride-1 descriptors only");
+  const OpPack o = op_pack_for(*d, d->Cout, d->c0 + d->c1);
+  geo[0] = o.geo.cc; geo[1] = o.geo.th; geo[2] = o.geo.mt; geo[3] = o.geo.dma;
+  return DVSR_OK;
 }
 
 extern "C" int dvsr_conv2d_forward_packed(const dvsr_conv2d_desc* d, void* workspace, size_t workspace_bytes,

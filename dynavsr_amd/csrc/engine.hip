@@ -162,7 +162,9 @@ struct Builder {
         return g;
       };
       // the K-split small-grid kernel takes plain inputs with an explicit pad of 1 and 32-channel chunks
-      const int ks_ok = pad < 0 && !wmap && (c1 == 0 || c0 % 32 == 0) && !p.cfg.bf16_mfma;
+      // (bit 0), the DMA-halo kernel plain inputs in whole 8-channel chunks (bit 1)
+      const bool plain = pad < 0 && !wmap && !p.cfg.bf16_mfma;
+      const int ks_ok = (plain && (c1 == 0 || c0 % 32 == 0) ? 1 : 0) | (plain && c0 % 8 == 0 && c1 % 8 == 0 ? 2 : 0);
       o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1, ks_ok), Ho, Wo, Cout);
       o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, o.geo.bf);
       o.wp_off = alloc("", o.wp_floats).off;
@@ -171,7 +173,7 @@ struct Builder {
         if (!ci) continue;
         // dgrad = stride-1 conv over the input grid with Cout' = ci, Ctot' = Cout
         // (data gradient: the gradient tensor is the plain input unless it is pixel-shuffled or zero-dilated)
-        o.dgeo[which] = as_bf(conv2_choose(ks, 1, N, H, W, ci, Cout, ks_ok && !ps && stride == 1), H, W, ci);
+        o.dgeo[which] = as_bf(conv2_choose(ks, 1, N, H, W, ci, Cout, (!ps && stride == 1) ? ks_ok : 0), H, W, ci);
         o.dpk_floats[which] = (size_t)ceil_div(ci, 64) * ceil_div(Cout, o.dgeo[which].cc) *
                               conv2_pch_cc(ks, o.dgeo[which].cc, o.dgeo[which].bf);
         o.dpk_off[which] = p.dpack_floats;
@@ -780,7 +782,7 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
       PackEntry& e = t.e[t.n++];
       e.w = wsrc; e.P = fwd_base + o.wp_off; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
       e.CC = o.geo.cc; e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
-      e.nchunks = ceil_div(ctot, e.CC); e.bf = o.geo.bf; e.pch = conv2_pch_cc(o.ks, e.CC, e.bf);
+      e.nchunks = ceil_div(ctot, e.CC); e.bf = o.geo.bf; e.perm = o.geo.dma; e.pch = conv2_pch_cc(o.ks, e.CC, e.bf);
       if (t.n == 48) { int rc = flush(); if (rc) return rc; }
     }
     if (bwd_base) {
@@ -791,7 +793,7 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
         e.w = wsrc; e.P = bwd_base + o.dpk_off[which]; e.Cout = ci; e.Ctot = o.Cout; e.KK = KK;
         e.CC = o.dgeo[which].cc; e.wt = 1; e.w_ctot = ctot; e.w_coff = which ? o.c0 : 0;
         e.ncb = ceil_div(ci, 64); e.nchunks = ceil_div(o.Cout, e.CC); e.bf = o.dgeo[which].bf;
-        e.pch = conv2_pch_cc(o.ks, e.CC, e.bf);
+        e.pch = conv2_pch_cc(o.ks, e.CC, e.bf); e.perm = o.dgeo[which].dma;
         if (t.n == 48) { int rc = flush(); if (rc) return rc; }
       }
     }
@@ -1070,8 +1072,8 @@ extern "C" int dvsr_edvr_op_info(const dvsr_edvr_plan* p, int index, char* kind,
   op_work(p->ops[index], &k, flops, bytes);
   snprintf(kind, kind_cap, "%s", k);
   if (p->ops[index].type == OP_CONV)
-    snprintf(name, name_cap, "%s[%d/%d/%d]", p->ops[index].name, p->ops[index].geo.cc, p->ops[index].geo.th,
-             p->ops[index].geo.mt);
+    snprintf(name, name_cap, "%s[%d/%d/%d%s]", p->ops[index].name, p->ops[index].geo.cc, p->ops[index].geo.th,
+             p->ops[index].geo.mt, p->ops[index].geo.dma ? "d" : "");
   else
     snprintf(name, name_cap, "%s", p->ops[index].name);
   return DVSR_OK;

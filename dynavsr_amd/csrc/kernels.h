@@ -27,6 +27,7 @@ struct PackEntry {
   const float* w; float* P;
   int Cout, Ctot, KK, CC, wt, w_ctot, w_coff, ncb, nchunks, pch;
   int bf = 0;  // 1: bf16 image for the bf16 MFMA kernel (pch still counts fp32-sized slots)
+  int perm = 0;  // 1: channel order of the DMA-halo kernel (ConvGeo::dma)
 };
 struct PackTable {
   int n;
@@ -35,7 +36,8 @@ struct PackTable {
 int conv2_pch(int ks, int stride);  // floats per packed (cout block, chunk)
 int conv2_cc(int ks, int stride);   // input channels per chunk
 int pack_weights_run(const PackTable& t, hipStream_t st);
-struct ConvGeo { int cc, th, mt; int bf = 0; };  // channels per chunk, tile rows (x32 px), 32-cout halves per workgroup
+struct ConvGeo { int cc, th, mt; int bf = 0; int dma = 0; };  // channels per chunk, tile rows (x32 px), 32-cout halves per workgroup
+// allow: bit 0 = the K-split small-grid kernel may be chosen, bit 1 = the DMA-halo kernel (plain pad-1 inputs, see conv2d_v2.hip)
 ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ctot, int allow_ksplit = 1);
 int conv2_pch_cc(int ks, int cc, int bf = 0);   // fp32-sized slots per packed (64-cout block, chunk of cc channels)
 int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo,

@@ -22,6 +22,7 @@ struct ConvK2 {
   int tiles_x, tiles_y, ntiles, ncb, nchunks, nitems, tiles_per_xcd;
   int in_ps, in_dil, Hs, Ws, accum;
   const float* gmask; int gmask_act;
+  int ablate;  // DVSR_CONV_ABLATE measurement aid (conv2d_dma_kernel); 0 in every product run
 #ifdef DVSR_CONV_TRACE
   long long* trace;  // debug build only (tools/conv_trace.py): 64 cycle stamps per workgroup
 #endif

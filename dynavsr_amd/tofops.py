@@ -41,7 +41,8 @@ class _Conv(torch.autograd.Function):
             L.check(L.lib().dvsr_conv2d_forward_packed(d, ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_forward_packed")
         else:
             L.check(L.lib().dvsr_conv2d_forward(d, L.stream()), "dvsr_conv2d_forward")
-        ctx.save_for_backward(x, w, y if act != L.ACT_NONE else None)
+        # the activation mask is the sign of the activated value, i.e. of y BEFORE the residual was added
+        ctx.save_for_backward(x, w, None if act == L.ACT_NONE else (y if res is None else y - res))
         ctx.act, ctx.has_res = act, res is not None
         return y
 

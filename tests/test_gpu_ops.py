@@ -348,3 +348,48 @@ def test_native_optimizer_matches_torch(kind):
     assert float((a[4] - b[4]).abs().max()) == 0.0
     if kind == "adam":
         assert oa.state[a[0]]['step'] == 4 and relerr(oa.state[a[0]]['exp_avg'], ob.state[b[0]]['exp_avg']) < 1e-6
+
+
+# ---- halo-by-DMA 3x3 kernel (conv2d_dma_kernel): chosen for grids of >= 700 32x4x32 workgroups ------------------
+@pytest.mark.parametrize("n,cin,cout,h,w,act,res", [
+    (4, 64, 64, 98, 160, 1, True),     # 5 x 25 x 4 tiles of 64 output channels; the last tile row holds 2 of 4 rows
+    (3, 72, 40, 90, 200, 0, False),    # W % 32 != 0 (partial right tiles), Cout % 32 != 0, nine 8-channel chunks
+    (1, 64, 64, 180, 320, 2, False),   # the reconstruction trunk of the headline clip
+    (2, 8, 64, 128, 128, 1, False),    # ONE chunk: prologue only, no steady state
+])
+def test_conv3x3_dma_halo(n, cin, cout, h, w, act, res):
+    """Forward and data gradient through dvsr_conv2d_forward_packed / _dgrad_packed on grids large enough for
+    the DMA-halo kernel, against fp64 torch on the CPU; dvsr_conv2d_packed_geometry confirms which kernel ran."""
+    import ctypes
+    from dynavsr_amd import _lib as L, tofops
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1 / np.sqrt(cin * 9))
+    b = rnd(cout, seed=3, scale=0.1)
+    r = rnd(n, cout, h, w, seed=4) if res else None
+    gy = rnd(n, cout, h, w, seed=5)
+    xd = dev(x).requires_grad_(True)
+    d = L.Conv2dDesc(L.ptr(xd), None, None, None, None, None, n, cin, 0, h, w, cout, 3, 1, 1, 0, 0, 1, 0, 0)
+    geo = (ctypes.c_int * 4)()
+    L.check(L.lib().dvsr_conv2d_packed_geometry(d, ctypes.byref(geo)), "dvsr_conv2d_packed_geometry")
+    assert list(geo)[0] == 8 and list(geo)[3] == 1, "expected the DMA-halo kernel, got %s" % list(geo)
+    got = tofops.conv(xd, dev(wt), dev(b), dev(r) if res else None, act)
+    x64 = x.double().requires_grad_(True)
+    ref = ACT[act](F.conv2d(x64, wt.double(), b.double(), 1, 1))
+    if res:
+        ref = ref + r.double()
+    assert relerr(got.detach(), ref.detach()) < TOL
+    got.backward(dev(gy))
+    ref.backward(gy.double())
+    assert relerr(xd.grad, x64.grad) < TOL
+
+
+def test_conv3x3_dma_halo_not_for_unaligned():
+    """W % 4 != 0 or channel counts % 8 != 0 keep the register-staged kernel."""
+    import ctypes
+    from dynavsr_amd import _lib as L
+    x = dev(rnd(4, 64, 98, 162))
+    geo = (ctypes.c_int * 4)()
+    for cin, wd in ((64, 162), (60, 160)):
+        d = L.Conv2dDesc(L.ptr(x), None, None, None, None, None, 4, cin, 0, 98, wd, 64, 3, 1, 1, 0, 0, 1, 0, 0)
+        L.check(L.lib().dvsr_conv2d_packed_geometry(d, ctypes.byref(geo)), "dvsr_conv2d_packed_geometry")
+        assert list(geo)[3] == 0
