@@ -109,6 +109,7 @@ def _declare(lib):
                                   POINTER(ctypes.c_double)]),
         "dvsr_edvr_forward_timed": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P, POINTER(c_float)]),
         "dvsr_debug_mfma_peak": (LL, [P, I, I, I, I, P]),
+        "dvsr_debug_mfma_shadow": (I, [P, P, I, I, I, I, I, P]),
         "dvsr_edvr_tensor_info": (I, [P, c_char_p, POINTER(LL), POINTER(LL)]),
     }
     for name, (res, args) in sig.items():

@@ -111,6 +111,16 @@ __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT]
             return reinterpret_cast<const float*>(
                 reinterpret_cast<const char*>(base + ((size_t)n * t.Cout + cu) * HWo) + voff);
           };
+          if (!t.res && !t.accum && !t.gmask) {
+            // the common case: three VALU instructions per value (nothing hides behind the fp32 MFMAs of the
+            // co-resident workgroups, profiles/r02_z_mfma_shadow.txt).  act(v) = max(v, slope v) for slope in [0, 1]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[mt][nt][r] + bv[mt][r];
+              *const_cast<float*>(addr(t.y, r)) = fmaxf(v, slope * v);
+            }
+            continue;
+          }
           float extra[16], gm[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) { extra[r] = 0.f; gm[r] = 1.f; }
@@ -129,7 +139,7 @@ __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT]
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[mt][nt][r] + bv[mt][r];
-            v = (fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)) + extra[r]) * gm[r];  // act: v > 0 ? v : slope * v
+            v = (fmaxf(v, slope * v) + extra[r]) * gm[r];  // act: v > 0 ? v : slope * v
             *const_cast<float*>(addr(t.y, r)) = v;
           }
         } else {
@@ -139,8 +149,8 @@ __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT]
           for (int r = 0; r < 16; r += 2) {
             const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
             float v0 = acc[mt][nt][r] + bv[mt][r], v1 = acc[mt][nt][r + 1] + bv[mt][r + 1];
-            v0 = fmaf(slope, fminf(v0, 0.f), fmaxf(v0, 0.f));
-            v1 = fmaf(slope, fminf(v1, 0.f), fmaxf(v1, 0.f));
+            v0 = fmaxf(v0, slope * v0);
+            v1 = fmaxf(v1, slope * v1);
             const int cq = co >> 2, dy = (co >> 1) & 1;
             *reinterpret_cast<f32x2*>(&t.y[(((size_t)n * (t.Cout >> 2) + cq) * (2 * t.Ho) + (2 * oy + dy)) * (size_t)(2 * t.Wo) +
                                          2 * ox]) = f32x2{v0, v1};
@@ -187,7 +197,7 @@ __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT]
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[mt][nt][r] + bv[mt][r];
-        v = (fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)) + extra[r]) * gm[r];
+        v = (fmaxf(v, slope * v) + extra[r]) * gm[r];
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, off[r], 0, 0);
       }
     }

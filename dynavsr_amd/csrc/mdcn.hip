@@ -631,6 +631,371 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_reg_kernel(DcnK2 a) {
   DCN_STAMP(63);
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// DMA-staged variant of the register-direct kernel (W % 4 == 0, 16-byte aligned x / offset / mask).
+//
+// mdcn_fwd_reg_kernel issues 83 vector-memory instructions per wave and 8-channel chunk (24 window loads,
+// 54 offset / mask loads -- each pixel's 27 values, twice: both lane halves -- and the weight DMA) next to
+// 144 MFMAs; at ~75 issue cycles apiece inside an MFMA stream (profiles/r02_z_conv_dma_ablation.txt) that is
+// two thirds of the matrix time.  Here all three inputs go global -> LDS by 16-byte DMA:
+//   * the sampling window: rows [oy0 - 5, oy0 + 13), the ALIGNED columns [ox0 - 8, ox0 + 40) (a ring of 4 rows,
+//     7 columns), 8 channels x 18 rows x 12 groups = 27 KiB, planar [channel][row][48];
+//   * the group's 27 offset / mask planes over the 8 x 32 tile: 27 x 64 groups = 27 KiB, [plane][row][32]
+//     (a plane is exactly one DMA instruction; once per deformable group);
+//   * the weight slice as before.
+// 18 DMA instructions per wave and chunk, no staging registers.  A bilinear corner pair (x, x + 1) of one channel is
+// a ds_read2_b32; offsets / masks are read from LDS in the sampler.  Groups outside the image are zeroed once (their
+// lanes stay masked in every DMA).  Samples outside the window take the exact global-gather path, as before.
+// -------------------------------------------------------------------------------------------------
+struct DcnDmaShape {
+  static constexpr int CPG = 8, KK = 9, TH = 8, TW = 32, HALO = 4, X0 = 8;
+  static constexpr int XH = TH + 2 + 2 * HALO, XW = 48, XG = XW / 4, XCH = XH * XW;
+  static constexpr int NXG = CPG * XH * XG, NXI = (NXG + 255) / 256;
+  static constexpr int HALF = KK * 2 * 32 * 4, WF = 2 * HALF, NPIECE = WF / 256;
+  static constexpr int OMP = 27, NOI = (OMP + 3) / 4;
+  static constexpr int X_FLOATS = CPG * XCH, OM_FLOATS = OMP * TH * TW;
+  static constexpr size_t LDS_BYTES = (size_t)(X_FLOATS + WF + OM_FLOATS) * sizeof(float);
+};
+
+template <bool MASK_LOGIT>
+__global__ __launch_bounds__(256, 2) void mdcn_fwd_dma_kernel(DcnK2 a) {
+  using Sh = DcnDmaShape;
+  constexpr int KK = Sh::KK, TH = Sh::TH, TW = Sh::TW, XH = Sh::XH, XW = Sh::XW, XG = Sh::XG, XCH = Sh::XCH;
+  extern __shared__ __attribute__((aligned(16))) float smem_dcn[];
+  float* const s_x = smem_dcn;
+  float* const s_w = smem_dcn + Sh::X_FLOATS;
+  float* const s_om = s_w + Sh::WF;
+
+  const int id = blockIdx.x;
+  const int tpx = (a.ntiles + 7) >> 3;
+  const int q_ = id >> 3;
+  const int cb = q_ % a.ncb;
+  const int tile = (id & 7) * tpx + q_ / a.ncb;
+  if (q_ / a.ncb >= tpx || tile >= a.ntiles) return;
+  const int tx_ = tile % a.tiles_x;
+  const int t2 = tile / a.tiles_x;
+  const int ty_ = t2 % a.tiles_y;
+  const int n = t2 / a.tiles_y;
+  const int oy0 = ty_ * TH, ox0 = tx_ * TW;
+  const int wy0 = oy0 - 1 - Sh::HALO, wx0 = ox0 - Sh::X0;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const size_t HW = (size_t)a.H * a.W;
+  const float* offn = a.off + (size_t)n * a.off_bstride;
+  const float* mskn = a.msk + (size_t)n * a.msk_bstride;
+  const int px = ox0 + lo;
+  int py[2], prow[2];
+  bool pv[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    py[nt] = oy0 + 2 * wave + nt;
+    pv[nt] = py[nt] < a.H && px < a.W;
+    prow[nt] = (2 * wave + nt) * TW + lo;
+  }
+
+  // window groups of this lane: L = 64 (wave + 4 jj) + lane = (channel, row, column group)
+  unsigned xo[Sh::NXI];
+  bool xv[Sh::NXI];
+#pragma unroll
+  for (int jj = 0; jj < Sh::NXI; ++jj) {
+    const int L = 64 * (wave + 4 * jj) + lane;
+    const int c = L / (XH * XG), r = L - c * (XH * XG);
+    const int y = r / XG, g4 = r - y * XG;
+    const int gy = wy0 + y, gx = wx0 + 4 * g4;
+    const bool ok = L < Sh::NXG && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    xo[jj] = ok ? (unsigned)(((size_t)c * HW + (size_t)gy * a.W + gx) * 4) : 0u;
+    xv[jj] = ok;
+    if (L < Sh::NXG && !ok) *reinterpret_cast<f32x4*>(s_x + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // offset / mask planes: plane p = wave + 4 jj is ONE instruction; this lane moves (row lane / 8, columns 4 (lane % 8) ..)
+  const int omy = oy0 + (lane >> 3), omx = ox0 + 4 * (lane & 7);
+  const bool omv = omy < a.H && omx < a.W;
+  const unsigned omo = omv ? (unsigned)(((size_t)omy * a.W + omx) * 4) : 0u;
+  if (!omv) {
+#pragma unroll
+    for (int jj = 0; jj < Sh::NOI; ++jj)
+      if (wave + 4 * jj < Sh::OMP) *reinterpret_cast<f32x4*>(s_om + (wave + 4 * jj) * 256 + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // LDS byte addresses of this lane's operands (inline-asm reads of the tap loop)
+  auto lds_addr = [](const float* p) { return (unsigned)(size_t)((__attribute__((address_space(3))) const float*)p); };
+  const unsigned a_x = lds_addr(s_x) + (unsigned)(hi * XCH) * 4u;    // channel 2 kk + hi: + 2 kk XCH floats
+  const unsigned a_w = lds_addr(s_w) + (unsigned)(hi * 32 + lo) * 16u;
+  unsigned a_om[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) a_om[nt] = lds_addr(s_om) + (unsigned)prow[nt] * 4u;
+
+  const float* wp_cb = a.wp + (size_t)cb * a.nchunks * Sh::WF;
+  const int sub = a.nchunks / a.dg;  // 8-channel chunks per deformable group (they share its offsets and masks)
+  DCN_STAMP(0);
+  for (int kc = 0; kc < a.nchunks; ++kc) {
+    const int g = kc / sub;
+    if (kc < 2) DCN_STAMP(1 + 30 * kc);
+    __syncthreads();  // the previous chunk's taps are done with s_x / s_w / s_om
+    {
+      const float* wsrc = wp_cb + (size_t)kc * Sh::WF;
+#pragma unroll
+      for (int j = 0; j < (Sh::NPIECE + 3) / 4; ++j) {
+        const int piece = j * 4 + wave;
+        if (piece < Sh::NPIECE)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + piece * 256 + lane * 4),
+                                           (__attribute__((address_space(3))) void*)(s_w + piece * 256), 16, 0, 0);
+      }
+    }
+    const float* xg = a.x + ((size_t)n * a.C + kc * Sh::CPG) * HW;
+    {
+      const char* xb = reinterpret_cast<const char*>(xg);
+#pragma unroll
+      for (int jj = 0; jj < Sh::NXI; ++jj)
+        if (xv[jj])
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + xo[jj]),
+                                           (__attribute__((address_space(3))) void*)(s_x + 256 * (wave + 4 * jj)), 16, 0, 0);
+    }
+    if (kc % sub == 0) {
+#pragma unroll
+      for (int jj = 0; jj < Sh::NOI; ++jj) {
+        const int p = wave + 4 * jj;
+        if (p < Sh::OMP) {
+          const float* pb = p < 18 ? offn + (size_t)(g * 18 + p) * HW : mskn + (size_t)(g * 9 + p - 18) * HW;
+          if (omv)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(pb) + omo),
+                                             (__attribute__((address_space(3))) void*)(s_om + 256 * p), 16, 0, 0);
+        }
+      }
+    }
+    if (kc < 2) DCN_STAMP(2 + 30 * kc);
+    __syncthreads();  // everything landed (the barrier's vmcnt(0) covers the DMAs)
+    if (kc < 2) DCN_STAMP(3 + 30 * kc);
+
+    // ---- the nine taps, software-pipelined by hand ---------------------------------------------------------
+    // The sampler of tap t+1 is cut into pieces that sit BETWEEN the 16 MFMAs of tap t, one piece per 64-cycle
+    // MFMA.  Left to the compiler, the sampler's LDS round trips (offsets, then corners) and its ~60 geometry
+    // instructions ran IN FRONT of the MFMAs of every tap: ~45 % of the matrix time exposed (70 TFLOP/s at
+    // 5x64x180x320, and 80 us per call whatever the size on the small inner-step grids).  Pinning takes three
+    // devices, because SelectionDAG places pure nodes by register pressure, i.e. at their use:
+    //   * every VALU piece ends in an empty asm volatile that "modifies" its results, every MFMA in one on its
+    //     accumulator, and sched_barrier(0) separates the slots;
+    //   * the LDS reads are inline asm (a volatile load would be waited for on the spot) and their results pass
+    //     through ONE "s_waitcnt lgkmcnt(0)" asm before the blends -- three MFMAs after the last read was issued.
+    //     (The compiler's own lgkmcnt bookkeeping stays valid: LDS returns in order, extra reads in flight only
+    //     make its waits conservative.)
+    //   * operands ping-pong between two register sets by tap parity (no copies that could be hoisted above the wait).
+    //   M0 M1: mask sigmoid + sample position of rows 0 / 1     M2 M3: geometry of row 0     M4 M5: its 16 corner reads
+    //   M6 M7: geometry of row 1     M8 M9: its corner reads    M10: offsets / mask of tap t+2, weights of tap t+1
+    //   M11 M12: blends of row 0     M13 M14: wait for the rest, blends of row 1      after M15: rare exact fix-up
+    // (~160 non-MFMA instructions per tap, at most ~12 in one slot: about what a wave can issue in the shadow of a
+    // 64-cycle MFMA; the cycle-stamp trace of the first version -- pieces of up to 35 instructions, 200 in all --
+    // showed 1950 cycles per tap against 1060 for the sampler-free last tap, profiles/r02_z_dcn_dma_trace.txt)
+    struct Geo { float w1, w2, w3, w4, h_im, w_im, m, lh, lw; int ry, rx; unsigned addr; bool inwin; };
+    auto om_issue = [&](auto TAP, float (&o)[2][3]) {
+      constexpr int tap = decltype(TAP)::value;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const unsigned ad = a_om[nt];  // (a local: asm operands of a generic lambda do not capture)
+        f32x2 hw2;  // (dh, dw): planes 2 tap and 2 tap + 1, 1 KiB = 4 x 64 dwords apart
+        asm volatile("ds_read2st64_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read_b32 %1, %2 offset:%5"
+                     : "=&v"(hw2), "=&v"(o[nt][2])
+                     : "v"(ad), "i"(2 * tap * 4), "i"((2 * tap + 1) * 4), "i"((18 + tap) * 1024));
+        o[nt][0] = hw2[0]; o[nt][1] = hw2[1];
+      }
+    };
+    auto a_issue = [&](auto TAP, f32x4 (&A)[2]) {
+      constexpr int tap = decltype(TAP)::value;
+      const unsigned ad = a_w;
+      asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                   : "=&v"(A[0]), "=&v"(A[1]) : "v"(ad), "i"(tap * 1024), "i"((KK + tap) * 1024));
+    };
+    // c[4 kk + {0,1,2,3}] = (y,x) (y,x+1) (y+1,x) (y+1,x+1) of channel 2 kk + hi; half 0 = kk 0,1, half 1 = kk 2,3
+    auto corners_issue = [&](unsigned addr, float (&c)[16], int half) {
+      if (half == 0)
+        asm volatile(
+            "ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:4\n\tds_read_b32 %2, %8 offset:192\n\tds_read_b32 %3, %8 offset:196\n\t"
+            "ds_read_b32 %4, %8 offset:6912\n\tds_read_b32 %5, %8 offset:6916\n\tds_read_b32 %6, %8 offset:7104\n\tds_read_b32 %7, %8 offset:7108"
+            : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+            : "v"(addr));
+      else
+        asm volatile(
+            "ds_read_b32 %0, %8 offset:13824\n\tds_read_b32 %1, %8 offset:13828\n\tds_read_b32 %2, %8 offset:14016\n\tds_read_b32 %3, %8 offset:14020\n\t"
+            "ds_read_b32 %4, %8 offset:20736\n\tds_read_b32 %5, %8 offset:20740\n\tds_read_b32 %6, %8 offset:20928\n\tds_read_b32 %7, %8 offset:20932"
+            : "=&v"(c[8]), "=&v"(c[9]), "=&v"(c[10]), "=&v"(c[11]), "=&v"(c[12]), "=&v"(c[13]), "=&v"(c[14]), "=&v"(c[15])
+            : "v"(addr));
+    };
+    static_assert(XW * 4 == 192 && 2 * XCH * 4 == 6912, "corners_issue hard-codes the window pitch");
+#define DCN_PIN8(c, o) asm volatile("" : "+v"(c[o]), "+v"(c[o + 1]), "+v"(c[o + 2]), "+v"(c[o + 3]), "+v"(c[o + 4]), "+v"(c[o + 5]), "+v"(c[o + 6]), "+v"(c[o + 7]))
+    // row 0's corners: everything but the 15 newest LDS reads has returned (row 1's and the operand prefetch follow it)
+    auto landed0 = [&](float (&c0)[16]) {
+      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c0[4]), "+v"(c0[5]), "+v"(c0[6]), "+v"(c0[7]));
+      DCN_PIN8(c0, 8);
+    };
+    auto landed1 = [&](float (&c1)[16]) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]), "+v"(c1[4]), "+v"(c1[5]), "+v"(c1[6]), "+v"(c1[7]));
+      DCN_PIN8(c1, 8);
+    };
+    auto landed_om = [&](float (&o)[2][3]) {
+      asm volatile("" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[0][2]), "+v"(o[1][0]), "+v"(o[1][1]), "+v"(o[1][2]));
+    };
+    auto landed_a = [&](f32x4 (&A)[2]) { asm volatile("" : "+v"(A[0]), "+v"(A[1])); };
+    auto geom_a = [&](auto TAP, int nt, const float (&o)[3], Geo& q) {
+      constexpr int tap = decltype(TAP)::value;
+      constexpr int ki = tap / 3, kj = tap - ki * 3;
+      float m = o[2];
+      if (MASK_LOGIT) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
+      q.m = m;
+      q.h_im = (float)(py[nt] - 1 + ki) + o[0];
+      q.w_im = (float)(px - 1 + kj) + o[1];
+      asm volatile("" : "+v"(q.m), "+v"(q.h_im), "+v"(q.w_im));
+    };
+    auto geom_b1 = [&](Geo& q) {
+      const float hf = floorf(q.h_im), wf = floorf(q.w_im);
+      q.lh = q.h_im - hf; q.lw = q.w_im - wf;
+      q.ry = (int)hf - wy0; q.rx = (int)wf - wx0;
+      const int ryc = min(max(q.ry, 0), XH - 2), rxc = min(max(q.rx, 0), XW - 2);
+      q.addr = a_x + (unsigned)(ryc * XW + rxc) * 4u;
+      asm volatile("" : "+v"(q.lh), "+v"(q.lw), "+v"(q.ry), "+v"(q.rx), "+v"(q.addr));
+    };
+    auto geom_b2 = [&](int nt, Geo& q, int& fix) {
+      // (bitwise on purpose: a short-circuit splits the tap into basic blocks)
+      const int inwin = ((unsigned)q.ry <= (unsigned)(XH - 2)) & ((unsigned)q.rx <= (unsigned)(XW - 2));
+      q.inwin = inwin;
+      const float hh = 1.f - q.lh, hw = 1.f - q.lw;
+      const float ms = ((int)pv[nt] & inwin) ? q.m : 0.f;
+      q.w1 = hh * hw * ms; q.w2 = hh * q.lw * ms; q.w3 = q.lh * hw * ms; q.w4 = q.lh * q.lw * ms;
+      fix |= (int)pv[nt] & (inwin ^ 1);  // outside the window: the exact path decides (it applies the image gate itself)
+      asm volatile("" : "+v"(q.w1), "+v"(q.w2), "+v"(q.w3), "+v"(q.w4), "+v"(fix));
+    };
+    auto blend2 = [&](const Geo& q, const float (&c)[16], int k0, f32x4& B) {
+      float b0 = q.w1 * c[4 * k0] + q.w2 * c[4 * k0 + 1] + q.w3 * c[4 * k0 + 2] + q.w4 * c[4 * k0 + 3];
+      float b1 = q.w1 * c[4 * k0 + 4] + q.w2 * c[4 * k0 + 5] + q.w3 * c[4 * k0 + 6] + q.w4 * c[4 * k0 + 7];
+      asm volatile("" : "+v"(b0), "+v"(b1));
+      B[k0] = b0; B[k0 + 1] = b1;
+    };
+    auto fixup = [&](const Geo (&q)[2], f32x4 (&B)[2]) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        if (!pv[nt] || q[nt].inwin) continue;
+        DcnTap tp;  // sample leaves the staged window: exact clamped global gathers
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (make_tap(q[nt].h_im, q[nt].w_im, a.H, a.W, tp)) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float* pl = xg + (size_t)(2 * c + hi) * HW;
+            const float v1 = tp.v1 ? pl[tp.o1] : 0.f, v2 = tp.v2 ? pl[tp.o2] : 0.f;
+            const float v3 = tp.v3 ? pl[tp.o3] : 0.f, v4 = tp.v4 ? pl[tp.o4] : 0.f;
+            b[c] = (tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4) * q[nt].m;
+          }
+        }
+        B[nt] = b;
+      }
+    };
+
+    f32x4 Bop[2][2], Aop[2][2];  // [tap parity][pixel row | cout half]
+    float om[2][2][3];           // [tap parity][pixel row][dh, dw, mask]
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    {  // tap 0 of the chunk: nothing to hide behind
+      Geo gq[2];
+      float c0[16], c1[16];
+      int fix = 0;
+      om_issue(I0{}, om[0]);
+      a_issue(I0{}, Aop[0]);
+      om_issue(I1{}, om[1]);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(om[0][0][0]), "+v"(om[0][0][1]), "+v"(om[0][0][2]), "+v"(om[0][1][0]), "+v"(om[0][1][1]), "+v"(om[0][1][2]));
+      landed_om(om[1]); landed_a(Aop[0]);
+      geom_a(I0{}, 0, om[0][0], gq[0]); geom_a(I0{}, 1, om[0][1], gq[1]);
+      geom_b1(gq[0]); geom_b2(0, gq[0], fix); corners_issue(gq[0].addr, c0, 0); corners_issue(gq[0].addr, c0, 1);
+      geom_b1(gq[1]); geom_b2(1, gq[1], fix); corners_issue(gq[1].addr, c1, 0); corners_issue(gq[1].addr, c1, 1);
+      landed1(c0); landed1(c1);
+      blend2(gq[0], c0, 0, Bop[0][0]); blend2(gq[0], c0, 2, Bop[0][0]);
+      blend2(gq[1], c1, 0, Bop[0][1]); blend2(gq[1], c1, 2, Bop[0][1]);
+      if (fix) fixup(gq, Bop[0]);
+    }
+    if (kc < 2) DCN_STAMP(4 + 30 * kc);
+#define DCN_SB __builtin_amdgcn_sched_barrier(0)
+#define DCN_MF(j, mt, nt)                                                                                     \
+  do {                                                                                                        \
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aop[cur][mt][j], Bop[cur][nt][j], acc[mt][nt], 0, 0, 0); \
+    asm volatile("" : "+v"(acc[mt][nt]));                                                                     \
+    DCN_SB;                                                                                                   \
+  } while (0)
+    auto tap_body = [&](auto TAP) {
+      constexpr int tap = decltype(TAP)::value;
+      constexpr int cur = tap & 1, nxt = cur ^ 1;
+      constexpr bool nx = tap + 1 < KK;
+      using TN = std::integral_constant<int, (tap + 1 < KK ? tap + 1 : tap)>;
+      using TNN = std::integral_constant<int, (tap + 2 < KK ? tap + 2 : tap)>;
+      Geo gq[2];
+      float c0[16], c1[16];
+      int fix = 0;
+      DCN_SB;
+      if (nx) geom_a(TN{}, 0, om[nxt][0], gq[0]);
+      DCN_MF(0, 0, 0);
+      if (nx) geom_a(TN{}, 1, om[nxt][1], gq[1]);
+      DCN_MF(0, 0, 1);
+      if (nx) geom_b1(gq[0]);
+      DCN_MF(0, 1, 0);
+      if (nx) geom_b2(0, gq[0], fix);
+      DCN_MF(0, 1, 1);
+      if (nx) corners_issue(gq[0].addr, c0, 0);
+      DCN_MF(1, 0, 0);
+      if (nx) corners_issue(gq[0].addr, c0, 1);
+      DCN_MF(1, 0, 1);
+      if (nx) geom_b1(gq[1]);
+      DCN_MF(1, 1, 0);
+      if (nx) geom_b2(1, gq[1], fix);
+      DCN_MF(1, 1, 1);
+      if (nx) corners_issue(gq[1].addr, c1, 0);
+      DCN_MF(2, 0, 0);
+      if (nx) corners_issue(gq[1].addr, c1, 1);
+      DCN_MF(2, 0, 1);
+      if (tap + 2 < KK) om_issue(TNN{}, om[cur]);  // (om[cur] held this tap's values: consumed one tap ago)
+      if (nx) a_issue(TN{}, Aop[nxt]);
+      DCN_MF(2, 1, 0);
+      if (nx) { landed0(c0); blend2(gq[0], c0, 0, Bop[nxt][0]); }
+      DCN_MF(2, 1, 1);
+      if (nx) blend2(gq[0], c0, 2, Bop[nxt][0]);
+      DCN_MF(3, 0, 0);
+      if (nx) {
+        landed1(c1);
+        if (tap + 2 < KK) landed_om(om[cur]);
+        landed_a(Aop[nxt]);
+        blend2(gq[1], c1, 0, Bop[nxt][1]);
+      }
+      DCN_MF(3, 0, 1);
+      if (nx) blend2(gq[1], c1, 2, Bop[nxt][1]);
+      DCN_MF(3, 1, 0);
+      DCN_MF(3, 1, 1);
+      if (nx) {
+        if (fix) fixup(gq, Bop[nxt]);
+      }
+      if (kc < 2) DCN_STAMP(5 + 30 * kc + tap);
+    };
+    tap_body(std::integral_constant<int, 0>{}); tap_body(std::integral_constant<int, 1>{});
+    tap_body(std::integral_constant<int, 2>{}); tap_body(std::integral_constant<int, 3>{});
+    tap_body(std::integral_constant<int, 4>{}); tap_body(std::integral_constant<int, 5>{});
+    tap_body(std::integral_constant<int, 6>{}); tap_body(std::integral_constant<int, 7>{});
+    tap_body(std::integral_constant<int, 8>{});
+#undef DCN_MF
+#undef DCN_SB
+#undef DCN_PIN8
+  }
+
+  DCN_STAMP(62);
+  const TileOut t{a.out, a.bias, nullptr, a.act, 0, 0, a.Cout, a.H, a.W};
+  store_mfma_tile<2, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
+  DCN_STAMP(63);
+}
+
 // wp = weights packed by pack_weights_kernel with KK=9, CC=8, wt=0 (one chunk per deformable group).
 int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, const float* msk,
                             long long msk_bs, int mask_logit, const float* wp, const float* b, float* out,
@@ -650,10 +1015,24 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
 #endif
   const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
   static int variant = -1;  // DVSR_DCN_FWD=lds selects the LDS-column-tile kernel (A/B aid)
-  if (variant < 0) { const char* v = getenv("DVSR_DCN_FWD"); variant = (v && v[0] == 'l') ? 1 : 0; }
+  if (variant < 0) { const char* v = getenv("DVSR_DCN_FWD"); variant = (v && v[0] == 'l') ? 1 : ((v && v[0] == 'r') ? 2 : 0); }
   if (variant == 1 && C == dg * 8) {
     hipLaunchKernelGGL(mdcn_fwd_lds_kernel<4>, dim3(grid), dim3(256), 0, st, k);
     return check_launch("mdcn_fwd_lds_kernel");
+  }
+  // DMA-staged kernel when the 16-byte groups line up (DVSR_DCN_FWD=reg keeps the register-staged one, A/B aid)
+  const bool aligned = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)off | (uintptr_t)msk) & 15) == 0 && off_bs % 4 == 0 &&
+                       msk_bs % 4 == 0;
+  if (variant == 0 && aligned) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipFuncSetAttribute((const void*)mdcn_fwd_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DcnDmaShape::LDS_BYTES);
+      hipFuncSetAttribute((const void*)mdcn_fwd_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DcnDmaShape::LDS_BYTES);
+      attr_done = true;
+    }
+    if (mask_logit) hipLaunchKernelGGL(mdcn_fwd_dma_kernel<true>, dim3(grid), dim3(256), DcnDmaShape::LDS_BYTES, st, k);
+    else hipLaunchKernelGGL(mdcn_fwd_dma_kernel<false>, dim3(grid), dim3(256), DcnDmaShape::LDS_BYTES, st, k);
+    return check_launch("mdcn_fwd_dma_kernel");
   }
   // (window ring: 5 and 6 pixels were measured 4-5 % slower than 4 -- the staging cost outweighs the rarer
   // fall-back)

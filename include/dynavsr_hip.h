@@ -196,6 +196,10 @@ int dvsr_edvr_forward_timed(const dvsr_edvr_plan* plan, const float* const* para
 /* Measurement aid: register-only fp32 MFMA loop (256-thread workgroups, `nacc` accumulators per wave,
  * `lds_bytes` of dynamic LDS to reproduce an occupancy); returns MFMA instructions per wave or -1. */
 long long dvsr_debug_mfma_peak(float* out, int blocks, int iters, int nacc, int lds_bytes, dvsr_stream_t stream);
+/* Measurement aid (tools/mfma_shadow.py): shader cycles of a stream of fp32 MFMAs with nv v_fma_f32 (kind 0) or
+ * ds_read_b32 (kind 1) behind each one, accumulators in VGPRs (acc 0) or AGPRs (acc 1). */
+int dvsr_debug_mfma_shadow(long long* cycles, float* out, int blocks, int iters, int nv, int kind, int acc,
+                           dvsr_stream_t stream);
 /* Offset (in floats, into the workspace) and size of a named intermediate, for layer-by-layer
  * parity checks ("L1_fea", "aligned", "tsa_out", "recon", ...). */
 int dvsr_edvr_tensor_info(const dvsr_edvr_plan* plan, const char* name, long long* offset_floats,
