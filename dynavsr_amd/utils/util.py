@@ -152,20 +152,76 @@ def _png_bytes(rgb):
             chunk(b'IDAT', zlib.compress(raw, 3)) + chunk(b'IEND', b''))
 
 
+# ---- PNG output off the critical path (test_dynavsr.py:285-288 writes three PNGs per frame inside the
+# adaptation loop) -------------------------------------------------------------------------------------------------
+# async_png(True), or DVSR_ASYNC_PNG=1 in the environment, hands the encode + write of save_img / write_png to ONE
+# background thread (zlib and file I/O release the GIL, so they overlap the next frame's kernels); the array is copied
+# at the call, so the caller may reuse its buffer.  flush_png() waits for the queue and re-raises the first error;
+# it also runs at interpreter exit.  Off by default: the reference's calls are synchronous.
+_png_state = {'on': os.environ.get('DVSR_ASYNC_PNG', '0') not in ('', '0'), 'q': None, 'thread': None, 'err': None}
+
+
+def _png_worker(q):
+    while True:
+        item = q.get()
+        try:
+            if item is None:
+                return
+            path, arr = item
+            with open(path, 'wb') as f:
+                f.write(_png_bytes(arr))
+        except Exception as e:  # surfaced by flush_png()
+            if _png_state['err'] is None:
+                _png_state['err'] = e
+        finally:
+            q.task_done()
+
+
+def async_png(on=True):
+    """Switch the background PNG writer on / off (off flushes first)."""
+    if not on:
+        flush_png()
+    _png_state['on'] = bool(on)
+
+
+def flush_png():
+    """Wait until every queued PNG is on disk; raise the first error a write hit."""
+    q = _png_state['q']
+    if q is not None:
+        q.join()
+    err, _png_state['err'] = _png_state['err'], None
+    if err is not None:
+        raise err
+
+
+def _emit_png(path, arr):
+    if not _png_state['on']:
+        with open(path, 'wb') as f:
+            f.write(_png_bytes(arr))
+        return
+    if _png_state['q'] is None:
+        import atexit
+        import queue
+        import threading
+        _png_state['q'] = queue.Queue(maxsize=64)   # bounded: at most 64 frames (~170 MB at 720x1280) wait in memory
+        _png_state['thread'] = threading.Thread(target=_png_worker, args=(_png_state['q'],), daemon=True)
+        _png_state['thread'].start()
+        atexit.register(flush_png)
+    _png_state['q'].put((path, np.array(arr, dtype=np.uint8, copy=True)))
+
+
 def save_img(img, img_path, mode='RGB'):
     """cv2.imwrite(img_path, img) of the reference: the array is taken as BGR (cv2's convention; `mode` is
     ignored there too).  PNG only."""
     a = np.asarray(img)
     if a.ndim == 3 and a.shape[2] >= 3:
         a = a[:, :, [2, 1, 0] + list(range(3, a.shape[2]))]
-    with open(img_path, 'wb') as f:
-        f.write(_png_bytes(a))
+    _emit_png(img_path, a)
 
 
 def write_png(path, rgb):
     """imageio.imwrite(path, rgb) for the uint8 RGB frames of test_dynavsr.py:288."""
-    with open(path, 'wb') as f:
-        f.write(_png_bytes(rgb))
+    _emit_png(path, rgb)
 
 
 def DUF_downsample(x, scale=4, sigma=None):

@@ -250,3 +250,32 @@ print(json.dumps({"checked": len(pairs), "bad": bad}))
     assert r.returncode == 0, r.stderr[-3000:]
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["checked"] == 12 and rep["bad"] == [], rep
+
+
+def test_async_png_writer(tmp_path):
+    """Background PNG writer: same bytes as the synchronous path, the caller's buffer may be reused
+    right after the call, errors surface at flush_png()."""
+    from dynavsr_amd.utils import util
+    rs = np.random.RandomState(1)
+    imgs = [rs.randint(0, 256, (24, 40, 3)).astype(np.uint8) for _ in range(6)]
+    for i, im in enumerate(imgs):
+        util.write_png(str(tmp_path / ("s%d.png" % i)), im)
+    util.async_png(True)
+    try:
+        buf = np.empty_like(imgs[0])
+        for i, im in enumerate(imgs):
+            buf[...] = im
+            util.write_png(str(tmp_path / ("a%d.png" % i)), buf)      # the writer copies at the call
+            buf[...] = 0
+        util.save_img(imgs[0], str(tmp_path / "a_bgr.png"))
+        util.flush_png()
+        for i in range(6):
+            assert (tmp_path / ("a%d.png" % i)).read_bytes() == (tmp_path / ("s%d.png" % i)).read_bytes()
+        util.write_png(str(tmp_path / "no_such_dir" / "x.png"), imgs[0])
+        with pytest.raises(OSError):
+            util.flush_png()
+        util.flush_png()                                               # the error is reported once
+    finally:
+        util.async_png(False)
+    util.save_img(imgs[0], str(tmp_path / "s_bgr.png"))
+    assert (tmp_path / "a_bgr.png").read_bytes() == (tmp_path / "s_bgr.png").read_bytes()
