@@ -89,8 +89,9 @@ def _sources_digest():
 def cpu_baseline(cfg, h, w, seed, y_gpu=None):
     """The CPU oracle (torch CPU convs + C restatement of the DCN) timed on this box's host cores on a bounded
     sample of the same workloads: forward @HxW on all cores (1 warm-up + median of 3), forward
-    @64x64 on ONE core and on all cores (1 warm-up + median of 3 each), one inner step @176x320 on all cores
-    (1 warm-up + median of 3).  The headline clip was run by the timed GPU loop on rank 0, so the oracle's
+    @64x64 on ONE core and on all cores (1 warm-up + median of 5 each, SURVEY 8d's protocol; the two full-size
+    legs take 8-10 s per pass and keep 3 so that the default run stays within minutes), one inner step @176x320 on
+    all cores (1 warm-up + median of 3).  The headline clip was run by the timed GPU loop on rank 0, so the oracle's
     output doubles as the full-size parity check (`y_gpu`)."""
     from collections import OrderedDict
     import torch.nn.functional as F
@@ -121,7 +122,7 @@ def cpu_baseline(cfg, h, w, seed, y_gpu=None):
     def fwd64():
         with torch.no_grad():
             oedvr.edvr_forward(P, x64)
-    t64_all = med(fwd64)
+    t64_all = med(fwd64, 5)
     def omp_threads(n):   # the C DCN oracle is plain OpenMP (libgomp); torch may run its own pool
         torch.set_num_threads(n)
         try:
@@ -131,7 +132,7 @@ def cpu_baseline(cfg, h, w, seed, y_gpu=None):
             pass
     omp_threads(1)
     try:
-        t64_one = med(fwd64)
+        t64_one = med(fwd64, 5)
     finally:
         omp_threads(all_threads)
     # one inner MAML step (test_dynavsr.py:235-277) at LR 176x320 through the oracle's functions
@@ -154,7 +155,7 @@ def cpu_baseline(cfg, h, w, seed, y_gpu=None):
                      "%d torch/OpenMP threads of %d host cpus; 1 warm-up, median of 3" % (h, w, all_threads, os.cpu_count()),
            "forward_64x64": {"all_cores": {"value": 1.0 / t64_all, "unit": "frames/s", "cores": all_threads},
                              "single_core": {"value": 1.0 / t64_one, "unit": "frames/s", "cores": 1},
-                             "sample": "1x5x3x64x64 (BASELINE configs[0] size), 1 warm-up, median of 3"},
+                             "sample": "1x5x3x64x64 (BASELINE configs[0] size), 1 warm-up, median of 5"},
            "inner_step_176x320": {"value": 1.0 / t_inner, "unit": "clips/s", "cores": all_threads,
                                   "sample": "MFDN fwd+bwd @176x320, EDVR fwd+bwd @44x80, Charbonnier + 10 L1, Adam; "
                                             "frozen MFDN hoisted like the GPU path; 1 warm-up, median of 3"}}
