@@ -31,11 +31,13 @@ namespace dvsr {
 // Debug timeline: thread 0 of every workgroup stamps s_memtime at the phase boundaries of the
 // pipeline.  Compiled in only with -DDVSR_CONV_TRACE (a separate library; the product build has none).
 #ifdef DVSR_CONV_TRACE
+#define DVSR_ABLATE(a) ((a).ablate)
 #define DVSR_STAMP(i)                                                                              \
   do {                                                                                             \
     if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
 #else
+#define DVSR_ABLATE(a) 0
 #define DVSR_STAMP(i) \
   do {                \
   } while (0)
@@ -634,8 +636,8 @@ __device__ __forceinline__ void conv2d_dma_item(const ConvK2& a, const int id, f
     const float* s_in = s_in0 + buf * Sh::BUF_FLOATS + bbase;
     const float* s_w = s_w0 + buf * Sh::BUF_FLOATS;
     if (HAS_NEXT) {
-      if (!(a.ablate & 4)) issue_w(k + 1, buf ^ 1);
-      if (!(a.ablate & 2)) issue_halo(k + 1, buf ^ 1);
+      if (!(DVSR_ABLATE(a) & 4)) issue_w(k + 1, buf ^ 1);
+      if (!(DVSR_ABLATE(a) & 2)) issue_halo(k + 1, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     f32x4 A[2][MT];
@@ -663,7 +665,7 @@ __device__ __forceinline__ void conv2d_dma_item(const ConvK2& a, const int id, f
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][mt][j], Bv[rb][nt][j], acc[mt][nt], 0, 0, 0);
     }
-    if (HAS_NEXT && !(a.ablate & 8)) __syncthreads();  // next buffers complete (the barrier's vmcnt(0) covers both DMAs)
+    if (HAS_NEXT && !(DVSR_ABLATE(a) & 8)) __syncthreads();  // next buffers complete (the barrier's vmcnt(0) covers both DMAs)
   };
 
   issue_w(0, 0);
@@ -672,7 +674,7 @@ __device__ __forceinline__ void conv2d_dma_item(const ConvK2& a, const int id, f
   for (int k = 0; k + 1 < a.nchunks; ++k) block(k, std::true_type{});
   block(a.nchunks - 1, std::false_type{});
 
-  if ((a.ablate & 1) && acc[0][0][0] != 12345.f) return;
+  if ((DVSR_ABLATE(a) & 1) && acc[0][0][0] != 12345.f) return;
   const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
   store_mfma_tile<MT, NT>(acc, t, n, cbi * MT * 32, oy0, TH, ox0, oy0 + NT * wave, lo, hi);
 }
@@ -830,9 +832,10 @@ int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const Conv
   k.nchunks = ceil_div(d.c0 + d.c1, geo.cc);
   k.in_ps = ex.in_ps; k.in_dil = ex.in_dil; k.Hs = ex.Hs; k.Ws = ex.Ws; k.accum = ex.accum;
   k.gmask = ex.gmask; k.gmask_act = ex.gmask_act;
+#ifdef DVSR_CONV_TRACE
   {
-    // measurement aid, results are WRONG when set (profiles/r02_z_conv_dma_ablation.txt): bit 0 no stores,
-    // bit 1 no halo DMA, bit 2 no weight DMA, bit 3 no chunk barriers (conv2d_dma_kernel only)
+    // measurement aid of the debug build, results are WRONG when set (profiles/r02_z_conv_dma_ablation.txt): bit 0 no
+    // stores, bit 1 no halo DMA, bit 2 no weight DMA, bit 3 no chunk barriers (conv2d_dma_kernel only)
     static int ablate = -1;
     if (ablate < 0) {
       const char* v = getenv("DVSR_CONV_ABLATE");
@@ -840,6 +843,7 @@ int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const Conv
     }
     k.ablate = ablate;
   }
+#endif
   if (k.in_ps) k.x0_bs = (long long)d.c0 * d.H * d.W;
   if (k.in_dil) k.x0_bs = (long long)d.c0 * ex.Hs * ex.Ws;
 #ifdef DVSR_CONV_TRACE

@@ -274,7 +274,9 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
   }
   out->grid = dim3(k.nsplit, k.nob, k.ncb);
   out->ks = ks; out->stride = stride;
+#ifdef DVSR_CONV_TRACE
   { static const int nf = getenv("DVSR_WGRAD_NOFLUSH") ? atoi(getenv("DVSR_WGRAD_NOFLUSH")) : 0; k.noflush = nf; }
+#endif
   // small pixel grids: one kernel row per workgroup (conv2d_wgrad_pipe_kernel<3, true>); the pixel split is then
   // sized for ~two workgroups per CU over the three rows.  DVSR_WGRAD_KYS_BELOW=<tiles x cout blocks x cin blocks>
   // moves the threshold (0 disables).

@@ -22,8 +22,8 @@ struct ConvK2 {
   int tiles_x, tiles_y, ntiles, ncb, nchunks, nitems, tiles_per_xcd;
   int in_ps, in_dil, Hs, Ws, accum;
   const float* gmask; int gmask_act;
-  int ablate;  // DVSR_CONV_ABLATE measurement aid (conv2d_dma_kernel); 0 in every product run
 #ifdef DVSR_CONV_TRACE
+  int ablate;  // DVSR_CONV_ABLATE measurement aid (conv2d_dma_kernel), debug build only
   long long* trace;  // debug build only (tools/conv_trace.py): 64 cycle stamps per workgroup
 #endif
 };
@@ -34,7 +34,9 @@ struct WgradK {
   int x_bdiv;
   int N, Cin, H, W, Cout, Ho, Wo, pad, gy_ps;
   int tiles_x, tiles_y, ntiles, nsplit, nob, ncb, nslot;
-  int noflush = 0;  // measurement aid (DVSR_WGRAD_NOFLUSH=1): skip the atomic flush, results are wrong
+#ifdef DVSR_CONV_TRACE
+  int noflush = 0;  // measurement aid of the debug build (DVSR_WGRAD_NOFLUSH=1): skip the atomic flush, results are wrong
+#endif
 };
 
 // host side: fill the argument structs without launching (conv2d_v2.hip / conv2d_wgrad.hip)
@@ -395,7 +397,9 @@ __device__ __forceinline__ void conv2d_wgrad_pipe_item(const WgradK& a, const in
   // ---- partial[slot][tap][o][c]  (o, c padded to the 64-blocks of the grid), slot = split % nslot
   const int OP = a.nob * 64, CP = a.ncb * 64;
   const int slot = split % a.nslot;
+#ifdef DVSR_CONV_TRACE
   if (a.noflush && acc[0][0] != 12345.f) return;
+#endif
 #pragma unroll
   for (int t = 0; t < KK; ++t)
 #pragma unroll
