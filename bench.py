@@ -469,17 +469,6 @@ def main():
         elapsed = float(t)
     assert torch.isfinite(y).all()
 
-    meta = None
-    if not args.no_meta:   # every rank takes part (the collective)
-        try:
-            meta = meta_step_rate(dev, world, dist)
-        except Exception as e:
-            if world > 1:
-                raise
-            meta = {"error": "%s: %s" % (type(e).__name__, e)}
-        if dist_err:
-            meta["process_group_error"] = dist_err
-
     line = None
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -543,14 +532,29 @@ def main():
         line["kernel_breakdown_ms_per_step"] = {k: round(a[0] / reps, 4) for k, a in
                                                 sorted(acc.items(), key=lambda kv: -kv[1][0])}
         line["end_to_end_tflops"] = sum(a[1] for a in acc.values()) / reps / (ms * 1e-3) / 1e12
-        if meta is not None:
-            line["meta_step"] = meta
         if world == 1 and not args.no_inner_step:
             line["inner_step"] = inner_step_rate(dev)
             line["per_frame_pipeline"] = per_frame_pipeline_rate(dev)
         if world == 1 and not args.no_split:
             line["experimental_bf16_split"] = split_mode_rate(cfg, h, w, x, y, args.steps, args.warmup)
             line["edvr_l_bf16"] = edvr_l_rates(dev)
+    # The meta-training iteration comes AFTER the single-GPU legs: once the RCCL communicator exists, its helper threads
+    # slow host-bound launch sequences down (EDVR-L bf16 forward+backward, ~700 launches in 10.5 ms, measured 14.1 ms
+    # when this leg ran first; the GPU-bound legs do not move).
+    meta = None
+    if not args.no_meta:   # every rank takes part (the collective)
+        try:
+            meta = meta_step_rate(dev, world, dist)
+        except Exception as e:
+            if world > 1:
+                raise
+            meta = {"error": "%s: %s" % (type(e).__name__, e)}
+        if dist_err:
+            meta["process_group_error"] = dist_err
+
+    if rank == 0:
+        if meta is not None:
+            line["meta_step"] = meta
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, h, w, 0, y)   # same clip (seed 1 + rank 0), same weights
     if dist is not None:

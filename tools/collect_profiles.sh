@@ -36,4 +36,15 @@ python tools/meta_bench.py 4 1 2>&1 | grep -v amdgpu > $out/${tag}_meta_train_st
 python tools/estimator_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_estimator.txt
 python tools/bf16_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_bf16_modes.txt
 python tools/backbone_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_backbones_tof_duf.txt
+# 7. EDVR-L x4 (configs[4]) forward+backward in bf16 mode: timing + kernel table
+rocprofv3 --kernel-trace --stats -d $out/db7 -o r -- python tools/edvr_l_step_profile.py 1 20 2>&1 | grep EDVR-L > $out/${tag}_edvr_l_bf16_step.txt
+python tools/rocprof_summary.py $out/db7/r_results.db >> $out/${tag}_edvr_l_bf16_step.txt; rm -rf $out/db7
+python tools/edvr_l_step_profile.py 1 20 2>&1 | grep EDVR-L >> $out/${tag}_edvr_l_bf16_step.txt
+python tools/edvr_l_step_profile.py 0 10 2>&1 | grep EDVR-L >> $out/${tag}_edvr_l_bf16_step.txt
+# 8. micro-measurements behind DESIGN 3.1 / 3.2: what hides behind an fp32 MFMA; cycle stamps of the DCN forward (debug build)
+python tools/mfma_shadow.py 2>&1 | grep "cycles per" > $out/${tag}_mfma_shadow.txt
+if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
+  python tools/dcn_dma_trace.py 2 2>&1 | grep -v amdgpu > $out/${tag}_dcn_dma_trace.txt
+  python tools/dcn_dma_trace.py 2 44 80 2>&1 | grep -v amdgpu >> $out/${tag}_dcn_dma_trace.txt
+fi
 du -sh gpurun_out
