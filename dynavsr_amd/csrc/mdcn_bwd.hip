@@ -148,7 +148,28 @@ struct DcnF {
   long long off_bs, msk_bs, goff_bs, gmsk_bs;
   int mask_logit, N, C, H, W, Cout, dg, tiles_x, tiles_y;
   int sub;  // 8-channel chunks per deformable group (1: EDVR-M, 2: EDVR-L); blockIdx.y walks the C/8 chunks
+#ifdef DVSR_CONV_TRACE
+  long long* trace;  // debug build only (tools/dcn_bwd_trace.py): 16 cycle stamps per workgroup
+#endif
 };
+#ifdef DVSR_CONV_TRACE
+#define DCNB_STAMP(i)                                                                                              \
+  do {                                                                                                             \
+    if (a.trace && threadIdx.x == 0)                                                                               \
+      a.trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+static long long* g_dcnb_trace = nullptr;
+static int g_dcnb_countdown = -1;
+extern "C" int dvsr_debug_dcn_bwd_trace(void* buf, int launch_index) {
+  g_dcnb_trace = (long long*)buf;
+  g_dcnb_countdown = launch_index;
+  return 0;
+}
+#else
+#define DCNB_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
 
 template <int HALO>
 __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
@@ -172,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   const int lo = lane & 31, hi = lane >> 5;
   const size_t HW = (size_t)a.H * a.W;
   const float* xg = a.x + ((size_t)n * a.C + kc * 8) * HW;
+  DCNB_STAMP(0);
 
   // ---- stage the input window (zero outside the image), clear the gradient window, stage W^T.
   // All global loads of a stage are issued before the first LDS write (a load per loop iteration would
@@ -232,7 +254,9 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       offv[tap][nt][1] = offn[(size_t)(g * 18 + 2 * tap + 1) * HW + pofs[nt]];
       offv[tap][nt][2] = mskn[(size_t)(g * 9 + tap) * HW + pofs[nt]];
     }
+  DCNB_STAMP(1);
   __syncthreads();
+  DCNB_STAMP(2);
 
   // ---- 1. dcol tile: D[mt][nt], pixel row 2*wave + nt, column lo.  gout operands are fetched 8 k-steps
   // (48 MFMAs) ahead.
@@ -273,17 +297,20 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
     mfma8(b1, kb + 8);
   }
 
+  DCNB_STAMP(3);
   // ---- gradient-window scale: the input gradient is accumulated in 64-bit fixed point with the
   // workgroup's largest |dcol * mask| mapped to [2^39, 2^40): at most 9216 contributions meet in a cell, so
   // the sums stay below 2^54, and every contribution keeps >= 24 significant bits down to 2^-16 of the
   // maximum (better than an fp32 running sum).  Integer adds are associative: the window is deterministic.
+  // (the mask sigmoid is taken once per (pixel row, tap), here, and kept in place of the logit)
   float amax = 0.f;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const float mraw = offv[tap][nt][2];
-      const float m = a.mask_logit ? sigmoidf_(mraw) : mraw;
+      const float m = a.mask_logit ? __builtin_amdgcn_rcpf(1.f + __expf(-mraw)) : mraw;
+      offv[tap][nt][2] = m;
 #pragma unroll
       for (int cq = 0; cq < 4; ++cq) amax = fmaxf(amax, fabsf(acc[tap >> 2][nt][(tap & 3) * 4 + cq] * m));
     }
@@ -297,12 +324,40 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   const float qinv = amax > 0.f ? ldexpf(1.f, aexp - 40) : 1.f;
   for (int idx = tid; idx < 8 * XPX; idx += 256) s_gq[idx] = 0ull;
   __syncthreads();
+  DCNB_STAMP(4);
 
-  // ---- 2. sampling: this lane's 4 channels (4*hi .. 4*hi+3) of every (pixel, tap)
+  // ---- 2. sampling: this lane's 4 channels (4*hi .. 4*hi+3) of every (pixel, tap).
+  // Straight-line fast path (round 2; the cycle-stamp trace, tools/dcn_bwd_trace.py, had this phase at half of the
+  // kernel: ~850 instructions per (pixel row, tap), most of them exec-mask bookkeeping of nested divergent branches,
+  // float -> int64 conversions and two divisions per sigmoid).  Window coordinates are clamped (always a legal LDS
+  // address) and a sample that is off the tile or outside the window contributes exact zeros; the window is zero outside
+  // the image, which reproduces the per-corner validity and -- but for the lower bound, tested -- the (-1,H)x(-1,W) gate
+  // for every in-window sample, as in the forward kernel.  Samples outside the window are flagged and redone exactly in the rare loop below.
   float* goffn = a.goff + (size_t)n * a.goff_bs;
   float* gmskn = a.gmsk + (size_t)n * a.gmsk_bs;
   float* coln = a.col + (size_t)n * a.C * 9 * HW;
   float* gxg = a.gx ? a.gx + ((size_t)n * a.C + kc * 8) * HW : nullptr;
+  // float -> int64 (round to nearest) through the double mantissa: bits(double(v) + 1.5 * 2^52) - bits(1.5 * 2^52) is the
+  // integer for |v| < 2^51: 4 VALU instructions (__float2ll_rn is a ~14-instruction sequence)
+  auto q64 = [](float v) {
+    return (unsigned long long)(__double_as_longlong((double)v + 6755399441055744.0) - 0x4338000000000000LL);
+  };
+  auto store_grads = [&](int tap, int nt, float gm, float gh, float gw, float m, const float (&colv)[4]) {
+    if (hi == 0) {
+      float* ph = goffn + (size_t)(g * 18 + 2 * tap) * HW + pofs[nt];
+      float* pm = gmskn + (size_t)(g * 9 + tap) * HW + pofs[nt];
+      const float gmv = a.mask_logit ? gm * m * (1.f - m) : gm;
+      if (a.sub == 1) {
+        ph[0] = gh; ph[HW] = gw; pm[0] = gmv;
+      } else {
+        unsafeAtomicAdd(ph, gh); unsafeAtomicAdd(ph + HW, gw); unsafeAtomicAdd(pm, gmv);
+      }
+    }
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq)
+      coln[((size_t)(kc * 8 + 4 * hi + cq) * 9 + tap) * HW + pofs[nt]] = colv[cq];
+  };
+  unsigned fixbits = 0;  // bit 2 tap + nt: this lane's sample left the staged window
 #pragma unroll
   for (int mt = 0; mt < 3; ++mt) {
 #pragma unroll
@@ -312,86 +367,133 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       const int ki = tap / 3, kj = tap - 3 * ki;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        // both lanes of a pair run the geometry (same pixel); pv is pair-uniform
-        float gm = 0.f, gh = 0.f, gw = 0.f, m = 0.f;
-        float colv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (pv[nt]) {
-          const float oh = offv[tap][nt][0], ow = offv[tap][nt][1], mraw = offv[tap][nt][2];
-          m = a.mask_logit ? sigmoidf_(mraw) : mraw;
-          const float h_im = (float)(py[nt] - 1 + ki) + oh;
-          const float w_im = (float)(px - 1 + kj) + ow;
-          if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
-            const float hf = floorf(h_im), wf = floorf(w_im);
-            const float lh = h_im - hf, lw = w_im - wf;
-            const float hh = 1.f - lh, hw = 1.f - lw;
-            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-            const int ry = (int)hf - wy0, rx = (int)wf - wx0;
-            const bool inwin = ry >= 0 && ry <= XH - 2 && rx >= 0 && rx <= XW - 2;
-            DcnTap tp;
-            if (!inwin) make_tap(h_im, w_im, a.H, a.W, tp);
+        const float m = offv[tap][nt][2];
+        const float h_im = (float)(py[nt] - 1 + ki) + offv[tap][nt][0];
+        const float w_im = (float)(px - 1 + kj) + offv[tap][nt][1];
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const float lh = h_im - hf, lw = w_im - wf;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const int ry = (int)hf - wy0, rx = (int)wf - wx0;
+        const int inwin = ((unsigned)ry <= (unsigned)(XH - 2)) & ((unsigned)rx <= (unsigned)(XW - 2));
+        // (h_im, w_im > -1: the zero padding reproduces the gate for the sample VALUE, but at exactly -1 the coordinate
+        // gradient of the padded image is not zero while the reference's gate returns 0; the upper bounds need no test)
+        const int ok = (int)pv[nt] & inwin & (h_im > -1.f) & (w_im > -1.f);
+        fixbits |= (unsigned)((int)pv[nt] & (inwin ^ 1)) << (2 * tap + nt);
+        const int cell = min(max(ry, 0), XH - 2) * XW + min(max(rx, 0), XW - 2);
+        const float mk = ok ? m : 0.f;               // zero for samples this path does not own
+        const float tsc = mk * qscale;
+        float gm = 0.f, gh = 0.f, gw = 0.f;
+        float colv[4];
 #pragma unroll
-            for (int cq = 0; cq < 4; ++cq) {
-              const int c = 4 * hi + cq;
-              const float d = acc[mt][nt][t4 * 4 + cq];
-              float v1, v2, v3, v4;
-              if (inwin) {
-                const float* p1 = s_x + c * XPX + ry * XW + rx;
-                v1 = p1[0]; v2 = p1[1]; v3 = p1[XW]; v4 = p1[XW + 1];
-              } else {
-                const float* pl = xg + (size_t)c * HW;
-                v1 = tp.v1 ? pl[tp.o1] : 0.f; v2 = tp.v2 ? pl[tp.o2] : 0.f;
-                v3 = tp.v3 ? pl[tp.o3] : 0.f; v4 = tp.v4 ? pl[tp.o4] : 0.f;
-              }
-              const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-              colv[cq] = val * m;
-              gm += d * val;                                              // kernel.cu:752
-              gh += (-hw * v1 - lw * v2 + hw * v3 + lw * v4) * d * m;     // :541-550
-              gw += (-hh * v1 + hh * v2 - lh * v3 + lh * v4) * d * m;     // :552-561
-              const float top = d * m;                                    // :672
-              if (gxg) {
-                if (inwin) {
-                  // 64-bit fixed point: ds_add_u64 runs at full LDS rate, ds_add_f32 ~10x slower (measured)
-                  unsigned long long* q1 = s_gq + c * XPX + ry * XW + rx;
-                  const float ts = top * qscale;
-                  atomicAdd(q1, (unsigned long long)__float2ll_rn(w1 * ts));
-                  atomicAdd(q1 + 1, (unsigned long long)__float2ll_rn(w2 * ts));
-                  atomicAdd(q1 + XW, (unsigned long long)__float2ll_rn(w3 * ts));
-                  atomicAdd(q1 + XW + 1, (unsigned long long)__float2ll_rn(w4 * ts));
-                } else {
-                  float* gp = gxg + (size_t)c * HW;
-                  if (tp.v1) unsafeAtomicAdd(gp + tp.o1, w1 * top);
-                  if (tp.v2) unsafeAtomicAdd(gp + tp.o2, w2 * top);
-                  if (tp.v3) unsafeAtomicAdd(gp + tp.o3, w3 * top);
-                  if (tp.v4) unsafeAtomicAdd(gp + tp.o4, w4 * top);
-                }
-              }
-            }
+        for (int cq = 0; cq < 4; ++cq) {
+          const int c = 4 * hi + cq;
+          const float d = acc[mt][nt][t4 * 4 + cq];
+          const float* p1 = s_x + c * XPX + cell;
+          const float v1 = p1[0], v2 = p1[1], v3 = p1[XW], v4 = p1[XW + 1];
+          const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+          colv[cq] = val * mk;
+          gm += d * val;                                              // kernel.cu:752
+          gh += (-hw * v1 - lw * v2 + hw * v3 + lw * v4) * d;         // :541-550 (x mask below)
+          gw += (-hh * v1 + hh * v2 - lh * v3 + lh * v4) * d;         // :552-561
+          if (gxg) {
+            // 64-bit fixed point: ds_add_u64 runs at full LDS rate, ds_add_f32 ~10x slower (measured)
+            unsigned long long* q1 = s_gq + c * XPX + cell;
+            const float ts = d * tsc;                                 // :672, scaled
+            atomicAdd(q1, q64(w1 * ts));
+            atomicAdd(q1 + 1, q64(w2 * ts));
+            atomicAdd(q1 + XW, q64(w3 * ts));
+            atomicAdd(q1 + XW + 1, q64(w4 * ts));
           }
         }
+        gm = ok ? gm : 0.f; gh *= mk; gw *= mk;
         // the partner lane (other 4 channels of the same pixel) completes the sums
         gm += __shfl_xor(gm, 32, 64);
         gh += __shfl_xor(gh, 32, 64);
         gw += __shfl_xor(gw, 32, 64);
-        if (pv[nt]) {
-          if (hi == 0) {
-            float* ph = goffn + (size_t)(g * 18 + 2 * tap) * HW + pofs[nt];
-            float* pm = gmskn + (size_t)(g * 9 + tap) * HW + pofs[nt];
-            const float gmv = a.mask_logit ? gm * m * (1.f - m) : gm;
-            if (a.sub == 1) {
-              ph[0] = gh; ph[HW] = gw; pm[0] = gmv;
-            } else {
-              unsafeAtomicAdd(ph, gh); unsafeAtomicAdd(ph + HW, gw); unsafeAtomicAdd(pm, gmv);
-            }
-          }
-#pragma unroll
-          for (int cq = 0; cq < 4; ++cq)
-            coln[((size_t)(kc * 8 + 4 * hi + cq) * 9 + tap) * HW + pofs[nt]] = colv[cq];
-        }
+        if (pv[nt]) store_grads(tap, nt, gm, gh, gw, m, colv);
       }
     }
   }
+  // ---- 2b. samples that left the window (|offset| > HALO pixels): exact clamped global gathers / atomics; their
+  // gradients overwrite the zeros the fast path stored.  Both lanes of a pixel pair take the same branch.
+  if (__builtin_amdgcn_ballot_w64(fixbits != 0) != 0) {
+#pragma unroll 1
+    for (int b = 0; b < 18; ++b) {
+      if (__builtin_amdgcn_ballot_w64((fixbits >> b) & 1) == 0) continue;
+      const int tap = b >> 1, nt = b & 1;
+      const int mt = tap >> 2, t4 = tap & 3;
+      const int ki = tap / 3, kj = tap - 3 * ki;
+      if ((fixbits >> b) & 1) {
+        // runtime-indexed register arrays would go to scratch: select the operands with compile-time indices
+        float oh = 0.f, ow = 0.f, m = 0.f, dsel[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            if (t == tap && r == nt) {
+              oh = offv[t][r][0]; ow = offv[t][r][1]; m = offv[t][r][2];
+#pragma unroll
+              for (int cq = 0; cq < 4; ++cq) dsel[cq] = acc[t >> 2][r][(t & 3) * 4 + cq];
+            }
+        (void)mt; (void)t4;
+        const int pyv = nt ? py[1] : py[0];
+        const size_t pof = nt ? pofs[1] : pofs[0];
+        const float h_im = (float)(pyv - 1 + ki) + oh;
+        const float w_im = (float)(px - 1 + kj) + ow;
+        float gm = 0.f, gh = 0.f, gw = 0.f;
+        float colv[4] = {0.f, 0.f, 0.f, 0.f};
+        DcnTap tp;
+        if (make_tap(h_im, w_im, a.H, a.W, tp)) {
+          const float hf = floorf(h_im), wf = floorf(w_im);
+          const float lh = h_im - hf, lw = w_im - wf;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+          for (int cq = 0; cq < 4; ++cq) {
+            const int c = 4 * hi + cq;
+            const float d = dsel[cq];
+            const float* pl = xg + (size_t)c * HW;
+            const float v1 = tp.v1 ? pl[tp.o1] : 0.f, v2 = tp.v2 ? pl[tp.o2] : 0.f;
+            const float v3 = tp.v3 ? pl[tp.o3] : 0.f, v4 = tp.v4 ? pl[tp.o4] : 0.f;
+            const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+            colv[cq] = val * m;
+            gm += d * val;
+            gh += (-hw * v1 - lw * v2 + hw * v3 + lw * v4) * d * m;
+            gw += (-hh * v1 + hh * v2 - lh * v3 + lh * v4) * d * m;
+            const float top = d * m;
+            if (gxg) {
+              float* gp = gxg + (size_t)c * HW;
+              if (tp.v1) unsafeAtomicAdd(gp + tp.o1, w1 * top);
+              if (tp.v2) unsafeAtomicAdd(gp + tp.o2, w2 * top);
+              if (tp.v3) unsafeAtomicAdd(gp + tp.o3, w3 * top);
+              if (tp.v4) unsafeAtomicAdd(gp + tp.o4, w4 * top);
+            }
+          }
+        }
+        gm += __shfl_xor(gm, 32, 64);
+        gh += __shfl_xor(gh, 32, 64);
+        gw += __shfl_xor(gw, 32, 64);
+        // (nt is wave-uniform here: b is)
+        if (hi == 0) {
+          float* ph = goffn + (size_t)(g * 18 + 2 * tap) * HW + pof;
+          float* pm = gmskn + (size_t)(g * 9 + tap) * HW + pof;
+          const float gmv = a.mask_logit ? gm * m * (1.f - m) : gm;
+          if (a.sub == 1) {
+            ph[0] = gh; ph[HW] = gw; pm[0] = gmv;
+          } else {
+            unsafeAtomicAdd(ph, gh); unsafeAtomicAdd(ph + HW, gw); unsafeAtomicAdd(pm, gmv);
+          }
+        }
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) coln[((size_t)(kc * 8 + 4 * hi + cq) * 9 + tap) * HW + pof] = colv[cq];
+      }
+    }
+  }
+  DCNB_STAMP(5);
   if (!gxg) return;
   __syncthreads();
+  DCNB_STAMP(6);
   // ---- 3. flush the gradient window
   for (int idx = tid; idx < 8 * XPX; idx += 256) {
     const long long q = (long long)s_gq[idx];
@@ -403,6 +505,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
     if ((unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W)
       unsafeAtomicAdd(gxg + (size_t)c * HW + (size_t)gy_ * a.W + gx_, v);
   }
+  DCNB_STAMP(7);
 }
 
 size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int stride, int pad, int dil) {
@@ -467,6 +570,10 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
                           (int)((8 * XPX + std::max(16 * XPX, 3 * 64 * 64)) * sizeof(float)));
       attr_done = true;
     }
+#ifdef DVSR_CONV_TRACE
+    f.trace = (g_dcnb_countdown == 0) ? g_dcnb_trace : nullptr;
+    if (g_dcnb_countdown >= 0) --g_dcnb_countdown;
+#endif
     hipLaunchKernelGGL(mdcn_bwd_fused_kernel<HALO>, dim3(f.tiles_x * f.tiles_y, C / 8, N), dim3(256), lds, st, f);
     int rc = check_launch("mdcn_bwd_fused_kernel");
     if (rc) return rc;

@@ -1,7 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-for f in "--no-meta --no-inner-step" "--no-inner-step" "--no-meta" ""; do
-python bench.py --no-cpu-baseline $f 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); e=d['edvr_l_bf16']; print('flags [$f]:', {k:(round(v['forward']['ms'],2), round(v['forward_backward']['ms'],2)) for k,v in e.items() if isinstance(v,dict)})"
-done
+mkdir -p gpurun_out/r02s
+timeout 1200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_edvr.py -m gpu -x -q -k "mdcn or dcn or backward or grad" > gpurun_out/r02s/pytest.log 2>&1
+tail -n 3 gpurun_out/r02s/pytest.log
