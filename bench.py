@@ -25,6 +25,8 @@ import statistics
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")   # see dynavsr_amd/_lib.py: must precede the first HIP call
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

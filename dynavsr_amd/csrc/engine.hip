@@ -16,6 +16,7 @@
 //    (dynavsr_amd/spec.py mirrors the walk below).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -755,6 +756,21 @@ struct Bases {
   }
 };
 
+// The weight-gradient side stream, one per device for the whole process (never destroyed).  Plans on different launch
+// streams share it: their weight gradients then queue behind each other, ordered by the plans' own fork / join events.
+static hipStream_t shared_side_stream() {
+  static std::mutex mu;
+  static hipStream_t streams[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lock(mu);
+  if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    streams[dev] = nullptr;
+  }
+  return streams[dev];
+}
+
 // Packs the weights of every conv of the tape (forward: wt=0; backward: the two transposed views).
 static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena_base, float* fwd_base,
                     float* bwd_base, hipStream_t st) {
@@ -882,8 +898,7 @@ extern "C" void dvsr_edvr_plan_destroy(dvsr_edvr_plan* p) {
   if (p->side) {
     (void)hipStreamSynchronize(p->side);
     (void)hipEventDestroy(p->ev_fork);
-    (void)hipEventDestroy(p->ev_join);
-    (void)hipStreamDestroy(p->side);
+    (void)hipEventDestroy(p->ev_join);   // (the side stream is the process-wide one of its device: not destroyed)
   }
   delete p;
 }
@@ -928,7 +943,13 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
   // fork/join state of the side stream (created on first use, owned by the plan)
   bool use_side = p->side_streams != 0;
   if (use_side && !p->side) {
-    if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
+    // ONE side stream per device for all plans (shared_side_stream): ROCm maps streams onto a few hardware queues
+    // (GPU_MAX_HW_QUEUES, 4 by default; more than ~6 in use and the command processor time-slices them: EDVR-L
+    // forward+backward 20 -> 31 ms), and streams that share a queue run behind each other.  With a stream per plan the
+    // mapping, and with it the overlap, depended on how many plans and other streams (an RCCL communicator holds some)
+    // the process had created before: the inner step measured 8.2 or 10.0 ms, EDVR-L fp32 forward+backward 20.1 or
+    // 23.5 ms.  dynavsr_amd/_lib.py asks for 6 queues: launch stream, RCCL's, this one, adapt_video's.
+    if ((p->side = shared_side_stream()) == nullptr ||
         hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
@@ -1240,7 +1261,6 @@ extern "C" void dvsr_estimator_plan_destroy(dvsr_estimator_plan* ep) {
     (void)hipStreamSynchronize(p.side);
     (void)hipEventDestroy(p.ev_fork);
     (void)hipEventDestroy(p.ev_join);
-    (void)hipStreamDestroy(p.side);
   }
   delete ep;
 }
