@@ -1,6 +1,8 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-for f in 1 2 3 4 6; do
-echo "fork_every $f: $(DVSR_BWD_FORK_EVERY=$f python tools/edvr_step_profile.py 44 80 40 2>&1 | grep EDVR) | $(DVSR_BWD_FORK_EVERY=$f python tools/rccl_effect.py 1 2>&1 | grep 'inner step')"
-done
+python tools/dcn_bwd_trace.py 5 44 80 2>&1 | grep -v amdgpu | grep "sampling\|lifetime\|flush"
+DVSR_DCN_BWD_F32=1 python tools/dcn_bwd_trace.py 5 44 80 2>&1 | grep -v amdgpu | grep "sampling\|lifetime\|flush"
+python tools/dcn_bwd_bench.py 2>&1 | grep -v amdgpu
+DVSR_DCN_BWD_F32=1 python tools/dcn_bwd_bench.py 2>&1 | grep -v amdgpu
+DVSR_DCN_BWD_F32=1 timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "mdcn" 2>&1 | tail -n 2
