@@ -303,3 +303,15 @@ def test_log_dict_reads_as_floats_without_an_eager_sync():
     from dynavsr_amd.models import create_model
     model, est = create_model(cpu_opt())
     assert isinstance(model.log_dict, LogDict) and model.get_current_log() is model.log_dict
+
+
+def test_hw_queue_default_is_set_once_and_respects_the_user(monkeypatch):
+    """dynavsr_amd/_lib.py asks ROCm for six hardware queues unless the user chose a value."""
+    import importlib
+    import dynavsr_amd._lib as L
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    importlib.reload(L)
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "6"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    importlib.reload(L)
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "4"
