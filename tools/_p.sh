@@ -1,8 +1,10 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-python tools/dcn_bwd_trace.py 5 44 80 2>&1 | grep -v amdgpu | grep "sampling\|lifetime\|flush"
-DVSR_DCN_BWD_F32=1 python tools/dcn_bwd_trace.py 5 44 80 2>&1 | grep -v amdgpu | grep "sampling\|lifetime\|flush"
-python tools/dcn_bwd_bench.py 2>&1 | grep -v amdgpu
-DVSR_DCN_BWD_F32=1 python tools/dcn_bwd_bench.py 2>&1 | grep -v amdgpu
-DVSR_DCN_BWD_F32=1 timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "mdcn" 2>&1 | tail -n 2
+out=gpurun_out/r02_z5; rm -rf $out; mkdir -p $out
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  rocprofv3 --pmc $c --kernel-trace -d $out/db_$c -o p -- python tools/edvr_step_profile.py 44 80 6 > /dev/null 2>&1
+done
+python tools/pmc_mfma.py $out/db_SQ_VALU_MFMA_BUSY_CYCLES/p_results.db $out/db_GRBM_GUI_ACTIVE/p_results.db > $out/r02_z_pmc_mfma_util_edvr_step_44x80.txt
+rm -rf $out/db_*
+head -30 $out/r02_z_pmc_mfma_util_edvr_step_44x80.txt
