@@ -1,10 +1,12 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/r02_z5; rm -rf $out; mkdir -p $out
-for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
-  rocprofv3 --pmc $c --kernel-trace -d $out/db_$c -o p -- python tools/edvr_step_profile.py 44 80 6 > /dev/null 2>&1
-done
-python tools/pmc_mfma.py $out/db_SQ_VALU_MFMA_BUSY_CYCLES/p_results.db $out/db_GRBM_GUI_ACTIVE/p_results.db > $out/r02_z_pmc_mfma_util_edvr_step_44x80.txt
-rm -rf $out/db_*
-head -30 $out/r02_z_pmc_mfma_util_edvr_step_44x80.txt
+mkdir -p gpurun_out/r02v
+timeout 1200 python -m pytest tests/test_gpu_edvr.py tests/test_gpu_ops.py tests/test_gpu_tof.py tests/test_gpu_duf.py -m gpu -x -q > gpurun_out/r02v/pytest.log 2>&1
+grep -E "passed|failed" gpurun_out/r02v/pytest.log | tail -n 2
+python tools/edvr_step_profile.py 44 80 40 2>&1 | grep EDVR
+DVSR_CONV_DMA=0 python tools/edvr_step_profile.py 44 80 40 2>&1 | grep EDVR
+python tools/op_profile.py 44 80 10 2>&1 | grep -v amdgpu > gpurun_out/r02v/op44_dma.txt
+DVSR_CONV_DMA=0 python tools/op_profile.py 44 80 10 2>&1 | grep -v amdgpu > gpurun_out/r02v/op44_reg.txt
+tail -n 1 gpurun_out/r02v/op44_dma.txt gpurun_out/r02v/op44_reg.txt
+python tools/rccl_effect.py 1 2>&1 | grep "inner step"
