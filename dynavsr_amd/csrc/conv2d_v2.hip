@@ -702,6 +702,189 @@ static int launch_dma(ConvK2 k, hipStream_t st) {
   return check_launch("conv2d_dma_kernel");
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Large kernels (7x7 of SpyNet, 9x9 of the TOFlow head; stride 1, pad KS/2, W % 4 == 0, 16-byte aligned plain input):
+// the DMA-halo kernel with the K loop split by KERNEL ROW.  A 64-cout x 8-channel x 49-tap weight image is 100 KB --
+// it cannot be double buffered -- so a step of the loop is (8-channel chunk, kernel row ky): KS taps, 7-9 KiB of
+// weights per 32-cout half by LDS-DMA into one of two buffers, while the chunk's halo tile ((TH + KS - 1) rows x the
+// aligned columns [ox0 - 4, ox0 + 36), which cover a pad of up to 4) stays in LDS for its KS steps and the next chunk's
+// arrives in the other halo buffer.  One barrier per step, KS x 4 x MT x NT MFMAs between barriers.  The packed image is
+// the ordinary one (KK = KS * KS taps, `perm` channel order): the taps of a kernel row are contiguous in it.
+// Channel counts that are not a multiple of 8 (the 21-channel 9x9 conv) multiply stale-but-finite LDS contents by the
+// pack's zero weights; both halo buffers are cleared once for that.
+// (TOFlow spends 96 % of its forward in these convolutions: 17.7 ms on the single-buffered conv2d_mfma_kernel.)
+// -------------------------------------------------------------------------------------------------
+template <int KS, int TH, int MT>
+struct RowShape {
+  static constexpr int CC = 8, NT = TH / 4, PADK = KS / 2, IH = TH + KS - 1, RP = 40, GR = RP / 4;
+  static_assert(PADK <= 4, "the 40-column window covers a pad of at most 4");
+  static constexpr int NG = CC * IH * GR, NI = (NG + 255) / 256;
+  static constexpr int IN_FLOATS = NG * 4;
+  static constexpr int WROW = KS * 2 * 32 * 4;          // one kernel row of one 32-cout half: [kx][hi][lo] x float4
+  static constexpr int W_FLOATS = MT * WROW;
+  static constexpr int NPIECE = W_FLOATS / 256;         // = MT * KS
+  static constexpr int HALF = KS * KS * 2 * 32 * 4;     // packed floats of one 32-cout half of a chunk
+  static constexpr size_t LDS_BYTES = (size_t)2 * (IN_FLOATS + W_FLOATS) * sizeof(float);
+};
+
+template <int KS, int TH, int MT>
+__global__ __launch_bounds__(256, 2) void conv2d_dmarow_kernel(ConvK2 a) {
+  using Sh = RowShape<KS, TH, MT>;
+  constexpr int CC = Sh::CC, IH = Sh::IH, NT = Sh::NT, RP = Sh::RP, GR = Sh::GR, NI = Sh::NI;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const s_in0 = smem;                       // two halo buffers
+  float* const s_w0 = smem + 2 * Sh::IN_FLOATS;    // two weight-row buffers
+
+  const int id = blockIdx.x;
+  const int q_ = id >> 3;  // XCD-aware order, as conv2d_pipe_item
+  const int cbi = q_ % a.ncb;
+  const int j_ = q_ / a.ncb;
+  const int tile = (id & 7) * a.tiles_per_xcd + j_;
+  if (j_ >= a.tiles_per_xcd || tile >= a.ntiles) return;
+  const int tx_ = tile % a.tiles_x;
+  const int t2 = tile / a.tiles_x;
+  const int ty_ = t2 % a.tiles_y;
+  const int n = t2 / a.tiles_y;
+  const int oy0 = ty_ * TH, ox0 = tx_ * 32;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int Ctot = a.c0 + a.c1;
+  const size_t HW = (size_t)a.H * a.W;
+  const float* x0n = a.x0 + (size_t)n * a.x0_bs;
+  const float* x1n = a.c1 ? a.x1 + (size_t)(n / a.x1_bdiv) * a.x1_bs : x0n;
+
+  if (Ctot % CC != 0) {  // a partial last chunk reads LDS the DMA never wrote: make it finite (x zero weights)
+    for (int i = tid; i < 2 * Sh::IN_FLOATS / 4; i += 256) reinterpret_cast<f32x4*>(s_in0)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+  }
+  unsigned hoff[NI];
+  bool hval[NI];
+  int hch[NI];
+#pragma unroll
+  for (int jj = 0; jj < NI; ++jj) {
+    const int L = 64 * (wave + 4 * jj) + lane;
+    const int c = L / (IH * GR), r = L - c * (IH * GR);
+    const int iy = r / GR, g = r - iy * GR;
+    const int gy = oy0 - Sh::PADK + iy, gx = ox0 - 4 + 4 * g;
+    const bool ok = L < Sh::NG && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    hoff[jj] = ok ? (unsigned)(((size_t)c * HW + (size_t)gy * a.W + gx) * 4) : 0u;
+    hval[jj] = ok;
+    hch[jj] = c;
+    if (L < Sh::NG && !ok) {
+      *reinterpret_cast<f32x4*>(s_in0 + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(s_in0 + Sh::IN_FLOATS + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* wp_cb = a.wp + ((size_t)((cbi * MT) >> 1) * a.nchunks * 2 + ((cbi * MT) & 1)) * Sh::HALF;
+
+  auto issue_halo = [&](int k, int buf) {
+    const int cbase = k * CC;
+    const bool second = cbase >= a.c0;  // a chunk never straddles the two inputs (host: c0 % 8 == 0 with two inputs)
+    const float* b = second ? x1n : x0n;
+    const int ci = second ? cbase - a.c0 : cbase;
+    const int nci = (second ? a.c1 : a.c0) - ci;  // channels of this input left from the chunk's first one
+    const char* p = reinterpret_cast<const char*>(b + (size_t)ci * HW);
+    float* dst = s_in0 + buf * Sh::IN_FLOATS;
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+      if (hval[jj] && hch[jj] < nci)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + hoff[jj]),
+                                         (__attribute__((address_space(3))) void*)(dst + 256 * (wave + 4 * jj)), 16, 0, 0);
+    }
+  };
+  auto issue_w = [&](int k, int ky, int buf) {
+    const float* wsrc = wp_cb + (size_t)k * (2 * Sh::HALF) + ky * (KS * 256);
+    float* wdst = s_w0 + buf * Sh::W_FLOATS;
+#pragma unroll
+    for (int j = 0; j < (Sh::NPIECE + 3) / 4; ++j) {
+      int piece = j * 4 + wave;
+      piece = piece < Sh::NPIECE ? piece : Sh::NPIECE - 1;
+      const int mt = piece / KS, kx = piece - mt * KS;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(wsrc + (size_t)mt * Sh::HALF + kx * 256 + lane * 4),
+          (__attribute__((address_space(3))) void*)(wdst + piece * 256), 16, 0, 0);
+    }
+  };
+
+  const int nsteps = a.nchunks * KS;
+  issue_w(0, 0, 0);
+  issue_halo(0, 0);
+  __syncthreads();
+  // B operand of (row nt of this wave, kernel row ky, tap kx, k-step j): channel 4 hi + j, row NT wave + nt + ky,
+  // column lo + kx + 4 - pad of the window
+  const int bbase = (4 * hi * IH + NT * wave) * RP + lo + 4 - Sh::PADK;
+  int k = 0, ky = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const bool has_next = s + 1 < nsteps;
+    if (has_next) {
+      const int ky1 = ky + 1 == KS ? 0 : ky + 1;
+      issue_w(ky1 == 0 ? k + 1 : k, ky1, (s + 1) & 1);
+      if (ky == 0 && k + 1 < a.nchunks) issue_halo(k + 1, (k + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float* s_in = s_in0 + (k & 1) * Sh::IN_FLOATS + bbase + ky * RP;
+    const float* s_w = s_w0 + (s & 1) * Sh::W_FLOATS;
+    f32x4 A[2][MT];
+    float Bv[2][NT][4];
+    auto load_ops = [&](int kx, int rb) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        A[rb][mt] = *reinterpret_cast<const f32x4*>(s_w + ((size_t)(((mt * KS + kx) * 2 + hi) * 32 + lo)) * 4);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bv[rb][nt][j] = s_in[(j * IH + nt) * RP + kx];
+    };
+    load_ops(0, 0);
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      const int rb = kx & 1;
+      if (kx + 1 < KS) load_ops(kx + 1, rb ^ 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][mt][j], Bv[rb][nt][j], acc[mt][nt], 0, 0, 0);
+    }
+    if (has_next) __syncthreads();  // next weight row (and, at a chunk boundary, the next halo tile) complete
+    if (++ky == KS) { ky = 0; ++k; }
+  }
+
+  const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
+  store_mfma_tile<MT, NT>(acc, t, n, cbi * MT * 32, oy0, TH, ox0, oy0 + NT * wave, lo, hi);
+}
+
+template <int KS, int TH, int MT>
+static int launch_dmarow(ConvK2 k, hipStream_t st) {
+  using Sh = RowShape<KS, TH, MT>;
+  auto kern = conv2d_dmarow_kernel<KS, TH, MT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
+    attr_done = true;
+  }
+  k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
+  k.ncb = ceil_div(k.Cout, 32 * MT);
+  k.tiles_per_xcd = ceil_div(k.ntiles, 8);
+  k.nitems = k.tiles_per_xcd * 8 * k.ncb;
+  hipLaunchKernelGGL(kern, dim3(k.nitems), dim3(256), Sh::LDS_BYTES, st, k);
+  return check_launch("conv2d_dmarow_kernel");
+}
+
 template <int MT, int NT>
 __global__ __launch_bounds__(256, 2) void conv2d_ksplit_kernel(ConvK2 a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -735,6 +918,19 @@ static double conv2_pipe_cost(int TH, int MT, int KK, int CC, int N, int Ho, int
 }
 
 ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ctot, int allow_ksplit) {
+  if (ks == 7 || ks == 9) {  // row-split DMA kernel (conv2d_dmarow_kernel) or nothing: dma = 2 when it applies
+    ConvGeo g{8, 4, 2};
+    const double c42 = conv2_pipe_cost(4, 2, ks * ks, 8, N, Ho, Wo, Cout);
+    const double c41 = conv2_pipe_cost(4, 1, ks * ks, 8, N, Ho, Wo, Cout);
+    if (c41 < 0.97 * c42) g.mt = 1;
+    static int row_on = -1;  // DVSR_CONV_DMAROW=0: the caller falls back to the single-buffered kernel (A/B aid)
+    if (row_on < 0) {
+      const char* v = getenv("DVSR_CONV_DMAROW");
+      row_on = v ? atoi(v) : 1;
+    }
+    if (row_on && (allow_ksplit & 2) && stride == 1 && Wo % 4 == 0 && Cout >= 16) g.dma = 2;
+    return g;
+  }
   // Small grids: the K-split kernel (geo {32, NT, MT} with ks == 3).  DVSR_CONV_KSPLIT_BELOW=<workgroups of the
   // 4x32x32 geometry> moves the threshold (0 disables); DVSR_CONV_KSPLIT_NT=1|2 pins the tile shape.
   // Threshold from profiles/r02_small_grid_ab.txt: below ~700 such workgroups (the 44x80 levels: 66..330) the K-split
@@ -817,7 +1013,8 @@ extern "C" int dvsr_debug_conv_trace(void* buf, int launch_index) {
 
 int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo, ConvK2* out) {
   DVSR_REQUIRE(d.x0 && wp && d.y, DVSR_ERR_INVALID, "conv2d_packed: null x0/wp/y");
-  DVSR_REQUIRE(((d.ks == 1 || d.ks == 2) && d.stride == 1) || (d.ks == 3 && (d.stride == 1 || d.stride == 2)),
+  DVSR_REQUIRE(((d.ks == 1 || d.ks == 2) && d.stride == 1) || (d.ks == 3 && (d.stride == 1 || d.stride == 2)) ||
+                   ((d.ks == 7 || d.ks == 9) && d.stride == 1 && geo.dma == 2),
                DVSR_ERR_UNSUPPORTED, "conv2d_packed: ks=%d stride=%d", d.ks, d.stride);
   DVSR_REQUIRE(d.c1 == 0 || (d.c0 % geo.cc == 0 && !ex.in_ps && !ex.in_dil), DVSR_ERR_UNSUPPORTED,
                "conv2d_packed: two inputs need c0 %% %d == 0 and a plain first input (c0=%d)", geo.cc, d.c0);
@@ -850,7 +1047,13 @@ int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const Conv
   k.trace = (g_trace_countdown == 0) ? g_trace_buf : nullptr;
   if (g_trace_countdown >= 0) --g_trace_countdown;
 #endif
-  if (geo.dma) {
+  if (geo.dma == 2) {
+    DVSR_REQUIRE((d.ks == 7 || d.ks == 9) && d.stride == 1 && d.pad == d.ks / 2 && !ex.in_ps && !ex.in_dil && geo.cc == 8 &&
+                     geo.th == 4 && d.W % 4 == 0 && (d.c1 == 0 || d.c0 % 8 == 0) && k.x0_bs % 4 == 0 && k.x1_bs % 4 == 0 &&
+                     ((uintptr_t)d.x0 & 15) == 0 && ((uintptr_t)d.x1 & 15) == 0,
+                 DVSR_ERR_UNSUPPORTED, "conv2d_packed: the row-split DMA kernel needs 7x7 / 9x9, stride 1, pad ks/2, plain "
+                 "16-byte aligned inputs and W %% 4 == 0 (W=%d c0=%d c1=%d)", d.W, d.c0, d.c1);
+  } else if (geo.dma) {
     DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && d.pad == 1 && !ex.in_ps && !ex.in_dil && geo.cc == 8 && (geo.th == 4 || geo.th == 8) &&
                      d.W % 4 == 0 && d.c0 % 8 == 0 && d.c1 % 8 == 0 && k.x0_bs % 4 == 0 && k.x1_bs % 4 == 0 &&
                      ((uintptr_t)d.x0 & 15) == 0 && ((uintptr_t)d.x1 & 15) == 0,
@@ -890,6 +1093,10 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
     }
     if (geo.mt == 2) return launch_conv2<3, 1, 16, 4, 2, 1>(k, st);
     return launch_conv2<3, 1, 16, 4, 1, 1>(k, st);
+  }
+  if (geo.dma == 2) {
+    if (d.ks == 7) return geo.mt == 2 ? launch_dmarow<7, 4, 2>(k, st) : launch_dmarow<7, 4, 1>(k, st);
+    return geo.mt == 2 ? launch_dmarow<9, 4, 2>(k, st) : launch_dmarow<9, 4, 1>(k, st);
   }
   if (geo.dma) {
     if (geo.th == 8) return geo.mt == 2 ? launch_dma<8, 2>(k, st) : launch_dma<8, 1>(k, st);
@@ -944,21 +1151,25 @@ struct OpPack {
 OpPack op_pack(int ks, int stride, int pad, int N, int Ho, int Wo, int Cout, int Ctot, bool plain, bool aligned = false) {
   using namespace dvsr;
   OpPack o;
-  const bool k3 = ks == 3 && stride == 1 && pad == 1;
-  o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, Ctot, (k3 && plain ? 1 : 0) | (k3 && aligned ? 2 : 0));
+  const bool k3 = ks == 3 && stride == 1 && pad == 1, kbig = (ks == 7 || ks == 9) && stride == 1 && pad == ks / 2;
+  o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, Ctot, (k3 && plain ? 1 : 0) | ((k3 || kbig) && aligned ? 2 : 0));
   o.floats = (size_t)ceil_div(Cout, 64) * ceil_div(Ctot, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, 0);
   return o;
 }
 OpPack op_pack_for(const dvsr_conv2d_desc& d, int Cout, int Ctot) {
-  const bool aligned = (((uintptr_t)d.x0 | (uintptr_t)d.x1) & 15) == 0 && d.c0 % 8 == 0 && d.c1 % 8 == 0 &&
-                       d.x0_bstride % 4 == 0 && d.x1_bstride % 4 == 0;
+  // (whole 8-channel chunks for the 3x3 DMA kernel; the row-split 7x7 / 9x9 kernel takes a partial last chunk)
+  const bool big = d.ks == 7 || d.ks == 9;
+  const bool aligned = (((uintptr_t)d.x0 | (uintptr_t)d.x1) & 15) == 0 && (big ? (d.c1 == 0 || d.c0 % 8 == 0) : (d.c0 % 8 == 0 && d.c1 % 8 == 0)) &&
+                       d.x0_bstride % 4 == 0 && d.x1_bstride % 4 == 0 && (d.H * d.W) % 4 == 0;
   return op_pack(d.ks, 1, d.pad, d.N, d.H, d.W, Cout, Ctot, d.c1 == 0 || d.c0 % 32 == 0, aligned);
 }
 int op_run(const dvsr_conv2d_desc& d, const dvsr::ConvExtra& ex, int Cout, int Ctot, void* ws, size_t bytes, hipStream_t st) {
   using namespace dvsr;
-  DVSR_REQUIRE((d.ks == 1 || d.ks == 3) && d.stride == 1 && d.pad == d.ks / 2, DVSR_ERR_UNSUPPORTED,
-               "conv2d (packed): ks=%d stride=%d pad=%d (1x1 / 3x3, stride 1, pad ks/2)", d.ks, d.stride, d.pad);
+  DVSR_REQUIRE((d.ks == 1 || d.ks == 3 || d.ks == 7 || d.ks == 9) && d.stride == 1 && d.pad == d.ks / 2, DVSR_ERR_UNSUPPORTED,
+               "conv2d (packed): ks=%d stride=%d pad=%d (1x1 / 3x3 / 7x7 / 9x9, stride 1, pad ks/2)", d.ks, d.stride, d.pad);
   const OpPack o = op_pack_for(d, Cout, Ctot);
+  DVSR_REQUIRE(d.ks <= 3 || o.geo.dma == 2, DVSR_ERR_UNSUPPORTED, "conv2d (packed): this %dx%d convolution is not eligible for the "
+               "row-split kernel (dvsr_conv2d_packed_geometry): use dvsr_conv2d_forward / _backward", d.ks, d.ks);
   DVSR_REQUIRE(ws && bytes >= o.floats * sizeof(float), DVSR_ERR_WORKSPACE, "conv2d (packed): workspace %zu < %zu bytes", bytes,
                o.floats * sizeof(float));
   PackTable t;
@@ -975,7 +1186,7 @@ int op_run(const dvsr_conv2d_desc& d, const dvsr::ConvExtra& ex, int Cout, int C
 }  // namespace
 
 extern "C" size_t dvsr_conv2d_packed_workspace_bytes(const dvsr_conv2d_desc* d) {
-  if (!d || (d->ks != 1 && d->ks != 3)) return 0;
+  if (!d || (d->ks != 1 && d->ks != 3 && d->ks != 7 && d->ks != 9)) return 0;
   // the larger of the forward pack and the data-gradient pack (roles of Cout and Ctot swapped)
   const int ctot = d->c0 + d->c1;
   const size_t a = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, d->Cout, ctot, true).floats;
@@ -985,8 +1196,8 @@ extern "C" size_t dvsr_conv2d_packed_workspace_bytes(const dvsr_conv2d_desc* d) 
 }
 
 extern "C" int dvsr_conv2d_packed_geometry(const dvsr_conv2d_desc* d, int geo[4]) {
-  DVSR_REQUIRE(d && geo && (d->ks == 1 || d->ks == 3) && d->stride == 1 && d->pad == d->ks / 2, DVSR_ERR_INVALID,
-               "conv2d_packed_geometry: 1x1 / 3x3 stride-1 descriptors only");
+  DVSR_REQUIRE(d && geo && (d->ks == 1 || d->ks == 3 || d->ks == 7 || d->ks == 9) && d->stride == 1 && d->pad == d->ks / 2,
+               DVSR_ERR_INVALID, "conv2d_packed_geometry: 1x1 / 3x3 / 7x7 / 9x9 stride-1 descriptors only");
   const OpPack o = op_pack_for(*d, d->Cout, d->c0 + d->c1);
   geo[0] = o.geo.cc; geo[1] = o.geo.th; geo[2] = o.geo.mt; geo[3] = o.geo.dma;
   return DVSR_OK;

@@ -6,6 +6,8 @@ convolutions (7x7 / 9x9 / 1x1 with bias, ReLU and residual fused) on the MFMA co
 flow_warp, the 2x2 average pool of the SpyNet pyramids, the align_corners=True flow up-sampling and the
 (de)normalisation.  fp32 CUDA(HIP) tensors only; there is no CPU path.
 """
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -19,6 +21,17 @@ def _chk(*ts):
 
 def _f(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _packed_ok(d, ks):
+    """1x1 / 3x3 always have a packed kernel; 7x7 / 9x9 only the row-split DMA kernel (W % 4 == 0, aligned, Cout >= 16)."""
+    if ks in (1, 3):
+        return True
+    if ks not in (7, 9):
+        return False
+    geo = (ctypes.c_int * 4)()
+    L.check(L.lib().dvsr_conv2d_packed_geometry(d, ctypes.byref(geo)), "dvsr_conv2d_packed_geometry")
+    return geo[3] == 2
 
 
 class _Conv(torch.autograd.Function):
@@ -36,7 +49,7 @@ class _Conv(torch.autograd.Function):
         y = x.new_empty((n, cout, h, wd))
         d = L.Conv2dDesc(L.ptr(x), None, L.ptr(w), L.ptr(b), L.ptr(res), L.ptr(y), n, c, 0, h, wd, cout, ks, 1, ks // 2,
                          act, 0, 1, 0, 0)
-        if ks in (1, 3):     # pipelined / small-grid kernels over a packed weight image
+        if _packed_ok(d, ks):   # pipelined / small-grid / DMA kernels over a packed weight image
             ws = torch.empty(max(int(L.lib().dvsr_conv2d_packed_workspace_bytes(d)), 16), dtype=torch.uint8, device=x.device)
             L.check(L.lib().dvsr_conv2d_forward_packed(d, ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_forward_packed")
         else:
@@ -62,7 +75,10 @@ class _Conv(torch.autograd.Function):
         ws = torch.empty(max(int(L.lib().dvsr_conv2d_backward_workspace_bytes(d)), 16), dtype=torch.uint8, device=x.device)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gw, gb = torch.empty_like(w), w.new_empty(cout)
-        packed = ks in (1, 3) and gx is not None
+        packed = False
+        if gx is not None:   # the data gradient is the forward kernel over gy with Cout and Cin swapped
+            dg = L.Conv2dDesc(L.ptr(gy), None, None, None, None, None, n, cout, 0, h, wd, c, ks, 1, ks // 2, 0, 0, 1, 0, 0)
+            packed = _packed_ok(dg, ks)
         L.check(L.lib().dvsr_conv2d_backward(d, L.ptr(gy), None if packed else L.ptr(gx), None, L.ptr(gw), L.ptr(gb),
                                              ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_backward")
         if packed:

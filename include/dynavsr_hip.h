@@ -269,8 +269,9 @@ int dvsr_conv2d_dgrad_packed(const dvsr_conv2d_desc* d, const float* gy, float* 
                              size_t workspace_bytes, dvsr_stream_t stream);
 /* Which kernel dvsr_conv2d_forward_packed runs for d (tests and tools): geo[0..3] = input channels per chunk,
  * tile rows (x 32 pixels), 32-output-channel halves per workgroup, 1 when the halo is staged by LDS-DMA
- * (conv2d_dma_kernel: 3x3 / stride 1, 16-byte aligned inputs, W % 4 == 0, channel counts % 8 == 0).
- * 32-channel chunks = the K-split small-grid kernel. */
+ * (conv2d_dma_kernel: 3x3 / stride 1, 16-byte aligned inputs, W % 4 == 0, channel counts % 8 == 0), 2 for the row-split
+ * DMA kernel of 7x7 / 9x9 convolutions (conv2d_dmarow_kernel) -- for those sizes the packed entries exist ONLY when
+ * geo[3] == 2, otherwise use dvsr_conv2d_forward / _backward.  32-channel chunks = the K-split small-grid kernel. */
 int dvsr_conv2d_packed_geometry(const dvsr_conv2d_desc* d, int geo[4]);
 
 /* Weight / bias gradient of a single-input 3x3 stride-1 convolution with both operands rounded to bf16 on

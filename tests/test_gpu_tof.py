@@ -20,10 +20,20 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize("ks,cin,cout,h,w", [(7, 8, 32, 20, 37), (7, 64, 32, 16, 32), (7, 16, 2, 9, 33), (9, 21, 64, 24, 40),
-                                             (9, 64, 64, 16, 16), (1, 64, 3, 12, 20)])
+                                             (9, 64, 64, 16, 16), (1, 64, 3, 12, 20),
+                                             # W % 4 == 0: the row-split DMA kernel (forward and / or data gradient)
+                                             (7, 8, 32, 21, 36), (7, 16, 2, 12, 36), (7, 32, 64, 41, 100), (7, 32, 16, 8, 64),
+                                             (9, 64, 64, 30, 72), (9, 21, 64, 9, 132)])
 def test_tof_conv_forward_backward(ks, cin, cout, h, w):
     """SpyNet's 7x7, the head's 9x9 / 1x1: bias + ReLU + residual fused forward, and dX / dW / db."""
+    import ctypes
     from dynavsr_amd import _lib as L, tofops as T
+    if ks > 3:   # which kernel: row-split DMA (geo[3] == 2) exactly when W % 4 == 0 and Cout >= 16
+        xa = torch.empty(2, cin, h, w, device="cuda")
+        geo = (ctypes.c_int * 4)()
+        d = L.Conv2dDesc(L.ptr(xa), None, None, None, None, None, 2, cin, 0, h, w, cout, ks, 1, ks // 2, 0, 0, 1, 0, 0)
+        L.check(L.lib().dvsr_conv2d_packed_geometry(d, ctypes.byref(geo)), "dvsr_conv2d_packed_geometry")
+        assert (geo[3] == 2) == (w % 4 == 0 and cout >= 16)
     x, wt, b = rnd(2, cin, h, w, seed=1), rnd(cout, cin, ks, ks, seed=2, scale=(cin * ks * ks) ** -0.5), rnd(cout, seed=3, scale=0.1)
     res, go = rnd(2, cout, h, w, seed=4), rnd(2, cout, h, w, seed=5)
     for act, use_res in ((L.ACT_NONE, True), (L.ACT_RELU, False)):
