@@ -28,12 +28,12 @@ def test_tof_conv_forward_backward(ks, cin, cout, h, w):
     """SpyNet's 7x7, the head's 9x9 / 1x1: bias + ReLU + residual fused forward, and dX / dW / db."""
     import ctypes
     from dynavsr_amd import _lib as L, tofops as T
-    if ks > 3:   # which kernel: row-split DMA (geo[3] == 2) exactly when W % 4 == 0 and Cout >= 16
+    if ks > 3:   # which kernel: row-split DMA (geo[3] == 2) exactly when W % 4 == 0
         xa = torch.empty(2, cin, h, w, device="cuda")
         geo = (ctypes.c_int * 4)()
         d = L.Conv2dDesc(L.ptr(xa), None, None, None, None, None, 2, cin, 0, h, w, cout, ks, 1, ks // 2, 0, 0, 1, 0, 0)
         L.check(L.lib().dvsr_conv2d_packed_geometry(d, ctypes.byref(geo)), "dvsr_conv2d_packed_geometry")
-        assert (geo[3] == 2) == (w % 4 == 0 and cout >= 16)
+        assert (geo[3] == 2) == (w % 4 == 0)
     x, wt, b = rnd(2, cin, h, w, seed=1), rnd(cout, cin, ks, ks, seed=2, scale=(cin * ks * ks) ** -0.5), rnd(cout, seed=3, scale=0.1)
     res, go = rnd(2, cout, h, w, seed=4), rnd(2, cout, h, w, seed=5)
     for act, use_res in ((L.ACT_NONE, True), (L.ACT_RELU, False)):
