@@ -25,12 +25,14 @@ import statistics
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")   # see dynavsr_amd/_lib.py: must precede the first HIP call
-
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+import dynavsr_amd  # noqa: E402
+
+dynavsr_amd.configure_runtime()   # six hardware queues unless the user chose; precedes the first HIP call
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, dense bf16
@@ -394,6 +396,76 @@ def split_mode_rate(cfg, h, w, x, y_fp32, steps, warmup):
             "note": "opt-in (bf16_mfma = 2), held to the fp32 parity bars by tests/test_gpu_edvr.py"}
 
 
+def _spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: re-run this file under torch.distributed.run with N local ranks
+    (rendezvous on 127.0.0.1, a free port) and hand its exit code back."""
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def _dry_run(rank, world, args):
+    """The N-rank skeleton of the bench with no kernels: gloo process group on the CPU, the barrier-bracketed timed loop,
+    the MAX-over-ranks reduction of the elapsed time, the flat meta-gradient all-reduce (dist.allreduce_meta_gradients on a
+    tensor list of the real size: 15.0 MB for EDVR-M + MFDN) and the round-robin frame shards with their metric reduction
+    (dist.shard_indices / reduce_metric_vectors).  Rank 0 returns the JSON line."""
+    import torch.distributed as tdist
+    from dynavsr_amd import dist as D
+    if world > 1 or "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        tdist.init_process_group("gloo", rank=rank, world_size=world)
+    grouped = tdist.is_initialized()
+
+    def barrier():
+        if grouped:
+            tdist.barrier()
+    work = torch.zeros(1)
+    for _ in range(args.warmup):
+        work += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        work += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    if grouped:
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+    elapsed = float(t)
+    # the one exchange step of the method, on parameters of the real sizes (values: rank + 1, averaged -> (world + 1) / 2)
+    holder = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(n)) for n in (3_300_131, 452_291)])
+    for p in holder:
+        p.grad = torch.full_like(p, float(rank + 1))
+    nbytes = D.allreduce_meta_gradients([holder], average=True, force=grouped)
+    ok = all(bool((p.grad == (world + 1) / 2.0).all()) for p in holder)
+    # distributed validation: frames range(rank, n, world), per-frame metric vector reduced to rank 0
+    frames = 10
+    vec = torch.zeros(frames, dtype=torch.float64)
+    for i in D.shard_indices(frames, rank, world):
+        vec[i] = 30.0 + i
+    D.reduce_metric_vectors([vec])
+    if grouped:
+        tdist.barrier()
+        tdist.destroy_process_group()
+    if rank != 0:
+        return None
+    return {"metric": "dry run: launcher and process-group plumbing only (gloo, CPU, no kernels)", "value": None,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+            "config": {"workload": "none (dry run)", "clips_per_step": world},
+            "meta_step": {"ranks": world, "allreduce": {"backend": "gloo", "bytes": nbytes, "executed": grouped,
+                                                         "averaged_correctly": ok}},
+            "validation": {"frames": frames, "sharding": "range(rank, frames, world)",
+                           "psnr_vector_complete": bool((vec == torch.arange(frames, dtype=torch.float64) + 30.0).all())}}
+
+
 def main():
     # The ONE JSON line must be the only thing on stdout: RCCL prints a version banner there (from C, flushed at exit),
     # so file descriptor 1 is pointed at stderr for the whole run and the line goes to the saved descriptor.
@@ -410,14 +482,29 @@ def main():
     ap.add_argument("--no-inner-step", action="store_true", help="skip the inner-step and per-frame-pipeline legs")
     ap.add_argument("--no-split", action="store_true", help="skip the bf16 legs (split-mode forward, EDVR-L)")
     ap.add_argument("--no-meta", action="store_true", help="skip the meta-training iteration with the RCCL all-reduce")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / process-group plumbing only, on the CPU over gloo (no kernels): what tests/ run here")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, the way the reference's
+        # README launches its trainer (README.md:92-96, `python -m torch.distributed.launch --nproc_per_node=8 ...`;
+        # train_dynavsr.py:23-30 reads the rendezvous from the environment).  Rank 0 of the children prints the JSON line
+        # to the stdout it inherits from this process.
+        os.dup2(real_stdout, 1)
+        sys.exit(_spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)"
-                         % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or with "
+                         "torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    if args.dry_run:
+        line = _dry_run(rank, world, args)
+        if line is not None:
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     torch.cuda.set_device(local_rank)

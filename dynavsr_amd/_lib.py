@@ -10,12 +10,28 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_s
 
 import torch
 
-# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and streams that share a queue run behind
-# each other.  The execution plans put their weight gradients on a side stream; with the default, as soon as another
-# component of the process holds streams (an initialised RCCL communicator does) that side stream shares a queue and the
-# inner MAML step measures 10.0 instead of 8.2 ms.  One more queue is enough.  The runtime reads the
-# variable when HIP is initialised, i.e. at the first device call, not at `import torch`: set your own value before that.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+_runtime = {"configured": False, "hw_queues": None, "effective": None}
+
+
+def configure_runtime(hw_queues=6):
+    """Process-wide runtime settings the execution plans want, applied EXPLICITLY (never at import).
+
+    ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and streams that share a queue run
+    behind each other.  The plans put their weight gradients on a side stream; with the default, as soon as another
+    component of the process holds streams (an initialised RCCL communicator does) that side stream shares a queue and
+    the inner MAML step measures 10.0 instead of 8.2 ms.  Two more queues are enough.  The runtime reads
+    the variable when HIP is initialised (the first device call), so this must run before that: `create_model`,
+    `bench.py` and the tools call it first thing.  A value the user exported is never overridden.  Returns
+    {"hw_queues": the value in force, "effective": False when HIP was already initialised and the value came too late}."""
+    if not _runtime["configured"]:
+        user = os.environ.get("GPU_MAX_HW_QUEUES")
+        late = torch.cuda.is_initialized()
+        if user is None and not late:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(int(hw_queues))
+        _runtime.update(configured=True, hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
+                        effective=(user is not None) or not late)
+    return {"hw_queues": _runtime["hw_queues"], "effective": _runtime["effective"]}
+
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libdynavsr_hip.so")

@@ -66,7 +66,8 @@ __device__ __forceinline__ int rx_channel(int c, int r, int R, int adapt) { retu
 // planes of the centre frame (zero padded), + residual, stored at the pixel-shuffled position.
 __global__ void dynamic_filter_fwd_kernel(const float* __restrict__ xc, const float* __restrict__ fx,
                                           const float* __restrict__ rx, float* __restrict__ out, int B, int H, int W,
-                                          int S, int adapt) {
+                                          int S, int flags) {
+  const int adapt = flags & 1, raw = flags & 2;
   const int R = S * S;
   const size_t HW = (size_t)H * W, total = (size_t)B * R * HW;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -78,10 +79,13 @@ __global__ void dynamic_filter_fwd_kernel(const float* __restrict__ xc, const fl
     float l[25], m = -3.4e38f;
 #pragma unroll
     for (int k = 0; k < 25; ++k) { l[k] = f[(size_t)k * R * HW]; m = fmaxf(m, l[k]); }
-    float den = 0.f;
+    float inv = 1.f;
+    if (!raw) {   // raw: the 25 values ARE the filter taps (DynamicUpsamplingFilter_3C as a module applies them as given)
+      float den = 0.f;
 #pragma unroll
-    for (int k = 0; k < 25; ++k) { l[k] = expf(l[k] - m); den += l[k]; }
-    const float inv = 1.f / den;
+      for (int k = 0; k < 25; ++k) { l[k] = expf(l[k] - m); den += l[k]; }
+      inv = 1.f / den;
+    }
     float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 25; ++k) {
@@ -104,7 +108,8 @@ __global__ void dynamic_filter_fwd_kernel(const float* __restrict__ xc, const fl
 // gfx (logits) and grx written in full; gxc (optional, zeroed by the caller) accumulated with atomics.
 __global__ void dynamic_filter_bwd_kernel(const float* __restrict__ xc, const float* __restrict__ fx,
                                           const float* __restrict__ gout, float* __restrict__ gfx, float* __restrict__ grx,
-                                          float* __restrict__ gxc, int B, int H, int W, int S, int adapt) {
+                                          float* __restrict__ gxc, int B, int H, int W, int S, int flags) {
+  const int adapt = flags & 1, raw = flags & 2;
   const int R = S * S;
   const size_t HW = (size_t)H * W, total = (size_t)B * R * HW;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -116,10 +121,13 @@ __global__ void dynamic_filter_bwd_kernel(const float* __restrict__ xc, const fl
     float l[25], m = -3.4e38f;
 #pragma unroll
     for (int k = 0; k < 25; ++k) { l[k] = f[(size_t)k * R * HW]; m = fmaxf(m, l[k]); }
-    float den = 0.f;
+    float inv = 1.f;
+    if (!raw) {
+      float den = 0.f;
 #pragma unroll
-    for (int k = 0; k < 25; ++k) { l[k] = expf(l[k] - m); den += l[k]; }
-    const float inv = 1.f / den;
+      for (int k = 0; k < 25; ++k) { l[k] = expf(l[k] - m); den += l[k]; }
+      inv = 1.f / den;
+    }
     const int oy = S * y + r / S, ox = S * x + r % S;
     float g[3];
 #pragma unroll
@@ -147,7 +155,7 @@ __global__ void dynamic_filter_bwd_kernel(const float* __restrict__ xc, const fl
     }
     float* gf = gfx + ((size_t)b * 25 * R + r) * HW + p;
 #pragma unroll
-    for (int k = 0; k < 25; ++k) gf[(size_t)k * R * HW] = l[k] * inv * (dp[k] - dot);
+    for (int k = 0; k < 25; ++k) gf[(size_t)k * R * HW] = raw ? dp[k] : l[k] * inv * (dp[k] - dot);
   }
 }
 

@@ -111,6 +111,7 @@ struct dvsr_edvr_plan {
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int side_streams = 1;                           // DVSR_BWD_STREAMS=0 disables
   int fork_every = 3;                             // weight gradients of this many layers share one fork (see backward)
+  const char* bwd_unsupported = nullptr;          // set by build_backward when the tape has an op it cannot differentiate
 };
 
 namespace dvsr {
@@ -489,6 +490,10 @@ static void build_backward(dvsr_edvr_plan& p) {
     switch (o.type) {
       case OP_CONV: {
         const int Ho = conv_out(o, o.H), Wo = conv_out(o, o.W);
+        // y = act(conv + b) + res: the residual gradient is the RAW gy, and act' would need the sign of the pre-residual
+        // value, which the tape does not keep (B_ACT masks gy in place by the sign of y; a deferred residual copy would
+        // then read the masked gy).  No tape combines the two (fe_rb_b, rc_rb_b, conv_last are ACT_NONE): refuse it.
+        if (o.res.valid() && o.act != ACT_NONE) p.bwd_unsupported = "a convolution with both a residual input and an activation";
         if (o.res.valid()) bb.copyadd(o.res, gy, o.y.numel, i);
         if (o.act != ACT_NONE && !act_fused[i]) {
           BOp a; a.type = B_ACT; a.fwd = i; a.a = gy; a.b = BackBuilder::act(o.y); a.n = o.y.numel;
@@ -921,6 +926,7 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
                                   const float* grad_out, float* const* grad_params, float* grad_x, void* ws,
                                   size_t ws_bytes, dvsr_stream_t stream) {
   DVSR_REQUIRE(p && params && x && grad_out && grad_params && ws, DVSR_ERR_INVALID, "edvr_backward: null argument");
+  DVSR_REQUIRE(!p->bwd_unsupported, DVSR_ERR_UNSUPPORTED, "edvr_backward: the tape holds %s", p->bwd_unsupported);
   DVSR_REQUIRE(ws_bytes >= dvsr_edvr_workspace_bytes(p, 1), DVSR_ERR_WORKSPACE,
                "edvr_backward: workspace %zu < %zu bytes (allocate with need_grad=1 BEFORE the forward)", ws_bytes,
                dvsr_edvr_workspace_bytes(p, 1));

@@ -78,7 +78,7 @@ class LRimgestimator_Model(BaseModel):
         self.optimizer_E.zero_grad()
         self.forward_without_optim()
         lr_loss = self.MyLoss(self.fake_L, self.real_L)
-        self.log_dict['l_pix'] = lr_loss.detach()
+        self.log_dict['l_pix'] = lr_loss.detach().clone()
         lr_loss.backward()
         self.optimizer_E.step()
 

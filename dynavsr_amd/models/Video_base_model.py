@@ -80,7 +80,7 @@ class VideoBaseModel(BaseModel):
 
     def calculate_loss(self):
         l_pix = self._pixel_loss()
-        self.log_dict['l_pix'] = l_pix.detach()
+        self.log_dict['l_pix'] = l_pix.detach().clone()   # own storage: the drivers add to the returned loss IN PLACE (test_dynavsr.py:264-274)
         return l_pix
 
     def optimize_parameters(self, step):
@@ -88,13 +88,13 @@ class VideoBaseModel(BaseModel):
         l_pix = self._pixel_loss()
         l_pix.backward()
         self.optimizer_G.step()
-        self.log_dict['l_pix'] = l_pix.detach()
+        self.log_dict['l_pix'] = l_pix.detach().clone()   # own storage: the drivers add to the returned loss IN PLACE (test_dynavsr.py:264-274)
 
     def optimize_by_loss(self, loss):
         self.optimizer_G.zero_grad()
         loss.backward()
         self.optimizer_G.step()
-        self.log_dict['l_pix'] = loss.detach()
+        self.log_dict['l_pix'] = loss.detach().clone()
 
     def test(self):
         self.netG.eval()

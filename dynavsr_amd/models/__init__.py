@@ -26,6 +26,8 @@ def _make(kind, opt):
 
 
 def create_model(opt):
+    from .. import configure_runtime
+    configure_runtime()     # before the wrappers touch the device (dynavsr_amd/_lib.py:configure_runtime)
     kinds = opt['model']
     if '+' in kinds:
         return [_make(k, opt) for k in kinds.split('+')]

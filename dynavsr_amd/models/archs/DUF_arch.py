@@ -99,8 +99,9 @@ class DenseBlock_52L(_DenseStack):
 
 
 class DynamicUpsamplingFilter_3C(nn.Module):
-    """x [B,3,H,W], filters [B,25,R,H,W] (already soft-maxed) -> [B,3R,H,W] (DUF_arch.py:86-110).  Kept for the
-    reference's module surface; DUF.forward uses the fused ``tofops.dynamic_filter`` instead."""
+    """x [B,3,H,W], filters [B,25,R,H,W] -> [B,3R,H,W] (DUF_arch.py:86-110): the filters are applied AS GIVEN, whatever
+    they sum to, and the gradient w.r.t. them is the plain one (the kernel's no-softmax mode).  Kept for the reference's
+    module surface; DUF.forward uses the fused ``tofops.dynamic_filter`` (softmax folded in) instead."""
 
     def __init__(self, filter_size=(1, 5, 5)):
         super().__init__()
@@ -110,8 +111,8 @@ class DynamicUpsamplingFilter_3C(nn.Module):
     def forward(self, x, filters):
         b, nf, r, h, w = filters.shape
         s = int(round(r ** 0.5))
-        logits = torch.log(filters.clamp_min(1e-30)).reshape(b, nf * r, h, w)     # softmax(log p) = p
-        out = T.dynamic_filter(x, logits, x.new_zeros((b, 3 * r, h, w)), s, False)   # [B,3,sH,sW] pixel-shuffled
+        out = T.dynamic_filter(x, filters.reshape(b, nf * r, h, w), x.new_zeros((b, 3 * r, h, w)), s, False,
+                               taps_given=True)                                 # [B,3,sH,sW] pixel-shuffled
         return torch.nn.functional.pixel_unshuffle(out, s)
 
 

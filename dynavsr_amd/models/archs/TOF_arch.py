@@ -87,14 +87,16 @@ class TOFlow(nn.Module):
         return mean, std
 
     def forward(self, x):
-        """x: [B,7,3,H,W] (H, W multiples of 16) -> [B,3,H,W]."""
+        """x: [B,7,3,H,W], H, W >= 16 -> [B,3,H,W].  Any size the reference takes: its pyramid floors (avg_pool2d), the
+        flow starts as zeros of H//16 x W//16 and is resized to each level's own size (TOF_arch.py:69-90) -- the drivers feed
+        180x320 (a 45x80 SLR clip x4), Vid4's 144x180, 22x22 patches."""
         if not x.is_cuda:
             raise RuntimeError("dynavsr_amd TOFlow runs on the MI355X only (input is on %s); there is no CPU fallback" % x.device)
         b, t, c, h, w = x.shape
         if t != 7 or c != 3:
             raise RuntimeError("TOFlow expects [B,7,3,H,W], got %s" % (tuple(x.shape),))
-        if h % 16 or w % 16:
-            raise RuntimeError("TOFlow: H=%d W=%d must be multiples of 16 (4-level SpyNet pyramid)" % (h, w))
+        if h < 16 or w < 16:
+            raise RuntimeError("TOFlow: H=%d W=%d must be at least 16 (4-level SpyNet pyramid, flow of H//16 x W//16)" % (h, w))
         mean, std = self._consts(x)
         x = T.channel_affine(x.reshape(-1, c, h, w), 1.0 / std, -mean / std).view(b, t, c, h, w)   # normalize (:13-16)
         ref_idx = 3

@@ -347,6 +347,7 @@ class _DynamicFilter(torch.autograd.Function):
         return gx, gl, gr, None, None
 
 
-def dynamic_filter(x_center, filter_logits, residual, scale, adapt_official):
-    """softmax over the 25 taps + DynamicUpsamplingFilter_3C + residual (adapt_official order) + pixel_shuffle."""
-    return _DynamicFilter.apply(x_center, filter_logits, residual, scale, adapt_official)
+def dynamic_filter(x_center, filter_logits, residual, scale, adapt_official, taps_given=False):
+    """softmax over the 25 taps + DynamicUpsamplingFilter_3C + residual (adapt_official order) + pixel_shuffle.
+    taps_given: `filter_logits` holds the filter taps themselves, applied as they are (no softmax)."""
+    return _DynamicFilter.apply(x_center, filter_logits, residual, scale, int(bool(adapt_official)) | (2 if taps_given else 0))

@@ -342,7 +342,9 @@ int dvsr_temporal_gather3_backward(const float* grad_y, float* grad_x, int B, in
  * (channel f*R + r, R = scale^2), DynamicUpsamplingFilter_3C (:86-110) of the centre frame x_center [B][3][H][W] (5x5
  * patch, zero padded), + residual [B][3R][H][W] (channel c*R + r, or 3r + c when adapt_official reorders it, :17-29),
  * F.pixel_shuffle(scale) -> out [B][3][scale*H][scale*W].  Backward: grad_logits and grad_residual are written in
- * full; grad_x_center may be NULL (the clip is data in the inner loop). */
+ * full; grad_x_center may be NULL (the clip is data in the inner loop).  adapt_official is a bit set: bit 0 = the
+ * residual's channel order above; bit 1 = `filter_logits` already holds the 25 filter TAPS, applied as given with no
+ * softmax (DynamicUpsamplingFilter_3C used as a module on its own, :100-110; grad_logits is then d/d(taps)). */
 int dvsr_dynamic_filter_forward(const float* x_center, const float* filter_logits, const float* residual, float* out,
                                 int B, int H, int W, int scale, int adapt_official, dvsr_stream_t stream);
 int dvsr_dynamic_filter_backward(const float* x_center, const float* filter_logits, const float* grad_out,

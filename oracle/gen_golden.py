@@ -252,6 +252,26 @@ def tof_cases():
          running_mean_b3_1=sd_after["SpyNet.blocks.3.block.1.running_mean"],
          running_var_b3_1=sd_after["SpyNet.blocks.3.block.1.running_var"],
          **{"grad__" + k.replace(".", "__"): ref_g[k] for k in keep})
+    # sizes that are NOT multiples of 16 (the drivers feed 180x320 = a 45x80 SLR clip x4, Vid4's 144x180, 22x22 patches):
+    # the pyramid floors, the first flow is H//16 x W//16 zeros resized to each level's own size (TOF_arch.py:69-90)
+    for (h, w, seed) in ((44, 40, 21), (20, 30, 22)):
+        x = synth.clip(seed, 1, 7, h, w)
+        tgt = synth.clip(seed + 100, 1, 1, h, w)[:, 0]
+        net = load_sd(TOF.TOFlow(adapt_official=True), P)
+        net.eval()
+        with torch.no_grad():
+            y_eval = net(x.clone())
+            yo = otof.toflow_forward(OrderedDict((k, v.clone()) for k, v in P.items()), x, training=False)
+        assert relerr(yo, y_eval) < 1e-6, relerr(yo, y_eval)
+        net.train()
+        y = net(x.clone())
+        loss = oedvr.charbonnier(y, tgt)
+        loss.backward()
+        ref_g = OrderedDict((k, p.grad.detach()) for k, p in net.named_parameters())
+        save("tof_%dx%d" % (h, w), wseed=2, xseed=seed, tseed=seed + 100, h=h, w=w, out_eval=y_eval, out_train=y,
+             loss=float(loss.detach()), grad_names=np.array(list(ref_g.keys())),
+             grad_norms=np.array([float(g.norm()) for g in ref_g.values()]),
+             **{"grad__" + k.replace(".", "__"): ref_g[k] for k in keep[:2]})
 
 
 def duf_cases():

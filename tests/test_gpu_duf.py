@@ -129,3 +129,14 @@ def test_duf_batch2_vs_oracle_and_module_surface():
     xc, fx = torch.rand(1, 3, 6, 7), torch.softmax(torch.randn(1, 25, 16, 6, 7), 1)
     want = oduf.dynamic_filter_3c(xc.double(), fx.double())
     assert relerr(DynamicUpsamplingFilter_3C((1, 5, 5))(xc.cuda(), fx.cuda()), want) < 1e-5
+    # ... and filters that do NOT sum to one (negative taps too) are applied as given, like the reference's matmul
+    # (DUF_arch.py:100-110), with the plain gradient w.r.t. them
+    fr = torch.randn(1, 25, 16, 6, 7)
+    xd, fd = xc.double().requires_grad_(), fr.double().requires_grad_()
+    want = oduf.dynamic_filter_3c(xd, fd)
+    go = torch.randn_like(want)
+    gx_w, gf_w = torch.autograd.grad(want, [xd, fd], go)
+    xg, fg = xc.cuda().requires_grad_(), fr.cuda().requires_grad_()
+    got = DynamicUpsamplingFilter_3C((1, 5, 5))(xg, fg)
+    gx_g, gf_g = torch.autograd.grad(got, [xg, fg], go.float().cuda())
+    assert relerr(got, want) < 1e-5 and relerr(gx_g, gx_w) < 1e-5 and relerr(gf_g, gf_w) < 1e-5

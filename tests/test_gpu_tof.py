@@ -184,6 +184,40 @@ def test_toflow_eval_and_training_golden():
     assert int(sd["SpyNet.blocks.0.block.1.num_batches_tracked"]) == 6
 
 
+@pytest.mark.parametrize("name", ["tof_44x40", "tof_20x30"])
+def test_toflow_sizes_not_multiples_of_16_golden(name):
+    """Sizes the drivers actually feed TOFlow (180x320 = a 45x80 SLR clip x4, Vid4's 144x180, 22x22 patches) are not
+    multiples of 16: the pyramid floors and the H//16 x W//16 zero flow is resized to each level's own size
+    (TOF_arch.py:69-90).  Goldens from the reference's module: eval forward, training forward, loss, all 80 gradient norms."""
+    from dynavsr_amd import hipops
+    g = load_golden(name)
+    h, w = int(g["h"]), int(g["w"])
+    x = synth.clip(int(g["xseed"]), 1, 7, h, w).cuda()
+    tgt = synth.clip(int(g["tseed"]), 1, 1, h, w)[:, 0].cuda()
+    net = _tof(int(g["wseed"]))
+    net.eval()
+    with torch.no_grad():
+        y = net(x)
+    assert relerr(y, g["out_eval"]) < 2e-4 and float((y.cpu() - torch.from_numpy(g["out_eval"])).abs().max()) < 1e-3
+    net.train()
+    y = net(x)
+    assert relerr(y, g["out_train"]) < 2e-4
+    loss = hipops.charbonnier(y, tgt)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss.backward()
+    by_name = dict(net.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    bad = [(k, float(by_name[k].grad.norm()), b) for k, b in zip(names, g["grad_norms"])
+           if abs(float(by_name[k].grad.norm()) - b) > 2e-3 * b + 1e-6]
+    assert not bad, bad[:6]
+    for key in g:
+        if key.startswith("grad__"):
+            name_ = key[len("grad__"):].replace("__", ".")
+            assert relerr(by_name[name_].grad, g[key]) < 1e-2, name_
+    with pytest.raises(RuntimeError, match="at least 16"):
+        net(x[..., :12, :])
+
+
 def test_toflow_batch2_vs_oracle_and_wrapper():
     """B = 2 at another size against oracle/tof.py (flows, warped stack, output), and the wrapper API with
     network_G.which_model_G = TOF (networks.py:37-39): feed_data / test() / calculate_loss / backward."""

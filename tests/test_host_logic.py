@@ -303,15 +303,63 @@ def test_log_dict_reads_as_floats_without_an_eager_sync():
     from dynavsr_amd.models import create_model
     model, est = create_model(cpu_opt())
     assert isinstance(model.log_dict, LogDict) and model.get_current_log() is model.log_dict
+    # the drivers add the SLR term to the returned loss IN PLACE (`loss_train += 10 * F.l1_loss(...)`, test_dynavsr.py:264-274):
+    # the logged value must stay the pixel loss the reference's eager .item() captured
+    model._pixel_loss = lambda: torch.tensor(2.0, requires_grad=True) * 1.0
+    loss = model.calculate_loss()
+    with torch.no_grad():
+        loss += 5.0
+    assert float(loss) == 7.0 and model.log_dict['l_pix'] == 2.0
 
 
-def test_hw_queue_default_is_set_once_and_respects_the_user(monkeypatch):
-    """dynavsr_amd/_lib.py asks ROCm for six hardware queues unless the user chose a value."""
+def test_hw_queue_default_is_explicit_and_respects_the_user(monkeypatch):
+    """Importing the package leaves GPU_MAX_HW_QUEUES alone; dynavsr_amd.configure_runtime() asks ROCm for six hardware
+    queues unless the user chose a value, once per process."""
     import importlib
+    import dynavsr_amd
     import dynavsr_amd._lib as L
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
     importlib.reload(L)
-    assert os.environ["GPU_MAX_HW_QUEUES"] == "6"
+    assert "GPU_MAX_HW_QUEUES" not in os.environ            # import time: no process-wide side effect
+    r = dynavsr_amd.configure_runtime()
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "6" and r == {"hw_queues": "6", "effective": True}
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    assert dynavsr_amd.configure_runtime()["hw_queues"] == "6"   # idempotent: the first call decided
     importlib.reload(L)
-    assert os.environ["GPU_MAX_HW_QUEUES"] == "4"
+    assert L.configure_runtime() == {"hw_queues": "4", "effective": True} and os.environ["GPU_MAX_HW_QUEUES"] == "4"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    importlib.reload(L)
+    from dynavsr_amd.models import create_model
+    create_model(cpu_opt())                                  # the wrappers configure the runtime themselves
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "6"
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_dry_run(launcher):
+    """`python bench.py --gpus 2` must start its own ranks (no launcher: README.md:92-96 starts the reference's trainer
+    as one process per GPU; train_dynavsr.py:23-30), and the torch.distributed.run form the driver uses for N > 1 must
+    keep working.  --dry-run runs the N-rank skeleton over gloo on the CPU: barriers, MAX of the elapsed time, the flat
+    15 MB meta-gradient all-reduce, the frame shards + metric reduction; rank 0 prints ONE JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"]
+    if launcher == "self":
+        cmd = [sys.executable, bench] + args
+    else:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), bench] + args
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry_run"] and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["meta_step"]["ranks"] == 2 and line["meta_step"]["allreduce"]["executed"]
+    assert line["meta_step"]["allreduce"]["averaged_correctly"] and line["meta_step"]["allreduce"]["bytes"] == 4 * (3300131 + 452291)
+    assert line["validation"]["psnr_vector_complete"]

@@ -7,6 +7,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dynavsr_amd  # noqa: E402
+dynavsr_amd.configure_runtime()   # hardware queues for the side streams, before the first HIP call
 from dynavsr_amd import hipops  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20

@@ -10,6 +10,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dynavsr_amd  # noqa: E402
+dynavsr_amd.configure_runtime()   # hardware queues for the side streams, before the first HIP call
 from dynavsr_amd.data.random_kernel_generator import Degradation  # noqa: E402
 
 for shape, what in (((5, 3, 256, 256), "training sample, HR patch 5x3x256x256 -> LR 64x64 -> SLR 16x16"),

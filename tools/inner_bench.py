@@ -10,6 +10,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import dynavsr_amd  # noqa: E402
+dynavsr_amd.configure_runtime()   # hardware queues for the side streams, before the first HIP call
 from dynavsr_amd import synth  # noqa: E402
 from dynavsr_amd.adapt import adapt_frame  # noqa: E402
 from dynavsr_amd.models import create_model  # noqa: E402

@@ -12,6 +12,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import dynavsr_amd  # noqa: E402
+dynavsr_amd.configure_runtime()   # hardware queues for the side streams, before the first HIP call
 import bench  # noqa: E402
 from dynavsr_amd import hipops, synth  # noqa: E402
 from dynavsr_amd.adapt import make_inner_optimizer  # noqa: E402

@@ -11,6 +11,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dynavsr_amd  # noqa: E402
+dynavsr_amd.configure_runtime()   # hardware queues for the side streams, before the first HIP call
 from dynavsr_amd.utils import util  # noqa: E402
 
 h = int(sys.argv[1]) if len(sys.argv) > 2 else 720

@@ -12,6 +12,8 @@ if os.environ.get('LATE_QUEUES'):   # set AFTER `import torch`, before the first
     os.environ['GPU_MAX_HW_QUEUES'] = os.environ['LATE_QUEUES']
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dynavsr_amd  # noqa: E402
+dynavsr_amd.configure_runtime()   # hardware queues for the side streams, before the first HIP call
 import bench  # noqa: E402
 
 dev = torch.device("cuda", 0)

@@ -1,6 +1,8 @@
 """Run-to-run spread of the EDVR weight gradients (fp32 MFMA vs itself, 3-way bf16 split vs fp32)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dynavsr_amd  # noqa: E402
+dynavsr_amd.configure_runtime()   # hardware queues for the side streams, before the first HIP call
 import torch
 from dynavsr_amd import synth
 from dynavsr_amd.models.archs.EDVR_arch import EDVR

@@ -7,6 +7,8 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dynavsr_amd  # noqa: E402
+dynavsr_amd.configure_runtime()   # hardware queues for the side streams, before the first HIP call
 from dynavsr_amd import hipops, synth  # noqa: E402
 from dynavsr_amd.models.archs import TOF_arch  # noqa: E402
 
