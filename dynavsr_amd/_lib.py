@@ -77,6 +77,7 @@ def _declare(lib):
         "dvsr_tsa_blend_forward": (I, [P] * 4 + [LL, P]),
         "dvsr_tsa_blend_backward": (I, [P] * 5 + [LL, P]),
         "dvsr_edvr_plan_create": (I, [POINTER(EdvrConfig), I, I, I, POINTER(c_void_p)]),
+        "dvsr_edvr_plan_create_grouped": (I, [POINTER(EdvrConfig), I, I, I, I, POINTER(c_void_p)]),
         "dvsr_edvr_plan_destroy": (None, [P]),
         "dvsr_edvr_num_params": (I, [P]),
         "dvsr_edvr_num_launches": (I, [P]),
@@ -85,6 +86,7 @@ def _declare(lib):
         "dvsr_edvr_backward": (I, [P, POINTER(c_void_p), P, P, POINTER(c_void_p), P, P, c_size_t, P]),
         "dvsr_edvr_num_backward_launches": (I, [P]),
         "dvsr_estimator_plan_create": (I, [POINTER(EstimatorConfig), I, I, I, POINTER(c_void_p)]),
+        "dvsr_estimator_plan_create_grouped": (I, [POINTER(EstimatorConfig), I, I, I, I, POINTER(c_void_p)]),
         "dvsr_estimator_plan_destroy": (None, [P]),
         "dvsr_estimator_num_params": (I, [P]),
         "dvsr_estimator_num_launches": (I, [P, I]),
@@ -128,6 +130,10 @@ def _declare(lib):
         "dvsr_l1_tail_forward": (I, [P, P, P, F, P, LL, P, c_size_t, P]),
         "dvsr_l1_tail_backward": (I, [P, P, P, F, P, LL, P]),
         "dvsr_charbonnier_backward": (I, [P, P, P, P, LL, F, P]),
+        "dvsr_charbonnier_forward_grouped": (I, [P, P, P, LL, I, F, P, c_size_t, P]),
+        "dvsr_charbonnier_backward_grouped": (I, [P, P, P, P, LL, I, F, P]),
+        "dvsr_l1_tail_forward_grouped": (I, [P, P, P, F, P, LL, I, P, c_size_t, P]),
+        "dvsr_l1_tail_backward_grouped": (I, [P, P, P, F, P, LL, I, P]),
         "dvsr_edvr_op_info": (I, [P, I, c_char_p, I, c_char_p, I, POINTER(ctypes.c_double),
                                   POINTER(ctypes.c_double)]),
         "dvsr_edvr_forward_timed": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P, POINTER(c_float)]),

@@ -247,6 +247,95 @@ def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, opt
     return {'loss_q': total_q, 'loss_train': log_train, 'loss_e': log_e}
 
 
+class FrameBatch:
+    """K frames adapted as ONE batch (north_star: the inner MAML step; test_dynavsr.py:208-277 with adapt_iter = 1).
+
+    The reference deep-copies netG / netE for every frame and takes one optimiser step on the copy.  All K copies start
+    from the same un-adapted weights, so the K forward + backward passes differ only in their data: they run as one
+    batch of K clips through the tapes (launches K times fatter than the 44x80 grids of a single SLR clip), with
+    PER-CLIP parameter gradients (dvsr_edvr_plan_create_grouped).  The K private copies are the slices of stacked
+    [K, *shape] tensors; ONE elementwise optimiser step over the stacks is the K independent inner updates.  The
+    per-frame modules `netG[k]` / `netE[k]` alias the slices (state-dict compatible with the reference's copies)."""
+
+    def __init__(self, opt, netG, netE, k):
+        self.k = k
+        m = opt['train']['maml']
+        self.sig = self.signature(opt, netG, netE)
+        with torch.no_grad():
+            self.g_stack = [torch.empty((k,) + tuple(p.shape), dtype=torch.float32, device=p.device).requires_grad_()
+                            for p in netG.ordered_parameters()]
+            self.e_stack = [torch.empty((k,) + tuple(p.shape), dtype=torch.float32, device=p.device).requires_grad_()
+                            for p in netE.ordered_parameters()]
+        params = self.g_stack + self.e_stack
+        if m['optimizer'] == 'Adam':
+            self.inner = optim.Adam(params, lr=m['lr_alpha'], betas=(m['beta1'], m['beta2']))
+        elif m['optimizer'] == 'SGD':
+            self.inner = optim.SGD(params, lr=m['lr_alpha'])
+        else:
+            raise NotImplementedError()
+        self.netG, self.netE = [], []
+        for i in range(k):                               # frame i's networks: parameters are slice i of the stacks
+            g, e = deepcopy(netG), deepcopy(netE)
+            for p, s_ in zip(g.ordered_parameters(), self.g_stack):
+                p.data = s_.data[i]
+            for p, s_ in zip(e.ordered_parameters(), self.e_stack):
+                p.data = s_.data[i]
+            self.netG.append(g); self.netE.append(e)
+        self.last_use = None                             # event: the last forward that read these weights
+
+    @staticmethod
+    def signature(opt, netG, netE):
+        m = opt['train']['maml']
+        return (m['optimizer'], m['lr_alpha'], m.get('beta1'), m.get('beta2'), type(netG), type(netE),
+                tuple(tuple(p.shape) for p in netG.ordered_parameters()), tuple(tuple(p.shape) for p in netE.ordered_parameters()),
+                str(next(netG.parameters()).device))
+
+    @staticmethod
+    def supported(opt, model, est_model):
+        """What the batched step covers; everything else takes the per-frame loop."""
+        m = opt['train']['maml']
+        from .models.loss import CharbonnierLoss
+        return (m['adapt_iter'] == 1 and not m['use_patch'] and not opt['train']['use_real']
+                and hasattr(model.netG, 'forward_stacked') and hasattr(est_model.netE, 'forward_stacked')
+                and isinstance(model.cri_pix, CharbonnierLoss) and next(model.netG.parameters()).is_cuda
+                and not list(model.netG.buffers()) and not list(est_model.netE.buffers()))
+
+    def refresh(self, netG, netE):
+        """Every slice = the un-adapted weights (the per-frame deepcopy), fresh optimiser state."""
+        with torch.no_grad():
+            src = [p.detach().unsqueeze(0).expand_as(s_) for p, s_ in
+                   zip(netG.ordered_parameters() + netE.ordered_parameters(), self.g_stack + self.e_stack)]
+            torch._foreach_copy_(self.g_stack + self.e_stack, src)
+        for s_ in self.g_stack + self.e_stack:
+            s_.grad = None
+        self.inner.reset()
+        for g, e in zip(self.netG, self.netE):
+            g.train(netG.training); e.train(netE.training)
+
+    def adapt(self, model, est_model, est_model_fixed, lqs, slr_weight=10.0):
+        """lqs [K,N,3,H,W] -> (per-frame losses [K], SLR clips [K,N,3,h,w]); afterwards slice k holds frame k's adapted
+        weights.  Same statements as adapt_frame's step, on the batch."""
+        assert lqs.size(0) == self.k
+        self.refresh(model.netG, est_model.netE)
+        center = lqs.size(1) // 2
+        est_model_fixed.feed_data({'LQs': lqs})
+        est_model_fixed.test()
+        slr_fixed = est_model_fixed.fake_L
+        est_model.feed_data({'LQs': lqs})                 # the wrapper's own layout handling ('video' / 'image' mode)
+        y = est_model.netE.forward_stacked(est_model.var_H, self.e_stack)
+        if est_model.mode != 'image':
+            slr = y.transpose(1, 2)
+        else:
+            b, t, c = lqs.shape[:3]
+            slr = y.reshape(b, t, c, y.shape[-2], y.shape[-1])
+        sr = model.netG.forward_stacked(slr, self.g_stack)
+        l_pix = model.l_pix_w * hipops.charbonnier_per_sample(sr, lqs[:, center], model.cri_pix.eps)
+        loss = hipops.inner_loss_per_sample(l_pix, slr, slr_fixed, slr_weight)
+        loss.sum().backward()                              # d loss_k / d (slice k) only: the losses share no weights
+        self.inner.step()
+        return loss.detach(), slr.detach()
+
+
 _STREAMS = {}
 
 
@@ -264,9 +353,14 @@ def _side_streams(lqs_device):
     return _STREAMS[key]
 
 
-def adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, clips, overlap=True):
+def adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, clips, overlap=True, frames_per_batch=1):
     """The frame loop of test_dynavsr.py:197-283 as a generator: for every clip {'LQs': [1,N,3,H,W]} yields
     (baseline SR, adapt_frame's result dict with the adapted 'sr').
+
+    frames_per_batch = K > 1: the inner steps of K consecutive frames run as ONE batch with per-frame parameter gradients
+    (FrameBatch; needs adapt_iter = 1, the value of every shipped YAML, Charbonnier pixel loss, no use_patch / use_real --
+    otherwise the per-frame loop below is taken).  Per-frame results are those of the per-frame loop (same kernels on the
+    same inputs; launch geometry and atomic summation order differ at the 1e-6 level).
 
     Per clip the loop is baseline forward (un-adapted network, :200-204) -> inner steps on copies -> adapted
     forward.  The two full-size forwards do not depend on the NEXT clip's adaptation, and the inner step works on a
@@ -275,6 +369,10 @@ def adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, cl
     (two alternating sets of copies, so a forward never reads weights that are being refreshed).  Results are
     those of the sequential loop (same kernels, same inputs).  A yielded result stays valid until the generator
     is advanced twice."""
+    if frames_per_batch > 1 and FrameBatch.supported(opt, model, est_model):
+        yield from _adapt_video_batched(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, clips, overlap,
+                                        frames_per_batch)
+        return
     clips = iter(clips)
     cur = next(clips, None)
     if cur is None:
@@ -338,3 +436,85 @@ def adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, cl
     p0.record_stream(main); p1.record_stream(main)
     pr['sr'] = p1
     yield p0, pr
+
+
+def _adapt_video_batched(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, clips, overlap, K):
+    """adapt_video with the inner steps of K consecutive frames as one batch.  With ``overlap`` the 2K full-size forwards
+    of a chunk (un-adapted baselines, adapted outputs) run on the side stream underneath the NEXT chunk's batched inner
+    step; two alternating FrameBatch sets, so a forward never reads weights that are being refreshed."""
+    it = iter(clips)
+
+    def take(first=None):
+        chunk = [first] if first is not None else []
+        if len(chunk) == K:
+            return chunk, None
+        for c in it:
+            lq = c['LQs'] if c['LQs'].is_cuda else c['LQs'].cuda()
+            assert lq.size(0) == 1
+            if chunk and lq.shape != chunk[0].shape:       # a new sequence size: close the chunk, keep the clip
+                return chunk, lq
+            chunk.append(lq)
+            if len(chunk) == K:
+                break
+        return chunk, None
+
+    main = torch.cuda.current_stream()
+    side = None
+    cache = getattr(modelcp, '_frame_batches', None)
+    if cache is None:
+        cache = modelcp._frame_batches = {}
+
+    def batch_for(parity, k):
+        fb = cache.get((parity, k))
+        if fb is None or fb.sig != FrameBatch.signature(opt, model.netG, est_model.netE):
+            fb = cache[(parity, k)] = FrameBatch(opt, model.netG, est_model.netE, k)
+        return fb
+
+    def forward_on(net, lq):
+        if side is None:
+            with torch.no_grad():
+                was = net.training
+                net.eval()
+                sr = net(backbone_input(opt, lq))
+                net.train(was)
+            return sr, None
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            was = net.training
+            net.eval()
+            sr = net(backbone_input(opt, lq))
+            net.train(was)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        lq.record_stream(side)
+        return sr, ev
+
+    def hand_out(out):
+        base, adapted, losses, slr, fb = out
+        for k_, ((b_sr, b_ev), (a_sr, a_ev)) in enumerate(zip(base, adapted)):
+            if b_ev is not None:
+                main.wait_event(b_ev); main.wait_event(a_ev)
+                b_sr.record_stream(main); a_sr.record_stream(main)
+            modelcp.netG, est_modelcp.netE = fb.netG[k_], fb.netE[k_]     # the frame's adapted copies, like the reference's modelcp
+            yield b_sr, {'sr': a_sr, 'losses': [losses[k_]], 'slr': slr[k_:k_ + 1]}
+
+    chunk, carry = take()
+    pending, ci = None, 0
+    while chunk:
+        if overlap and side is None:
+            side = _side_streams(chunk[0].device)[0]
+        base = [forward_on(model.netG, lq) for lq in chunk]              # enqueued first: run underneath the adaptation
+        fb = batch_for(ci & 1, len(chunk))
+        if fb.last_use is not None:
+            main.wait_event(fb.last_use)                                 # this set's previous adapted forwards are done
+        lqs = torch.cat(chunk) if len(chunk) > 1 else chunk[0]
+        losses, slr = fb.adapt(model, est_model, est_model_fixed, lqs)
+        adapted = [forward_on(fb.netG[k_], lq) for k_, lq in enumerate(chunk)]
+        fb.last_use = adapted[-1][1]
+        if pending is not None:
+            yield from hand_out(pending)
+        pending = (base, adapted, losses, slr, fb)
+        chunk, carry = take(carry)          # (a clip of another size that closed this chunk starts the next one)
+        ci += 1
+    if pending is not None:
+        yield from hand_out(pending)

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float db = 0.f;
 
-  for (int tile = split; tile < a.ntiles; tile += a.nsplit) {
+  const WgSpan sp = wg_span(a, split);
+  for (int tile = sp.tile0; tile < sp.tile_end; tile += a.nsplit) {
     const int tx_ = tile % a.tiles_x;
     const int t2 = tile / a.tiles_x;
     const int ty_ = t2 % a.tiles_y;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
 
   // ---- partial[slot][tap][o][c]  (o, c padded to the 64-blocks of the grid), slot = split % nslot
   const int OP = a.nob * 64, CP = a.ncb * 64;
-  const int slot = split % a.nslot;
+  const int slot = sp.slot;
 #pragma unroll
   for (int t = 0; t < KK; ++t)
 #pragma unroll
@@ -145,7 +146,13 @@ __global__ __launch_bounds__(256, KYS ? 2 : 1) void conv2d_wgrad_pipe_kernel(Wgr
 // accumulate into them without a memset of its own (conv2d_wgrad_run's `scratch_is_zero` contract).
 __global__ void wgrad_reduce_kernel(float* __restrict__ partial, float* __restrict__ dbp,
                                     float* __restrict__ dW, float* __restrict__ db, int nsplit, int KK,
-                                    int OP, int CP, int Cout, int Cin, int Ctot, int c_off) {
+                                    int OP, int CP, int Cout, int Cin, int Ctot, int c_off, long long dW_gs,
+                                    long long db_gs) {
+  // blockIdx.y = group (per-group gradients): its own nsplit slots, its own output
+  partial += (size_t)blockIdx.y * nsplit * KK * OP * CP;
+  dbp += (size_t)blockIdx.y * nsplit * OP;
+  dW += (size_t)blockIdx.y * dW_gs;
+  if (db) db += (size_t)blockIdx.y * db_gs;
   const int total = Cout * Cin * KK;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int c = i % Cin;
@@ -174,6 +181,12 @@ __global__ void wgrad_reduce_kernel(float* __restrict__ partial, float* __restri
 // per-layer reduce is a 6 us kernel plus a launch gap behind every 44 us weight-gradient kernel.
 __global__ void wgrad_reduce_batch_kernel(WgradReduceTable t) {
   const WgradReduceEntry& e = t.e[blockIdx.y];
+  const int g = blockIdx.z;   // group of a per-group gradient (launch: z = the largest group count of the table)
+  if (g >= e.ngroups) return;
+  float* const partial = e.partial + (size_t)g * e.nslot * e.KK * e.OP * e.CP;
+  float* const dbp = e.dbp + (size_t)g * e.nslot * e.OP;
+  float* const dW = e.dW + (size_t)g * e.dW_gs;
+  float* const db = e.db ? e.db + (size_t)g * e.db_gs : nullptr;
   const int total = e.Cout * e.Cin * e.KK;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int c = i % e.Cin;
@@ -182,19 +195,19 @@ __global__ void wgrad_reduce_batch_kernel(WgradReduceTable t) {
     const int tp = t2 / e.Cout;
     float s = 0.f;
     for (int sp = 0; sp < e.nslot; ++sp) {
-      float* q = e.partial + (((size_t)sp * e.KK + tp) * e.OP + o) * e.CP + c;
+      float* q = partial + (((size_t)sp * e.KK + tp) * e.OP + o) * e.CP + c;
       s += *q;
       *q = 0.f;
     }
-    e.dW[((size_t)o * e.Ctot + e.c_off + c) * e.KK + tp] = s;
+    dW[((size_t)o * e.Ctot + e.c_off + c) * e.KK + tp] = s;
   }
   for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < e.OP; o += gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int sp = 0; sp < e.nslot; ++sp) {
-      s += e.dbp[(size_t)sp * e.OP + o];
-      e.dbp[(size_t)sp * e.OP + o] = 0.f;
+      s += dbp[(size_t)sp * e.OP + o];
+      dbp[(size_t)sp * e.OP + o] = 0.f;
     }
-    if (e.db && o < e.Cout) e.db[o] = s;
+    if (db && o < e.Cout) db[o] = s;
   }
 }
 
@@ -202,8 +215,9 @@ int wgrad_reduce_batch(const WgradReduceEntry* entries, int n, hipStream_t st) {
   for (int base = 0; base < n; base += WGRAD_REDUCE_BATCH) {
     WgradReduceTable t;
     t.n = n - base < WGRAD_REDUCE_BATCH ? n - base : WGRAD_REDUCE_BATCH;
-    for (int i = 0; i < t.n; ++i) t.e[i] = entries[base + i];
-    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(96, t.n), dim3(256), 0, st, t);
+    int gmax = 1;
+    for (int i = 0; i < t.n; ++i) { t.e[i] = entries[base + i]; gmax = t.e[i].ngroups > gmax ? t.e[i].ngroups : gmax; }
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(96, t.n, gmax), dim3(256), 0, st, t);
     int rc = check_launch("wgrad_reduce_batch_kernel");
     if (rc) return rc;
   }
@@ -237,45 +251,53 @@ static int wgrad_splits(int ntiles, int nob, int ncb, int KK, bool one_per_cu = 
   return s < 1 ? 1 : s;
 }
 
-size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad) {
+// Pixel splits PER GROUP: the launch as a whole (groups x splits x cout blocks x cin blocks) aims at the same number of
+// workgroups as an ungrouped one over the same tensor.
+static int wgrad_group_splits(int gtiles, int nob, int ncb, int KK, int groups, bool one_per_cu = false) {
+  if (groups <= 1) return wgrad_splits(gtiles, nob, ncb, KK, one_per_cu);
+  int s = ceil_div(wgrad_splits(gtiles * groups, nob, ncb, KK, one_per_cu), groups);
+  if (s > gtiles) s = gtiles;
+  return s < 1 ? 1 : s;
+}
+
+size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad, int groups) {
   if (pad < 0) pad = ks / 2;
+  if (groups < 1) groups = 1;
   const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
-  const int ntiles = ceil_div(Wo, 32) * ceil_div(Ho, 2) * N;
+  const int gtiles = ceil_div(Wo, 32) * ceil_div(Ho, 2) * (N / groups);
   const int nob = ceil_div(Cout, 64), ncb = ceil_div(Cin, 64), KK = ks * ks;
-  const int ns = wgrad_splits(ntiles, nob, ncb, KK) < 8 ? wgrad_splits(ntiles, nob, ncb, KK) : 8;
-  return ((size_t)ns * KK * nob * 64 * ncb * 64 + (size_t)ns * nob * 64) * sizeof(float);
+  const int sp = wgrad_group_splits(gtiles, nob, ncb, KK, groups);
+  const int ns = sp < 8 ? sp : 8;
+  return (size_t)groups * ((size_t)ns * KK * nob * 64 * ncb * 64 + (size_t)ns * nob * 64) * sizeof(float);
 }
 
 int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW, float* db,
                          int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks, int stride, void* ws,
                          size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad, WgradReduceEntry* defer,
-                         WgradLaunch* out, int bf16) {
+                         WgradLaunch* out, int bf16, int groups, long long dW_gs, long long db_gs) {
   DVSR_REQUIRE(x && gy && dW && ws, DVSR_ERR_INVALID, "conv2d_wgrad: null pointer");
   DVSR_REQUIRE(((ks == 1 || ks == 2 || ks == 7 || ks == 9) && stride == 1) || (ks == 3 && (stride == 1 || stride == 2)),
                DVSR_ERR_UNSUPPORTED, "conv2d_wgrad: ks=%d stride=%d unsupported", ks, stride);
+  if (groups < 1) groups = 1;
+  DVSR_REQUIRE(N % groups == 0, DVSR_ERR_INVALID, "conv2d_wgrad: N=%d is not a multiple of groups=%d", N, groups);
   if (pad < 0) pad = ks / 2;
-  const size_t need = conv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ks, stride, pad);
+  const size_t need = conv2d_wgrad_workspace_bytes(N, Cin, H, W, Cout, ks, stride, pad, groups);
   DVSR_REQUIRE(ws_bytes >= need, DVSR_ERR_WORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
   WgradK& k = out->k;
   k.x = x; k.gy = gy; k.x_bs = x_bs > 0 ? x_bs : (long long)Cin * H * W; k.x_bdiv = x_bdiv > 0 ? x_bdiv : 1;
   k.N = N; k.Cin = Cin; k.H = H; k.W = W; k.Cout = Cout; k.pad = pad; k.gy_ps = gy_ps;
   k.Ho = (H + 2 * k.pad - ks) / stride + 1;
   k.Wo = (W + 2 * k.pad - ks) / stride + 1;
-  k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, 2); k.ntiles = k.tiles_x * k.tiles_y * N;
+  k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, 2);
+  k.ngroups = groups; k.gtiles = k.tiles_x * k.tiles_y * (N / groups); k.ntiles = k.gtiles * groups;
   k.nob = ceil_div(Cout, 64); k.ncb = ceil_div(Cin, 64);
   const int KK = ks * ks;
-  k.nsplit = wgrad_splits(k.ntiles, k.nob, k.ncb, KK, stride == 1);
+  // (all split counts below are PER GROUP; groups == 1 is the plain batch-summed gradient)
+  k.nsplit = wgrad_group_splits(k.gtiles, k.nob, k.ncb, KK, groups, stride == 1);
   // (the estimator's 4x4 stride-2 convs, ks == 2 here: 128 / 256 / 512 / 1024 workgroups per launch measured 2.79 / 2.51 /
   // 2.54 / 2.56 ms per MFDN forward+backward -- the kernel is staging-bound, 16 accumulator tiles per staged tile against
   // 36 for 3x3, not parallelism-bound)
   k.nslot = k.nsplit < 8 ? k.nsplit : 8;
-  k.partial = (float*)ws;
-  k.dbp = k.partial + (size_t)k.nslot * KK * k.nob * 64 * k.ncb * 64;
-  if (!scratch_is_zero) {
-    const size_t zbytes = ((size_t)k.nslot * KK * k.nob * 64 * k.ncb * 64 + (size_t)k.nslot * k.nob * 64) * sizeof(float);
-    DVSR_REQUIRE(hipMemsetAsync(ws, 0, zbytes, st) == hipSuccess, DVSR_ERR_HIP, "conv2d_wgrad: memset failed");
-  }
-  out->grid = dim3(k.nsplit, k.nob, k.ncb);
   out->ks = ks; out->stride = stride;
 #ifdef DVSR_CONV_TRACE
   { static const int nf = getenv("DVSR_WGRAD_NOFLUSH") ? atoi(getenv("DVSR_WGRAD_NOFLUSH")) : 0; k.noflush = nf; }
@@ -288,6 +310,10 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
     const char* v = getenv("DVSR_WGRAD_KYS_BELOW");
     kys_below = v ? atoi(v) : 4096;
   }
+  auto per_group = [&](int s) {   // a launch-wide split count -> per group, never more than a group has tiles
+    s = ceil_div(s, groups);
+    return s > k.gtiles ? k.gtiles : (s < 1 ? 1 : s);
+  };
   out->bf = bf16 && ks == 3 && stride == 1;
   if (out->bf) {
     // the bf16 kernel is staging- and flush-bound (36 MFMAs per tile): fewer workgroups, each with more tiles, keep the
@@ -301,13 +327,8 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
     // about eight tiles per workgroup, at most 512 workgroups)
     int target = k.ntiles / 8;
     target = target < bf_wgs ? bf_wgs : (target > 512 ? 512 : target);
-    int s2 = ceil_div(target, k.nob * k.ncb);
-    s2 = s2 > k.ntiles ? k.ntiles : (s2 < 1 ? 1 : s2);
-    if (s2 < k.nsplit) {
-      k.nsplit = s2;
-      if (k.nslot > k.nsplit) k.nslot = k.nsplit;
-      out->grid = dim3(k.nsplit, k.nob, k.ncb);
-    }
+    const int s2 = per_group(ceil_div(target, k.nob * k.ncb));
+    if (s2 < k.nsplit) k.nsplit = s2;
   }
   out->kys = !out->bf && ((ks == 3 && stride == 1 && (long long)k.ntiles * k.nob * k.ncb < kys_below) || ks == 7 || ks == 9);
   if (out->kys) {
@@ -316,13 +337,22 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
       const char* v = getenv("DVSR_WGRAD_KYS_WGS");
       kys_wgs = v ? atoi(v) : 288;
     }
-    int s = ceil_div(ks == 3 ? kys_wgs : 512, ks * k.nob * k.ncb);
-    k.nsplit = s > k.ntiles ? k.ntiles : (s < 1 ? 1 : s);
-    if (k.nslot > k.nsplit) k.nslot = k.nsplit;   // (the slot region was sized for the un-split launch: never larger)
-    out->grid = dim3(ks * k.nsplit, k.nob, k.ncb);
+    k.nsplit = per_group(ceil_div(ks == 3 ? kys_wgs : 512, ks * k.nob * k.ncb));
   }
-  if (defer)  // the caller reduces a batch of layers later (wgrad_reduce_batch); `ws` must stay untouched until then
+  if (k.nslot > k.nsplit) k.nslot = k.nsplit;   // (the slot region was sized for the un-split launch: never larger)
+  out->grid = dim3((out->kys ? ks : 1) * groups * k.nsplit, k.nob, k.ncb);
+  // slot regions: [group][slot][tap][o][c] partial sums, then [group][slot][o] bias sums
+  const size_t pfloats = (size_t)groups * k.nslot * KK * k.nob * 64 * k.ncb * 64;
+  k.partial = (float*)ws;
+  k.dbp = k.partial + pfloats;
+  if (!scratch_is_zero) {
+    const size_t zbytes = (pfloats + (size_t)groups * k.nslot * k.nob * 64) * sizeof(float);
+    DVSR_REQUIRE(hipMemsetAsync(ws, 0, zbytes, st) == hipSuccess, DVSR_ERR_HIP, "conv2d_wgrad: memset failed");
+  }
+  if (defer) {  // the caller reduces a batch of layers later (wgrad_reduce_batch); `ws` must stay untouched until then
     *defer = WgradReduceEntry{k.partial, k.dbp, dW, db, k.nslot, KK, k.nob * 64, k.ncb * 64, Cout, Cin, Ctot, c_off};
+    defer->ngroups = groups; defer->dW_gs = dW_gs; defer->db_gs = db_gs;
+  }
   return DVSR_OK;
 }
 
@@ -368,17 +398,17 @@ int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st) {
 int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
                      float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
                      int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad,
-                     WgradReduceEntry* defer) {
+                     WgradReduceEntry* defer, int groups, long long dW_gs, long long db_gs) {
   WgradLaunch l;
   int rc = conv2d_wgrad_prepare(x, x_bs, x_bdiv, gy, gy_ps, dW, db, N, Cin, H, W, Cout, Ctot, c_off, ks, stride, ws,
-                                ws_bytes, st, scratch_is_zero, pad, defer, &l);
+                                ws_bytes, st, scratch_is_zero, pad, defer, &l, 0, groups, dW_gs, db_gs);
   if (rc) return rc;
   rc = conv2d_wgrad_launch(l, st);
   if (rc || defer) return rc;
   const WgradK& k = l.k;
   const int KK = ks * ks, total = Cout * Cin * KK;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, k.partial, k.dbp,
-                     dW, db, k.nslot, KK, k.nob * 64, k.ncb * 64, Cout, Cin, Ctot, c_off);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256), k.ngroups), dim3(256), 0, st, k.partial, k.dbp,
+                     dW, db, k.nslot, KK, k.nob * 64, k.ncb * 64, Cout, Cin, Ctot, c_off, dW_gs, db_gs);
   return check_launch("wgrad_reduce_kernel");
 }
 
@@ -451,7 +481,7 @@ extern "C" int dvsr_conv2d_wgrad_bf16(const dvsr_conv2d_desc* d, const float* gy
   const WgradK& k = l.k;
   const int total = d->Cout * d->c0 * 9;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, k.partial, k.dbp, gw, gb, k.nslot, 9,
-                     k.nob * 64, k.ncb * 64, d->Cout, d->c0, d->c0, 0);
+                     k.nob * 64, k.ncb * 64, d->Cout, d->c0, d->c0, 0, 0LL, 0LL);
   return check_launch("wgrad_reduce_kernel");
 }
 

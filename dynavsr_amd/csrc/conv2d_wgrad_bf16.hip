@@ -146,11 +146,12 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_bf16_kernel(WgradK a) {
     }
   };
 
-  int tile = split;
-  if (tile < a.ntiles) issue_loads(tile);
-  for (; tile < a.ntiles; tile += a.nsplit) {
+  const WgSpan sp = wg_span(a, split);
+  int tile = sp.tile0;
+  if (tile < sp.tile_end) issue_loads(tile);
+  for (; tile < sp.tile_end; tile += a.nsplit) {
     write_lds();
-    if (tile + a.nsplit < a.ntiles) issue_loads(tile + a.nsplit);  // in flight under the MFMAs below
+    if (tile + a.nsplit < sp.tile_end) issue_loads(tile + a.nsplit);  // in flight under the MFMAs below
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_bf16_kernel(WgradK a) {
 
   // ---- partial[slot][tap][o][c], as conv2d_wgrad_pipe_kernel
   const int OP = a.nob * 64, CP = a.ncb * 64;
-  const int slot = split % a.nslot;
+  const int slot = sp.slot;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll

@@ -112,6 +112,11 @@ struct dvsr_edvr_plan {
   int side_streams = 1;                           // DVSR_BWD_STREAMS=0 disables
   int fork_every = 3;                             // weight gradients of this many layers share one fork (see backward)
   const char* bwd_unsupported = nullptr;          // set by build_backward when the tape has an op it cannot differentiate
+  // Per-group parameter gradients: the batch holds `wgroups` groups of B / wgroups consecutive clips and the backward
+  // writes one gradient PER GROUP (grad_params[i] = [wgroups][numel_i]) -- the frames of a video adapted from the same
+  // weights run as one batch (test_dynavsr.py:208-277 with adapt_iter = 1; train_dynavsr.py:355-426), each keeping its own
+  // gradient.  Data gradients and activations are per sample anyway; only the weight-gradient launches change.
+  int wgroups = 1;
 };
 
 namespace dvsr {
@@ -151,7 +156,8 @@ struct Builder {
     o.act = act; o.ps = ps; o.x1_bdiv = x1_bdiv; o.x0_bs = x0_bs; o.x1_bs = x1_bs;
     const int Ho = conv_out(o, H), Wo = conv_out(o, W);
     o.y = y_override.valid() ? y_override : alloc(name, (size_t)N * Cout * Ho * Wo);
-    if (wmap) o.w2_off = alloc("", (size_t)Cout * (c0 + c1) * ks * ks).off;
+    // (the gradient arena mirrors this slot: one re-laid-out gradient per group)
+    if (wmap) o.w2_off = alloc("", (size_t)p.wgroups * Cout * (c0 + c1) * ks * ks).off;
     {
       const bool bf = p.cfg.bf16_mfma && ks == 3 && stride == 1 && pad < 0 && (c1 == 0 || c0 % 16 == 0);
       // bf16_mfma = 2: 8-row tiles (two 32-pixel rows per wave) once they still give ~a workgroup per CU
@@ -507,7 +513,7 @@ static void build_backward(dvsr_edvr_plan& p) {
           // batched launch at the end of the backward (wgrad_reduce_batch)
           BOp& wr = p.bops.back();
           wr.ws_bytes = (conv2d_wgrad_workspace_bytes(o.N, which ? o.c1 : o.c0, o.H, o.W, o.Cout, o.ks, o.stride,
-                                                      conv_pad(o)) + 255) & ~(size_t)255;
+                                                      conv_pad(o), p.wgroups) + 255) & ~(size_t)255;
           wr.ws_off = wscratch;
           wscratch += wr.ws_bytes;
           if (o.wmap) {  // dW of the re-laid-out copy -> gradient of the 4x4 parameter (same stream as the wgrad)
@@ -561,7 +567,7 @@ static void build_backward(dvsr_edvr_plan& p) {
         bb.contribute(o.x1, true, i);      // om gradient is written in full
         d.a = BackBuilder::grad(o.x0); d.c = BackBuilder::grad(o.x1);
         p.bops.push_back(d);
-        scratch = std::max(scratch, mdcn_backward_workspace_bytes(o.N, o.c0, o.H, o.W, o.Cout, 1, 1, 1));
+        scratch = std::max(scratch, mdcn_backward_workspace_bytes(o.N, o.c0, o.H, o.W, o.Cout, 1, 1, 1, p.wgroups));
         break;
       }
       case OP_UP: {
@@ -651,7 +657,8 @@ static int prep_wgrad(const dvsr_edvr_plan& p, const BOp& b, float* const* GP, c
   return conv2d_wgrad_prepare(bs.at(b.a), b.which ? o->x1_bs : o->x0_bs, b.which ? o->x1_bdiv : 1, bs.at(b.b), o->ps, dW,
                               b.which ? nullptr : GP[o->pb], o->N, ci, o->H, o->W, o->Cout, o->c0 + o->c1,
                               b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st, 1, conv_pad(*o), defer, out,
-                              p.cfg.bf16_mfma == 1 && !o->wmap);
+                              p.cfg.bf16_mfma == 1 && !o->wmap, p.wgroups,
+                              (long long)o->Cout * (o->c0 + o->c1) * o->ks * o->ks, o->Cout);
 }
 
 static void dgrad_desc(const dvsr_edvr_plan& p, const BOp& b, const float* const* P, const BBases& bs,
@@ -697,10 +704,11 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
       return conv2d_wgrad_run(bs.at(b.a), b.which ? o->x1_bs : o->x0_bs, b.which ? o->x1_bdiv : 1, bs.at(b.b),
                               o->ps, dW, b.which ? nullptr : GP[o->pb], o->N, ci, o->H, o->W, o->Cout,
                               o->c0 + o->c1, b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st,
-                              scratch_is_zero, conv_pad(*o), defer);
+                              scratch_is_zero, conv_pad(*o), defer, p.wgroups,
+                              (long long)o->Cout * (o->c0 + o->c1) * o->ks * o->ks, o->Cout);
     }
-    case B_WUNMAP:
-      return w4_to_s2d(bs.garena + o->w2_off, GP[o->pw], o->Cout, o->c0 / 4, 1, st);
+    case B_WUNMAP:   // (the map is per output channel: the stacked per-group gradients are a [wgroups * Cout] tensor)
+      return w4_to_s2d(bs.garena + o->w2_off, GP[o->pw], p.wgroups * o->Cout, o->c0 / 4, 1, st);
     case B_PADFOLD: {
       float* gx = bs.at(b.a);
       if (!gx) return DVSR_OK;
@@ -731,7 +739,7 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
       return mdcn_backward_run(bs.arena + o->x0.off, om, bstride, om + (size_t)o->dg * 18 * P_, bstride, 1, P[o->pw],
                                bs.at(b.b), bs.at(b.a), gom, bstride, gom + (size_t)o->dg * 18 * P_, bstride,
                                GP[o->pw], GP[o->pb], o->N, o->c0, o->H, o->W, o->Cout, 1, 1, 1, o->dg, scratch,
-                               scratch_bytes, st);
+                               scratch_bytes, st, p.wgroups, (long long)o->Cout * o->c0 * 9, o->Cout);
     }
     case B_UP: {
       float* gx = bs.at(b.a);
@@ -875,9 +883,16 @@ using namespace dvsr;
 
 extern "C" int dvsr_edvr_plan_create(const dvsr_edvr_config* cfg, int B, int H, int W,
                                      dvsr_edvr_plan** out) {
+  return dvsr_edvr_plan_create_grouped(cfg, B, H, W, 1, out);
+}
+
+extern "C" int dvsr_edvr_plan_create_grouped(const dvsr_edvr_config* cfg, int B, int H, int W, int grad_groups,
+                                             dvsr_edvr_plan** out) {
   DVSR_REQUIRE(cfg && out, DVSR_ERR_INVALID, "edvr_plan_create: null argument");
   DVSR_REQUIRE(B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, DVSR_ERR_INVALID,
                "edvr_plan_create: B=%d H=%d W=%d (H, W must be positive multiples of 4)", B, H, W);
+  DVSR_REQUIRE(grad_groups >= 1 && B % grad_groups == 0, DVSR_ERR_INVALID,
+               "edvr_plan_create: grad_groups=%d must divide the batch B=%d", grad_groups, B);
   DVSR_REQUIRE(cfg->nf > 0 && cfg->nf % cfg->groups == 0 && cfg->nframes > 0 && cfg->front_RBs >= 0 &&
                    cfg->back_RBs >= 0, DVSR_ERR_INVALID, "edvr_plan_create: bad network config");
   DVSR_REQUIRE(cfg->scale == 4 || cfg->scale == 2, DVSR_ERR_UNSUPPORTED,
@@ -888,7 +903,7 @@ extern "C" int dvsr_edvr_plan_create(const dvsr_edvr_config* cfg, int B, int H, 
   DVSR_REQUIRE(cpg == 4 || cpg == 8 || cpg == 16, DVSR_ERR_UNSUPPORTED,
                "edvr_plan_create: nf/groups=%d (supported: 4, 8, 16)", cpg);
   dvsr_edvr_plan* p = new dvsr_edvr_plan();
-  p->cfg = *cfg; p->B = B; p->H = H; p->W = W;
+  p->cfg = *cfg; p->B = B; p->H = H; p->W = W; p->wgroups = grad_groups;
   { const char* v = getenv("DVSR_CONV_V1"); p->use_v1 = v && v[0] == '1'; }
   { const char* v = getenv("DVSR_BWD_STREAMS"); p->side_streams = (v && v[0] == '0') ? 0 : 1; }
   int rc = build_plan(*p);
@@ -1231,7 +1246,14 @@ static int build_estimator(dvsr_estimator_plan& ep) {
 
 extern "C" int dvsr_estimator_plan_create(const dvsr_estimator_config* cfg, int B, int H, int W,
                                           dvsr_estimator_plan** out) {
+  return dvsr_estimator_plan_create_grouped(cfg, B, H, W, 1, out);
+}
+
+extern "C" int dvsr_estimator_plan_create_grouped(const dvsr_estimator_config* cfg, int B, int H, int W, int grad_groups,
+                                                  dvsr_estimator_plan** out) {
   DVSR_REQUIRE(cfg && out, DVSR_ERR_INVALID, "estimator_plan_create: null argument");
+  DVSR_REQUIRE(grad_groups >= 1 && B > 0 && B % grad_groups == 0, DVSR_ERR_INVALID,
+               "estimator_plan_create: grad_groups=%d must divide the batch B=%d", grad_groups, B);
   DVSR_REQUIRE(cfg->kind == DVSR_ESTIMATOR_MFDN || cfg->kind == DVSR_ESTIMATOR_SFDN, DVSR_ERR_INVALID,
                "estimator_plan_create: kind=%d", cfg->kind);
   DVSR_REQUIRE(cfg->nf > 0 && cfg->in_nc > 0, DVSR_ERR_INVALID, "estimator_plan_create: nf=%d in_nc=%d", cfg->nf,
@@ -1250,7 +1272,7 @@ extern "C" int dvsr_estimator_plan_create(const dvsr_estimator_config* cfg, int 
   ep->ecfg = *cfg;
   dvsr_edvr_plan& p = ep->core;
   p.cfg = dvsr_edvr_config{cfg->nf, cfg->nframes, 1, 0, 0, cfg->scale, 0, 0};
-  p.B = B; p.H = H; p.W = W;
+  p.B = B; p.H = H; p.W = W; p.wgroups = grad_groups;
   { const char* v = getenv("DVSR_BWD_STREAMS"); p.side_streams = (v && v[0] == '0') ? 0 : 1; }
   p.fork_every = 1;   // seven layers whose weight gradients outlast the data-gradient chain: every fork at once
   int rc = build_estimator(*ep);

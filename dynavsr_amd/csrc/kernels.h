@@ -50,24 +50,29 @@ int conv3x3_small_cout_run(const float* x, const float* w, const float* bias, co
 struct WgradReduceEntry {
   float* partial; float* dbp; float* dW; float* db;
   int nslot, KK, OP, CP, Cout, Cin, Ctot, c_off;
+  // per-group gradients: group g reads the slots [g * nslot, (g + 1) * nslot) and writes dW + g * dW_gs, db + g * db_gs
+  int ngroups = 1;
+  long long dW_gs = 0, db_gs = 0;
 };
-constexpr int WGRAD_REDUCE_BATCH = 56;  // entries per launch (kernel-argument limit: 56 x 64 B < 4 KB)
+constexpr int WGRAD_REDUCE_BATCH = 44;  // entries per launch (kernel-argument limit: 44 x 88 B < 4 KB)
 struct WgradReduceTable {
   int n;
   WgradReduceEntry e[WGRAD_REDUCE_BATCH];
 };
 int wgrad_reduce_batch(const WgradReduceEntry* entries, int n, hipStream_t st);
-size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad = -1);
+size_t conv2d_wgrad_workspace_bytes(int N, int Cin, int H, int W, int Cout, int ks, int stride, int pad = -1, int groups = 1);
+// groups > 1: one gradient per group of N / groups consecutive batch items, written to dW + g * dW_gs (db + g * db_gs)
 int conv2d_wgrad_run(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW,
                      float* db, int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks,
                      int stride, void* ws, size_t ws_bytes, hipStream_t st, int scratch_is_zero = 0,
-                     int pad = -1, WgradReduceEntry* defer = nullptr);  // pad < 0: ks / 2
-size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int stride, int pad, int dil);
+                     int pad = -1, WgradReduceEntry* defer = nullptr, int groups = 1, long long dW_gs = 0,
+                     long long db_gs = 0);  // pad < 0: ks / 2
+size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int stride, int pad, int dil, int groups = 1);
 int mdcn_backward_run(const float* x, const float* off, long long off_bs, const float* msk, long long msk_bs,
                       int mask_logit, const float* w, const float* gout, float* gx, float* goff,
                       long long goff_bs, float* gmsk, long long gmsk_bs, float* gw, float* gb, int N, int C,
                       int H, int W, int Cout, int stride, int pad, int dil, int dg, void* ws,
-                      size_t ws_bytes, hipStream_t st);
+                      size_t ws_bytes, hipStream_t st, int groups = 1, long long gw_gs = 0, long long gb_gs = 0);
 
 int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, const float* msk,
                             long long msk_bs, int mask_logit, const float* wp, const float* b, float* out,

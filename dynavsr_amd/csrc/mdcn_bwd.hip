@@ -509,10 +509,10 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   DCNB_STAMP(7);
 }
 
-size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int stride, int pad, int dil) {
+size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int stride, int pad, int dil, int groups) {
   const int Ho = (H + 2 * pad - (dil * 2 + 1)) / stride + 1, Wo = (W + 2 * pad - (dil * 2 + 1)) / stride + 1;
   const size_t col = (size_t)N * C * 9 * Ho * Wo * sizeof(float);
-  return col + conv2d_wgrad_workspace_bytes(N, C * 9, Ho, Wo, Cout, 1, 1);
+  return col + conv2d_wgrad_workspace_bytes(N, C * 9, Ho, Wo, Cout, 1, 1, -1, groups);
 }
 
 // gout: gradient w.r.t. the PRE-activation output.  gx is accumulated into (atomics) -- zero it
@@ -521,11 +521,12 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
                       int mask_logit, const float* w, const float* gout, float* gx, float* goff,
                       long long goff_bs, float* gmsk, long long gmsk_bs, float* gw, float* gb, int N, int C,
                       int H, int W, int Cout, int stride, int pad, int dil, int dg, void* ws,
-                      size_t ws_bytes, hipStream_t st) {
+                      size_t ws_bytes, hipStream_t st, int groups, long long gw_gs, long long gb_gs) {
   DVSR_REQUIRE(x && off && msk && w && gout && goff && gmsk && ws, DVSR_ERR_INVALID,
                "mdcn_backward: null pointer");
   DVSR_REQUIRE(C % dg == 0, DVSR_ERR_INVALID, "mdcn_backward: C %% dg != 0");
-  const size_t need = mdcn_backward_workspace_bytes(N, C, H, W, Cout, stride, pad, dil);
+  if (groups < 1) groups = 1;   // > 1: one weight / bias gradient per group of N / groups batch items (gw + g * gw_gs)
+  const size_t need = mdcn_backward_workspace_bytes(N, C, H, W, Cout, stride, pad, dil, groups);
   DVSR_REQUIRE(ws_bytes >= need, DVSR_ERR_WORKSPACE, "mdcn_backward: workspace %zu < %zu", ws_bytes, need);
   DcnB a;
   a.x = x; a.off = off; a.msk = msk; a.mask_logit = mask_logit;
@@ -579,7 +580,8 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
     int rc = check_launch("mdcn_bwd_fused_kernel");
     if (rc) return rc;
     if (gw)  // dW = gout . col^T, db = gout . 1 (the kernel above wrote the modulated samples to col)
-      rc = conv2d_wgrad_run(col, 0, 1, gout, 0, gw, gb, N, C * 9, a.Ho, a.Wo, Cout, C * 9, 0, 1, 1, ws2, ws2_bytes, st);
+      rc = conv2d_wgrad_run(col, 0, 1, gout, 0, gw, gb, N, C * 9, a.Ho, a.Wo, Cout, C * 9, 0, 1, 1, ws2, ws2_bytes, st, 0, -1,
+                            nullptr, groups, gw_gs, gb_gs);
     return rc;
   }
   // 1) dcol[n][C*9][P] = W^T . gout  as a 1x1 conv with the transposed weight view
@@ -603,7 +605,7 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
     rc = check_launch("mdcn_im2col_kernel");
     if (rc) return rc;
     rc = conv2d_wgrad_run(col, 0, 1, gout, 0, gw, gb, N, C * 9, a.Ho, a.Wo, Cout, C * 9, 0, 1, 1, ws2,
-                          ws2_bytes, st);
+                          ws2_bytes, st, 0, -1, nullptr, groups, gw_gs, gb_gs);
   }
   return rc;
 }

@@ -459,9 +459,11 @@ __global__ void reduce_frames_kernel(float* __restrict__ dst, long long dst_bs, 
 // ---- Charbonnier loss: mean(sqrt((x-y)^2 + eps)) (models/loss.py:26-30), two-stage deterministic
 // reduction: CHARB_BLOCKS per-block partial sums, then one block folds them in a fixed order.
 constexpr int CHARB_BLOCKS = 1024;
+// (blockIdx.y = group of a per-group loss: n elements and one row of partial sums each; 1 row for the scalar loss)
 __global__ void charbonnier_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                            float* __restrict__ partial, size_t n, float eps) {
   __shared__ float red[256];
+  x += blockIdx.y * n; y += blockIdx.y * n; partial += blockIdx.y * (size_t)CHARB_BLOCKS;
   float s = 0.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float d = x[i] - y[i];
@@ -478,6 +480,7 @@ __global__ void charbonnier_partial_kernel(const float* __restrict__ x, const fl
 __global__ void charbonnier_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nb,
                                          float inv_n) {
   __shared__ float red[256];
+  partial += blockIdx.x * (size_t)CHARB_BLOCKS; out += blockIdx.x;
   float s = 0.f;
   for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
   red[threadIdx.x] = s;
@@ -492,7 +495,8 @@ __global__ void charbonnier_final_kernel(const float* __restrict__ partial, floa
 __global__ void charbonnier_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                        const float* __restrict__ gscale, float* __restrict__ gx, size_t n,
                                        float eps, float inv_n) {
-  const float g = gscale[0] * inv_n;
+  const float g = gscale[blockIdx.y] * inv_n;
+  x += blockIdx.y * n; y += blockIdx.y * n; gx += blockIdx.y * n;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float d = x[i] - y[i];
     gx[i] = g * d / sqrtf(d * d + eps);
@@ -504,6 +508,7 @@ __global__ void charbonnier_bwd_kernel(const float* __restrict__ x, const float*
 __global__ void l1_partial_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ partial,
                                   size_t n) {
   __shared__ float red[256];
+  x += blockIdx.y * n; y += blockIdx.y * n; partial += blockIdx.y * (size_t)CHARB_BLOCKS;
   float s = 0.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     s += fabsf(x[i] - y[i]);
@@ -518,6 +523,7 @@ __global__ void l1_partial_kernel(const float* __restrict__ x, const float* __re
 __global__ void l1_final_kernel(const float* __restrict__ partial, const float* __restrict__ base, float* __restrict__ out,
                                 int nb, float scale) {
   __shared__ float red[256];
+  partial += blockIdx.x * (size_t)CHARB_BLOCKS;
   float s = 0.f;
   for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
   red[threadIdx.x] = s;
@@ -526,12 +532,13 @@ __global__ void l1_final_kernel(const float* __restrict__ partial, const float* 
     if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = (base ? base[0] : 0.f) + red[0] * scale;
+  if (threadIdx.x == 0) out[blockIdx.x] = (base ? base[blockIdx.x] : 0.f) + red[0] * scale;
 }
 // gx = gscale * scale * sign(x - y)   (torch's l1_loss backward: sign(0) = 0)
 __global__ void l1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gscale,
                               float* __restrict__ gx, size_t n, float scale) {
-  const float g = gscale[0] * scale;
+  const float g = gscale[blockIdx.y] * scale;
+  x += blockIdx.y * n; y += blockIdx.y * n; gx += blockIdx.y * n;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float d = x[i] - y[i];
     gx[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
@@ -723,47 +730,71 @@ using namespace dvsr;
 
 extern "C" size_t dvsr_charbonnier_workspace_bytes(void) { return CHARB_BLOCKS * sizeof(float); }
 
-extern "C" int dvsr_charbonnier_forward(const float* x, const float* y, float* loss, long long n, float eps,
-                                        void* workspace, size_t workspace_bytes, dvsr_stream_t stream) {
-  DVSR_REQUIRE(x && y && loss && workspace && n > 0, DVSR_ERR_INVALID, "charbonnier_forward: bad argument");
-  DVSR_REQUIRE(workspace_bytes >= CHARB_BLOCKS * sizeof(float), DVSR_ERR_WORKSPACE,
+extern "C" int dvsr_charbonnier_forward_grouped(const float* x, const float* y, float* loss, long long n, int groups,
+                                                float eps, void* workspace, size_t workspace_bytes,
+                                                dvsr_stream_t stream) {
+  DVSR_REQUIRE(x && y && loss && workspace && n > 0 && groups > 0, DVSR_ERR_INVALID, "charbonnier_forward: bad argument");
+  DVSR_REQUIRE(workspace_bytes >= (size_t)groups * CHARB_BLOCKS * sizeof(float), DVSR_ERR_WORKSPACE,
                "charbonnier_forward: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   int nb = (int)(((size_t)n + 255) / 256);
   if (nb > CHARB_BLOCKS) nb = CHARB_BLOCKS;
-  hipLaunchKernelGGL(charbonnier_partial_kernel, dim3(nb), dim3(256), 0, st, x, y, (float*)workspace,
+  hipLaunchKernelGGL(charbonnier_partial_kernel, dim3(nb, groups), dim3(256), 0, st, x, y, (float*)workspace,
                      (size_t)n, eps);
-  hipLaunchKernelGGL(charbonnier_final_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, loss, nb,
+  hipLaunchKernelGGL(charbonnier_final_kernel, dim3(groups), dim3(256), 0, st, (const float*)workspace, loss, nb,
                      1.f / (float)n);
   return check_launch("charbonnier_forward");
 }
 
-extern "C" int dvsr_charbonnier_backward(const float* x, const float* y, const float* grad_loss, float* gx,
-                                         long long n, float eps, dvsr_stream_t stream) {
-  DVSR_REQUIRE(x && y && grad_loss && gx && n > 0, DVSR_ERR_INVALID, "charbonnier_backward: bad argument");
-  LAUNCH(charbonnier_bwd_kernel, (size_t)n, (hipStream_t)stream, x, y, grad_loss, gx, (size_t)n, eps,
-         1.f / (float)n);
+extern "C" int dvsr_charbonnier_forward(const float* x, const float* y, float* loss, long long n, float eps,
+                                        void* workspace, size_t workspace_bytes, dvsr_stream_t stream) {
+  return dvsr_charbonnier_forward_grouped(x, y, loss, n, 1, eps, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dvsr_charbonnier_backward_grouped(const float* x, const float* y, const float* grad_loss, float* gx,
+                                                 long long n, int groups, float eps, dvsr_stream_t stream) {
+  DVSR_REQUIRE(x && y && grad_loss && gx && n > 0 && groups > 0, DVSR_ERR_INVALID, "charbonnier_backward: bad argument");
+  hipLaunchKernelGGL(charbonnier_bwd_kernel, dim3(stream_grid((size_t)n), groups), dim3(256), 0, (hipStream_t)stream, x, y,
+                     grad_loss, gx, (size_t)n, eps, 1.f / (float)n);
   return check_launch("charbonnier_bwd_kernel");
 }
 
-extern "C" int dvsr_l1_tail_forward(const float* x, const float* y, const float* base, float weight, float* loss,
-                                    long long n, void* workspace, size_t workspace_bytes, dvsr_stream_t stream) {
-  DVSR_REQUIRE(x && y && loss && workspace && n > 0, DVSR_ERR_INVALID, "l1_tail_forward: bad argument");
-  DVSR_REQUIRE(workspace_bytes >= CHARB_BLOCKS * sizeof(float), DVSR_ERR_WORKSPACE, "l1_tail_forward: workspace too small");
+extern "C" int dvsr_charbonnier_backward(const float* x, const float* y, const float* grad_loss, float* gx,
+                                         long long n, float eps, dvsr_stream_t stream) {
+  return dvsr_charbonnier_backward_grouped(x, y, grad_loss, gx, n, 1, eps, stream);
+}
+
+extern "C" int dvsr_l1_tail_forward_grouped(const float* x, const float* y, const float* base, float weight, float* loss,
+                                            long long n, int groups, void* workspace, size_t workspace_bytes,
+                                            dvsr_stream_t stream) {
+  DVSR_REQUIRE(x && y && loss && workspace && n > 0 && groups > 0, DVSR_ERR_INVALID, "l1_tail_forward: bad argument");
+  DVSR_REQUIRE(workspace_bytes >= (size_t)groups * CHARB_BLOCKS * sizeof(float), DVSR_ERR_WORKSPACE,
+               "l1_tail_forward: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   int nb = (int)(((size_t)n + 255) / 256);
   if (nb > CHARB_BLOCKS) nb = CHARB_BLOCKS;
-  hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, st, x, y, (float*)workspace, (size_t)n);
-  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, base, loss, nb,
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(nb, groups), dim3(256), 0, st, x, y, (float*)workspace, (size_t)n);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(groups), dim3(256), 0, st, (const float*)workspace, base, loss, nb,
                      weight / (float)n);
   return check_launch("l1_tail_forward");
 }
 
+extern "C" int dvsr_l1_tail_forward(const float* x, const float* y, const float* base, float weight, float* loss,
+                                    long long n, void* workspace, size_t workspace_bytes, dvsr_stream_t stream) {
+  return dvsr_l1_tail_forward_grouped(x, y, base, weight, loss, n, 1, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dvsr_l1_tail_backward_grouped(const float* x, const float* y, const float* grad_loss, float weight,
+                                             float* gx, long long n, int groups, dvsr_stream_t stream) {
+  DVSR_REQUIRE(x && y && grad_loss && gx && n > 0 && groups > 0, DVSR_ERR_INVALID, "l1_tail_backward: bad argument");
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(stream_grid((size_t)n), groups), dim3(256), 0, (hipStream_t)stream, x, y, grad_loss,
+                     gx, (size_t)n, weight / (float)n);
+  return check_launch("l1_bwd_kernel");
+}
+
 extern "C" int dvsr_l1_tail_backward(const float* x, const float* y, const float* grad_loss, float weight, float* gx,
                                      long long n, dvsr_stream_t stream) {
-  DVSR_REQUIRE(x && y && grad_loss && gx && n > 0, DVSR_ERR_INVALID, "l1_tail_backward: bad argument");
-  LAUNCH(l1_bwd_kernel, (size_t)n, (hipStream_t)stream, x, y, grad_loss, gx, (size_t)n, weight / (float)n);
-  return check_launch("l1_bwd_kernel");
+  return dvsr_l1_tail_backward_grouped(x, y, grad_loss, weight, gx, n, 1, stream);
 }
 
 extern "C" int dvsr_upsample_bilinear_forward(const float* x, float* y, long long planes, int H,

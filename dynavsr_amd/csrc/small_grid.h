@@ -34,10 +34,22 @@ struct WgradK {
   int x_bdiv;
   int N, Cin, H, W, Cout, Ho, Wo, pad, gy_ps;
   int tiles_x, tiles_y, ntiles, nsplit, nob, ncb, nslot;
+  // per-group gradients (one dW per group of N / ngroups consecutive batch items: the per-FRAME gradients of a batch of
+  // frames adapted from the same weights).  nsplit / nslot count per group; gtiles = tiles of one group.
+  int ngroups = 1, gtiles = 0;
 #ifdef DVSR_CONV_TRACE
   int noflush = 0;  // measurement aid of the debug build (DVSR_WGRAD_NOFLUSH=1): skip the atomic flush, results are wrong
 #endif
 };
+
+// The tiles and the slot of pixel split `split` (block index along x, kernel-row factor removed): group g owns the splits
+// [g * nsplit, (g + 1) * nsplit), walks its own tiles only and flushes into its own nslot slots.
+struct WgSpan { int tile0, tile_end, slot; };
+__device__ __forceinline__ WgSpan wg_span(const WgradK& a, int split) {
+  int g = 0, s = split;
+  if (a.ngroups > 1) { g = split / a.nsplit; s = split - g * a.nsplit; }
+  return WgSpan{g * a.gtiles + s, (g + 1) * a.gtiles, g * a.nslot + s % a.nslot};
+}
 
 // host side: fill the argument structs without launching (conv2d_v2.hip / conv2d_wgrad.hip)
 int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo, ConvK2* k);
@@ -50,7 +62,7 @@ struct WgradLaunch {
 int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW, float* db,
                          int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks, int stride, void* ws,
                          size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad, WgradReduceEntry* defer,
-                         WgradLaunch* out, int bf16 = 0);
+                         WgradLaunch* out, int bf16 = 0, int groups = 1, long long dW_gs = 0, long long db_gs = 0);
 int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st);
 int conv2d_wgrad_bf16_launch(const WgradLaunch& l, hipStream_t st);
 
@@ -377,15 +389,16 @@ __device__ __forceinline__ void conv2d_wgrad_pipe_item(const WgradK& a, const in
     }
   };
 
-  int tile = split;
-  if (tile < a.ntiles) {
+  const WgSpan sp = wg_span(a, split);
+  int tile = sp.tile0;
+  if (tile < sp.tile_end) {
     issue_loads(tile);
     write_lds(0);
   }
   __syncthreads();
   int buf = 0;
-  for (; tile < a.ntiles; tile += a.nsplit) {
-    const bool has_next = tile + a.nsplit < a.ntiles;
+  for (; tile < sp.tile_end; tile += a.nsplit) {
+    const bool has_next = tile + a.nsplit < sp.tile_end;
     if (has_next) issue_loads(tile + a.nsplit);
     mfma_steps(buf, 0, 3 * NPX / 8);
     if (has_next) write_lds(buf ^ 1);
@@ -396,7 +409,7 @@ __device__ __forceinline__ void conv2d_wgrad_pipe_item(const WgradK& a, const in
 
   // ---- partial[slot][tap][o][c]  (o, c padded to the 64-blocks of the grid), slot = split % nslot
   const int OP = a.nob * 64, CP = a.ncb * 64;
-  const int slot = split % a.nslot;
+  const int slot = sp.slot;
 #ifdef DVSR_CONV_TRACE
   if (a.noflush && acc[0][0] != 12345.f) return;
 #endif

@@ -198,6 +198,77 @@ def charbonnier(x, y, eps=1e-6):
     return _Charbonnier.apply(x, y, eps)
 
 
+class _CharbonnierPerSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, eps):
+        if x.shape != y.shape:
+            raise RuntimeError("charbonnier: prediction %s and target %s differ in shape" % (tuple(x.shape), tuple(y.shape)))
+        x, y = x.contiguous(), y.contiguous()
+        k = x.shape[0]
+        n = x.numel() // k
+        ws = torch.empty(k * int(L.lib().dvsr_charbonnier_workspace_bytes()), dtype=torch.uint8, device=x.device)
+        loss = x.new_empty((k,))
+        L.check(L.lib().dvsr_charbonnier_forward_grouped(L.ptr(x), L.ptr(y), loss.data_ptr(), n, k, eps, ws.data_ptr(),
+                                                         ws.numel(), L.stream()), "dvsr_charbonnier_forward_grouped")
+        ctx.save_for_backward(x, y)
+        ctx.eps = eps
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        g = g.contiguous().float()
+        k = x.shape[0]
+        L.check(L.lib().dvsr_charbonnier_backward_grouped(L.ptr(x), L.ptr(y), g.data_ptr(), L.ptr(gx), x.numel() // k, k,
+                                                          ctx.eps, L.stream()), "dvsr_charbonnier_backward_grouped")
+        return (gx if ctx.needs_input_grad[0] else None, -gx if ctx.needs_input_grad[1] else None, None)
+
+
+def charbonnier_per_sample(x, y, eps=1e-6):
+    """[K, ...] x 2 -> [K]: loss[k] = mean(sqrt((x[k]-y[k])^2 + eps)), each reduced exactly as `charbonnier` reduces a
+    single sample (bit-identical values) -- the pixel losses of K frames adapted as one batch."""
+    return _CharbonnierPerSample.apply(x, y, eps)
+
+
+class _InnerLossPerSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, base, x, y, weight):
+        if x.shape != y.shape or base.shape != (x.shape[0],):
+            raise RuntimeError("inner_loss: %s vs %s, base %s" % (tuple(x.shape), tuple(y.shape), tuple(base.shape)))
+        x, y = x.contiguous(), y.contiguous()
+        k = x.shape[0]
+        b = base.detach().contiguous().float()
+        ws = torch.empty(k * int(L.lib().dvsr_charbonnier_workspace_bytes()), dtype=torch.uint8, device=x.device)
+        loss = x.new_empty((k,))
+        L.check(L.lib().dvsr_l1_tail_forward_grouped(L.ptr(x), L.ptr(y), b.data_ptr(), float(weight), loss.data_ptr(),
+                                                     x.numel() // k, k, ws.data_ptr(), ws.numel(), L.stream()),
+                "dvsr_l1_tail_forward_grouped")
+        ctx.save_for_backward(x, y)
+        ctx.weight = float(weight)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = g.contiguous().float()
+        gx = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gx = torch.empty_like(x)
+            k = x.shape[0]
+            L.check(L.lib().dvsr_l1_tail_backward_grouped(L.ptr(x), L.ptr(y), g.data_ptr(), ctx.weight, L.ptr(gx),
+                                                          x.numel() // k, k, L.stream()), "dvsr_l1_tail_backward_grouped")
+        return (g if ctx.needs_input_grad[0] else None, gx if ctx.needs_input_grad[1] else None,
+                -gx if ctx.needs_input_grad[2] else None, None)
+
+
+def inner_loss_per_sample(loss_pix, slr, slr_fixed, weight=10.0):
+    """[K] + weight * per-sample F.l1_loss(slr[k], slr_fixed[k]) -> [K] (see inner_loss)."""
+    return _InnerLossPerSample.apply(loss_pix, slr, slr_fixed, weight)
+
+
 class _InnerLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, base, x, y, weight):

@@ -14,7 +14,7 @@ import math
 import torch
 import torch.nn as nn
 
-from dynavsr_amd.engine import EdvrFunction
+from dynavsr_amd.engine import EdvrFunction, EdvrStackedFunction
 from dynavsr_amd.spec import edvr_param_spec
 
 
@@ -91,3 +91,9 @@ class EDVR(nn.Module):
 
     def forward(self, x):
         return EdvrFunction.apply(x, self._cfg(), self._debug_ws, *self.ordered_parameters())
+
+    def forward_stacked(self, x, stacked):
+        """K clips [K,N,3,H,W] as one batch with PER-CLIP parameter gradients: `stacked` = this network's parameters
+        (ordered_parameters order) as [K, *shape] leaf tensors whose K slices are equal -- the private copies of K
+        frames before their first inner step (engine.EdvrStackedFunction)."""
+        return EdvrStackedFunction.apply(x, self._cfg(), *stacked)

@@ -35,6 +35,12 @@ class DirectKernelEstimatorVideo(nn.Module):
         cfg = (engine.MFDN, self.nf, self.in_nc, self.scale, x.shape[2])
         return engine.EstimatorFunction.apply(x, cfg, *self.ordered_parameters())
 
+    def forward_stacked(self, x, stacked):
+        """K clips with per-clip parameter gradients: `stacked` = the parameters as [K, *shape] tensors with equal
+        slices (engine.EstimatorStackedFunction)."""
+        cfg = (engine.MFDN, self.nf, self.in_nc, self.scale, x.shape[2])
+        return engine.EstimatorStackedFunction.apply(x, cfg, *stacked)
+
 
 class DirectKernelEstimator_CMS(nn.Module):
     """SFDN: single-frame estimator (x2), input N,3,H,W -> N,3,H/2,W/2 (LRimg_estimator.py:38-67)."""
@@ -57,3 +63,7 @@ class DirectKernelEstimator_CMS(nn.Module):
     def forward(self, x):
         cfg = (engine.SFDN, self.nf, 3, 2, 1)
         return engine.EstimatorFunction.apply(x, cfg, *self.ordered_parameters())
+
+    def forward_stacked(self, x, stacked):
+        cfg = (engine.SFDN, self.nf, 3, 2, 1)
+        return engine.EstimatorStackedFunction.apply(x, cfg, *stacked)

@@ -169,6 +169,16 @@ typedef struct dvsr_edvr_config {
 typedef struct dvsr_edvr_plan dvsr_edvr_plan;
 
 int dvsr_edvr_plan_create(const dvsr_edvr_config* cfg, int B, int H, int W, dvsr_edvr_plan** out);
+/* The same plan with PER-GROUP parameter gradients: the batch is `grad_groups` groups of B / grad_groups consecutive
+ * clips, and dvsr_edvr_backward writes one gradient per group -- every grad_params[i] then points to
+ * [grad_groups][numel(param i)] floats, group-major.  This is how the frames of a video that all adapt from the SAME
+ * weights (test_dynavsr.py:208-277 deep-copies the un-adapted networks for every frame; with adapt_iter = 1, the value of
+ * every shipped YAML, the K forward + backward passes differ only in their data) run as ONE batch of K clips whose
+ * launches fill the device, while each frame still gets the gradient its own sequential step would have seen; the meta
+ * tasks of train_dynavsr.py:355-426 likewise.  Forward, activations and data gradients are per sample in any case;
+ * grad_groups = 1 is dvsr_edvr_plan_create.  The workspace grows by the extra weight-gradient partial sums. */
+int dvsr_edvr_plan_create_grouped(const dvsr_edvr_config* cfg, int B, int H, int W, int grad_groups,
+                                  dvsr_edvr_plan** out);
 void dvsr_edvr_plan_destroy(dvsr_edvr_plan* plan);
 int dvsr_edvr_num_params(const dvsr_edvr_plan* plan);
 int dvsr_edvr_num_launches(const dvsr_edvr_plan* plan);
@@ -227,6 +237,9 @@ typedef struct dvsr_estimator_config {
 } dvsr_estimator_config;
 typedef struct dvsr_estimator_plan dvsr_estimator_plan;
 int dvsr_estimator_plan_create(const dvsr_estimator_config* cfg, int B, int H, int W, dvsr_estimator_plan** out);
+/* Per-group parameter gradients, as dvsr_edvr_plan_create_grouped: grad_params[i] = [grad_groups][numel(param i)]. */
+int dvsr_estimator_plan_create_grouped(const dvsr_estimator_config* cfg, int B, int H, int W, int grad_groups,
+                                       dvsr_estimator_plan** out);
 void dvsr_estimator_plan_destroy(dvsr_estimator_plan* plan);
 int dvsr_estimator_num_params(const dvsr_estimator_plan* plan);
 /* tape length: forward ops (backward = 0) or backward ops (backward = 1); a measurement aid like
@@ -247,6 +260,14 @@ int dvsr_charbonnier_forward(const float* x, const float* y, float* loss, long l
                              void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
 int dvsr_charbonnier_backward(const float* x, const float* y, const float* grad_loss, float* gx, long long n,
                               float eps, dvsr_stream_t stream);
+/* Per-group losses of a batch: x, y = [groups][n]; loss[g], grad_loss[g] per group; every group is reduced exactly as a
+ * scalar call on its n elements would be (same partial sums, same order -> bit-identical values).  The K frames adapted
+ * as one batch (dvsr_edvr_plan_create_grouped) each have their own `cri_pix(netG(SLR), LR_center)`, models/loss.py:26-30.
+ * Workspace: groups * dvsr_charbonnier_workspace_bytes(). */
+int dvsr_charbonnier_forward_grouped(const float* x, const float* y, float* loss, long long n, int groups, float eps,
+                                     void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
+int dvsr_charbonnier_backward_grouped(const float* x, const float* y, const float* grad_loss, float* gx, long long n,
+                                      int groups, float eps, dvsr_stream_t stream);
 
 /* ---- loss tail of the inner MAML step (test_dynavsr.py:264-274) ------------------------------------------
  * loss = cri_pix(netG(SLR), LR_center) + 10 * F.l1_loss(SLR, SLR_fixed): loss[0] = (base ? base[0] : 0) +
@@ -257,6 +278,11 @@ int dvsr_l1_tail_forward(const float* x, const float* y, const float* base, floa
                          void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
 int dvsr_l1_tail_backward(const float* x, const float* y, const float* grad_loss, float weight, float* gx, long long n,
                           dvsr_stream_t stream);
+/* Per-group form, as dvsr_charbonnier_*_grouped: x, y = [groups][n]; base, loss, grad_loss = [groups]. */
+int dvsr_l1_tail_forward_grouped(const float* x, const float* y, const float* base, float weight, float* loss, long long n,
+                                 int groups, void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
+int dvsr_l1_tail_backward_grouped(const float* x, const float* y, const float* grad_loss, float weight, float* gx,
+                                  long long n, int groups, dvsr_stream_t stream);
 
 /* ---- op-level entries to the pipelined / small-grid conv kernels ---------------------------------------------------
  * dvsr_conv2d_forward needs no workspace and runs the un-packed kernel.  These pack the weights into a caller

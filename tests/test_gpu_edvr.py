@@ -826,3 +826,96 @@ def test_edvr_l_config4_forward_backward(mode):
         assert psnr > 35.0
         assert abs(float(loss.detach()) - loss_o) < 2e-2 * loss_o
         assert np.median(rel) < 0.05 and rel.max() < 0.5, (np.median(rel), rel.max())
+
+
+# ---- per-clip parameter gradients: K clips through one tape (dvsr_edvr_plan_create_grouped) -----------------------------
+def _stack(params, k):
+    return [p.detach().unsqueeze(0).repeat((k,) + (1,) * p.dim()).contiguous().requires_grad_() for p in params]
+
+
+@pytest.mark.parametrize("k,h,w", [(3, 16, 24), (2, 44, 80)])
+def test_edvr_stacked_tape_gives_per_clip_gradients(k, h, w):
+    """EdvrStackedFunction: K clips as one batch, parameters stacked [K, ...] with equal slices; slice k of every gradient
+    must be what a B = 1 pass over clip k alone produces (same kernels; launch geometry and atomic order may differ:
+    1e-3 per tensor, outputs 1e-6), the per-sample Charbonnier losses bit-equal to the scalar kernel's."""
+    from dynavsr_amd import engine, hipops
+    net = make_net(0)
+    x = synth.clip(61, k, 5, h, w).cuda().requires_grad_()
+    tgt = synth.clip(62, k, 1, 4 * h, 4 * w)[:, 0].cuda()
+    want = []
+    for i in range(k):
+        xi = x[i:i + 1].detach().requires_grad_()
+        yi = net(xi)
+        li = hipops.charbonnier(yi, tgt[i:i + 1])
+        gs = torch.autograd.grad(li, [xi] + net.ordered_parameters())
+        want.append((yi.detach(), li.detach(), gs))
+    stacked = _stack(net.ordered_parameters(), k)
+    y = engine.EdvrStackedFunction.apply(x, net._cfg(), *stacked)
+    losses = hipops.charbonnier_per_sample(y, tgt)
+    losses.sum().backward()
+    for i in range(k):
+        assert relerr(y[i:i + 1], want[i][0]) < 1e-6
+        assert abs(float(losses[i]) - float(want[i][1])) <= 1e-6 * abs(float(want[i][1]))
+        assert relerr(x.grad[i:i + 1], want[i][2][0]) < 1e-2      # through every ReLU / max-pool / floor() kink of the net
+        bad = [(n, relerr(s.grad[i], g)) for n, s, g in zip(net._names, stacked, want[i][2][1:]) if relerr(s.grad[i], g) > 2e-3]
+        assert not bad, (i, bad[:6])
+    # scalar and per-sample loss kernels reduce a sample identically
+    assert torch.equal(hipops.charbonnier_per_sample(y.detach()[:1], tgt[:1])[0], hipops.charbonnier(y.detach()[:1], tgt[:1]))
+    a, b = torch.randn(k, 3, 5, 11, 13, device="cuda"), torch.randn(k, 3, 5, 11, 13, device="cuda")
+    base = torch.rand(k, device="cuda")
+    ps = hipops.inner_loss_per_sample(base, a, b, 10.0)
+    for i in range(k):
+        assert torch.equal(ps[i], hipops.inner_loss(base[i], a[i], b[i], 10.0))
+    with pytest.raises(RuntimeError, match="K="):
+        engine.EdvrStackedFunction.apply(x, net._cfg(), *[s[:1] for s in stacked])
+
+
+@pytest.mark.parametrize("optimizer,overlap", [("Adam", True), ("SGD", False)])
+def test_adapt_video_batched_frames_equal_the_per_frame_loop(optimizer, overlap):
+    """adapt_video(frames_per_batch=K): the inner steps of K consecutive frames as ONE batch with per-frame parameter
+    gradients (FrameBatch) must give every frame what the reference's per-frame loop gives it (test_dynavsr.py:208-283,
+    adapt_iter = 1): baseline SR bit-equal, loss, SLR clip, adapted SR and the adapted copies' weights.  5 clips with
+    K = 2 -> chunks of 2, 2, 1; a clip of another size closes a chunk early."""
+    from dynavsr_amd.adapt import FrameBatch, adapt_frame, adapt_video
+    from dynavsr_amd.models import create_model
+    opt = _gpu_opt(optimizer)
+    assert opt["train"]["maml"]["adapt_iter"] == 1
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    model.netG.load_state_dict(synth.edvr_state_dict(0)); est.netE.load_state_dict(synth.mfdn_state_dict(0))
+    est_fixed.netE.load_state_dict(synth.mfdn_state_dict(1))
+    assert FrameBatch.supported(opt, model, est)
+    sizes = [(32, 48)] * 3 + [(48, 32)] + [(32, 48)]            # chunks: [0,1] [2] (size change) [3] (size change) [4]
+    clips = [{"LQs": synth.clip(50 + i, 1, 5, h, w).cuda()} for i, (h, w) in enumerate(sizes)]
+    want = []
+    for c in clips:
+        model.feed_data(c, need_GT=False); model.test()
+        base = model.fake_H.clone()
+        r = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, c)
+        want.append((base, r["sr"].clone(), float(r["losses"][0]), r["slr"].clone(),
+                     [p.detach().clone() for p in modelcp.netG.ordered_parameters()],
+                     [p.detach().clone() for p in estcp.netE.ordered_parameters()]))
+    PG = {k: v.clone() for k, v in model.netG.state_dict().items()}
+    n = 0
+    for (base, r), w_ in zip(adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips, overlap=overlap,
+                                         frames_per_batch=2), want):
+        assert torch.equal(base, w_[0])
+        assert abs(float(r["losses"][0]) - w_[2]) <= 2e-6 * abs(w_[2])
+        assert relerr(r["slr"], w_[3]) < 1e-6
+        assert relerr(r["sr"], w_[1]) < 1e-4
+        # the frame's adapted copies: the update is lr * sign-like for Adam (a flipped tiny gradient moves an element by 2 lr)
+        for name, p, q, p0 in zip(model.netG._names, modelcp.netG.ordered_parameters(), w_[4], model.netG.ordered_parameters()):
+            assert relerr(p - p0, q - p0) < (2e-2 if optimizer == "Adam" else 2e-3), name
+        for p, q, p0 in zip(estcp.netE.ordered_parameters(), w_[5], est.netE.ordered_parameters()):
+            assert relerr(p - p0, q - p0) < (2e-2 if optimizer == "Adam" else 2e-3)
+        assert set(modelcp.netG.state_dict().keys()) == set(PG.keys())
+        n += 1
+    assert n == len(clips)
+    for k, v in model.netG.state_dict().items():                 # the meta-parameters are untouched
+        assert torch.equal(v, PG[k]), k
+    # what the batched step does not cover takes the per-frame loop
+    opt["train"]["maml"]["adapt_iter"] = 2
+    assert not FrameBatch.supported(opt, model, est)
+    got = list(adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips[:2], overlap=overlap, frames_per_batch=2))
+    assert len(got) == 2 and len(got[0][1]["losses"]) == 2

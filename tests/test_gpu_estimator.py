@@ -119,3 +119,26 @@ def test_estimator_rejects_input_grad_and_bad_shapes():
         net(x.clone().requires_grad_(True))
     with pytest.raises(RuntimeError, match="multiples of the scale"):
         net(synth.clip(1, 1, 5, 18, 16).transpose(1, 2).contiguous().cuda())
+
+
+@pytest.mark.parametrize("scale,k,t,h,w", [(4, 3, 5, 32, 48), (2, 2, 3, 24, 40)])
+def test_mfdn_stacked_tape_gives_per_clip_gradients(scale, k, t, h, w):
+    """EstimatorStackedFunction (dvsr_estimator_plan_create_grouped): K clips as one batch, per-clip parameter
+    gradients in the slices of the stacked parameters == K separate B = 1 passes (incl. the re-laid-out 4x4 stride-2
+    weights, whose gradient is mapped back per group)."""
+    from dynavsr_amd import engine
+    net = _mfdn(synth.mfdn_state_dict(3, scale=scale), nf=64, in_nc=3, scale=scale)
+    x = synth.clip(71, k, t, h, w).transpose(1, 2).contiguous().cuda()        # [K,3,T,H,W]
+    go = _go(72, (k, 3, t, h // scale, w // scale)).cuda()
+    want = []
+    for i in range(k):
+        yi = net(x[i:i + 1])
+        want.append((yi.detach(), torch.autograd.grad(yi, net.ordered_parameters(), go[i:i + 1])))
+    stacked = [p.detach().unsqueeze(0).repeat((k,) + (1,) * p.dim()).contiguous().requires_grad_() for p in net.ordered_parameters()]
+    cfg = (engine.MFDN, 64, 3, scale, t)
+    y = engine.EstimatorStackedFunction.apply(x, cfg, *stacked)
+    y.backward(go)
+    for i in range(k):
+        assert relerr(y[i:i + 1], want[i][0]) < 1e-6
+        bad = [(j, relerr(s.grad[i], g)) for j, (s, g) in enumerate(zip(stacked, want[i][1])) if relerr(s.grad[i], g) > 1e-4]
+        assert not bad, (i, bad)
