@@ -99,6 +99,7 @@ def _declare(lib):
         "dvsr_mdcn_backward": (I, [P] * 10 + [I] * 12 + [P, c_size_t, P]),
         "dvsr_adam_step": (I, [POINTER(c_void_p)] * 4 + [POINTER(LL), I, F, F, F, F, F, I, P]),
         "dvsr_sgd_step": (I, [POINTER(c_void_p)] * 2 + [POINTER(LL), I, F, F, P]),
+        "dvsr_replicate_tensors": (I, [POINTER(c_void_p)] * 2 + [POINTER(LL), I, I, P]),
         "dvsr_degrade_apply": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
         "dvsr_frame_metrics_workspace_bytes": (c_size_t, [I, I, I]),
         "dvsr_frame_metrics": (I, [P, P, I, I, I, F, F, P, P, P, c_size_t, P]),

@@ -160,8 +160,51 @@ def adapt_frame(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, va
     return {'sr': modelcp.fake_H, 'losses': losses, 'slr': slr.detach()}
 
 
+def _meta_batchable(opt, model, est_model, inner):
+    m = opt['train']['maml']
+    from .models.loss import CharbonnierLoss
+    return (inner == 'reference' and not m['use_patch'] and not opt['train']['use_real']
+            and hasattr(model.netG, 'forward_stacked') and hasattr(est_model.netE, 'forward_stacked')
+            and isinstance(model.cri_pix, CharbonnierLoss) and isinstance(est_model.MyLoss, torch.nn.L1Loss)
+            and next(model.netG.parameters()).is_cuda)
+
+
+def _meta_train_step_batched(opt, model, est_model, train_data, optimizer, group, force_collective):
+    """inner='reference' with all B tasks as ONE batch.  In the driver as shipped (quirk Q1) every loss of
+    every task is evaluated at the SAME meta-parameters and every gradient lands in the same `.grad`:
+        d theta = sum_b [ steps * grad l_train_b + grad l_q_b / B ],   d phi = sum_b [ steps * grad l_train_b + grad l_e_b / (10 B) ]
+    (the `steps` inner iterations of a task repeat the same evaluation: the inner optimiser steps nothing).  So the
+    estimator runs once on the B clips -- its output serves the inner loss AND loss_e, which the loop computes twice --,
+    the backbone once on the B SLR clips and once on the B LR clips, with per-task losses (each task's own mean) summed
+    with those weights; one backward.  Same numbers as the task loop (train_dynavsr.py:300-426), B-times fatter launches."""
+    from . import dist as D
+    m = opt['train']['maml']
+    steps = m['adapt_iter']
+    lqs, slq, gt = train_data['LQs'], train_data['SuperLQs'], train_data['GT']
+    B, center = lqs.size(0), lqs.size(1) // 2
+    optimizer.zero_grad()
+    est_model.feed_data({'LQs': lqs, 'SuperLQs': slq})
+    est_model.forward_without_optim()
+    slr = est_model.fake_L                                                   # [B,N,3,h,w], graph into netE
+    model.feed_data({'LQs': backbone_input(opt, slr), 'GT': lqs[:, center]})
+    model.fake_H = model.netG(model.var_L)
+    l_pix = model.l_pix_w * hipops.charbonnier_per_sample(model.fake_H, model.real_H, model.cri_pix.eps)   # [B]
+    l1 = hipops.inner_loss_per_sample(torch.zeros_like(l_pix), slr, slq.to(slr.device), 1.0)                 # [B] = loss_e
+    l_train = l_pix + l1                                                     # :393, per task
+    sr_q = model.netG(backbone_input(opt, lqs))                              # meta test at the same weights (:403)
+    l_q = model.l_pix_w * hipops.charbonnier_per_sample(sr_q, gt[:, center], model.cri_pix.eps)
+    total = float(steps) * l_train.sum() + l_q.sum() / B + l1.sum() / (B * 10)
+    total.backward()
+    if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        D.allreduce_meta_gradients([model.netG, est_model.netE], average=True, group=group, force=force_collective)
+    optimizer.step()
+    lt, le = l_train.detach(), l1.detach()
+    return {'loss_q': float(l_q.detach().sum()) / B, 'loss_train': [lt[b] for b in range(B) for _ in range(steps)],
+            'loss_e': [le[b] for b in range(B)], 'batched': True}
+
+
 def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, optimizer, inner='reference',
-                    group=None, force_collective=False):
+                    group=None, force_collective=False, batched=True):
     """One outer (meta) iteration of the DynaVSR training driver, codes/train_dynavsr.py:265-438, over the
     wrapper API: the tasks of the batch are looped one clip at a time (:300), every task contributes its
     meta-gradient to ``model.netG`` / ``est_model.netE``'s ``.grad``, and the meta optimiser steps once (:438).
@@ -180,7 +223,13 @@ def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, opt
     Multi-GPU: each rank runs this on its shard of the tasks; with ``group`` given (or a default
     process group initialised) the accumulated gradients are all-reduced ONCE (mean over ranks) before the meta
     step -- the reference instead lets DDP hooks fire on every inner backward and leaves loss_q un-reduced; at
-    world_size 1 the two coincide.  Returns {'loss_q': Σ loss_q / B, 'loss_train': [...], 'loss_e': [...]}."""
+    world_size 1 the two coincide.  Returns {'loss_q': Σ loss_q / B, 'loss_train': [...], 'loss_e': [...]}.
+
+    batched (default): in 'reference' mode all tasks are evaluated at the same weights, so they run as ONE batch
+    (_meta_train_step_batched: same numbers, B-times fatter launches, the estimator's forward shared between the inner
+    loss and loss_e); batched=False keeps the task loop."""
+    if batched and _meta_batchable(opt, model, est_model, inner):
+        return _meta_train_step_batched(opt, model, est_model, train_data, optimizer, group, force_collective)
     from . import dist as D
     m = opt['train']['maml']
     steps = m['adapt_iter']
@@ -282,6 +331,7 @@ class FrameBatch:
                 p.data = s_.data[i]
             self.netG.append(g); self.netE.append(e)
         self.last_use = None                             # event: the last forward that read these weights
+        self._rep = None                                 # cached pointer arrays of refresh()
 
     @staticmethod
     def signature(opt, netG, netE):
@@ -302,15 +352,26 @@ class FrameBatch:
 
     def refresh(self, netG, netE):
         """Every slice = the un-adapted weights (the per-frame deepcopy), fresh optimiser state."""
-        with torch.no_grad():
-            src = [p.detach().unsqueeze(0).expand_as(s_) for p, s_ in
-                   zip(netG.ordered_parameters() + netE.ordered_parameters(), self.g_stack + self.e_stack)]
-            torch._foreach_copy_(self.g_stack + self.e_stack, src)
+        import ctypes
+        from . import _lib as L
+        src = netG.ordered_parameters() + netE.ordered_parameters()
+        n = len(src)
+        if self._rep is None:
+            dst = self.g_stack + self.e_stack
+            self._rep = ((ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(*[L.ptr(d) for d in dst]),
+                         (ctypes.c_longlong * n)(*[p.numel() for p in src]))
+        for i, p in enumerate(src):            # (the meta-parameters may have been re-pointed: `param.data = ...`)
+            self._rep[0][i] = L.ptr(p.detach() if p.is_contiguous() else p.detach().contiguous())
+        L.check(L.lib().dvsr_replicate_tensors(self._rep[0], self._rep[1], self._rep[2], n, self.k, L.stream()),
+                "dvsr_replicate_tensors")
         for s_ in self.g_stack + self.e_stack:
             s_.grad = None
         self.inner.reset()
-        for g, e in zip(self.netG, self.netE):
-            g.train(netG.training); e.train(netE.training)
+        for g, e in zip(self.netG, self.netE):       # (train() walks ~150 holder modules: only when the mode differs)
+            if g.training != netG.training:
+                g.train(netG.training)
+            if e.training != netE.training:
+                e.train(netE.training)
 
     def adapt(self, model, est_model, est_model_fixed, lqs, slr_weight=10.0):
         """lqs [K,N,3,H,W] -> (per-frame losses [K], SLR clips [K,N,3,h,w]); afterwards slice k holds frame k's adapted

@@ -304,11 +304,14 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
 #endif
   // small pixel grids: one kernel row per workgroup (conv2d_wgrad_pipe_kernel<3, true>); the pixel split is then
   // sized for ~two workgroups per CU over the three rows.  DVSR_WGRAD_KYS_BELOW=<tiles x cout blocks x cin blocks>
-  // moves the threshold (0 disables).
+  // moves the threshold (0 disables).  1024 (r03; 4096 before): the row split pays when a workgroup would otherwise
+  // get less than ~4 tiles; above that its three-fold re-staging of x costs more than the parallelism gives -- the
+  // batched inner step (8 frames, 40 x 44x80 = 2640 tiles per layer) measured 5.96 ms per frame with the row split on
+  // those layers and 5.45 without (profiles/r03_inner_batch_sweeps.txt).
   static int kys_below = -1;
   if (kys_below < 0) {
     const char* v = getenv("DVSR_WGRAD_KYS_BELOW");
-    kys_below = v ? atoi(v) : 4096;
+    kys_below = v ? atoi(v) : 1024;
   }
   auto per_group = [&](int s) {   // a launch-wide split count -> per group, never more than a group has tiles
     s = ceil_div(s, groups);

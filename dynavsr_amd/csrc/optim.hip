@@ -39,9 +39,38 @@ __global__ void sgd_step_kernel(OptTable t, float lr, float weight_decay) {
   }
 }
 
+// dst[i][c][:] = src[i][:] for c < copies: the per-frame deep copies of the networks (test_dynavsr.py:208) for a batch
+// of frames, every tensor's copies stacked along a leading axis (dynavsr_amd/adapt.py: FrameBatch).  e.g = source.
+__global__ void replicate_kernel(OptTable t) {
+  const OptEntry& e = t.e[blockIdx.y];
+  float* const dst = e.p + (long long)blockIdx.z * e.n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < e.n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = e.g[i];
+}
+
 }  // namespace dvsr
 
 using namespace dvsr;
+
+extern "C" int dvsr_replicate_tensors(const float* const* src, float* const* dst, const long long* numel, int n_tensors,
+                                      int copies, dvsr_stream_t stream) {
+  DVSR_REQUIRE(src && dst && numel && n_tensors >= 0 && copies >= 1, DVSR_ERR_INVALID, "replicate_tensors: bad argument");
+  OptTable t;
+  t.count = 0;
+  auto flush = [&]() -> int {
+    if (!t.count) return DVSR_OK;
+    hipLaunchKernelGGL(replicate_kernel, dim3(16, t.count, copies), dim3(256), 0, (hipStream_t)stream, t);
+    t.count = 0;
+    return check_launch("replicate_kernel");
+  };
+  for (int i = 0; i < n_tensors; ++i) {
+    if (numel[i] <= 0) continue;
+    DVSR_REQUIRE(src[i] && dst[i], DVSR_ERR_INVALID, "replicate_tensors: null tensor %d", i);
+    t.e[t.count++] = OptEntry{dst[i], src[i], nullptr, nullptr, numel[i]};
+    if (t.count == OPT_BATCH) { int rc = flush(); if (rc) return rc; }
+  }
+  return flush();
+}
 
 extern "C" int dvsr_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
                               float* const* exp_avg_sq, const long long* numel, int n_tensors, float lr, float beta1,

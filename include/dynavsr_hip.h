@@ -399,6 +399,11 @@ int dvsr_adam_step(float* const* params, const float* const* grads, float* const
                    float beta2, float eps, float weight_decay, int step, dvsr_stream_t stream);
 int dvsr_sgd_step(float* const* params, const float* const* grads, const long long* numel, int n_tensors,
                   float lr, float weight_decay, dvsr_stream_t stream);
+/* The per-frame deep copies of the networks (test_dynavsr.py:208 `modelcp.netG = deepcopy(model.netG)`) for a batch of
+ * frames: dst[i] = [copies][numel[i]] floats, every copy = src[i].  HOST arrays of device pointers, one launch per 48
+ * tensors (the framework's foreach copy with broadcast sources is one launch per tensor: 158 for netG + netE). */
+int dvsr_replicate_tensors(const float* const* src, float* const* dst, const long long* numel, int n_tensors, int copies,
+                           dvsr_stream_t stream);
 
 /* ---- per-frame image metrics on the device ------------------------------------------
  * Replaces, per super-resolved frame of test_dynavsr.py:285-292 (and of the validation loops of

@@ -537,16 +537,19 @@ def _meta_setup(adapt_iter=2):
     return opt, model, est, modelcp, estcp, params, data, PG, PE
 
 
-def test_meta_train_step_golden():
+@pytest.mark.parametrize("batched", [True, False])
+def test_meta_train_step_golden(batched):
     """One outer iteration of train_dynavsr.py:265-438 (B = 2 tasks, adapt_iter = 2, inner Adam, meta SGD) against
     the golden produced by driving the reference's wrappers through the same statements on CPU: loss_q, the inner
-    losses, every meta-gradient norm, five full gradient tensors, and the SGD update of the meta-parameters."""
+    losses, every meta-gradient norm, five full gradient tensors, and the SGD update of the meta-parameters -- for the
+    task loop and for all tasks as one batch (every loss of the shipped driver is taken at the same weights, quirk Q1)."""
     from dynavsr_amd.adapt import meta_train_step
     g = load_golden("meta_step")
     opt, model, est, modelcp, estcp, params, data, PG, PE = _meta_setup()
     lr_G = float(g["lr_G"])
     optimizer = torch.optim.SGD(params, lr=lr_G)
-    r = meta_train_step(opt, model, est, modelcp, estcp, data, optimizer, inner="reference")
+    r = meta_train_step(opt, model, est, modelcp, estcp, data, optimizer, inner="reference", batched=batched)
+    assert bool(r.get("batched")) == batched
     assert abs(r["loss_q"] - float(g["loss_q"])) < 2e-5 * abs(float(g["loss_q"]))
     lt = np.array([float(v) for v in r["loss_train"]])
     assert np.abs(lt - g["loss_train"]).max() < 2e-5 * np.abs(g["loss_train"]).max()
