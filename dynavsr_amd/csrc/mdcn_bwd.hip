@@ -8,9 +8,12 @@
 //  * EDVR's configuration (3x3, stride/pad/dilation 1, C/dg a multiple of 8): ONE fused kernel,
 //    mdcn_bwd_fused_kernel -- dcol = W^T . gout on the MFMA stays in registers (never in HBM), the per-(pixel,
 //    tap) sampler produces the offset / mask gradients in registers, the input gradient is accumulated in an
-//    LDS window with 64-bit fixed-point ds_add_u64 and leaves as one fp32 atomic per touched element; only the
-//    column buffer of the weight gradient round-trips HBM (1x1 wgrad over it).  Groups of 16 channels are walked
-//    as two 8-channel chunks.
+//    LDS window with 64-bit fixed-point ds_add_u64 and leaves as one fp32 atomic per touched element; the weight
+//    gradient is contracted IN the kernel as well (r03): the modulated samples the sampler has in registers go through
+//    LDS into a second MFMA phase, dW_tile[o][tap, c] = sum over the tile's pixels of gout * sample, and leave as one
+//    [Cout][72] partial per workgroup (plain stores) that a small kernel sums -- NO column buffer anywhere (the
+//    reference, and this file until r02, wrote [N, C*9, H*W] floats and ran a 1x1 weight-gradient GEMM over them:
+//    663 MB written + read per L1 call at 5x64x180x320).  Groups of 16 channels are walked as two 8-channel chunks.
 //  * every other configuration (C/dg = 4, other strides / dilations; DVSR_DCN_BWD=unfused forces it): the
 //    three-kernel form of the reference -- the two contractions on the MFMA conv kernels (dcol = 1x1 "dgrad"
 //    over the flattened [Cout][C*9] weight, dW/db = 1x1 wgrad over the column buffer) around the fused
@@ -144,7 +147,9 @@ __global__ void mdcn_col2im_coord_kernel(DcnB a, const float* __restrict__ dcol,
 // -------------------------------------------------------------------------------------------------
 struct DcnF {
   const float* x; const float* off; const float* msk; const float* w; const float* gout;
-  float* gx; float* goff; float* gmsk; float* col;
+  float* gx; float* goff; float* gmsk;
+  float* dwp;  // [N][C/8][tiles][Cout][72] weight-gradient partials (m = tap * 8 + c), or null: no weight gradient
+  float* dbp;  // [N][tiles][Cout] bias-gradient partials
   long long off_bs, msk_bs, goff_bs, gmsk_bs;
   int mask_logit, N, C, H, W, Cout, dg, tiles_x, tiles_y;
   int sub;  // 8-channel chunks per deformable group (1: EDVR-M, 2: EDVR-L); blockIdx.y walks the C/8 chunks
@@ -335,14 +340,16 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   // for every in-window sample, as in the forward kernel.  Samples outside the window are flagged and redone exactly in the rare loop below.
   float* goffn = a.goff + (size_t)n * a.goff_bs;
   float* gmskn = a.gmsk + (size_t)n * a.gmsk_bs;
-  float* coln = a.col + (size_t)n * a.C * 9 * HW;
   float* gxg = a.gx ? a.gx + ((size_t)n * a.C + kc * 8) * HW : nullptr;
   // float -> int64 (round to nearest) through the double mantissa: bits(double(v) + 1.5 * 2^52) - bits(1.5 * 2^52) is the
   // integer for |v| < 2^51: 4 VALU instructions (__float2ll_rn is a ~14-instruction sequence)
   auto q64 = [](float v) {
     return (unsigned long long)(__double_as_longlong((double)v + 6755399441055744.0) - 0x4338000000000000LL);
   };
-  auto store_grads = [&](int tap, int nt, float gm, float gh, float gw, float m, const float (&colv)[4]) {
+  // The modulated samples of this lane's (pixel, tap, 4 channels) -- the B operands of phase 4 -- REPLACE the dcol values
+  // in the accumulator registers as those are consumed (72 more live registers would spill: the kernel sits at 256).
+#define COLR(tap_, nt_, cq_) acc[(tap_) >> 2][nt_][((tap_) & 3) * 4 + (cq_)]
+  auto store_grads = [&](int tap, int nt, float gm, float gh, float gw, float m) {
     if (hi == 0) {
       float* ph = goffn + (size_t)(g * 18 + 2 * tap) * HW + pofs[nt];
       float* pm = gmskn + (size_t)(g * 9 + tap) * HW + pofs[nt];
@@ -353,9 +360,6 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
         unsafeAtomicAdd(ph, gh); unsafeAtomicAdd(ph + HW, gw); unsafeAtomicAdd(pm, gmv);
       }
     }
-#pragma unroll
-    for (int cq = 0; cq < 4; ++cq)
-      coln[((size_t)(kc * 8 + 4 * hi + cq) * 9 + tap) * HW + pofs[nt]] = colv[cq];
   };
   unsigned fixbits = 0;  // bit 2 tap + nt: this lane's sample left the staged window
 #pragma unroll
@@ -384,7 +388,6 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
         const float mk = ok ? m : 0.f;               // zero for samples this path does not own
         const float tsc = mk * qscale;
         float gm = 0.f, gh = 0.f, gw = 0.f;
-        float colv[4];
 #pragma unroll
         for (int cq = 0; cq < 4; ++cq) {
           const int c = 4 * hi + cq;
@@ -392,7 +395,6 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
           const float* p1 = s_x + c * XPX + cell;
           const float v1 = p1[0], v2 = p1[1], v3 = p1[XW], v4 = p1[XW + 1];
           const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-          colv[cq] = val * mk;
           gm += d * val;                                              // kernel.cu:752
           gh += (-hw * v1 - lw * v2 + hw * v3 + lw * v4) * d;         // :541-550 (x mask below)
           gw += (-hh * v1 + hh * v2 - lh * v3 + lh * v4) * d;         // :552-561
@@ -406,13 +408,15 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
             atomicAdd(q1 + XW, q64(w3 * ts));
             atomicAdd(q1 + XW + 1, q64(w4 * ts));
           }
+          // (a sample that left the window keeps d: loop 2b needs it, and stores the exact sample instead)
+          COLR(tap, nt, cq) = ((int)pv[nt] & (inwin ^ 1)) ? d : val * mk;
         }
         gm = ok ? gm : 0.f; gh *= mk; gw *= mk;
         // the partner lane (other 4 channels of the same pixel) completes the sums
         gm += __shfl_xor(gm, 32, 64);
         gh += __shfl_xor(gh, 32, 64);
         gw += __shfl_xor(gw, 32, 64);
-        if (pv[nt]) store_grads(tap, nt, gm, gh, gw, m, colv);
+        if (pv[nt]) store_grads(tap, nt, gm, gh, gw, m);
       }
     }
   }
@@ -487,15 +491,21 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
           }
         }
 #pragma unroll
-        for (int cq = 0; cq < 4; ++cq) coln[((size_t)(kc * 8 + 4 * hi + cq) * 9 + tap) * HW + pof] = colv[cq];
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            if (t == tap && r == nt) {
+#pragma unroll
+              for (int cq = 0; cq < 4; ++cq) COLR(t, r, cq) = colv[cq];
+            }
       }
     }
   }
   DCNB_STAMP(5);
-  if (!gxg) return;
   __syncthreads();
   DCNB_STAMP(6);
   // ---- 3. flush the gradient window
+  if (gxg)
   for (int idx = tid; idx < 8 * XPX; idx += 256) {
     const long long q = (long long)s_gq[idx];
     if (q == 0) continue;
@@ -507,12 +517,150 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       unsafeAtomicAdd(gxg + (size_t)c * HW + (size_t)gy_ * a.W + gx_, v);
   }
   DCNB_STAMP(7);
+  if (!a.dwp) return;
+  // ---- 4. weight gradient of the tile: D[o][m] = sum_p gout[o][p] * sample[m = tap * 8 + c][p] on the MFMA with
+  // K = the tile's 256 pixels, in two halves of 4 pixel rows (LDS: both operands pixel-minor with an odd row pitch, so a
+  // lane's operand -- row o or m = lane & 31, pixel 2 kk + hi -- is a conflict-free ds_read_b32).  A operand rows = o,
+  // B operand columns = m (72 of 96 used).  Every wave takes a quarter of a half's k-steps for all 2 x 3 tiles (the dcol
+  // accumulators are dead by now); the four partial tiles are summed through LDS and leave as ONE [64][72] block of
+  // plain coalesced stores per workgroup and 64-cout block (mdcn_dw_reduce_kernel sums the blocks: at ~5 k floats per
+  // workgroup, atomics would be 26 M per L1 call of a batch of 8 frames).  The bias gradient falls out of the A operands.
+  constexpr int HP = 129;
+  float* const s_go = smem;                 // [64][HP]
+  float* const s_ct = smem + 64 * HP;       // [72][HP]  (70 KB together: within the 72.6 KB of phases 0-3, two workgroups per CU)
+  float* const s_out = smem;                // [64][73] (after the MFMAs)
+  float* const s_db = smem + 64 * 73;       // [4][64]
+  const size_t wg = ((size_t)n * gridDim.y + kc) * gridDim.x + tile;
+#pragma unroll 1
+  for (int ob = 0; ob < (a.Cout >> 6); ++ob) {
+    // wave -> (32-cout half ot, half kh of a step's pixels): 3 tiles per wave, ONE exchange between the two k halves
+    const int ot = wave & 1, kh = wave >> 1;
+    f32x16 dw[3];
+#pragma unroll
+    for (int j2 = 0; j2 < 3; ++j2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dw[j2][r] = 0.f;
+    float db0 = 0.f;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();   // the previous user of this LDS (gradient window / previous half / previous block) is done
+      // gout half tile, zero outside the image: 64 channels x 4 rows x 32 pixels (two batches of 16 loads per lane:
+      // 32 at once spill)
+#pragma unroll 1
+      for (int eb = 0; eb < 32; eb += 16) {
+        float rg[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int idx = tid + 256 * (eb + e);        // = o * 128 + p
+          const int o = ob * 64 + (idx >> 7), p = idx & 127;
+          const int gy_ = oy0 + 4 * half + (p >> 5), gx_ = ox0 + (p & 31);
+          rg[e] = (gy_ < a.H && gx_ < a.W) ? gon[(size_t)o * HW + (size_t)gy_ * a.W + gx_] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int idx = tid + 256 * (eb + e);
+          s_go[(idx >> 7) * HP + (idx & 127)] = rg[e];
+        }
+      }
+      if ((wave >> 1) == half) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int p = (2 * (wave & 1) + nt) * 32 + lo;
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq)
+              s_ct[(tap * 8 + 4 * hi + cq) * HP + p] = pv[nt] ? COLR(tap, nt, cq) : 0.f;
+          }
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int kk = 32 * kh; kk < 32 * kh + 32; ++kk) {
+        const int p = 2 * kk + hi;
+        const float av = s_go[(ot * 32 + lo) * HP + p];
+        db0 += av;
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+          const float bv = (mt < 2 || lo < 8) ? s_ct[(mt * 32 + lo) * HP + p] : 0.f;   // m = mt * 32 + lo < 72
+          dw[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dw[mt], 0, 0, 0);
+        }
+      }
+    }
+    // the two k halves meet in LDS: out[o][m], m < 72
+    __syncthreads();
+    s_db[(2 * kh + hi) * 64 + ot * 32 + lo] = db0;
+#pragma unroll 1
+    for (int w = 0; w < 2; ++w) {
+      if (kh == w) {
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, m = mt * 32 + lo;
+            if (m < 72) {
+              float* q = s_out + o * 73 + m;
+              *q = (w == 0 ? 0.f : *q) + dw[mt][r];
+            }
+          }
+      }
+      __syncthreads();
+    }
+    float* dst = a.dwp + (wg * (size_t)(a.Cout >> 6) + ob) * (size_t)(64 * 72);
+    for (int idx = tid; idx < 64 * 72; idx += 256) dst[idx] = s_out[(idx / 72) * 73 + (idx % 72)];
+    if (kc == 0 && tid < 64) {
+      float sdb = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sdb += s_db[q * 64 + tid];
+      a.dbp[((size_t)n * gridDim.x + tile) * a.Cout + ob * 64 + tid] = sdb;
+    }
+  }
+#undef COLR
 }
 
+// dW[g][o][kc * 8 + c][tap] += sum over a chunk of the (frame, tile) rows of batch group g of
+// partial[n][kc][tile][ob][o][tap * 8 + c]; db[g][o] likewise.  grid (ceil(64 * 72 / 256), C / 8 * Cout / 64, groups * nsp):
+// the rows of a group are split nsp ways (one thread summing all ~1000 rows of a 180x320 call serially took 800 us for
+// 170 MB); the splits meet with fp32 atomics in the zeroed outputs.
+constexpr int DW_ROWS = 32;
+__global__ void mdcn_dw_reduce_kernel(const float* __restrict__ dwp, const float* __restrict__ dbp, float* __restrict__ gw,
+                                      float* __restrict__ gb, int N, int nkc, int ntile, int Cout, int C, int groups,
+                                      int nsp, long long gw_gs, long long gb_gs) {
+  const int nob = Cout >> 6;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int kc = blockIdx.y / nob, ob = blockIdx.y - kc * nob;
+  const int g = blockIdx.z / nsp, sp = blockIdx.z - g * nsp;
+  const int per = N / groups, rows = per * ntile;
+  const int r0 = sp * DW_ROWS, r1 = min(r0 + DW_ROWS, rows);
+  if (e < 64 * 72) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    auto at = [&](int r) {
+      const int n = g * per + r / ntile, t = r - (r / ntile) * ntile;
+      return dwp[((((size_t)n * nkc + kc) * ntile + t) * nob + ob) * (size_t)(64 * 72) + e];
+    };
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) { s0 += at(r); s1 += at(r + 1); s2 += at(r + 2); s3 += at(r + 3); }
+    for (; r < r1; ++r) s0 += at(r);
+    const int o = ob * 64 + e / 72, m = e % 72;
+    unsafeAtomicAdd(gw + (size_t)g * gw_gs + ((size_t)o * C + kc * 8 + (m & 7)) * 9 + (m >> 3), (s0 + s1) + (s2 + s3));
+  }
+  if (gb && kc == 0 && e < 64) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const int n = g * per + r / ntile, t = r - (r / ntile) * ntile;
+      s += dbp[((size_t)n * ntile + t) * Cout + ob * 64 + e];
+    }
+    unsafeAtomicAdd(gb + (size_t)g * gb_gs + ob * 64 + e, s);
+  }
+}
+
+// Workspace: the general path's column buffer [N][C*9][P] + the 1x1 weight gradient's slots; the fused path's per-
+// workgroup weight / bias gradient partials.
 size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int stride, int pad, int dil, int groups) {
   const int Ho = (H + 2 * pad - (dil * 2 + 1)) / stride + 1, Wo = (W + 2 * pad - (dil * 2 + 1)) / stride + 1;
   const size_t col = (size_t)N * C * 9 * Ho * Wo * sizeof(float);
-  return col + conv2d_wgrad_workspace_bytes(N, C * 9, Ho, Wo, Cout, 1, 1, -1, groups);
+  const size_t ntile = (size_t)ceil_div(Wo, 32) * ceil_div(Ho, 8);
+  const size_t fused = ((size_t)N * (C / 8) * ntile * Cout * 72 + (size_t)N * ntile * Cout) * sizeof(float);
+  return std::max(col + conv2d_wgrad_workspace_bytes(N, C * 9, Ho, Wo, Cout, 1, 1, -1, groups), fused);
 }
 
 // gout: gradient w.r.t. the PRE-activation output.  gx is accumulated into (atomics) -- zero it
@@ -546,10 +694,13 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
     const char* v = getenv("DVSR_DCN_BWD");
     use_fused = (v && v[0] == 'u') ? 0 : 1;
   }
-  if (use_fused && a.cpg % 8 == 0 && stride == 1 && pad == 1 && dil == 1 && Cout % 32 == 0 && Cout <= 128) {
+  if (use_fused && a.cpg % 8 == 0 && stride == 1 && pad == 1 && dil == 1 && Cout % 64 == 0 && Cout <= 128) {
     constexpr int HALO = 4, XPX = (8 + 2 + 2 * HALO) * (32 + 2 + 2 * HALO);
     DcnF f;
-    f.x = x; f.off = off; f.msk = msk; f.w = w; f.gout = gout; f.gx = gx; f.goff = goff; f.gmsk = gmsk; f.col = col;
+    f.x = x; f.off = off; f.msk = msk; f.w = w; f.gout = gout; f.gx = gx; f.goff = goff; f.gmsk = gmsk;
+    const int ntile = ceil_div(W, 32) * ceil_div(H, 8);
+    f.dwp = gw ? (float*)ws : nullptr;
+    f.dbp = gw ? f.dwp + (size_t)N * (C / 8) * ntile * Cout * 72 : nullptr;
     f.off_bs = a.off_bs; f.msk_bs = a.msk_bs; f.goff_bs = goff_bs; f.gmsk_bs = gmsk_bs;
     f.mask_logit = mask_logit; f.N = N; f.C = C; f.H = H; f.W = W; f.Cout = Cout; f.dg = dg;
     f.tiles_x = ceil_div(W, 32); f.tiles_y = ceil_div(H, 8);
@@ -565,11 +716,12 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
         DVSR_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, DVSR_ERR_HIP, "mdcn_backward: memset of goff/gmsk failed");
       }
     }
-    const size_t lds = (size_t)(8 * XPX + std::max(16 * XPX, 3 * (Cout / 2) * 64)) * sizeof(float);
+    // LDS: input window + max(gradient window, W^T operands); the weight-gradient phase re-uses it ([64 + 72][129] floats)
+    const size_t lds = (size_t)std::max(8 * XPX + std::max(16 * XPX, 3 * (Cout / 2) * 64), (64 + 72) * 129) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
       hipFuncSetAttribute((const void*)mdcn_bwd_fused_kernel<HALO>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)((8 * XPX + std::max(16 * XPX, 3 * 64 * 64)) * sizeof(float)));
+                          (int)(std::max(8 * XPX + std::max(16 * XPX, 3 * 64 * 64), (64 + 72) * 129) * sizeof(float)));
       attr_done = true;
     }
 #ifdef DVSR_CONV_TRACE
@@ -578,11 +730,17 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
 #endif
     hipLaunchKernelGGL(mdcn_bwd_fused_kernel<HALO>, dim3(f.tiles_x * f.tiles_y, C / 8, N), dim3(256), lds, st, f);
     int rc = check_launch("mdcn_bwd_fused_kernel");
-    if (rc) return rc;
-    if (gw)  // dW = gout . col^T, db = gout . 1 (the kernel above wrote the modulated samples to col)
-      rc = conv2d_wgrad_run(col, 0, 1, gout, 0, gw, gb, N, C * 9, a.Ho, a.Wo, Cout, C * 9, 0, 1, 1, ws2, ws2_bytes, st, 0, -1,
-                            nullptr, groups, gw_gs, gb_gs);
-    return rc;
+    if (rc || !gw) return rc;
+    // dW / db: sum the per-workgroup partials (per batch group when per-group gradients are asked for) into zeroed outputs
+    for (int g = 0; g < groups; ++g) {
+      hipError_t e1 = hipMemsetAsync(gw + (size_t)g * gw_gs, 0, (size_t)Cout * C * 9 * sizeof(float), st);
+      hipError_t e2 = gb ? hipMemsetAsync(gb + (size_t)g * gb_gs, 0, (size_t)Cout * sizeof(float), st) : hipSuccess;
+      DVSR_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, DVSR_ERR_HIP, "mdcn_backward: memset of the weight gradient failed");
+    }
+    const int nsp = ceil_div((N / groups) * ntile, DW_ROWS);
+    hipLaunchKernelGGL(mdcn_dw_reduce_kernel, dim3(ceil_div(64 * 72, 256), (C / 8) * (Cout / 64), groups * nsp), dim3(256), 0,
+                       st, f.dwp, f.dbp, gw, gb, N, C / 8, ntile, Cout, C, groups, nsp, gw_gs, gb_gs);
+    return check_launch("mdcn_dw_reduce_kernel");
   }
   // 1) dcol[n][C*9][P] = W^T . gout  as a 1x1 conv with the transposed weight view
   dvsr_conv2d_desc g = {};
