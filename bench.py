@@ -171,7 +171,7 @@ def cpu_baseline(cfg, h, w, seed, y_gpu=None):
 
 
 # ---- inner MAML step (SURVEY §8d ii) --------------------------------------------------------------
-def inner_step_rate(dev, steps=60, h=176, w=320, frames_per_batch=8):
+def inner_step_rate(dev, steps=60, h=176, w=320, frames_per_batch=16):
     """One inner MAML step per frame at LR 176x320 -> SLR 44x80 (test_dynavsr.py:208-277): refresh of the frame's copies,
     frozen-estimator forward, MFDN forward with grad, EDVR forward+backward on the SLR clip, Charbonnier + 10*L1 losses,
     MFDN backward, Adam step over G u E parameters.  north_star target: >= 50 clips/s.

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <type_traits>
+#include <utility>
 
 namespace dvsr {
 
@@ -31,6 +33,17 @@ int check_launch(const char* what);  // hipGetLastError -> DVSR_ERR_HIP + messag
   } while (0)
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// f(integral_constant<int, I>) for I in [B, E): a loop whose index is a compile-time constant in the body (operand
+// addresses become immediates, register arrays stay in registers).
+template <int B, int... I, class F>
+__host__ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, B + I>{}), ...);
+}
+template <int B, int E, class F>
+__host__ __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (E > B) static_for_impl<B>(std::make_integer_sequence<int, E - B>{}, static_cast<F&&>(f));
+}
 
 // Activation codes shared by conv / dcn epilogues.
 enum : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2 };

@@ -138,7 +138,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(WgradK a) {
 template <int KS, bool KYS = false>
 __global__ __launch_bounds__(256, KYS ? 2 : 1) void conv2d_wgrad_pipe_kernel(WgradK a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  conv2d_wgrad_pipe_item<KS, KYS>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+  // (7x7 / 9x9 kernel rows: 112 / 144 accumulators at two workgroups per CU leave no room for the fast path's operand ring)
+  if constexpr (KS <= 3) {
+    if (a.Cin - (int)blockIdx.z * 64 > 32 && a.Cout - (int)blockIdx.y * 64 > 32) {
+      conv2d_wgrad_pipe_item<KS, KYS, true>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+      return;
+    }
+  }
+  conv2d_wgrad_pipe_item<KS, KYS, false>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // dW[o][c_off + c][tap] = sum_s partial[s][tap][o][c];  db[o] = sum_s dbp[s][o]
@@ -253,9 +260,11 @@ static int wgrad_splits(int ntiles, int nob, int ncb, int KK, bool one_per_cu = 
 
 // Pixel splits PER GROUP: the launch as a whole (groups x splits x cout blocks x cin blocks) aims at the same number of
 // workgroups as an ungrouped one over the same tensor.
+// (rounded DOWN: the un-split kernel runs one workgroup per CU, and 12 groups x ceil(256 / 12) = 264 workgroups are two
+// rounds on 256 CUs -- the batched inner step measured 6.07 ms per frame at 12 frames against 5.38 at 8 and 5.09 at 16)
 static int wgrad_group_splits(int gtiles, int nob, int ncb, int KK, int groups, bool one_per_cu = false) {
   if (groups <= 1) return wgrad_splits(gtiles, nob, ncb, KK, one_per_cu);
-  int s = ceil_div(wgrad_splits(gtiles * groups, nob, ncb, KK, one_per_cu), groups);
+  int s = wgrad_splits(gtiles * groups, nob, ncb, KK, one_per_cu) / groups;
   if (s > gtiles) s = gtiles;
   return s < 1 ? 1 : s;
 }
@@ -313,8 +322,8 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
     const char* v = getenv("DVSR_WGRAD_KYS_BELOW");
     kys_below = v ? atoi(v) : 1024;
   }
-  auto per_group = [&](int s) {   // a launch-wide split count -> per group, never more than a group has tiles
-    s = ceil_div(s, groups);
+  auto per_group = [&](int s) {   // a launch-wide split count -> per group (rounded down), never more than a group has tiles
+    s = groups > 1 ? s / groups : s;
     return s > k.gtiles ? k.gtiles : (s < 1 ? 1 : s);
   };
   out->bf = bf16 && ks == 3 && stride == 1;

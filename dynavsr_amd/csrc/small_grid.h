@@ -274,7 +274,11 @@ struct WgPipeShape {
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(float);
 };
 
-template <int KS, bool KYS>
+// FAST: every wave of the workgroup owns a populated 32 x 32 block (more than 32 channels on both sides of this
+// (cout, cin) block: kinc == 1) -- the MFMA loop is straight-line, software-pipelined code.  The two variants are two
+// separate instantiations of the WHOLE body (the kernel branches once, on block-uniform values): with both loops in
+// one function the accumulators got different registers on the two paths and every tile paid ~600 v_accvgpr_mov.
+template <int KS, bool KYS, bool FAST>
 __device__ __forceinline__ void conv2d_wgrad_pipe_item(const WgradK& a, const int bx, const int by, const int bz,
                                                        float* const smem) {
   using Sh = WgPipeShape<KS, KYS>;
@@ -388,6 +392,39 @@ __device__ __forceinline__ void conv2d_wgrad_pipe_item(const WgradK& a, const in
       }
     }
   };
+  // The common case (every wave owns a populated 32 x 32 block: kinc == 1) as straight-line code (r03).  The loop above
+  // does not unroll (run-time step), so each k-step waited for its own LDS reads in front of the MFMAs that need them --
+  // four exposed LDS latencies per nine MFMAs for 3x3, one per MFMA for 1x1 (the ISA: ds_read, s_waitcnt lgkmcnt(0),
+  // v_mfma; 84 TFLOP/s at best for 3x3, 15 for 1x1).  Here the k range is a compile-time constant: every operand address
+  // is the lane's base plus an immediate, and the operands of k-step kk + D are read before the MFMAs of k-step kk
+  // (ring of D + 1 register sets), so a read has D x KK x 64 cycles to land.
+  auto mfma_fast = [&](int buf, auto k0c, auto k1c) {
+    constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
+    constexpr int D = KK >= 9 ? 1 : (KK >= 3 ? 2 : 6);
+    const float* ga = smem + buf * BUF + (ot * 32 + lo) * GROW + hi;
+    const float* xb = smem + buf * BUF + 64 * GROW + (ct * 32 + lo) * PLANEP + hi;
+    float av[D + 1], bv[D + 1][KK];
+    auto load = [&](auto kkc) {
+      constexpr int kk = decltype(kkc)::value;
+      constexpr int slot = (kk - K0) % (D + 1);
+      av[slot] = ga[2 * kk];
+#pragma unroll
+      for (int t = 0; t < KK; ++t) bv[slot][t] = xb[(kk >> 4) * IW + 2 * (kk & 15) + (t / KS) * IW + (t % KS)];
+    };
+    static_for<0, (D < K1 - K0 ? D : K1 - K0)>([&](auto i) { load(std::integral_constant<int, K0 + decltype(i)::value>{}); });
+    static_for<K0, K1>([&](auto kkc) {
+      constexpr int kk = decltype(kkc)::value;
+      constexpr int slot = (kk - K0) % (D + 1);
+      if constexpr (kk + D < K1) load(std::integral_constant<int, kk + D>{});
+      db += av[slot];
+#pragma unroll
+      for (int t = 0; t < KK; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[slot], bv[slot][t], acc[t], 0, 0, 0);
+    });
+  };
+  auto mfma_range = [&](int buf, auto k0c, auto k1c) {
+    if constexpr (FAST) mfma_fast(buf, k0c, k1c);
+    else mfma_steps(buf, decltype(k0c)::value, decltype(k1c)::value);
+  };
 
   const WgSpan sp = wg_span(a, split);
   int tile = sp.tile0;
@@ -400,9 +437,9 @@ __device__ __forceinline__ void conv2d_wgrad_pipe_item(const WgradK& a, const in
   for (; tile < sp.tile_end; tile += a.nsplit) {
     const bool has_next = tile + a.nsplit < sp.tile_end;
     if (has_next) issue_loads(tile + a.nsplit);
-    mfma_steps(buf, 0, 3 * NPX / 8);
+    mfma_range(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, 3 * NPX / 8>{});
     if (has_next) write_lds(buf ^ 1);
-    mfma_steps(buf, 3 * NPX / 8, NPX / 2);
+    mfma_range(buf, std::integral_constant<int, 3 * NPX / 8>{}, std::integral_constant<int, NPX / 2>{});
     __syncthreads();
     buf ^= 1;
   }

@@ -28,9 +28,13 @@ def timeit(fn):
 
 
 torch.manual_seed(0)
-for (n, cin, cout, h, w, ks) in [(5, 64, 64, 44, 80, 3), (5, 128, 64, 44, 80, 3), (5, 64, 216, 44, 80, 3),
-                                 (1, 64, 64, 176, 320, 3), (1, 320, 64, 44, 80, 1), (5, 64, 64, 22, 40, 3),
-                                 (5, 64, 64, 180, 320, 3), (1, 64, 64, 720, 1280, 3)]:
+shapes = [(5, 64, 64, 44, 80, 3), (5, 128, 64, 44, 80, 3), (5, 64, 216, 44, 80, 3),
+          (1, 64, 64, 176, 320, 3), (1, 320, 64, 44, 80, 1), (5, 64, 64, 22, 40, 3),
+          (5, 64, 64, 180, 320, 3), (1, 64, 64, 720, 1280, 3)]
+if os.environ.get("WGRAD_BENCH_BATCHED"):   # the layers of the batched inner step (8 frames as one batch)
+    shapes = [(8, 64, 64, 44, 80, 3), (40, 64, 64, 44, 80, 3), (40, 64, 216, 44, 80, 3), (8, 64, 64, 176, 320, 3),
+              (40, 64, 64, 176, 320, 3), (40, 64, 64, 22, 40, 3), (8, 320, 64, 44, 80, 1)]
+for (n, cin, cout, h, w, ks) in shapes:
     x = torch.randn(n, cin, h, w, device="cuda")
     gy = torch.randn(n, cout, h, w, device="cuda")
     wt = torch.randn(cout, cin, ks, ks, device="cuda")
