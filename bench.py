@@ -353,6 +353,53 @@ def meta_step_rate(dev, world, dist, tasks_per_rank=2, iters=4):
                         "5x3x64x64 / SLR 16x16 / HR 256x256, 1 inner Adam step, meta Adam; weak scaling over ranks" % B}
 
 
+# ---- distributed validation: frames sharded round-robin over the ranks -----------------------------------
+def validation_rate(dev, world, dist, frames_per_rank=8, h=176, w=320, frames_per_batch=8):
+    """train_dynavsr.py:500-728 / the test driver's frame loop on N ranks: the frames range(rank, n, world) are adapted
+    and super-resolved on each rank (adapt.validate_video: baseline forward, inner step, adapted forward, PSNR of both on
+    the device), the PSNR vectors are reduced to rank 0.  Weak scaling: `frames_per_rank` per rank."""
+    from dynavsr_amd import synth
+    from dynavsr_amd.adapt import validate_video
+    from dynavsr_amd.models import create_model
+    rank = dist.get_rank() if dist is not None else 0
+    opt = _opt()
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    model.netG.load_state_dict(synth.edvr_state_dict(0)); est.netE.load_state_dict(synth.mfdn_state_dict(0))
+    est_fixed.netE.load_state_dict(synth.mfdn_state_dict(1))
+    n = frames_per_rank * world
+    mine = set(range(rank, n, world))
+    # (only this rank's frames are materialised; the others are placeholders that are never touched)
+    clips = [{"LQs": synth.clip(400 + i, 1, 5, h, w, smooth=True).to(dev)} if i in mine else None for i in range(n)]
+    gts = [synth.clip(500 + i, 1, 1, 4 * h, 4 * w, smooth=True)[0, 0].to(dev) if i in mine else None for i in range(n)]
+
+    def run():
+        return validate_video(opt, model, est, modelcp, estcp, est_fixed, clips, gts, rank, world, frames_per_batch=frames_per_batch)
+    run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    r = run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ps, pf = r["psnr_start"], r["psnr_final"]
+    return {"value": n / dt, "unit": "frames/s (all ranks)", "frames": n, "frames_per_rank": frames_per_rank, "ranks": world,
+            "ms_per_frame_per_rank": dt / frames_per_rank * 1e3,
+            "psnr_vector_complete_on_rank0": bool((ps > 0).all() and (pf > 0).all()) if rank == 0 else None,
+            "mean_psnr_start_db": float(ps[ps > 0].mean()), "mean_psnr_final_db": float(pf[pf > 0].mean()),
+            "workload": "per frame: un-adapted EDVR-M x4 forward @%dx%d + 1 inner MAML step (%d frames per batch) + adapted "
+                        "forward + PSNR of both vs GT on the device; frames range(rank, n, world) per rank, PSNR vectors "
+                        "reduced to rank 0 (train_dynavsr.py:509, :721-728)" % (h, w, frames_per_batch)}
+
+
 # ---- configs[4]: EDVR-L on the three MFMA modes -----------------------------------------------------
 def edvr_l_rates(dev, steps=10):
     from dynavsr_amd import hipops, synth
@@ -513,6 +560,7 @@ def main():
     ap.add_argument("--no-inner-step", action="store_true", help="skip the inner-step and per-frame-pipeline legs")
     ap.add_argument("--no-split", action="store_true", help="skip the bf16 legs (split-mode forward, EDVR-L)")
     ap.add_argument("--no-meta", action="store_true", help="skip the meta-training iteration with the RCCL all-reduce")
+    ap.add_argument("--no-validation", action="store_true", help="skip the sharded validation leg (frames over ranks)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only, on the CPU over gloo (no kernels): what tests/ run here")
     args = ap.parse_args()
@@ -671,10 +719,20 @@ def main():
             meta = {"error": "%s: %s" % (type(e).__name__, e)}
         if dist_err:
             meta["process_group_error"] = dist_err
+    val = None
+    if not args.no_validation:   # every rank takes part (its shard of the frames, the metric reduction)
+        try:
+            val = validation_rate(dev, world, dist if world > 1 else None)
+        except Exception as e:
+            if world > 1:
+                raise
+            val = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         if meta is not None:
             line["meta_step"] = meta
+        if val is not None:
+            line["validation"] = val
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, h, w, 0, y)   # same clip (seed 1 + rank 0), same weights
     if dist is not None:

@@ -296,6 +296,30 @@ def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, opt
     return {'loss_q': total_q, 'loss_train': log_train, 'loss_e': log_e}
 
 
+def validate_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, clips, gts, rank=0, world=1, group=None,
+                   frames_per_batch=1, overlap=True):
+    """The validation loop of train_dynavsr.py:500-728 / the test driver's per-frame evaluation: this rank adapts and
+    super-resolves the frames range(rank, len(clips), world) (adapt_video), PSNR of the un-adapted ('start') and of the
+    adapted ('final') output against ``gts[i]`` [3,sH,sW] with the reference's uint8 definition, computed on the device
+    (utils.util.frame_metrics, no per-frame host sync); the two vectors are reduced to rank 0 (dist.validate_sharded).
+    Returns {'psnr_start', 'psnr_final'} as float64 tensors of length len(clips) (complete on rank 0) and 'frames'."""
+    from . import dist as D
+    from .utils import util
+    dev = next(model.netG.parameters()).device
+
+    def run(indices):
+        mine = [clips[i] for i in indices]
+        for i, (base, r) in zip(indices, adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, mine,
+                                                     overlap=overlap, frames_per_batch=frames_per_batch)):
+            gt = gts[i].to(dev)
+            yield (util.frame_metrics(base[0], gt, need_img=None)[0], util.frame_metrics(r['sr'][0], gt, need_img=None)[0])
+    mse_s, mse_f = D.validate_sharded(len(clips), run, rank, world, group, dev)
+    # (entries of other ranks' frames are 0 before the reduction and stay 0 off rank 0: PSNR is taken where mse > 0 ...
+    # an exact match would read as "not evaluated", as in the reference's `(v != 0).sum()`, :735-737)
+    psnr = lambda m: torch.where(m > 0, 20 * torch.log10(255.0 / torch.sqrt(m.clamp_min(1e-300))), torch.zeros_like(m))
+    return {'psnr_start': psnr(mse_s), 'psnr_final': psnr(mse_f), 'frames': D.shard_indices(len(clips), rank, world)}
+
+
 class FrameBatch:
     """K frames adapted as ONE batch (north_star: the inner MAML step; test_dynavsr.py:208-277 with adapt_iter = 1).
 

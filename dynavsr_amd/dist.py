@@ -62,3 +62,18 @@ def reduce_metric_vectors(vectors, dst=0, group=None):
             dist.reduce(v, dst, group=group)
         dist.barrier(group=group)
     return vectors
+
+
+def validate_sharded(n_frames, run_frames, rank=0, world=1, group=None, device=None, n_metrics=2):
+    """The distributed validation of train_dynavsr.py:500-728: rank r evaluates the frames range(r, n, world) (:509),
+    writes its results into zero-initialised vectors of length n (:527-532), the vectors are reduce(sum)-ed to rank 0
+    and a barrier follows (:721-728).  ``run_frames(indices)`` yields one tuple of ``n_metrics`` values (floats or 0-dim
+    tensors: e.g. PSNR before / after adaptation) per index, in order.  Returns the list of vectors (float64, on
+    ``device``); complete on rank 0, this rank's entries elsewhere."""
+    idx = shard_indices(n_frames, rank, world)
+    vecs = [torch.zeros(n_frames, dtype=torch.float64, device=device) for _ in range(n_metrics)]
+    for i, vals in zip(idx, run_frames(idx)):
+        for v, x in zip(vecs, vals):
+            v[i] = x
+    reduce_metric_vectors(vecs, 0, group)
+    return vecs

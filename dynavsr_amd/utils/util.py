@@ -362,7 +362,9 @@ def frame_metrics(sr, gt, min_max=(0, 1), need_img=False):
     (codes/utils/util.py:112-142, :262-269, :271-313) -- same quantisation, same float64 SSIM -- without
     moving the fp32 frame to the host.  sr, gt: [3,H,W] or [1,3,H,W] fp32 tensors on the GPU (there is no
     CPU path: calculate_psnr / calculate_ssim above are the host-side helpers).  Returns (psnr, ssim) or, with
-    need_img, (psnr, ssim, uint8 HWC RGB numpy image of sr for the PNG writer)."""
+    need_img, (psnr, ssim, uint8 HWC RGB numpy image of sr for the PNG writer); need_img=None returns the DEVICE
+    tensor [mse, ssim] (float64) without synchronising -- psnr = 20 log10(255 / sqrt(mse)) (validation loops collect
+    these per frame and convert once)."""
     import torch
     from dynavsr_amd import _lib as L
     sr, gt = sr.squeeze(), gt.squeeze()
@@ -381,6 +383,8 @@ def frame_metrics(sr, gt, min_max=(0, 1), need_img=False):
     L.check(lib.dvsr_frame_metrics(L.ptr(sr), L.ptr(gt), c, h, w, float(min_max[0]), float(min_max[1]),
                                    img.data_ptr() if need_img else None, out.data_ptr(), ws.data_ptr(),
                                    ws.numel(), L.stream()), "frame_metrics")
+    if need_img is None:        # device result, no host synchronisation: [mse of the uint8 images, mean SSIM] (float64)
+        return out
     mse, ssim_v = out.tolist()
     psnr = float('inf') if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse))
     if need_img:

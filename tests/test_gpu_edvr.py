@@ -831,6 +831,33 @@ def test_edvr_l_config4_forward_backward(mode):
         assert np.median(rel) < 0.05 and rel.max() < 0.5, (np.median(rel), rel.max())
 
 
+def test_edvr_l_bf16_psnr_gate_in_north_star_terms():
+    """BASELINE configs[4] / north_star: reduced precision is gated by PSNR-vs-ground-truth within 0.02 dB of the
+    reference arithmetic.  No checkpoints or REDS tiles exist on the box, so -- as SURVEY 8d prescribes for configs[2] --
+    the substitute is a seeded smooth synthetic clip and its synthetic HR ground truth: EDVR-L x4 (nf 128, 7 frames, 40
+    blocks) 1x7x3x64x64 -> 3x256x256 through the exact-fp32 path (mode 0, itself held to the reference's golden), the
+    three-way bf16 split (mode 2) and the plain bf16-operand path (mode 1), PSNR of each against the same GT with the
+    reference's uint8 definition (utils/util.py:262-269 on tensor2img).
+    Finding (r03): mode 2 passes the gate (|delta| ~ 3e-6 dB); mode 1 does NOT on this substitute (0.030 dB with
+    random-init weights, which amplify the 2^-9 operand rounding through 95 convolutions) -- so the bf16-MFMA path of
+    configs[4] that is held to the reference's accuracy is mode 2; mode 1 stays an opt-in whose deviation is bounded
+    here at 0.1 dB and reported by bench.py."""
+    from dynavsr_amd.utils import util
+    x = synth.clip(91, 1, 7, 64, 64).cuda()
+    gt = synth.clip(92, 1, 1, 256, 256)[0, 0]
+    hr = util.tensor2img(gt, mode="rgb")
+    psnr = {}
+    for mode in (0, 1, 2):
+        net = make_net(8, bf16_mfma=mode, **EDVR_L)
+        with torch.no_grad():
+            sr = net(x)
+        psnr[mode] = util.calculate_psnr(util.tensor2img(sr[0], mode="rgb"), hr)
+        del net
+    print("EDVR-L PSNR vs synthetic GT: fp32 %.4f dB, bf16 operands %.4f dB, bf16 split-3 %.4f dB" % (psnr[0], psnr[1], psnr[2]))
+    assert abs(psnr[2] - psnr[0]) <= 0.02, psnr          # the gate, on the path that claims it
+    assert abs(psnr[1] - psnr[0]) <= 0.1, psnr           # stated bound of the opt-in path (measured 0.030 dB)
+
+
 # ---- per-clip parameter gradients: K clips through one tape (dvsr_edvr_plan_create_grouped) -----------------------------
 def _stack(params, k):
     return [p.detach().unsqueeze(0).repeat((k,) + (1,) * p.dim()).contiguous().requires_grad_() for p in params]
@@ -922,3 +949,26 @@ def test_adapt_video_batched_frames_equal_the_per_frame_loop(optimizer, overlap)
     assert not FrameBatch.supported(opt, model, est)
     got = list(adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips[:2], overlap=overlap, frames_per_batch=2))
     assert len(got) == 2 and len(got[0][1]["losses"]) == 2
+
+
+def test_validate_video_psnr_vectors_match_the_host_definition():
+    """adapt.validate_video (train_dynavsr.py:500-728 on one rank): PSNR of the un-adapted and of the adapted frame against
+    GT, computed on the device, must be the reference's uint8 PSNR (utils/util.py:262-269 on tensor2img) of the very
+    frames adapt_video yields; vectors have one entry per frame, in frame order."""
+    from dynavsr_amd.adapt import adapt_video, validate_video
+    from dynavsr_amd.models import create_model
+    from dynavsr_amd.utils import util
+    opt = _gpu_opt("Adam")
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    model.netG.load_state_dict(synth.edvr_state_dict(0)); est.netE.load_state_dict(synth.mfdn_state_dict(0))
+    est_fixed.netE.load_state_dict(synth.mfdn_state_dict(1))
+    clips = [{"LQs": synth.clip(80 + i, 1, 5, 32, 48).cuda()} for i in range(3)]
+    gts = [synth.clip(90 + i, 1, 1, 128, 192)[0, 0].cuda() for i in range(3)]
+    r = validate_video(opt, model, est, modelcp, estcp, est_fixed, clips, gts, frames_per_batch=2)
+    assert r["frames"] == [0, 1, 2] and r["psnr_start"].shape == (3,) and r["psnr_final"].dtype == torch.float64
+    for i, (base, res) in enumerate(adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips, frames_per_batch=2)):
+        hr = util.tensor2img(gts[i], mode="rgb")
+        assert abs(float(r["psnr_start"][i]) - util.calculate_psnr(util.tensor2img(base[0], mode="rgb"), hr)) < 1e-9
+        assert abs(float(r["psnr_final"][i]) - util.calculate_psnr(util.tensor2img(res["sr"][0], mode="rgb"), hr)) < 2e-3

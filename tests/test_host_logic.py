@@ -363,3 +363,39 @@ def test_bench_two_ranks_dry_run(launcher):
     assert line["meta_step"]["ranks"] == 2 and line["meta_step"]["allreduce"]["executed"]
     assert line["meta_step"]["allreduce"]["averaged_correctly"] and line["meta_step"]["allreduce"]["bytes"] == 4 * (3300131 + 452291)
     assert line["validation"]["psnr_vector_complete"]
+
+
+def _val_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as tdist
+    from dynavsr_amd import dist as D
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 7
+    seen = []
+
+    def run(indices):
+        for i in indices:
+            seen.append(i)
+            yield (30.0 + i, torch.tensor(31.0 + i))
+    a, b = D.validate_sharded(n, run, rank, world)
+    q.put((rank, seen, a.tolist(), b.tolist()))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_validate_sharded_round_robin_and_reduce_gloo():
+    """train_dynavsr.py:500-728: frames range(rank, n, world) per rank, zero-initialised vectors, reduce(sum) to rank 0."""
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_val_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+    (r0, seen0, a0, b0), (r1, seen1, a1, b1) = out
+    assert seen0 == [0, 2, 4, 6] and seen1 == [1, 3, 5]
+    assert a0 == [30.0 + i for i in range(7)] and b0 == [31.0 + i for i in range(7)]          # complete on rank 0
+    assert [a1[i] for i in (1, 3, 5)] == [31.0, 33.0, 35.0]                                   # own entries elsewhere
