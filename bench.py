@@ -405,9 +405,14 @@ def edvr_l_rates(dev, steps=10):
     from dynavsr_amd import hipops, synth
     from dynavsr_amd.models.archs.EDVR_arch import EDVR
     cfg = dict(nf=128, nframes=7, groups=8, front_RBs=5, back_RBs=40, scale=4)
+    from dynavsr_amd.utils import util
     x = synth.clip(9, 1, 7, 64, 64, smooth=False).to(dev)
     tgt = synth.clip(109, 1, 1, 256, 256, smooth=False)[:, 0].to(dev)
-    out, y0 = {}, None
+    # north_star's accuracy gate (PSNR vs ground truth within 0.02 dB of the reference arithmetic) on the synthetic
+    # substitute of tests/test_gpu_edvr.py::test_edvr_l_bf16_psnr_gate_in_north_star_terms
+    xs = synth.clip(91, 1, 7, 64, 64).to(dev)
+    hr = util.tensor2img(synth.clip(92, 1, 1, 256, 256)[0, 0], mode="rgb")
+    out, y0, p0 = {}, None, None
     for mode, name in ((0, "fp32_mfma"), (1, "bf16_operands"), (2, "bf16_split3")):
         net = EDVR(bf16_mfma=mode, **cfg)
         net.load_state_dict(synth.edvr_state_dict(8, **cfg), strict=True)
@@ -432,9 +437,13 @@ def edvr_l_rates(dev, steps=10):
             res[key] = {"ms": ms, "tflops": mult * F_EDVR_L_64 / (ms * 1e-3) / 1e12}
             if key == "forward":
                 yf = y
+        with torch.no_grad():
+            res["psnr_vs_synthetic_gt_db"] = util.calculate_psnr(util.tensor2img(net(xs)[0], mode="rgb"), hr)
         if mode == 0:
-            y0 = yf
+            y0, p0 = yf, res["psnr_vs_synthetic_gt_db"]
         else:
+            res["delta_psnr_vs_fp32_db"] = res["psnr_vs_synthetic_gt_db"] - p0
+            res["passes_0p02_db_gate"] = abs(res["delta_psnr_vs_fp32_db"]) <= 0.02
             d = (yf - y0).double()
             res["rel_l2_vs_fp32_mfma"] = float(d.norm() / y0.double().norm())
             res["psnr_db_vs_fp32_mfma"] = float(10 * torch.log10(1.0 / (d ** 2).mean()))

@@ -578,7 +578,9 @@ def _adapt_video_batched(opt, model, est_model, modelcp, est_modelcp, est_model_
         base, adapted, losses, slr, fb = out
         for k_, ((b_sr, b_ev), (a_sr, a_ev)) in enumerate(zip(base, adapted)):
             if b_ev is not None:
-                main.wait_event(b_ev); main.wait_event(a_ev)
+                if k_ == 0:
+                    main.wait_event(b_ev)
+                main.wait_event(a_ev)
                 b_sr.record_stream(main); a_sr.record_stream(main)
             modelcp.netG, est_modelcp.netE = fb.netG[k_], fb.netE[k_]     # the frame's adapted copies, like the reference's modelcp
             yield b_sr, {'sr': a_sr, 'losses': [losses[k_]], 'slr': slr[k_:k_ + 1]}
@@ -588,11 +590,15 @@ def _adapt_video_batched(opt, model, est_model, modelcp, est_modelcp, est_model_
     while chunk:
         if overlap and side is None:
             side = _side_streams(chunk[0].device)[0]
-        base = [forward_on(model.netG, lq) for lq in chunk]              # enqueued first: run underneath the adaptation
+        lqs = torch.cat(chunk) if len(chunk) > 1 else chunk[0]
+        # the un-adapted baselines of the chunk share their weights too: ONE forward over the K clips (N = K through the
+        # trunk instead of 450 tiles on 256 CUs; the small pyramid levels K times fatter); enqueued first, it runs
+        # underneath the adaptation
+        b_sr, b_ev = forward_on(model.netG, lqs)
+        base = [(b_sr[k_:k_ + 1], b_ev) for k_ in range(len(chunk))]
         fb = batch_for(ci & 1, len(chunk))
         if fb.last_use is not None:
             main.wait_event(fb.last_use)                                 # this set's previous adapted forwards are done
-        lqs = torch.cat(chunk) if len(chunk) > 1 else chunk[0]
         losses, slr = fb.adapt(model, est_model, est_model_fixed, lqs)
         adapted = [forward_on(fb.netG[k_], lq) for k_, lq in enumerate(chunk)]
         fb.last_use = adapted[-1][1]

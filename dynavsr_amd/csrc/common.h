@@ -217,12 +217,81 @@ __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT]
   }
 }
 
+// Store modes carried in TileOut::ps beyond 0 (plain) and 2 (PixelShuffle(2)): the tile goes STRAIGHT into the
+// explicitly padded tensor the next convolution of the estimator reads (LRimg_estimator.py:82-86: ReflectionPad2d(1) in
+// front of every 2-D conv), so that no pad kernel re-reads and re-writes the whole activation (r03):
+//   PS_PAD_REFLECT      P[n][c][oy + 1][ox + 1] of a [N][C][Ho + 2][Wo + 2] tensor, plus the mirrored copies the
+//                       reflection ring holds of rows 1, Ho - 2 and columns 1, Wo - 2 (up to four stores per value,
+//                       in the tiles that touch them);
+//   PS_PAD_REFLECT_S2D  the same padded image in the space-to-depth layout [N][4C][(Ho + 2) / 2][(Wo + 2) / 2] of the
+//                       re-expressed 4x4 stride-2 convs (channel 4c + 2 (py & 1) + (px & 1), position (py >> 1, px >> 1)).
+enum : int { PS_PAD_REFLECT = 16, PS_PAD_REFLECT_S2D = 17 };
+
+template <int MT, int NT>
+__device__ __forceinline__ void store_mfma_tile_padded(const f32x16 (&acc)[MT][NT], const TileOut& t, int n, int co_block,
+                                                       int hi, int oy_first, int ox) {
+  const bool s2d = t.ps == PS_PAD_REFLECT_S2D;
+  const int Hp = t.Ho + 2, Wp = t.Wo + 2;
+  const int Hs = s2d ? Hp >> 1 : Hp, Ws = s2d ? Wp >> 1 : Wp, cmul = s2d ? 4 : 1;
+  const size_t plane = (size_t)Hs * Ws, img = (size_t)t.Cout * cmul * plane;
+  const __amdgpu_buffer_rsrc_t ry = image_rsrc(t.y + (size_t)n * img, img);
+  const float slope = t.act == ACT_LRELU ? 0.1f : (t.act == ACT_RELU ? 0.f : 1.f);
+  const int co_base = co_block + 4 * hi;
+  // element offset of padded position (py, px) inside channel group 0 (the channel term is added per register)
+  auto loff = [&](int py, int px) -> size_t {
+    return s2d ? (size_t)(2 * (py & 1) + (px & 1)) * plane + (size_t)(py >> 1) * Ws + (px >> 1) : (size_t)py * Ws + px;
+  };
+  const bool col_ok = ox < t.Wo;
+  const int pxm = ox == 1 ? 0 : (ox == t.Wo - 2 ? Wp - 1 : -1);       // this lane's column also feeds the ring
+  const bool col_ring = __builtin_amdgcn_ballot_w64(pxm >= 0 && col_ok) != 0;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float v[NT][16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+        const float x = acc[mt][nt][r] + (t.bias ? t.bias[co < t.Cout ? co : t.Cout - 1] : 0.f);
+        v[nt][r] = fmaxf(x, slope * x);
+      }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int oy = oy_first + nt;                                    // wave-uniform
+      if (oy >= t.Ho) continue;
+      const int pys[3] = {oy + 1, oy == 1 ? 0 : -1, oy == t.Ho - 2 ? Hp - 1 : -1};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (pys[a] < 0) continue;                                      // wave-uniform
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (b == 1 && !col_ring) continue;                           // wave-uniform
+          const int px = b == 0 ? ox + 1 : pxm;
+          const bool ok = col_ok && px >= 0;
+          const size_t lo_ = ok ? loff(pys[a], px) : 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+            const size_t o = (size_t)co * cmul * plane + lo_;
+            const unsigned off = (ok && co < t.Cout) ? (unsigned)(o * 4) : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[nt][r]), ry, off, 0, 0);
+          }
+        }
+      }
+    }
+  }
+}
+
 // co_block: first output channel of the workgroup's 32*MT block; (oy0, ox0): tile origin, TH rows;
 // oy_first: first of the NT rows this wave owns; lane = (lo, hi).
 template <int MT, int NT>
 __device__ __forceinline__ void store_mfma_tile(const f32x16 (&acc)[MT][NT], const TileOut& t, int n,
                                                 int co_block, int oy0, int th, int ox0, int oy_first, int lo,
                                                 int hi) {
+  if (t.ps >= PS_PAD_REFLECT) {   // (no residual / accumulate / gradient mask in these modes: forward of the estimator)
+    store_mfma_tile_padded<MT, NT>(acc, t, n, co_block, hi, oy_first, ox0 + lo);
+    return;
+  }
   const bool full = oy0 + th <= t.Ho && ox0 + 32 <= t.Wo && co_block + MT * 32 <= t.Cout;
   const int ox = ox0 + lo;
   if (full) {

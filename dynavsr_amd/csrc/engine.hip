@@ -50,6 +50,12 @@ struct Op {
   int wmap = 0;
   size_t w2_off = 0;
   int no_dgrad = 0;  // the input does not need a gradient (it derives from the network input only)
+  // OP_CONV: the output is stored straight into the explicitly padded tensor of the next conv (PS_PAD_REFLECT*, common.h)
+  // = the y of the OP_PAD that follows; the dense y slot is never written (its GRADIENT slot is: backward is unchanged).
+  // OP_PAD: fused_into >= 0: no forward launch, the producer (that op index) wrote the padded tensor.
+  int pad_out = 0;
+  struct T ypad;
+  int fused_into = -1;
   long long x0_bs = 0, x1_bs = 0;
   // streaming ops
   int S = 1;
@@ -626,6 +632,9 @@ static void build_backward(dvsr_edvr_plan& p) {
     }
   }
   for (size_t ai = 0; ai < p.allocs.size(); ++ai) bb.materialize((int)ai);
+  for (size_t i = 0; i < p.ops.size(); ++i)   // a conv without a dense output needs its activation backward in the pad fold
+    if (p.ops[i].type == OP_CONV && p.ops[i].pad_out && p.ops[i].act != ACT_NONE && !act_fused[i])
+      p.bwd_unsupported = "a padded-store convolution whose activation backward is not fused into the pad fold";
   p.tmp_floats = (tmp + 63) & ~(size_t)63;
   p.scratch_bytes = (scratch + 255) & ~(size_t)255;
   p.wscratch_bytes = (wscratch + 255) & ~(size_t)255;
@@ -712,9 +721,11 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
     case B_PADFOLD: {
       float* gx = bs.at(b.a);
       if (!gx) return DVSR_OK;
+      // (a producer that stored straight into this op's padded tensor left no dense output: its mask is read there)
+      const bool mpad = b.mask_op >= 0 && p.ops[b.mask_op].pad_out;
       return pad_bwd(bs.at(b.b), gx, o->pmode, o->N, o->c0, o->H, o->W, o->T, b.accum, st,
-                     b.mask_op >= 0 ? bs.arena + p.ops[b.mask_op].y.off : nullptr,
-                     b.mask_op >= 0 ? p.ops[b.mask_op].act : 0);
+                     b.mask_op >= 0 ? bs.arena + (mpad ? o->y.off : p.ops[b.mask_op].y.off) : nullptr,
+                     b.mask_op >= 0 ? p.ops[b.mask_op].act : 0, mpad ? 1 : 0);
     }
     case B_ADDMEAN:
       return addmean_bwd(bs.at(b.b), bs.at(b.a), o->N / o->T, o->c0, o->T, (size_t)o->H * o->W, st);
@@ -838,6 +849,7 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
       d.y = bs.at(o.y);
       d.N = o.N; d.c0 = o.c0; d.c1 = o.c1; d.H = o.H; d.W = o.W; d.Cout = o.Cout; d.ks = o.ks;
       d.stride = o.stride; d.pad = conv_pad(o); d.act = o.act; d.pixel_shuffle = o.ps;
+      if (o.pad_out) { d.y = bs.at(o.ypad); d.pixel_shuffle = o.pad_out; }
       if (o.wmap) d.w = bs.arena + o.w2_off;
       d.x1_bdiv = o.x1_bdiv; d.x0_bstride = o.x0_bs; d.x1_bstride = o.x1_bs;
       if (bs.use_v1) return conv2d_run(d, ConvExtra(), st);
@@ -866,6 +878,7 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
     case OP_BLEND:
       return tsa_blend_fwd(bs.at(o.x0), bs.at(o.x1), bs.at(o.res), bs.at(o.y), o.y.numel, st);
     case OP_PAD:
+      if (o.fused_into >= 0) return DVSR_OK;   // the producing conv stored the padded tensor itself
       return pad_fwd(bs.at(o.x0), bs.at(o.y), o.pmode, o.N, o.c0, o.H, o.W, o.T, st);
     case OP_MEANSUB:
       return meansub_fwd(bs.at(o.x0), bs.at(o.y), bs.at(o.y2), bs.at(o.res), o.N / o.T, o.c0, o.T, o.H, o.W, st);
@@ -1199,8 +1212,24 @@ static int build_estimator(dvsr_estimator_plan& ep) {
     o.N = BT; o.c0 = ic; o.H = H; o.W = W; o.T = Tn;
     p.ops.push_back(o);
   }
+  // DVSR_EST_FUSE_PAD=0 keeps every padding a separate launch (A/B aid).  Fused: the conv that produces x stores it
+  // straight into the reflect-padded (space-to-depth) tensor this conv reads -- the pad op stays on the tape for the
+  // backward (its fold + the producer's activation backward) but launches nothing in the forward.
+  static const bool fuse_pad = [] { const char* v = getenv("DVSR_EST_FUSE_PAD"); return !(v && v[0] == '0'); }();
+  auto fuse = [&](int mode) {
+    // the op before the pad op just pushed must be the conv that produced its input, with this pad as its only reader
+    const int pi = (int)p.ops.size() - 1;
+    if (!fuse_pad || pi < 1 || (mode != PAD_REFLECT && mode != PAD_REFLECT_S2D)) return;
+    Op& pad = p.ops[pi];
+    Op& prod = p.ops[pi - 1];
+    if (prod.type != OP_CONV || prod.y.space != SP_ARENA || prod.y.off != pad.x0.off || prod.ps || prod.res.valid()) return;
+    prod.pad_out = mode == PAD_REFLECT ? PS_PAD_REFLECT : PS_PAD_REFLECT_S2D;
+    prod.ypad = pad.y;
+    pad.fused_into = pi - 1;
+  };
   auto conv3 = [&](const char* pn, const char* cn, T x, int cin, int cout, int mode, bool first) {
     T xp = b.padop(pn, x, mode, BT, cin, H, W, Tn);
+    fuse(mode);
     if (first) p.ops.back().no_dgrad = 1;
     const int cin_eff = mode == PAD_REPL_T3 ? 3 * cin : cin;
     T y = b.conv(cn, b.take(), xp, cin_eff, none, 0, BT, H + 2, W + 2, cout, 3, 1, L, none, 0, 1, 0, 0, T(), 0);
@@ -1209,6 +1238,7 @@ static int build_estimator(dvsr_estimator_plan& ep) {
   };
   auto conv4s2 = [&](const char* pn, const char* cn, T x, int cin, int cout) {
     T xp = b.padop(pn, x, PAD_REFLECT_S2D, BT, cin, H, W, Tn);
+    fuse(PAD_REFLECT_S2D);
     T y = b.conv(cn, b.take(), xp, 4 * cin, none, 0, BT, (H + 2) / 2, (W + 2) / 2, cout, 2, 1, L, none, 0, 1, 0, 0,
                  T(), 0, 1);
     H /= 2; W /= 2;

@@ -106,7 +106,7 @@ enum : int { PAD_REFLECT = 0, PAD_REFLECT_S2D = 1, PAD_REPL_T3 = 2 };
 size_t pad_out_numel(int mode, size_t N, int C, int H, int W);
 int pad_fwd(const float* x, float* y, int mode, int N, int C, int H, int W, int T, hipStream_t st);
 int pad_bwd(const float* gy, float* gx, int mode, int N, int C, int H, int W, int T, int accumulate,
-            hipStream_t st, const float* gmask = nullptr, int gmask_act = 0);
+            hipStream_t st, const float* gmask = nullptr, int gmask_act = 0, int gmask_padded = 0);
 int meansub_slices();  // scratch floats per plane
 int meansub_fwd(const float* x, float* xm, float* mean, float* part, int B, int C, int T, int H, int W,
                 hipStream_t st);

@@ -55,10 +55,13 @@ __global__ void pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 
 // adjoint: one thread per INPUT element, gathering every padded position that maps to it
+// gmask_padded: the mask tensor is the PADDED forward tensor itself (same layout as gy) -- the producing conv stored
+// straight into it (PS_PAD_REFLECT*), a dense copy of its output does not exist; element (yy, xx) sits at padded
+// position (yy + 1, xx + 1).
 template <int mode>
 __global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int planes, int C,
                                int H, int W, int T, int accumulate, const float* __restrict__ gmask,
-                               int gmask_act) {
+                               int gmask_act, int gmask_padded) {
   const int Hp = H + 2, Wp = W + 2, ipix = H * W;
   for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {  // plane = n*C + c
     const int n = plane / C, c = plane - n * C;
@@ -117,7 +120,13 @@ __global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__
       if (accumulate) s += dst[i];
       if (gmask) {  // fused activation backward of the layer that produced the padded tensor
         const float neg = gmask_act == ACT_LRELU ? 0.1f : (gmask_act == ACT_RELU ? 0.f : 1.f);
-        s *= gmask[(size_t)plane * ipix + i] > 0.f ? 1.f : neg;
+        float mv;
+        if (!gmask_padded) mv = gmask[(size_t)plane * ipix + i];
+        else if (mode == PAD_REFLECT_S2D) {
+          const int Wh = Wp / 2, Hh = Hp / 2, r = yy + 1, q = xx + 1;
+          mv = gmask[((size_t)n * 4 * C + c * 4 + (r & 1) * 2 + (q & 1)) * (size_t)Hh * Wh + (size_t)(r >> 1) * Wh + (q >> 1)];
+        } else mv = gmask[(size_t)plane * Hp * Wp + (size_t)(yy + 1) * Wp + xx + 1];
+        s *= mv > 0.f ? 1.f : neg;
       }
       dst[i] = s;
     }
@@ -130,7 +139,7 @@ __global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__
 template <int mode>
 __global__ void pad_bwd4_kernel(const float* __restrict__ gy, float* __restrict__ gx, int planes, int C,
                                 int H, int W, int T, int accumulate, const float* __restrict__ gmask,
-                                int gmask_act) {
+                                int gmask_act, int gmask_padded) {
   const int Hp = H + 2, Wp = W + 2, Wq = W >> 2, iq = H * Wq;
   constexpr int NPL = mode == PAD_REPL_T3 ? 5 : 1;
   const int lo_edge = mode == PAD_REPL_T3 ? 0 : 1;
@@ -161,7 +170,7 @@ __global__ void pad_bwd4_kernel(const float* __restrict__ gy, float* __restrict_
       return sp[k][r * Wp + q];
     };
     float* dst = gx + (size_t)plane * H * W;
-    const float* msk = gmask ? gmask + (size_t)plane * H * W : nullptr;
+    const float* msk = gmask ? (gmask_padded ? gmask : gmask + (size_t)plane * H * W) : nullptr;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < iq; i += gridDim.x * blockDim.x) {
       const int yy = i / Wq, x0 = (i - yy * Wq) * 4;
       float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -199,7 +208,18 @@ __global__ void pad_bwd4_kernel(const float* __restrict__ gy, float* __restrict_
       if (accumulate) o += *d4;
       if (msk) {
         const float neg = gmask_act == ACT_LRELU ? 0.1f : (gmask_act == ACT_RELU ? 0.f : 1.f);
-        const f32x4 m = *reinterpret_cast<const f32x4*>(msk + (size_t)yy * W + x0);
+        f32x4 m;
+        if (!gmask_padded) m = *reinterpret_cast<const f32x4*>(msk + (size_t)yy * W + x0);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = yy + 1, q = x0 + j + 1;
+            if (mode == PAD_REFLECT_S2D) {
+              const int Wh = Wp / 2, Hh = Hp / 2;
+              m[j] = msk[((size_t)n * 4 * C + c * 4 + (r & 1) * 2 + (q & 1)) * (size_t)Hh * Wh + (size_t)(r >> 1) * Wh + (q >> 1)];
+            } else m[j] = msk[(size_t)plane * Hp * Wp + (size_t)r * Wp + q];
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] *= m[j] > 0.f ? 1.f : neg;
       }
@@ -235,33 +255,33 @@ int pad_fwd(const float* x, float* y, int mode, int N, int C, int H, int W, int 
 }
 
 int pad_bwd(const float* gy, float* gx, int mode, int N, int C, int H, int W, int T, int accumulate,
-            hipStream_t st, const float* gmask, int gmask_act) {
+            hipStream_t st, const float* gmask, int gmask_act, int gmask_padded) {
   DVSR_REQUIRE(gy && gx, DVSR_ERR_INVALID, "pad_bwd: null pointer");
   DVSR_REQUIRE(mode >= PAD_REFLECT && mode <= PAD_REPL_T3, DVSR_ERR_INVALID, "pad_bwd: mode %d", mode);
   const int planes = N * C;
-  if (W % 4 == 0 && (((uintptr_t)gx | (uintptr_t)gmask) & 15) == 0) {
+  if (W % 4 == 0 && (((uintptr_t)gx | (gmask_padded ? (uintptr_t)0 : (uintptr_t)gmask)) & 15) == 0) {
     const dim3 g4(ceil_div(H * (W / 4), 256), planes < 65535 ? planes : 65535);
     if (mode == PAD_REFLECT)
       hipLaunchKernelGGL(pad_bwd4_kernel<PAD_REFLECT>, g4, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate, gmask,
-                         gmask_act);
+                         gmask_act, gmask_padded);
     else if (mode == PAD_REFLECT_S2D)
       hipLaunchKernelGGL(pad_bwd4_kernel<PAD_REFLECT_S2D>, g4, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate,
-                         gmask, gmask_act);
+                         gmask, gmask_act, gmask_padded);
     else
       hipLaunchKernelGGL(pad_bwd4_kernel<PAD_REPL_T3>, g4, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate, gmask,
-                         gmask_act);
+                         gmask_act, gmask_padded);
     return check_launch("pad_bwd4_kernel");
   }
   const dim3 grid(ceil_div(H * W, 256), planes < 65535 ? planes : 65535);
   if (mode == PAD_REFLECT)
     hipLaunchKernelGGL(pad_bwd_kernel<PAD_REFLECT>, grid, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate, gmask,
-                       gmask_act);
+                       gmask_act, gmask_padded);
   else if (mode == PAD_REFLECT_S2D)
     hipLaunchKernelGGL(pad_bwd_kernel<PAD_REFLECT_S2D>, grid, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate,
-                       gmask, gmask_act);
+                       gmask, gmask_act, gmask_padded);
   else
     hipLaunchKernelGGL(pad_bwd_kernel<PAD_REPL_T3>, grid, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate, gmask,
-                       gmask_act);
+                       gmask_act, gmask_padded);
   return check_launch("pad_bwd_kernel");
 }
 

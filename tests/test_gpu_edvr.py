@@ -930,7 +930,7 @@ def test_adapt_video_batched_frames_equal_the_per_frame_loop(optimizer, overlap)
     n = 0
     for (base, r), w_ in zip(adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips, overlap=overlap,
                                          frames_per_batch=2), want):
-        assert torch.equal(base, w_[0])
+        assert relerr(base, w_[0]) < 1e-6               # (the chunk's baselines are one batched forward: launch geometry may differ)
         assert abs(float(r["losses"][0]) - w_[2]) <= 2e-6 * abs(w_[2])
         assert relerr(r["slr"], w_[3]) < 1e-6
         assert relerr(r["sr"], w_[1]) < 1e-4
@@ -970,5 +970,5 @@ def test_validate_video_psnr_vectors_match_the_host_definition():
     assert r["frames"] == [0, 1, 2] and r["psnr_start"].shape == (3,) and r["psnr_final"].dtype == torch.float64
     for i, (base, res) in enumerate(adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips, frames_per_batch=2)):
         hr = util.tensor2img(gts[i], mode="rgb")
-        assert abs(float(r["psnr_start"][i]) - util.calculate_psnr(util.tensor2img(base[0], mode="rgb"), hr)) < 1e-9
+        assert abs(float(r["psnr_start"][i]) - util.calculate_psnr(util.tensor2img(base[0], mode="rgb"), hr)) < 1e-9   # same call path
         assert abs(float(r["psnr_final"][i]) - util.calculate_psnr(util.tensor2img(res["sr"][0], mode="rgb"), hr)) < 2e-3
