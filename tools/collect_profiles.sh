@@ -7,7 +7,7 @@ tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag; rm -rf "$out"; mkdir -p "$out"
-B="--no-cpu-baseline --no-inner-step --no-split --no-meta"
+B="--no-cpu-baseline --no-inner-step --no-split --no-meta --no-validation"
 # 1. the driver's bench line (all legs)
 python bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench_stderr.txt
 # 2. kernel trace of the headline forward
@@ -47,4 +47,24 @@ if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
   python tools/dcn_dma_trace.py 2 2>&1 | grep -v amdgpu > $out/${tag}_dcn_dma_trace.txt
   python tools/dcn_dma_trace.py 2 44 80 2>&1 | grep -v amdgpu >> $out/${tag}_dcn_dma_trace.txt
 fi
+# 9. r03: K frames as one batch with per-frame parameter gradients -- phases, kernel table, launch timeline; the
+#    weight-gradient kernel alone on the batch shapes; DCN backward alone
+python tools/inner_batch_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_inner_batch.txt
+for K in 8 16; do
+  python tools/inner_batch_profile.py $K 10 2>&1 | grep -v amdgpu >> $out/${tag}_inner_batch.txt
+done
+rocprofv3 --kernel-trace --stats -d $out/db9 -o r -- python tools/inner_batch_profile.py 8 6 > /dev/null 2>&1
+python tools/rocprof_summary.py $out/db9/r_results.db > $out/${tag}_inner_batch_K8_kernels.txt
+python tools/trace_dump.py $out/db9/r_results.db l1_final > $out/${tag}_inner_batch_K8_timeline.txt; rm -rf $out/db9
+WGRAD_BENCH_BATCHED=1 python tools/wgrad_bench.py 20 2>&1 | grep wgrad > $out/${tag}_wgrad_kernel.txt
+python tools/wgrad_bench.py 20 2>&1 | grep wgrad >> $out/${tag}_wgrad_kernel.txt
+python tools/dcn_bwd_bench.py 20 2>&1 | grep -v amdgpu > $out/${tag}_dcn_bwd.txt
+rocprofv3 --kernel-trace --stats -d $out/db9b -o r -- python tools/dcn_bwd_bench.py 20 > /dev/null 2>&1
+python tools/rocprof_summary.py $out/db9b/r_results.db | head -8 >> $out/${tag}_dcn_bwd.txt; rm -rf $out/db9b
+# PMC: matrix-pipe utilisation of the batched inner step's kernels
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  rocprofv3 --pmc $c --kernel-trace -d $out/dbi_$c -o p -- python tools/inner_batch_profile.py 8 3 > /dev/null 2>&1
+done
+python tools/pmc_mfma.py $out/dbi_SQ_VALU_MFMA_BUSY_CYCLES/p_results.db $out/dbi_GRBM_GUI_ACTIVE/p_results.db > $out/${tag}_pmc_mfma_util_inner_batch.txt
+rm -rf $out/dbi_SQ_VALU_MFMA_BUSY_CYCLES $out/dbi_GRBM_GUI_ACTIVE
 du -sh gpurun_out
