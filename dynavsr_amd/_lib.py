@@ -78,6 +78,7 @@ def _declare(lib):
         "dvsr_tsa_blend_backward": (I, [P] * 5 + [LL, P]),
         "dvsr_edvr_plan_create": (I, [POINTER(EdvrConfig), I, I, I, POINTER(c_void_p)]),
         "dvsr_edvr_plan_create_grouped": (I, [POINTER(EdvrConfig), I, I, I, I, POINTER(c_void_p)]),
+        "dvsr_edvr_plan_create_ex": (I, [POINTER(EdvrConfig), I, I, I, I, I, POINTER(c_void_p)]),
         "dvsr_edvr_plan_destroy": (None, [P]),
         "dvsr_edvr_num_params": (I, [P]),
         "dvsr_edvr_num_launches": (I, [P]),
@@ -87,6 +88,7 @@ def _declare(lib):
         "dvsr_edvr_num_backward_launches": (I, [P]),
         "dvsr_estimator_plan_create": (I, [POINTER(EstimatorConfig), I, I, I, POINTER(c_void_p)]),
         "dvsr_estimator_plan_create_grouped": (I, [POINTER(EstimatorConfig), I, I, I, I, POINTER(c_void_p)]),
+        "dvsr_estimator_plan_create_ex": (I, [POINTER(EstimatorConfig), I, I, I, I, I, POINTER(c_void_p)]),
         "dvsr_estimator_plan_destroy": (None, [P]),
         "dvsr_estimator_num_params": (I, [P]),
         "dvsr_estimator_num_launches": (I, [P, I]),

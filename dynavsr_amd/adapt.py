@@ -369,7 +369,7 @@ class FrameBatch:
         """What the batched step covers; everything else takes the per-frame loop."""
         m = opt['train']['maml']
         from .models.loss import CharbonnierLoss
-        return (m['adapt_iter'] == 1 and not m['use_patch'] and not opt['train']['use_real']
+        return (m['adapt_iter'] >= 1 and not m['use_patch'] and not opt['train']['use_real']
                 and hasattr(model.netG, 'forward_stacked') and hasattr(est_model.netE, 'forward_stacked')
                 and isinstance(model.cri_pix, CharbonnierLoss) and next(model.netG.parameters()).is_cuda
                 and not list(model.netG.buffers()) and not list(est_model.netE.buffers()))
@@ -397,9 +397,9 @@ class FrameBatch:
             if e.training != netE.training:
                 e.train(netE.training)
 
-    def adapt(self, model, est_model, est_model_fixed, lqs, slr_weight=10.0):
-        """lqs [K,N,3,H,W] -> (per-frame losses [K], SLR clips [K,N,3,h,w]); afterwards slice k holds frame k's adapted
-        weights.  Same statements as adapt_frame's step, on the batch."""
+    def adapt(self, model, est_model, est_model_fixed, lqs, slr_weight=10.0, steps=1):
+        """lqs [K,N,3,H,W] -> (per-step list of per-frame losses [K], SLR clips [K,N,3,h,w]); afterwards slice k holds
+        frame k's adapted weights.  Same statements as adapt_frame's step loop, on the batch."""
         assert lqs.size(0) == self.k
         self.refresh(model.netG, est_model.netE)
         center = lqs.size(1) // 2
@@ -407,18 +407,30 @@ class FrameBatch:
         est_model_fixed.test()
         slr_fixed = est_model_fixed.fake_L
         est_model.feed_data({'LQs': lqs})                 # the wrapper's own layout handling ('video' / 'image' mode)
-        y = est_model.netE.forward_stacked(est_model.var_H, self.e_stack)
-        if est_model.mode != 'image':
-            slr = y.transpose(1, 2)
-        else:
-            b, t, c = lqs.shape[:3]
-            slr = y.reshape(b, t, c, y.shape[-2], y.shape[-1])
-        sr = model.netG.forward_stacked(slr, self.g_stack)
-        l_pix = model.l_pix_w * hipops.charbonnier_per_sample(sr, lqs[:, center], model.cri_pix.eps)
-        loss = hipops.inner_loss_per_sample(l_pix, slr, slr_fixed, slr_weight)
-        loss.sum().backward()                              # d loss_k / d (slice k) only: the losses share no weights
-        self.inner.step()
-        return loss.detach(), slr.detach()
+        losses = []
+        for step in range(steps):
+            # step 0: every slice still equals the un-adapted network -> one weight set for the batch (one pack);
+            # later steps: the copies have diverged -> clip k runs on slice k (dvsr_*_plan_create_ex, weight_sets = K)
+            diverged = step > 0
+            y = est_model.netE.forward_stacked(est_model.var_H, self.e_stack, per_slice=diverged)
+            if est_model.mode != 'image':
+                slr = y.transpose(1, 2)
+            else:
+                b, t, c = lqs.shape[:3]
+                slr = y.reshape(b, t, c, y.shape[-2], y.shape[-1])
+            sr = model.netG.forward_stacked(slr, self.g_stack, per_slice=diverged)
+            l_pix = model.l_pix_w * hipops.charbonnier_per_sample(sr, lqs[:, center], model.cri_pix.eps)
+            loss = hipops.inner_loss_per_sample(l_pix, slr, slr_fixed, slr_weight)
+            self.inner.zero_grad()
+            loss.sum().backward()                          # d loss_k / d (slice k) only: the losses share no weights
+            self.inner.step()
+            losses.append(loss.detach())
+        return losses, slr.detach()
+
+    def super_resolve(self, lqs):
+        """The adapted outputs of the K frames (test_dynavsr.py:279-283) as ONE forward: clip k on slice k."""
+        with torch.no_grad():
+            return self.netG[0].forward_stacked(lqs, [s_.detach() for s_ in self.g_stack], per_slice=True)
 
 
 _STREAMS = {}
@@ -555,20 +567,22 @@ def _adapt_video_batched(opt, model, est_model, modelcp, est_modelcp, est_model_
             fb = cache[(parity, k)] = FrameBatch(opt, model.netG, est_model.netE, k)
         return fb
 
+    def run(net, lq):
+        if isinstance(net, FrameBatch):
+            return net.super_resolve(lq)
+        was = net.training
+        net.eval()
+        sr = net(backbone_input(opt, lq))
+        net.train(was)
+        return sr
+
     def forward_on(net, lq):
         if side is None:
             with torch.no_grad():
-                was = net.training
-                net.eval()
-                sr = net(backbone_input(opt, lq))
-                net.train(was)
-            return sr, None
+                return run(net, lq), None
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
-            was = net.training
-            net.eval()
-            sr = net(backbone_input(opt, lq))
-            net.train(was)
+            sr = run(net, lq)
             ev = torch.cuda.Event()
             ev.record(side)
         lq.record_stream(side)
@@ -579,11 +593,10 @@ def _adapt_video_batched(opt, model, est_model, modelcp, est_modelcp, est_model_
         for k_, ((b_sr, b_ev), (a_sr, a_ev)) in enumerate(zip(base, adapted)):
             if b_ev is not None:
                 if k_ == 0:
-                    main.wait_event(b_ev)
-                main.wait_event(a_ev)
+                    main.wait_event(b_ev); main.wait_event(a_ev)
                 b_sr.record_stream(main); a_sr.record_stream(main)
             modelcp.netG, est_modelcp.netE = fb.netG[k_], fb.netE[k_]     # the frame's adapted copies, like the reference's modelcp
-            yield b_sr, {'sr': a_sr, 'losses': [losses[k_]], 'slr': slr[k_:k_ + 1]}
+            yield b_sr, {'sr': a_sr, 'losses': [l_[k_] for l_ in losses], 'slr': slr[k_:k_ + 1]}
 
     chunk, carry = take()
     pending, ci = None, 0
@@ -599,9 +612,12 @@ def _adapt_video_batched(opt, model, est_model, modelcp, est_modelcp, est_model_
         fb = batch_for(ci & 1, len(chunk))
         if fb.last_use is not None:
             main.wait_event(fb.last_use)                                 # this set's previous adapted forwards are done
-        losses, slr = fb.adapt(model, est_model, est_model_fixed, lqs)
-        adapted = [forward_on(fb.netG[k_], lq) for k_, lq in enumerate(chunk)]
-        fb.last_use = adapted[-1][1]
+        losses, slr = fb.adapt(model, est_model, est_model_fixed, lqs, steps=opt['train']['maml']['adapt_iter'])
+        # the K adapted forwards as ONE forward with per-frame weights (backbone_input: identity for EDVR, the only
+        # backbone FrameBatch takes)
+        a_sr, a_ev = forward_on(fb, lqs)
+        adapted = [(a_sr[k_:k_ + 1], a_ev) for k_ in range(len(chunk))]
+        fb.last_use = a_ev
         if pending is not None:
             yield from hand_out(pending)
         pending = (base, adapted, losses, slr, fb)

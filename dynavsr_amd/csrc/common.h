@@ -45,6 +45,11 @@ __host__ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (E > B) static_for_impl<B>(std::make_integer_sequence<int, E - B>{}, static_cast<F&&>(f));
 }
 
+// Per-sample weight sets: batch item n takes the weights / bias at p + (n / wdiv) * gs (gs == 0: one set for the batch).
+__device__ __forceinline__ const float* wset_ptr(const float* p, long long gs, int n, int wdiv) {
+  return (gs && p) ? p + (size_t)(n / wdiv) * gs : p;
+}
+
 // Activation codes shared by conv / dcn epilogues.
 enum : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2 };
 

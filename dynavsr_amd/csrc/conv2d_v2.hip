@@ -231,7 +231,7 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
   // packed weights of this workgroup's cout block: 64-cout block (cbi*MT)/2, starting half (cbi*MT)%2
   // global image: [64-cout block][chunk][piece][half][HALF]
   constexpr int PIECES = Sh::PIECES;
-  const float* wp_cb = a.wp + ((size_t)((cbi * MT) >> 1) * a.nchunks * PIECES * 2 + ((cbi * MT) & 1)) * Sh::HALF;
+  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + ((size_t)((cbi * MT) >> 1) * a.nchunks * PIECES * 2 + ((cbi * MT) & 1)) * Sh::HALF;
 
   // Halo loads of chunk k into registers (raw; masked when they are written to LDS).  All address
   // math is wave-uniform scalar work: one base pointer per chunk (a chunk never straddles the two
@@ -472,7 +472,7 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
 
   // ---- epilogue: bias, activation, residual / accumulate, (pixel-shuffled) store
   DVSR_STAMP(40);
-  const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
+  const TileOut t{a.y, wset_ptr(a.bias, a.b_gs, n, a.wdiv), a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
   store_mfma_tile<MT, NT>(acc, t, n, cbi * MT * 32, oy0, TH, ox0, oy0 + NT * wave, lo, hi);
 #ifdef DVSR_CONV_TRACE
   DVSR_STAMP(41);
@@ -600,7 +600,7 @@ __device__ __forceinline__ void conv2d_dma_item(const ConvK2& a, const int id, f
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const float* wp_cb = a.wp + ((size_t)((cbi * MT) >> 1) * a.nchunks * 2 + ((cbi * MT) & 1)) * Sh::HALF;
+  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + ((size_t)((cbi * MT) >> 1) * a.nchunks * 2 + ((cbi * MT) & 1)) * Sh::HALF;
 
   auto issue_halo = [&](int k, int buf) {
     const int cbase = k * CC;
@@ -675,7 +675,7 @@ __device__ __forceinline__ void conv2d_dma_item(const ConvK2& a, const int id, f
   block(a.nchunks - 1, std::false_type{});
 
   if ((DVSR_ABLATE(a) & 1) && acc[0][0][0] != 12345.f) return;
-  const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
+  const TileOut t{a.y, wset_ptr(a.bias, a.b_gs, n, a.wdiv), a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
   store_mfma_tile<MT, NT>(acc, t, n, cbi * MT * 32, oy0, TH, ox0, oy0 + NT * wave, lo, hi);
 }
 
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_dmarow_kernel(ConvK2 a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const float* wp_cb = a.wp + ((size_t)((cbi * MT) >> 1) * a.nchunks * 2 + ((cbi * MT) & 1)) * Sh::HALF;
+  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + ((size_t)((cbi * MT) >> 1) * a.nchunks * 2 + ((cbi * MT) & 1)) * Sh::HALF;
 
   auto issue_halo = [&](int k, int buf) {
     const int cbase = k * CC;
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_dmarow_kernel(ConvK2 a) {
     if (++ky == KS) { ky = 0; ++k; }
   }
 
-  const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
+  const TileOut t{a.y, wset_ptr(a.bias, a.b_gs, n, a.wdiv), a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
   store_mfma_tile<MT, NT>(acc, t, n, cbi * MT * 32, oy0, TH, ox0, oy0 + NT * wave, lo, hi);
 }
 
@@ -1031,6 +1031,7 @@ int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const Conv
   k.nchunks = ceil_div(d.c0 + d.c1, geo.cc);
   k.in_ps = ex.in_ps; k.in_dil = ex.in_dil; k.Hs = ex.Hs; k.Ws = ex.Ws; k.accum = ex.accum;
   k.gmask = ex.gmask; k.gmask_act = ex.gmask_act;
+  k.wdiv = ex.wdiv > 0 ? ex.wdiv : 1; k.w_gs = ex.w_gs; k.b_gs = ex.b_gs;
 #ifdef DVSR_CONV_TRACE
   {
     // measurement aid of the debug build, results are WRONG when set (profiles/r02_z_conv_dma_ablation.txt): bit 0 no

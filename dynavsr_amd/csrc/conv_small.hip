@@ -13,6 +13,7 @@ namespace dvsr {
 struct SmallK {
   const float* x; const float* w; const float* bias; const float* res; float* y;
   int N, C, H, W, Cout, act, tiles_x, tiles_y, ntiles;
+  int wdiv; long long w_gs; int b_gs;   // per-sample weight sets (common.h: wset_ptr)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -43,6 +44,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(SmallK a) {
   const int py = tid >> 5, px2 = (tid & 31) * 2;
   const size_t HW = (size_t)a.H * a.W;
   const float* xn = a.x + (size_t)n * a.C * HW;
+  const float* wn = wset_ptr(a.w, a.w_gs, n, a.wdiv);
+  const float* bn = wset_ptr(a.bias, a.b_gs, n, a.wdiv);
 
   unsigned eoff[E];
   bool evalid[E];
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(SmallK a) {
   for (int i = tid; i < nch * CC * WPC; i += 256) {
     const int ci = i / WPC, r = i - ci * WPC;
     const int tap = r / COUT, o = r - tap * COUT;
-    s_w[i] = (ci < a.C && tap < 9) ? a.w[((size_t)o * a.C + ci) * 9 + tap] : 0.f;
+    s_w[i] = (ci < a.C && tap < 9) ? wn[((size_t)o * a.C + ci) * 9 + tap] : 0.f;
   }
   auto prefetch = [&](int k) {
 #pragma unroll
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(SmallK a) {
   const bool two = ox + 1 < a.W;
 #pragma unroll
   for (int o = 0; o < COUT; ++o) {
-    const float bv = a.bias ? a.bias[o] : 0.f;
+    const float bv = bn ? bn[o] : 0.f;
     f32x2 v = {apply_act(acc[o][0] + bv, a.act), apply_act(acc[o][1] + bv, a.act)};
     const size_t idx = ((size_t)n * a.Cout + o) * HW + (size_t)oy * a.W + ox;
     if (two && (idx & 1) == 0) {  // whole, 8-byte aligned pair
@@ -128,10 +131,11 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(SmallK a) {
 
 // x [N][C][H][W] (dense), w [Cout][C][3][3], Cout <= 4, stride 1, pad 1.
 int conv3x3_small_cout_run(const float* x, const float* w, const float* bias, const float* res, float* y, int N,
-                           int C, int H, int W, int Cout, int act, hipStream_t st) {
+                           int C, int H, int W, int Cout, int act, hipStream_t st, int wdiv, long long w_gs, int b_gs) {
   DVSR_REQUIRE(x && w && y && Cout >= 1 && Cout <= 4, DVSR_ERR_INVALID, "conv3x3_small_cout: bad argument");
   SmallK k;
   k.x = x; k.w = w; k.bias = bias; k.res = res; k.y = y; k.N = N; k.C = C; k.H = H; k.W = W; k.Cout = Cout; k.act = act;
+  k.wdiv = wdiv > 0 ? wdiv : 1; k.w_gs = w_gs; k.b_gs = b_gs;
   k.tiles_x = ceil_div(W, 64); k.tiles_y = ceil_div(H, 8); k.ntiles = k.tiles_x * k.tiles_y * N;
   auto wbytes = [&](int cout) { return (size_t)ceil_div(C, 8) * 8 * (((9 * cout + 3) / 4) * 4) * sizeof(float); };
   switch (Cout) {  // exact channel count: no wasted accumulators

@@ -123,6 +123,10 @@ struct dvsr_edvr_plan {
   // weights run as one batch (test_dynavsr.py:208-277 with adapt_iter = 1; train_dynavsr.py:355-426), each keeping its own
   // gradient.  Data gradients and activations are per sample anyway; only the weight-gradient launches change.
   int wgroups = 1;
+  // Per-group WEIGHTS as well (wsets == wgroups) or one set for the batch (wsets == 1): with per-group weights every
+  // params[i] points to [wsets][numel_i] floats and batch group g convolves with set g -- the private copies of K frames
+  // that have diverged (second and later inner steps; the adapted forwards) still run as one batch.
+  int wsets = 1;
 };
 
 namespace dvsr {
@@ -163,7 +167,7 @@ struct Builder {
     const int Ho = conv_out(o, H), Wo = conv_out(o, W);
     o.y = y_override.valid() ? y_override : alloc(name, (size_t)N * Cout * Ho * Wo);
     // (the gradient arena mirrors this slot: one re-laid-out gradient per group)
-    if (wmap) o.w2_off = alloc("", (size_t)p.wgroups * Cout * (c0 + c1) * ks * ks).off;
+    if (wmap) o.w2_off = alloc("", (size_t)std::max(p.wgroups, p.wsets) * Cout * (c0 + c1) * ks * ks).off;
     {
       const bool bf = p.cfg.bf16_mfma && ks == 3 && stride == 1 && pad < 0 && (c1 == 0 || c0 % 16 == 0);
       // bf16_mfma = 2: 8-row tiles (two 32-pixel rows per wave) once they still give ~a workgroup per CU
@@ -181,7 +185,7 @@ struct Builder {
       const int ks_ok = (plain && (c1 == 0 || c0 % 32 == 0) ? 1 : 0) | (plain && c0 % 8 == 0 && c1 % 8 == 0 ? 2 : 0);
       o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1, ks_ok), Ho, Wo, Cout);
       o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, o.geo.bf);
-      o.wp_off = alloc("", o.wp_floats).off;
+      o.wp_off = alloc("", o.wp_floats * p.wsets).off;   // one pack per weight set, consecutive
       for (int which = 0; which < 2; ++which) {
         const int ci = which ? c1 : c0;
         if (!ci) continue;
@@ -191,7 +195,7 @@ struct Builder {
         o.dpk_floats[which] = (size_t)ceil_div(ci, 64) * ceil_div(Cout, o.dgeo[which].cc) *
                               conv2_pch_cc(ks, o.dgeo[which].cc, o.dgeo[which].bf);
         o.dpk_off[which] = p.dpack_floats;
-        p.dpack_floats += o.dpk_floats[which];
+        p.dpack_floats += o.dpk_floats[which] * p.wsets;
       }
     }
     p.ops.push_back(o);
@@ -204,7 +208,7 @@ struct Builder {
     o.y = alloc(name, (size_t)N * C * H * W);
     if (C % (dg * 8) == 0) {  // LDS-sampler kernel: weights packed like a conv with 8-channel chunks
       o.wp_floats = (size_t)ceil_div(C, 64) * (C / 8) * conv2_pch(3, 1);
-      o.wp_off = alloc("", o.wp_floats).off;
+      o.wp_off = alloc("", o.wp_floats * p.wsets).off;
     }
     p.ops.push_back(o);
     return o.y;
@@ -670,6 +674,12 @@ static int prep_wgrad(const dvsr_edvr_plan& p, const BOp& b, float* const* GP, c
                               (long long)o->Cout * (o->c0 + o->c1) * o->ks * o->ks, o->Cout);
 }
 
+// ConvExtra of a launch whose batch items take per-sample weight sets (plan.wsets > 1)
+static inline void set_wsets(const dvsr_edvr_plan& p, int N, size_t pack_floats, int cout, ConvExtra* ex) {
+  if (p.wsets <= 1) return;
+  ex->wdiv = N / p.wsets; ex->w_gs = (long long)pack_floats; ex->b_gs = cout;
+}
+
 static void dgrad_desc(const dvsr_edvr_plan& p, const BOp& b, const float* const* P, const BBases& bs,
                        dvsr_conv2d_desc* gd, ConvExtra* exd) {
   const Op* o = &p.ops[b.fwd];
@@ -684,6 +694,7 @@ static void dgrad_desc(const dvsr_edvr_plan& p, const BOp& b, const float* const
   if (b.mask_op >= 0 && !bs.use_v1) { ex.gmask = bs.arena + p.ops[b.mask_op].y.off; ex.gmask_act = p.ops[b.mask_op].act; }
   if (o->stride == 2) { ex.in_dil = 2; ex.Hs = Ho; ex.Ws = Wo; g.H = o->H; g.W = o->W; }
   else { g.H = Ho; g.W = Wo; }
+  set_wsets(p, o->N, o->dpk_floats[b.which], 0, &ex);
   *gd = g; *exd = ex;
 }
 
@@ -750,7 +761,8 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
       return mdcn_backward_run(bs.arena + o->x0.off, om, bstride, om + (size_t)o->dg * 18 * P_, bstride, 1, P[o->pw],
                                bs.at(b.b), bs.at(b.a), gom, bstride, gom + (size_t)o->dg * 18 * P_, bstride,
                                GP[o->pw], GP[o->pb], o->N, o->c0, o->H, o->W, o->Cout, 1, 1, 1, o->dg, scratch,
-                               scratch_bytes, st, p.wgroups, (long long)o->Cout * o->c0 * 9, o->Cout);
+                               scratch_bytes, st, p.wgroups, (long long)o->Cout * o->c0 * 9, o->Cout,
+                               p.wsets > 1 ? (long long)o->Cout * o->c0 * 9 : 0);
     }
     case B_UP: {
       float* gx = bs.at(b.a);
@@ -801,47 +813,55 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
   PackTable t;
   t.n = 0;
   auto flush = [&]() { int rc = pack_weights_run(t, st); t.n = 0; return rc; };
+  const int S = p.wsets;   // weight sets: params are [S][numel], every pack slot holds S consecutive packs
   for (const Op& o : p.ops) {
     if (o.type == OP_DCN && fwd_base && o.wp_floats) {
-      PackEntry& e = t.e[t.n++];
-      e.w = P[o.pw]; e.P = fwd_base + o.wp_off; e.Cout = o.Cout; e.Ctot = o.c0; e.KK = 9; e.CC = 8; e.wt = 0;
-      e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64); e.nchunks = o.c0 / 8; e.pch = conv2_pch(3, 1); e.bf = 0;
-      if (t.n == 48) { int rc = flush(); if (rc) return rc; }
+      for (int ws = 0; ws < S; ++ws) {
+        PackEntry& e = t.e[t.n++];
+        e.w = P[o.pw] + (size_t)ws * o.Cout * o.c0 * 9; e.P = fwd_base + o.wp_off + (size_t)ws * o.wp_floats;
+        e.Cout = o.Cout; e.Ctot = o.c0; e.KK = 9; e.CC = 8; e.wt = 0;
+        e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64); e.nchunks = o.c0 / 8; e.pch = conv2_pch(3, 1); e.bf = 0;
+        if (t.n == 48) { int rc = flush(); if (rc) return rc; }
+      }
     }
     if (o.type != OP_CONV) continue;
     const int ctot = o.c0 + o.c1, KK = o.ks * o.ks;
+    const size_t wnum = (size_t)o.Cout * ctot * KK;
     const float* wsrc = P[o.pw];
     if (o.wmap) {  // the re-laid-out copy is (re)built by the forward; the backward packs read the same slot
       wsrc = arena_base + o.w2_off;
-      if (fwd_base) {
-        int rc = w4_to_s2d(P[o.pw], arena_base + o.w2_off, o.Cout, ctot / 4, 0, st);
+      if (fwd_base) {   // (the map is per output channel: S stacked sets are one [S * Cout] tensor)
+        int rc = w4_to_s2d(P[o.pw], arena_base + o.w2_off, S * o.Cout, ctot / 4, 0, st);
         if (rc) return rc;
       }
     }
-    if (fwd_base) {
-      PackEntry& e = t.e[t.n++];
-      e.w = wsrc; e.P = fwd_base + o.wp_off; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
-      e.CC = o.geo.cc; e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
-      e.nchunks = ceil_div(ctot, e.CC); e.bf = o.geo.bf; e.perm = o.geo.dma; e.pch = conv2_pch_cc(o.ks, e.CC, e.bf);
-      if (t.n == 48) { int rc = flush(); if (rc) return rc; }
-    }
-    if (bwd_base) {
-      for (int which = 0; which < 2; ++which) {
-        const int ci = which ? o.c1 : o.c0;
-        if (!ci) continue;
+    for (int ws = 0; ws < S; ++ws) {
+      if (fwd_base) {
         PackEntry& e = t.e[t.n++];
-        e.w = wsrc; e.P = bwd_base + o.dpk_off[which]; e.Cout = ci; e.Ctot = o.Cout; e.KK = KK;
-        e.CC = o.dgeo[which].cc; e.wt = 1; e.w_ctot = ctot; e.w_coff = which ? o.c0 : 0;
-        e.ncb = ceil_div(ci, 64); e.nchunks = ceil_div(o.Cout, e.CC); e.bf = o.dgeo[which].bf;
-        e.pch = conv2_pch_cc(o.ks, e.CC, e.bf); e.perm = o.dgeo[which].dma;
+        e.w = wsrc + ws * wnum; e.P = fwd_base + o.wp_off + (size_t)ws * o.wp_floats; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
+        e.CC = o.geo.cc; e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
+        e.nchunks = ceil_div(ctot, e.CC); e.bf = o.geo.bf; e.perm = o.geo.dma; e.pch = conv2_pch_cc(o.ks, e.CC, e.bf);
         if (t.n == 48) { int rc = flush(); if (rc) return rc; }
+      }
+      if (bwd_base) {
+        for (int which = 0; which < 2; ++which) {
+          const int ci = which ? o.c1 : o.c0;
+          if (!ci) continue;
+          PackEntry& e = t.e[t.n++];
+          e.w = wsrc + ws * wnum; e.P = bwd_base + o.dpk_off[which] + (size_t)ws * o.dpk_floats[which]; e.Cout = ci; e.Ctot = o.Cout;
+          e.KK = KK;
+          e.CC = o.dgeo[which].cc; e.wt = 1; e.w_ctot = ctot; e.w_coff = which ? o.c0 : 0;
+          e.ncb = ceil_div(ci, 64); e.nchunks = ceil_div(o.Cout, e.CC); e.bf = o.dgeo[which].bf;
+          e.pch = conv2_pch_cc(o.ks, e.CC, e.bf); e.perm = o.dgeo[which].dma;
+          if (t.n == 48) { int rc = flush(); if (rc) return rc; }
+        }
       }
     }
   }
   return flush();
 }
 
-static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, hipStream_t st) {
+static int run_forward_op(const dvsr_edvr_plan& p, const Op& o, const float* const* P, const Bases& bs, hipStream_t st) {
   switch (o.type) {
     case OP_CONV: {
       dvsr_conv2d_desc d;
@@ -854,8 +874,12 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
       d.x1_bdiv = o.x1_bdiv; d.x0_bstride = o.x0_bs; d.x1_bstride = o.x1_bs;
       if (bs.use_v1) return conv2d_run(d, ConvExtra(), st);
       if (o.Cout <= 4 && o.ks == 3 && o.stride == 1 && !o.c1 && !o.ps && !o.x0_bs && o.pad < 0)  // conv_last
-        return conv3x3_small_cout_run(d.x0, d.w, d.bias, d.res, d.y, o.N, o.c0, o.H, o.W, o.Cout, o.act, st);
-      return conv2d_packed_run(d, bs.arena + o.wp_off, ConvExtra(), o.geo, st);
+        return conv3x3_small_cout_run(d.x0, d.w, d.bias, d.res, d.y, o.N, o.c0, o.H, o.W, o.Cout, o.act, st,
+                                      p.wsets > 1 ? o.N / p.wsets : 1, p.wsets > 1 ? (long long)o.Cout * o.c0 * 9 : 0,
+                                      p.wsets > 1 ? o.Cout : 0);
+      ConvExtra ex;
+      set_wsets(p, o.N, o.wp_floats, o.Cout, &ex);
+      return conv2d_packed_run(d, bs.arena + o.wp_off, ex, o.geo, st);
     }
     case OP_DCN: {
       const float* om = bs.at(o.x1);
@@ -863,7 +887,8 @@ static int run_forward_op(const Op& o, const float* const* P, const Bases& bs, h
       if (!bs.use_v1 && o.wp_floats)
         return mdcn_forward_packed_run(bs.at(o.x0), om, bstride, om + (size_t)o.dg * 18 * o.H * o.W, bstride, 1,
                                        bs.arena + o.wp_off, P[o.pb], bs.at(o.y), o.N, o.c0, o.H, o.W, o.Cout,
-                                       o.dg, o.act, st);
+                                       o.dg, o.act, st, p.wsets > 1 ? o.N / p.wsets : 1,
+                                       p.wsets > 1 ? (long long)o.wp_floats : 0, p.wsets > 1 ? o.Cout : 0);
       return mdcn_forward_run(bs.at(o.x0), om, bstride, om + (size_t)o.dg * 18 * o.H * o.W, bstride, 1,
                               P[o.pw], P[o.pb], bs.at(o.y), o.N, o.c0, o.H, o.W, o.Cout, 3, 3, 1, 1,
                               1, 1, o.dg, o.act, st);
@@ -901,7 +926,14 @@ extern "C" int dvsr_edvr_plan_create(const dvsr_edvr_config* cfg, int B, int H, 
 
 extern "C" int dvsr_edvr_plan_create_grouped(const dvsr_edvr_config* cfg, int B, int H, int W, int grad_groups,
                                              dvsr_edvr_plan** out) {
+  return dvsr_edvr_plan_create_ex(cfg, B, H, W, grad_groups, 1, out);
+}
+
+extern "C" int dvsr_edvr_plan_create_ex(const dvsr_edvr_config* cfg, int B, int H, int W, int grad_groups,
+                                        int weight_sets, dvsr_edvr_plan** out) {
   DVSR_REQUIRE(cfg && out, DVSR_ERR_INVALID, "edvr_plan_create: null argument");
+  DVSR_REQUIRE(weight_sets == 1 || weight_sets == grad_groups, DVSR_ERR_INVALID,
+               "edvr_plan_create: weight_sets=%d must be 1 or grad_groups=%d", weight_sets, grad_groups);
   DVSR_REQUIRE(B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, DVSR_ERR_INVALID,
                "edvr_plan_create: B=%d H=%d W=%d (H, W must be positive multiples of 4)", B, H, W);
   DVSR_REQUIRE(grad_groups >= 1 && B % grad_groups == 0, DVSR_ERR_INVALID,
@@ -916,8 +948,13 @@ extern "C" int dvsr_edvr_plan_create_grouped(const dvsr_edvr_config* cfg, int B,
   DVSR_REQUIRE(cpg == 4 || cpg == 8 || cpg == 16, DVSR_ERR_UNSUPPORTED,
                "edvr_plan_create: nf/groups=%d (supported: 4, 8, 16)", cpg);
   dvsr_edvr_plan* p = new dvsr_edvr_plan();
-  p->cfg = *cfg; p->B = B; p->H = H; p->W = W; p->wgroups = grad_groups;
+  p->cfg = *cfg; p->B = B; p->H = H; p->W = W; p->wgroups = grad_groups; p->wsets = weight_sets;
   { const char* v = getenv("DVSR_CONV_V1"); p->use_v1 = v && v[0] == '1'; }
+  if (weight_sets > 1 && (p->use_v1 || cpg % 8 != 0)) {
+    delete p;
+    DVSR_REQUIRE(false, DVSR_ERR_UNSUPPORTED, "edvr_plan_create: per-sample weight sets need the packed kernels (no "
+                 "DVSR_CONV_V1) and nf/groups a multiple of 8");
+  }
   { const char* v = getenv("DVSR_BWD_STREAMS"); p->side_streams = (v && v[0] == '0') ? 0 : 1; }
   int rc = build_plan(*p);
   if (rc != DVSR_OK) { delete p; return rc; }
@@ -1080,7 +1117,7 @@ extern "C" int dvsr_edvr_forward(const dvsr_edvr_plan* p, const float* const* pa
     if (rc != DVSR_OK) return rc;
   }
   for (const Op& o : p->ops) {
-    int rc = run_forward_op(o, params, bs, (hipStream_t)stream);
+    int rc = run_forward_op(*p, o, params, bs, (hipStream_t)stream);
     if (rc != DVSR_OK) return rc;
   }
   return DVSR_OK;
@@ -1150,7 +1187,7 @@ extern "C" int dvsr_edvr_forward_timed(const dvsr_edvr_plan* p, const float* con
   int rc = p->use_v1 ? DVSR_OK : pack_all(*p, params, bs.arena, bs.arena, nullptr, st);
   hipEventRecord(ev[0], st);
   for (size_t i = 0; i < n && rc == DVSR_OK; ++i) {
-    rc = run_forward_op(p->ops[i], params, bs, st);
+    rc = run_forward_op(*p, p->ops[i], params, bs, st);
     hipEventRecord(ev[i + 1], st);
   }
   if (rc == DVSR_OK && hipStreamSynchronize(st) != hipSuccess) {
@@ -1281,7 +1318,14 @@ extern "C" int dvsr_estimator_plan_create(const dvsr_estimator_config* cfg, int 
 
 extern "C" int dvsr_estimator_plan_create_grouped(const dvsr_estimator_config* cfg, int B, int H, int W, int grad_groups,
                                                   dvsr_estimator_plan** out) {
+  return dvsr_estimator_plan_create_ex(cfg, B, H, W, grad_groups, 1, out);
+}
+
+extern "C" int dvsr_estimator_plan_create_ex(const dvsr_estimator_config* cfg, int B, int H, int W, int grad_groups,
+                                             int weight_sets, dvsr_estimator_plan** out) {
   DVSR_REQUIRE(cfg && out, DVSR_ERR_INVALID, "estimator_plan_create: null argument");
+  DVSR_REQUIRE(weight_sets == 1 || weight_sets == grad_groups, DVSR_ERR_INVALID,
+               "estimator_plan_create: weight_sets=%d must be 1 or grad_groups=%d", weight_sets, grad_groups);
   DVSR_REQUIRE(grad_groups >= 1 && B > 0 && B % grad_groups == 0, DVSR_ERR_INVALID,
                "estimator_plan_create: grad_groups=%d must divide the batch B=%d", grad_groups, B);
   DVSR_REQUIRE(cfg->kind == DVSR_ESTIMATOR_MFDN || cfg->kind == DVSR_ESTIMATOR_SFDN, DVSR_ERR_INVALID,
@@ -1302,7 +1346,7 @@ extern "C" int dvsr_estimator_plan_create_grouped(const dvsr_estimator_config* c
   ep->ecfg = *cfg;
   dvsr_edvr_plan& p = ep->core;
   p.cfg = dvsr_edvr_config{cfg->nf, cfg->nframes, 1, 0, 0, cfg->scale, 0, 0};
-  p.B = B; p.H = H; p.W = W; p.wgroups = grad_groups;
+  p.B = B; p.H = H; p.W = W; p.wgroups = grad_groups; p.wsets = weight_sets;
   { const char* v = getenv("DVSR_BWD_STREAMS"); p.side_streams = (v && v[0] == '0') ? 0 : 1; }
   p.fork_every = 1;   // seven layers whose weight gradients outlast the data-gradient chain: every fork at once
   int rc = build_estimator(*ep);

@@ -14,6 +14,8 @@ struct ConvExtra {
   int accum = 0;               // y += result
   const float* gmask = nullptr;  // dgrad: multiply by act'(gmask) (fused activation backward of the producer)
   int gmask_act = 0;
+  // per-sample weight sets: batch item n takes the packed weights at + (n / wdiv) * w_gs floats, the bias at + (n / wdiv) * b_gs
+  int wdiv = 1; long long w_gs = 0; int b_gs = 0;
 };
 int conv2d_run(const dvsr_conv2d_desc& d, const ConvExtra& ex, hipStream_t st);
 
@@ -44,7 +46,8 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
                       hipStream_t st);
 
 int conv3x3_small_cout_run(const float* x, const float* w, const float* bias, const float* res, float* y, int N,
-                           int C, int H, int W, int Cout, int act, hipStream_t st);
+                           int C, int H, int W, int Cout, int act, hipStream_t st, int wdiv = 1, long long w_gs = 0,
+                           int b_gs = 0);
 
 // Deferred slot reduction of a weight gradient (conv2d_wgrad_run(..., defer = &entry) + wgrad_reduce_batch)
 struct WgradReduceEntry {
@@ -72,11 +75,13 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
                       int mask_logit, const float* w, const float* gout, float* gx, float* goff,
                       long long goff_bs, float* gmsk, long long gmsk_bs, float* gw, float* gb, int N, int C,
                       int H, int W, int Cout, int stride, int pad, int dil, int dg, void* ws,
-                      size_t ws_bytes, hipStream_t st, int groups = 1, long long gw_gs = 0, long long gb_gs = 0);
+                      size_t ws_bytes, hipStream_t st, int groups = 1, long long gw_gs = 0, long long gb_gs = 0,
+                      long long w_gs = 0);  // w_gs != 0: group g of the batch convolves with w + g * w_gs (per-sample weights)
 
 int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, const float* msk,
                             long long msk_bs, int mask_logit, const float* wp, const float* b, float* out,
-                            int N, int C, int H, int W, int Cout, int dg, int act, hipStream_t st);
+                            int N, int C, int H, int W, int Cout, int dg, int act, hipStream_t st, int wdiv = 1,
+                            long long w_gs = 0, int b_gs = 0);
 
 // misc.hip
 int upsample_bilinear_fwd(const float* x, float* y, size_t planes, int H, int W, int S, float mul,

@@ -207,6 +207,7 @@ struct DcnK2 {
   int mask_logit;
   int N, C, H, W, Cout, dg, act;
   int tiles_x, tiles_y, ntiles, ncb, nchunks;
+  int wdiv = 1; long long w_gs = 0; int b_gs = 0;   // per-sample weight sets (common.h: wset_ptr)
 #ifdef DVSR_CONV_TRACE
   long long* trace;  // debug build only (tools/dcn_trace.py): 64 cycle stamps per workgroup
 #endif
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_lds_kernel(DcnK2 a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const float* wp_cb = a.wp + (size_t)cb * a.nchunks * WF;
+  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + (size_t)cb * a.nchunks * WF;
   prefetch_x(0);
   for (int g = 0; g < a.dg; ++g) {
     __syncthreads();  // previous group's MFMAs are done with s_w / s_col, its sampling with s_x
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_lds_kernel(DcnK2 a) {
     }
   }
 
-  const TileOut t{a.out, a.bias, nullptr, a.act, 0, 0, a.Cout, a.H, a.W};
+  const TileOut t{a.out, wset_ptr(a.bias, a.b_gs, n, a.wdiv), nullptr, a.act, 0, 0, a.Cout, a.H, a.W};
   store_mfma_tile<2, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
 }
 
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_reg_kernel(DcnK2 a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const float* wp_cb = a.wp + (size_t)cb * a.nchunks * WF;
+  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + (size_t)cb * a.nchunks * WF;
   DCN_STAMP(0);
   // One pass per 8-channel chunk; a deformable group spans a.nchunks / a.dg of them (1 for EDVR-M's 64
   // channels, 2 for EDVR-L's 128) which share the group's offsets and masks.
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_reg_kernel(DcnK2 a) {
   }
 
   DCN_STAMP(62);
-  const TileOut t{a.out, a.bias, nullptr, a.act, 0, 0, a.Cout, a.H, a.W};
+  const TileOut t{a.out, wset_ptr(a.bias, a.b_gs, n, a.wdiv), nullptr, a.act, 0, 0, a.Cout, a.H, a.W};
   store_mfma_tile<2, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
   DCN_STAMP(63);
 }
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_dma_kernel(DcnK2 a) {
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) a_om[nt] = lds_addr(s_om) + (unsigned)prow[nt] * 4u;
 
-  const float* wp_cb = a.wp + (size_t)cb * a.nchunks * Sh::WF;
+  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + (size_t)cb * a.nchunks * Sh::WF;
   const int sub = a.nchunks / a.dg;  // 8-channel chunks per deformable group (they share its offsets and masks)
   DCN_STAMP(0);
   for (int kc = 0; kc < a.nchunks; ++kc) {
@@ -991,7 +992,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_dma_kernel(DcnK2 a) {
   }
 
   DCN_STAMP(62);
-  const TileOut t{a.out, a.bias, nullptr, a.act, 0, 0, a.Cout, a.H, a.W};
+  const TileOut t{a.out, wset_ptr(a.bias, a.b_gs, n, a.wdiv), nullptr, a.act, 0, 0, a.Cout, a.H, a.W};
   store_mfma_tile<2, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
   DCN_STAMP(63);
 }
@@ -999,7 +1000,8 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_dma_kernel(DcnK2 a) {
 // wp = weights packed by pack_weights_kernel with KK=9, CC=8, wt=0 (one chunk per deformable group).
 int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, const float* msk,
                             long long msk_bs, int mask_logit, const float* wp, const float* b, float* out,
-                            int N, int C, int H, int W, int Cout, int dg, int act, hipStream_t st) {
+                            int N, int C, int H, int W, int Cout, int dg, int act, hipStream_t st, int wdiv,
+                            long long w_gs, int b_gs) {
   DVSR_REQUIRE(x && off && msk && wp && out, DVSR_ERR_INVALID, "mdcn_forward_packed: null pointer");
   DVSR_REQUIRE(dg > 0 && C % (dg * 8) == 0, DVSR_ERR_UNSUPPORTED,
                "mdcn_forward_packed: needs C/dg to be a multiple of 8 (got %d/%d)", C, dg);
@@ -1009,6 +1011,7 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
   k.N = N; k.C = C; k.H = H; k.W = W; k.Cout = Cout; k.dg = dg; k.act = act;
   k.tiles_x = ceil_div(W, 32); k.tiles_y = ceil_div(H, 8); k.ntiles = k.tiles_x * k.tiles_y * N;
   k.ncb = ceil_div(Cout, 64); k.nchunks = C / 8;
+  k.wdiv = wdiv > 0 ? wdiv : 1; k.w_gs = w_gs; k.b_gs = b_gs;
 #ifdef DVSR_CONV_TRACE
   k.trace = (g_dcn_countdown == 0) ? g_dcn_trace : nullptr;
   if (g_dcn_countdown >= 0) --g_dcn_countdown;

@@ -153,6 +153,7 @@ struct DcnF {
   long long off_bs, msk_bs, goff_bs, gmsk_bs;
   int mask_logit, N, C, H, W, Cout, dg, tiles_x, tiles_y;
   int sub;  // 8-channel chunks per deformable group (1: EDVR-M, 2: EDVR-L); blockIdx.y walks the C/8 chunks
+  int wdiv = 1; long long w_gs = 0;  // per-sample weight sets: frame n convolves with w + (n / wdiv) * w_gs
 #ifdef DVSR_CONV_TRACE
   long long* trace;  // debug build only (tools/dcn_bwd_trace.py): 16 cycle stamps per workgroup
 #endif
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       if (idx < 8 * XPX) s_x[idx] = rx_[e];
     }
   }
+  const float* wn = wset_ptr(a.w, a.w_gs, n, a.wdiv);
   for (int base = 0; base < 3 * KST * 64; base += 256 * 8) {
     float rw[8];
 #pragma unroll
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       const int idx = base + tid + 256 * e;
       const int l = idx & 63, kk = (idx >> 6) % KST, mt = idx / (64 * KST);
       const int m = mt * 32 + (l & 31), o = 2 * kk + (l >> 5);
-      rw[e] = (idx < 3 * KST * 64 && m < 72) ? a.w[((size_t)o * a.C + kc * 8 + (m & 7)) * 9 + (m >> 3)] : 0.f;
+      rw[e] = (idx < 3 * KST * 64 && m < 72) ? wn[((size_t)o * a.C + kc * 8 + (m & 7)) * 9 + (m >> 3)] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -669,7 +671,7 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
                       int mask_logit, const float* w, const float* gout, float* gx, float* goff,
                       long long goff_bs, float* gmsk, long long gmsk_bs, float* gw, float* gb, int N, int C,
                       int H, int W, int Cout, int stride, int pad, int dil, int dg, void* ws,
-                      size_t ws_bytes, hipStream_t st, int groups, long long gw_gs, long long gb_gs) {
+                      size_t ws_bytes, hipStream_t st, int groups, long long gw_gs, long long gb_gs, long long w_gs) {
   DVSR_REQUIRE(x && off && msk && w && gout && goff && gmsk && ws, DVSR_ERR_INVALID,
                "mdcn_backward: null pointer");
   DVSR_REQUIRE(C % dg == 0, DVSR_ERR_INVALID, "mdcn_backward: C %% dg != 0");
@@ -705,6 +707,8 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
     f.mask_logit = mask_logit; f.N = N; f.C = C; f.H = H; f.W = W; f.Cout = Cout; f.dg = dg;
     f.tiles_x = ceil_div(W, 32); f.tiles_y = ceil_div(H, 8);
     f.sub = a.cpg / 8;
+    f.wdiv = groups > 0 ? N / groups : N; f.w_gs = w_gs;
+    if (f.wdiv < 1) f.wdiv = 1;
     if (f.sub > 1 && gmsk == goff + (size_t)dg * 18 * P && goff_bs == gmsk_bs && goff_bs == (long long)dg * 27 * P) {
       // offsets and masks are the two parts of one [N, 27 dg, H, W] tensor (the engine's layout): one memset
       DVSR_REQUIRE(hipMemsetAsync(goff, 0, (size_t)N * goff_bs * sizeof(float), st) == hipSuccess, DVSR_ERR_HIP,
@@ -742,6 +746,8 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
                        st, f.dwp, f.dbp, gw, gb, N, C / 8, ntile, Cout, C, groups, nsp, gw_gs, gb_gs);
     return check_launch("mdcn_dw_reduce_kernel");
   }
+  DVSR_REQUIRE(w_gs == 0, DVSR_ERR_UNSUPPORTED, "mdcn_backward: per-sample weights need the fused path (C/dg %% 8 == 0, 3x3, "
+               "stride / pad / dilation 1, Cout %% 64 == 0)");
   // 1) dcol[n][C*9][P] = W^T . gout  as a 1x1 conv with the transposed weight view
   dvsr_conv2d_desc g = {};
   g.x0 = gout; g.w = w; g.y = col; g.N = N; g.c0 = Cout; g.H = a.Ho; g.W = a.Wo; g.Cout = C * 9; g.ks = 1;

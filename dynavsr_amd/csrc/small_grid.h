@@ -22,6 +22,10 @@ struct ConvK2 {
   int tiles_x, tiles_y, ntiles, ncb, nchunks, nitems, tiles_per_xcd;
   int in_ps, in_dil, Hs, Ws, accum;
   const float* gmask; int gmask_act;
+  // per-sample weight sets (r03): batch item n uses the packed weights wp + (n / wdiv) * w_gs and the bias
+  // bias + (n / wdiv) * b_gs -- K frames whose private copies of the network have DIVERGED (after their first inner
+  // step; the adapted forwards) still run as one batch.  w_gs == 0: one set for the whole batch.
+  int wdiv = 1; long long w_gs = 0; int b_gs = 0;
 #ifdef DVSR_CONV_TRACE
   int ablate;  // DVSR_CONV_ABLATE measurement aid (conv2d_dma_kernel), debug build only
   long long* trace;  // debug build only (tools/conv_trace.py): 64 cycle stamps per workgroup
@@ -175,7 +179,7 @@ __device__ __forceinline__ void conv2d_ksplit_item(const ConvK2& a, const int id
   };
 
   // weights of this workgroup's 32*MT-cout block; this wave's operand group (q = wave) of every tap
-  const float* wp_cb = a.wp + ((size_t)((cbi * MT) >> 1) * a.nchunks * 2 + ((cbi * MT) & 1)) * Sh::HALF +
+  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + ((size_t)((cbi * MT) >> 1) * a.nchunks * 2 + ((cbi * MT) & 1)) * Sh::HALF +
                        (size_t)(wave * 64 + lane) * 4;
   f32x4 Ag[3][MT];
   auto load_a = [&](int k, int tap, int slot) {
@@ -257,7 +261,7 @@ __device__ __forceinline__ void conv2d_ksplit_item(const ConvK2& a, const int id
     for (int w = 0; w < 4; ++w) v += red[((((w * MT + smt) * NT + snt) * 16 + r) << 6) + lane];
     sum[0][0][r] = v;
   }
-  const TileOut t{a.y, a.bias, a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
+  const TileOut t{a.y, wset_ptr(a.bias, a.b_gs, n, a.wdiv), a.res, a.act, a.ps, a.accum, a.Cout, a.Ho, a.Wo, a.gmask, a.gmask_act};
   store_mfma_tile<1, 1>(sum, t, n, (cbi * MT + smt) * 32, oy0 + snt, 1, ox0, oy0 + snt, lo, hi);
 }
 

@@ -18,14 +18,14 @@ _plans = {}
 class Plan:
     """Owns one dvsr_edvr_plan (shape-specialised launch tape)."""
 
-    def __init__(self, cfg, b, h, w, grad_groups=1):
-        self.key = (cfg, b, h, w, grad_groups)
+    def __init__(self, cfg, b, h, w, grad_groups=1, weight_sets=1):
+        self.key = (cfg, b, h, w, grad_groups, weight_sets)
         cfg = tuple(cfg) + (0,) * (8 - len(cfg))  # older 7-tuples: fp32 MFMA
         self.cfg = dict(zip(("nf", "nframes", "groups", "front_RBs", "back_RBs", "scale", "center", "bf16_mfma"), cfg))
-        self.b, self.h, self.w, self.grad_groups = b, h, w, grad_groups
+        self.b, self.h, self.w, self.grad_groups, self.weight_sets = b, h, w, grad_groups, weight_sets
         self._h = ctypes.c_void_p()
-        L.check(L.lib().dvsr_edvr_plan_create_grouped(L.EdvrConfig(*cfg), b, h, w, grad_groups, ctypes.byref(self._h)),
-                "dvsr_edvr_plan_create_grouped")
+        L.check(L.lib().dvsr_edvr_plan_create_ex(L.EdvrConfig(*cfg), b, h, w, grad_groups, weight_sets,
+                                                 ctypes.byref(self._h)), "dvsr_edvr_plan_create_ex")
         self.n_params = L.lib().dvsr_edvr_num_params(self._h)
         self.n_launches = L.lib().dvsr_edvr_num_launches(self._h)
         self.n_backward_launches = L.lib().dvsr_edvr_num_backward_launches(self._h)
@@ -81,17 +81,17 @@ class Plan:
             pass
 
 
-def get_plan(cfg, b, h, w, device=None, grad_groups=1):
+def get_plan(cfg, b, h, w, device=None, grad_groups=1, weight_sets=1):
     """One plan per (config, shape, device): a plan owns a side stream and events of the device it was first
     used on.  A plan is single-threaded: two host threads must not drive the same plan concurrently.
     grad_groups > 1: per-group parameter gradients (dvsr_edvr_plan_create_grouped)."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     # ... and per HIP stream: the plan's side stream and fork / join events belong to ONE in-flight backward, so two
     # clips adapted concurrently on two streams (adapt_video(concurrency=2)) must not share them
-    key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream, grad_groups)
+    key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream, grad_groups, weight_sets)
     p = _plans.get(key)
     if p is None:
-        p = _plans[key] = Plan(tuple(cfg), b, h, w, grad_groups)
+        p = _plans[key] = Plan(tuple(cfg), b, h, w, grad_groups, weight_sets)
     return p
 
 
@@ -161,14 +161,16 @@ class EdvrStackedFunction(torch.autograd.Function):
     """K clips through ONE tape with PER-CLIP parameter gradients (dvsr_edvr_plan_create_grouped).
 
     x: [K,N,3,H,W]; every parameter arrives STACKED, [K, *shape]: slice k is frame k's private copy of the weights
-    (test_dynavsr.py:208 deep-copies the networks for every frame).  Contract: all K slices hold the SAME values when
-    this runs -- the first inner step, where every copy still equals the un-adapted network; the tape reads slice 0.
+    (test_dynavsr.py:208 deep-copies the networks for every frame).  per_slice = False: all K slices hold the SAME values
+    when this runs (contract) -- the first inner step, where every copy still equals the un-adapted network -- and the
+    tape reads slice 0.  per_slice = True: clip k is convolved with slice k (dvsr_edvr_plan_create_ex, weight_sets = K):
+    the copies have diverged (later inner steps, the adapted forwards).
     backward returns d loss_k / d theta in slice k (the caller sums the per-clip losses, so the incoming gradient of
     out[k] is that of loss_k alone): an elementwise optimiser stepping the stacked tensors once performs the K
     independent inner updates of the sequential loop."""
 
     @staticmethod
-    def forward(ctx, x, cfg, *stacked):
+    def forward(ctx, x, cfg, per_slice, *stacked):
         if not x.is_cuda:
             raise RuntimeError("dynavsr_amd EDVR runs on the MI355X only (input is on %s); there is no CPU fallback" % x.device)
         x = _prep(x)
@@ -177,17 +179,18 @@ class EdvrStackedFunction(torch.autograd.Function):
             raise RuntimeError("EDVR expects [K,%d,3,H,W], got %s" % (cfg[1], tuple(x.shape)))
         if any(p.shape[0] != k for p in stacked):
             raise RuntimeError("EDVR (stacked): every parameter must be [K=%d, ...]" % k)
-        plan = get_plan(cfg, k, h, w, x.device, grad_groups=k)
+        plan = get_plan(cfg, k, h, w, x.device, grad_groups=k, weight_sets=k if per_slice else 1)
         if len(stacked) != plan.n_params:
             raise RuntimeError("EDVR engine expects %d parameter tensors, got %d" % (plan.n_params, len(stacked)))
         stacked = [_prep(p.detach()) for p in stacked]
-        params = [p[0] for p in stacked]
+        params = stacked if per_slice else [p[0] for p in stacked]
         need_grad = any(ctx.needs_input_grad)
         ws = torch.empty(plan.workspace_bytes(need_grad), dtype=torch.uint8, device=x.device)
         out = x.new_empty((k, 3, cfg[5] * h, cfg[5] * w))
         plan.forward(params, x, out, ws)
         if need_grad:
             _stash(ctx, plan, ws, x, stacked)
+            ctx.per_slice = per_slice
         return out
 
     @staticmethod
@@ -197,9 +200,9 @@ class EdvrStackedFunction(torch.autograd.Function):
         gout = _prep(gout)
         gparams = [torch.empty_like(p) for p in ctx.params]          # [K, *shape]: group-major, as the plan writes them
         gx = torch.empty_like(ctx.x) if ctx.needs_input_grad[0] else None
-        ctx.plan.backward([p[0] for p in ctx.params], ctx.x, gout, gparams, gx, ctx.ws)
+        ctx.plan.backward(ctx.params if ctx.per_slice else [p[0] for p in ctx.params], ctx.x, gout, gparams, gx, ctx.ws)
         ctx.ws = None
-        return (gx, None) + tuple(gparams)
+        return (gx, None, None) + tuple(gparams)
 
 
 # ---- down-scaling estimators (csrc/engine.hip: dvsr_estimator_*) ---------------------------------
@@ -210,12 +213,12 @@ _eplans = {}
 class EstimatorPlan:
     """Owns one dvsr_estimator_plan: MFDN / SFDN forward + parameter-gradient tape for one shape."""
 
-    def __init__(self, cfg, b, h, w, grad_groups=1):
+    def __init__(self, cfg, b, h, w, grad_groups=1, weight_sets=1):
         self.cfg = dict(zip(("kind", "nf", "in_nc", "scale", "nframes"), cfg))
-        self.b, self.h, self.w, self.grad_groups = b, h, w, grad_groups
+        self.b, self.h, self.w, self.grad_groups, self.weight_sets = b, h, w, grad_groups, weight_sets
         self._h = ctypes.c_void_p()
-        L.check(L.lib().dvsr_estimator_plan_create_grouped(L.EstimatorConfig(*cfg), b, h, w, grad_groups,
-                                                           ctypes.byref(self._h)), "dvsr_estimator_plan_create_grouped")
+        L.check(L.lib().dvsr_estimator_plan_create_ex(L.EstimatorConfig(*cfg), b, h, w, grad_groups, weight_sets,
+                                                      ctypes.byref(self._h)), "dvsr_estimator_plan_create_ex")
         self.n_params = L.lib().dvsr_estimator_num_params(self._h)
         self.n_launches = L.lib().dvsr_estimator_num_launches(self._h, 0)
         self.n_backward_launches = L.lib().dvsr_estimator_num_launches(self._h, 1)
@@ -244,12 +247,12 @@ class EstimatorPlan:
             pass
 
 
-def get_estimator_plan(cfg, b, h, w, device=None, grad_groups=1):
+def get_estimator_plan(cfg, b, h, w, device=None, grad_groups=1, weight_sets=1):
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream, grad_groups)
+    key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream, grad_groups, weight_sets)
     p = _eplans.get(key)
     if p is None:
-        p = _eplans[key] = EstimatorPlan(tuple(cfg), b, h, w, grad_groups)
+        p = _eplans[key] = EstimatorPlan(tuple(cfg), b, h, w, grad_groups, weight_sets)
     return p
 
 
@@ -302,7 +305,7 @@ class EstimatorStackedFunction(torch.autograd.Function):
     of a clip consecutive), every parameter stacked [K, *shape] with K equal slices (see EdvrStackedFunction)."""
 
     @staticmethod
-    def forward(ctx, x, cfg, *stacked):
+    def forward(ctx, x, cfg, per_slice, *stacked):
         if not x.is_cuda:
             raise RuntimeError("dynavsr_amd estimator (MFDN/SFDN) runs on the MI355X only (input is on %s); "
                                "there is no CPU fallback" % x.device)
@@ -321,16 +324,17 @@ class EstimatorStackedFunction(torch.autograd.Function):
         k = stacked[0].shape[0] if stacked else 0
         if k < 1 or b % k or any(p.shape[0] != k for p in stacked):   # (SFDN in 'image' mode: batch = K clips x T frames)
             raise RuntimeError("estimator (stacked): every parameter must be [K, ...] with K dividing the batch %d" % b)
-        plan = get_estimator_plan(cfg, b, h, w, x.device, grad_groups=k)
+        plan = get_estimator_plan(cfg, b, h, w, x.device, grad_groups=k, weight_sets=k if per_slice else 1)
         if len(stacked) != plan.n_params:
             raise RuntimeError("estimator engine expects %d parameter tensors, got %d" % (plan.n_params, len(stacked)))
         stacked = [_prep(p.detach()) for p in stacked]
         need_grad = any(ctx.needs_input_grad)
         ws = torch.empty(plan.workspace_bytes(need_grad), dtype=torch.uint8, device=x.device)
         out = x.new_empty(oshape)
-        plan.forward([p[0] for p in stacked], x, out, ws)
+        plan.forward(stacked if per_slice else [p[0] for p in stacked], x, out, ws)
         if need_grad:
             _stash(ctx, plan, ws, x, stacked)
+            ctx.per_slice = per_slice
         return out
 
     @staticmethod
@@ -339,6 +343,6 @@ class EstimatorStackedFunction(torch.autograd.Function):
         _check_stash(ctx, "estimator (stacked)")
         gout = _prep(gout)
         gparams = [torch.empty_like(p) for p in ctx.params]
-        ctx.plan.backward([p[0] for p in ctx.params], ctx.x, gout, gparams, ctx.ws)
+        ctx.plan.backward(ctx.params if ctx.per_slice else [p[0] for p in ctx.params], ctx.x, gout, gparams, ctx.ws)
         ctx.ws = None
-        return (None, None) + tuple(gparams)
+        return (None, None, None) + tuple(gparams)

@@ -92,8 +92,9 @@ class EDVR(nn.Module):
     def forward(self, x):
         return EdvrFunction.apply(x, self._cfg(), self._debug_ws, *self.ordered_parameters())
 
-    def forward_stacked(self, x, stacked):
+    def forward_stacked(self, x, stacked, per_slice=False):
         """K clips [K,N,3,H,W] as one batch with PER-CLIP parameter gradients: `stacked` = this network's parameters
-        (ordered_parameters order) as [K, *shape] leaf tensors whose K slices are equal -- the private copies of K
-        frames before their first inner step (engine.EdvrStackedFunction)."""
-        return EdvrStackedFunction.apply(x, self._cfg(), *stacked)
+        (ordered_parameters order) as [K, *shape] leaf tensors -- the private copies of K frames.  per_slice=False: the K
+        slices are equal (before the first inner step), slice 0 is read; True: clip k runs on slice k
+        (engine.EdvrStackedFunction)."""
+        return EdvrStackedFunction.apply(x, self._cfg(), bool(per_slice), *stacked)

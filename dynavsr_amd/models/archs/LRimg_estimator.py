@@ -35,11 +35,11 @@ class DirectKernelEstimatorVideo(nn.Module):
         cfg = (engine.MFDN, self.nf, self.in_nc, self.scale, x.shape[2])
         return engine.EstimatorFunction.apply(x, cfg, *self.ordered_parameters())
 
-    def forward_stacked(self, x, stacked):
-        """K clips with per-clip parameter gradients: `stacked` = the parameters as [K, *shape] tensors with equal
-        slices (engine.EstimatorStackedFunction)."""
+    def forward_stacked(self, x, stacked, per_slice=False):
+        """K clips with per-clip parameter gradients: `stacked` = the parameters as [K, *shape] tensors; per_slice=False:
+        equal slices, slice 0 is read; True: clip k runs on slice k (engine.EstimatorStackedFunction)."""
         cfg = (engine.MFDN, self.nf, self.in_nc, self.scale, x.shape[2])
-        return engine.EstimatorStackedFunction.apply(x, cfg, *stacked)
+        return engine.EstimatorStackedFunction.apply(x, cfg, bool(per_slice), *stacked)
 
 
 class DirectKernelEstimator_CMS(nn.Module):
@@ -64,6 +64,6 @@ class DirectKernelEstimator_CMS(nn.Module):
         cfg = (engine.SFDN, self.nf, 3, 2, 1)
         return engine.EstimatorFunction.apply(x, cfg, *self.ordered_parameters())
 
-    def forward_stacked(self, x, stacked):
+    def forward_stacked(self, x, stacked, per_slice=False):
         cfg = (engine.SFDN, self.nf, 3, 2, 1)
-        return engine.EstimatorStackedFunction.apply(x, cfg, *stacked)
+        return engine.EstimatorStackedFunction.apply(x, cfg, bool(per_slice), *stacked)

@@ -179,6 +179,13 @@ int dvsr_edvr_plan_create(const dvsr_edvr_config* cfg, int B, int H, int W, dvsr
  * grad_groups = 1 is dvsr_edvr_plan_create.  The workspace grows by the extra weight-gradient partial sums. */
 int dvsr_edvr_plan_create_grouped(const dvsr_edvr_config* cfg, int B, int H, int W, int grad_groups,
                                   dvsr_edvr_plan** out);
+/* ... and PER-GROUP WEIGHTS (weight_sets == grad_groups; 1 = dvsr_edvr_plan_create_grouped): every params[i] then points to
+ * [weight_sets][numel(param i)] floats and the clips of batch group g are convolved with set g, in forward, data gradient
+ * and (per group, as above) weight gradient.  This is the K private copies of test_dynavsr.py:208 AFTER they have diverged:
+ * the second and later inner steps (adapt_iter > 1: BASELINE configs[2] takes 3) and the adapted forwards of K frames
+ * (:279-283) still run as one batch.  Every launch indexes its packed weights and bias by n / (N / weight_sets). */
+int dvsr_edvr_plan_create_ex(const dvsr_edvr_config* cfg, int B, int H, int W, int grad_groups, int weight_sets,
+                             dvsr_edvr_plan** out);
 void dvsr_edvr_plan_destroy(dvsr_edvr_plan* plan);
 int dvsr_edvr_num_params(const dvsr_edvr_plan* plan);
 int dvsr_edvr_num_launches(const dvsr_edvr_plan* plan);
@@ -240,6 +247,9 @@ int dvsr_estimator_plan_create(const dvsr_estimator_config* cfg, int B, int H, i
 /* Per-group parameter gradients, as dvsr_edvr_plan_create_grouped: grad_params[i] = [grad_groups][numel(param i)]. */
 int dvsr_estimator_plan_create_grouped(const dvsr_estimator_config* cfg, int B, int H, int W, int grad_groups,
                                        dvsr_estimator_plan** out);
+/* ... with per-group weights, as dvsr_edvr_plan_create_ex. */
+int dvsr_estimator_plan_create_ex(const dvsr_estimator_config* cfg, int B, int H, int W, int grad_groups, int weight_sets,
+                                  dvsr_estimator_plan** out);
 void dvsr_estimator_plan_destroy(dvsr_estimator_plan* plan);
 int dvsr_estimator_num_params(const dvsr_estimator_plan* plan);
 /* tape length: forward ops (backward = 0) or backward ops (backward = 1); a measurement aid like

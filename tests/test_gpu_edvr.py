@@ -880,7 +880,7 @@ def test_edvr_stacked_tape_gives_per_clip_gradients(k, h, w):
         gs = torch.autograd.grad(li, [xi] + net.ordered_parameters())
         want.append((yi.detach(), li.detach(), gs))
     stacked = _stack(net.ordered_parameters(), k)
-    y = engine.EdvrStackedFunction.apply(x, net._cfg(), *stacked)
+    y = engine.EdvrStackedFunction.apply(x, net._cfg(), False, *stacked)
     losses = hipops.charbonnier_per_sample(y, tgt)
     losses.sum().backward()
     for i in range(k):
@@ -897,7 +897,44 @@ def test_edvr_stacked_tape_gives_per_clip_gradients(k, h, w):
     for i in range(k):
         assert torch.equal(ps[i], hipops.inner_loss(base[i], a[i], b[i], 10.0))
     with pytest.raises(RuntimeError, match="K="):
-        engine.EdvrStackedFunction.apply(x, net._cfg(), *[s[:1] for s in stacked])
+        engine.EdvrStackedFunction.apply(x, net._cfg(), False, *[s[:1] for s in stacked])
+
+
+@pytest.mark.parametrize("k,h,w", [(3, 16, 24), (2, 44, 80)])
+def test_edvr_stacked_tape_per_slice_weights(k, h, w):
+    """dvsr_edvr_plan_create_ex with weight_sets = K: clip k is convolved with ITS OWN copy of the weights (the private
+    copies of K frames after they have diverged: later inner steps, adapted forwards).  Every slice is a differently
+    perturbed network; output, d/dx and slice k of every parameter gradient must equal a B = 1 pass of clip k through a
+    network holding slice k -- forward, data gradients and weight gradients all index their weights by the clip."""
+    from dynavsr_amd import engine, hipops
+    net = make_net(0)
+    base = [p.detach().clone() for p in net.ordered_parameters()]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    stacked = []
+    for p in base:
+        s_ = p.unsqueeze(0).repeat((k,) + (1,) * p.dim())
+        s_ = s_ * (1.0 + 0.05 * torch.randn(s_.shape, device="cuda", generator=g))
+        stacked.append(s_.contiguous().requires_grad_())
+    x = synth.clip(63, k, 5, h, w).cuda().requires_grad_()
+    tgt = synth.clip(64, k, 1, 4 * h, 4 * w)[:, 0].cuda()
+    y = engine.EdvrStackedFunction.apply(x, net._cfg(), True, *stacked)
+    losses = hipops.charbonnier_per_sample(y, tgt)
+    losses.sum().backward()
+    for i in range(k):
+        with torch.no_grad():
+            for p, s_ in zip(net.ordered_parameters(), stacked):
+                p.copy_(s_[i])
+        xi = x[i:i + 1].detach().requires_grad_()
+        yi = net(xi)
+        gs = torch.autograd.grad(hipops.charbonnier(yi, tgt[i:i + 1]), [xi] + net.ordered_parameters())
+        assert relerr(y[i:i + 1], yi) < 1e-6, i
+        assert relerr(x.grad[i:i + 1], gs[0]) < 1e-2
+        bad = [(n, relerr(s_.grad[i], g_)) for n, s_, g_ in zip(net._names, stacked, gs[1:]) if relerr(s_.grad[i], g_) > 2e-3]
+        assert not bad, (i, bad[:6])
+    # forward only (the adapted forwards of a chunk): no gradient workspace
+    with torch.no_grad():
+        y2 = engine.EdvrStackedFunction.apply(x.detach(), net._cfg(), True, *[s_.detach() for s_ in stacked])
+    assert torch.equal(y2, y.detach())
 
 
 @pytest.mark.parametrize("optimizer,overlap", [("Adam", True), ("SGD", False)])
@@ -944,11 +981,24 @@ def test_adapt_video_batched_frames_equal_the_per_frame_loop(optimizer, overlap)
     assert n == len(clips)
     for k, v in model.netG.state_dict().items():                 # the meta-parameters are untouched
         assert torch.equal(v, PG[k]), k
-    # what the batched step does not cover takes the per-frame loop
-    opt["train"]["maml"]["adapt_iter"] = 2
-    assert not FrameBatch.supported(opt, model, est)
+    # more than one inner step (BASELINE configs[2] takes 3): after the first step the K copies have diverged and the
+    # batch runs with per-frame weight sets (dvsr_*_plan_create_ex) -- same results as the per-frame loop
+    opt["train"]["maml"]["adapt_iter"] = 3
+    assert FrameBatch.supported(opt, model, est)
+    want = []
+    for c in clips[:2]:
+        r = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, c)
+        want.append((r["sr"].clone(), [float(v) for v in r["losses"]]))
     got = list(adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips[:2], overlap=overlap, frames_per_batch=2))
-    assert len(got) == 2 and len(got[0][1]["losses"]) == 2
+    assert len(got) == 2
+    for (base, r), (sr_w, l_w) in zip(got, want):
+        assert len(r["losses"]) == 3
+        assert all(abs(float(a) - b) <= 1e-5 * abs(b) for a, b in zip(r["losses"], l_w)), (r["losses"], l_w)
+        assert relerr(r["sr"], sr_w) < 2e-4
+    # what the batched step does not cover takes the per-frame loop
+    opt["train"]["maml"]["use_patch"] = True
+    assert not FrameBatch.supported(opt, model, est)
+    opt["train"]["maml"]["use_patch"] = False
 
 
 def test_validate_video_psnr_vectors_match_the_host_definition():

@@ -136,9 +136,35 @@ def test_mfdn_stacked_tape_gives_per_clip_gradients(scale, k, t, h, w):
         want.append((yi.detach(), torch.autograd.grad(yi, net.ordered_parameters(), go[i:i + 1])))
     stacked = [p.detach().unsqueeze(0).repeat((k,) + (1,) * p.dim()).contiguous().requires_grad_() for p in net.ordered_parameters()]
     cfg = (engine.MFDN, 64, 3, scale, t)
-    y = engine.EstimatorStackedFunction.apply(x, cfg, *stacked)
+    y = engine.EstimatorStackedFunction.apply(x, cfg, False, *stacked)
     y.backward(go)
     for i in range(k):
         assert relerr(y[i:i + 1], want[i][0]) < 1e-6
         bad = [(j, relerr(s.grad[i], g)) for j, (s, g) in enumerate(zip(stacked, want[i][1])) if relerr(s.grad[i], g) > 1e-4]
+        assert not bad, (i, bad)
+
+
+@pytest.mark.parametrize("scale,k,t,h,w", [(4, 3, 5, 32, 48), (2, 2, 3, 24, 40)])
+def test_mfdn_stacked_tape_per_slice_weights(scale, k, t, h, w):
+    """dvsr_estimator_plan_create_ex with weight_sets = K: clip k runs on slice k of the stacked parameters (copies that
+    have diverged), output and slice k of every gradient == a B = 1 pass through a network holding slice k."""
+    from dynavsr_amd import engine
+    net = _mfdn(synth.mfdn_state_dict(3, scale=scale), nf=64, in_nc=3, scale=scale)
+    x = synth.clip(73, k, t, h, w).transpose(1, 2).contiguous().cuda()
+    go = _go(74, (k, 3, t, h // scale, w // scale)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(6)
+    stacked = []
+    for p in net.ordered_parameters():
+        s_ = p.detach().unsqueeze(0).repeat((k,) + (1,) * p.dim())
+        stacked.append((s_ * (1.0 + 0.05 * torch.randn(s_.shape, device="cuda", generator=g))).contiguous().requires_grad_())
+    y = engine.EstimatorStackedFunction.apply(x, (engine.MFDN, 64, 3, scale, t), True, *stacked)
+    y.backward(go)
+    for i in range(k):
+        with torch.no_grad():
+            for p, s_ in zip(net.ordered_parameters(), stacked):
+                p.copy_(s_[i])
+        yi = net(x[i:i + 1])
+        gs = torch.autograd.grad(yi, net.ordered_parameters(), go[i:i + 1])
+        assert relerr(y[i:i + 1], yi) < 1e-6
+        bad = [(j, relerr(s_.grad[i], g_)) for j, (s_, g_) in enumerate(zip(stacked, gs)) if relerr(s_.grad[i], g_) > 1e-4]
         assert not bad, (i, bad)
