@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256, KYS ? 2 : 1) void conv2d_wgrad_pipe_kernel(Wgr
   // (7x7 / 9x9 kernel rows: 112 / 144 accumulators at two workgroups per CU leave no room for the fast path's operand ring)
   if constexpr (KS <= 3) {
     if (a.Cin - (int)blockIdx.z * 64 > 32 && a.Cout - (int)blockIdx.y * 64 > 32) {
-      conv2d_wgrad_pipe_item<KS, KYS, true>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+      if (a.vx == 4) conv2d_wgrad_wide_item<KS, KYS, 4>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+      else if (a.vx == 2) conv2d_wgrad_wide_item<KS, KYS, 2>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+      else conv2d_wgrad_pipe_item<KS, KYS, true>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
       return;
     }
   }
@@ -351,6 +353,17 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
     }
     k.nsplit = per_group(ceil_div(ks == 3 ? kys_wgs : 512, ks * k.nob * k.ncb));
   }
+  // wide staging: gy rows as float4 (Wo % 4 == 0, not pixel-shuffled), x as float4 / float2 when the row pitch, the batch
+  // stride and the pointers allow it (DVSR_WGRAD_WIDE=0 keeps the scalar loads: A/B aid)
+  k.vx = 0;
+  {
+    static const bool wide = [] { const char* v = getenv("DVSR_WGRAD_WIDE"); return !(v && v[0] == '0'); }();
+    const bool gy_ok = !gy_ps && k.Wo % 4 == 0 && ((uintptr_t)gy & 15) == 0;
+    if (wide && gy_ok && stride == 1 && ks <= 3 && !out->bf) {
+      if (W % 4 == 0 && k.x_bs % 4 == 0 && ((uintptr_t)x & 15) == 0) k.vx = 4;
+      else if (W % 2 == 0 && k.x_bs % 2 == 0 && ((uintptr_t)x & 7) == 0) k.vx = 2;
+    }
+  }
   if (k.nslot > k.nsplit) k.nslot = k.nsplit;   // (the slot region was sized for the un-split launch: never larger)
   out->grid = dim3((out->kys ? ks : 1) * groups * k.nsplit, k.nob, k.ncb);
   // slot regions: [group][slot][tap][o][c] partial sums, then [group][slot][o] bias sums
@@ -382,7 +395,10 @@ int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st) {
     auto launch_pipe = [&](auto ks_tag, auto kys_tag) {
       constexpr int KS_ = decltype(ks_tag)::value;
       constexpr bool KYS_ = decltype(kys_tag)::value;
-      constexpr size_t lds = WgPipeShape<KS_, KYS_>::LDS_BYTES;
+      constexpr size_t lds_a = WgPipeShape<KS_, KYS_>::LDS_BYTES;
+      constexpr size_t lds_b = KS_ <= 3 ? (WgWideShape<KS_, KYS_, 4>::LDS_BYTES > WgWideShape<KS_, KYS_, 2>::LDS_BYTES
+                                               ? WgWideShape<KS_, KYS_, 4>::LDS_BYTES : WgWideShape<KS_, KYS_, 2>::LDS_BYTES) : 0;
+      constexpr size_t lds = lds_a > lds_b ? lds_a : lds_b;
       static bool done = false;
       if (!done) {
         hipFuncSetAttribute((const void*)conv2d_wgrad_pipe_kernel<KS_, KYS_>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -41,6 +41,7 @@ struct WgradK {
   // per-group gradients (one dW per group of N / ngroups consecutive batch items: the per-FRAME gradients of a batch of
   // frames adapted from the same weights).  nsplit / nslot count per group; gtiles = tiles of one group.
   int ngroups = 1, gtiles = 0;
+  int vx = 0;   // wide staging (conv2d_wgrad_wide_item): 4 / 2 = float4 / float2 x vectors (and float4 gy), 0 = scalar loads
 #ifdef DVSR_CONV_TRACE
   int noflush = 0;  // measurement aid of the debug build (DVSR_WGRAD_NOFLUSH=1): skip the atomic flush, results are wrong
 #endif
@@ -440,11 +441,19 @@ __device__ __forceinline__ void conv2d_wgrad_pipe_item(const WgradK& a, const in
   int buf = 0;
   for (; tile < sp.tile_end; tile += a.nsplit) {
     const bool has_next = tile + a.nsplit < sp.tile_end;
+#ifdef DVSR_CONV_TRACE   // ablations of the debug build (DVSR_WGRAD_NOFLUSH bits 1 / 2 / 3: no global loads / no LDS writes / no barrier)
+    if (has_next && !(a.noflush & 2)) issue_loads(tile + a.nsplit);
+    mfma_range(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, 3 * NPX / 8>{});
+    if (has_next && !(a.noflush & 4)) write_lds(buf ^ 1);
+    mfma_range(buf, std::integral_constant<int, 3 * NPX / 8>{}, std::integral_constant<int, NPX / 2>{});
+    if (!(a.noflush & 8)) __syncthreads();
+#else
     if (has_next) issue_loads(tile + a.nsplit);
     mfma_range(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, 3 * NPX / 8>{});
     if (has_next) write_lds(buf ^ 1);
     mfma_range(buf, std::integral_constant<int, 3 * NPX / 8>{}, std::integral_constant<int, NPX / 2>{});
     __syncthreads();
+#endif
     buf ^= 1;
   }
 
@@ -452,7 +461,7 @@ __device__ __forceinline__ void conv2d_wgrad_pipe_item(const WgradK& a, const in
   const int OP = a.nob * 64, CP = a.ncb * 64;
   const int slot = sp.slot;
 #ifdef DVSR_CONV_TRACE
-  if (a.noflush && acc[0][0] != 12345.f) return;
+  if ((a.noflush & 1) && acc[0][0] != 12345.f) return;
 #endif
 #pragma unroll
   for (int t = 0; t < KK; ++t)
@@ -463,6 +472,173 @@ __device__ __forceinline__ void conv2d_wgrad_pipe_item(const WgradK& a, const in
       unsafeAtomicAdd(a.partial + (((size_t)slot * (KS * KS) + ky * KS + t) * OP + o) * CP + c, acc[t][r]);
     }
   // lane (lo, hi) summed gy[o = ot*32 + lo] over the pixels of parity hi
+  if (do_db) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + ob * 64 + ot * 32 + lo, db);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Wide staging (r03).  Ablations of the debug build (DVSR_WGRAD_NOFLUSH bits, profiles/r03_b_wgrad_ablation.txt) price
+// the staging of the kernel above: with its 64 global_load_dword per lane and tile compiled out the 40x64x176x320 layer
+// runs at 122 instead of 95 TFLOP/s, without its 64 ds_write_b32 at 106, without both at 140 -- the MFMA loop itself is
+// at 0.89 of the peak.  Here both operands move as VECTORS whenever the tensors allow it:
+//   gy   float4 along a row (Wo % 4 == 0, 16-byte aligned): 4 loads + 4 ds_write_b128 per lane and tile instead of 16 + 16;
+//   x    VX = 4: the tile's window widened to the 16-byte aligned columns [ox0 - pad - s, ..) (pad 1: [ox0 - 4, ox0 + 36),
+//        ten float4 per row -- every group lies entirely inside or outside the image since W % 4 == 0): 10 loads + 10
+//        ds_write_b128 instead of 48 + 48;  VX = 2: float2 (the estimator's explicitly padded tensors: even pitch, pad 0).
+// The LDS images keep the window as it was loaded ([channel][row][WWIN]), so a vector is ONE aligned LDS write; the
+// channel pitch is an odd number of vectors: lanes (= channels) of an operand read spread over 32 / VX banks, a VX-way
+// conflict that 10 reads per 9 MFMAs do not notice.  Every wave owns a populated 32 x 32 block (the FAST case above).
+// -------------------------------------------------------------------------------------------------
+template <int KS, bool KYS, int VX>
+struct WgWideShape {
+  static constexpr int KR = KYS ? 1 : KS, NTAP = KR * KS, IW = 31 + KS, IH = 1 + KR, NPX = 64;
+  static constexpr int WWIN = ((IW + 2 * (VX - 1)) / VX) * VX;   // window floats per row: start rounded down, end up
+  static constexpr int RV = WWIN / VX;                           // vectors per row
+  static constexpr int XV = IH * RV;                             // vectors per channel
+  static constexpr int PX = ((XV % 2) ? XV : XV + 1) * VX;       // channel pitch: an odd number of vectors
+  static constexpr int GP = 68;                                  // gy: 16 float4 per channel + 1
+  static constexpr int BUF = 64 * GP + 64 * PX;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(float);
+};
+
+template <int KS, bool KYS, int VX>
+__device__ __forceinline__ void conv2d_wgrad_wide_item(const WgradK& a, const int bx, const int by, const int bz,
+                                                       float* const smem) {
+  using Sh = WgWideShape<KS, KYS, VX>;
+  typedef float xvec __attribute__((ext_vector_type(VX)));
+  constexpr int KK = Sh::NTAP, WWIN = Sh::WWIN, RV = Sh::RV, XV = Sh::XV, PX = Sh::PX, GP = Sh::GP, NPX = Sh::NPX, BUF = Sh::BUF;
+  constexpr int XM = (16 * XV + 63) / 64;   // x vectors per lane and tile (16 channels per wave)
+
+  const int split = KYS ? bx / KS : bx, ky = KYS ? bx % KS : 0;
+  const int ob = by, cbk = bz;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int ot = wave >> 1, ct = wave & 1;
+  const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
+  const int shift = (VX - a.pad % VX) % VX;   // the window starts `shift` columns left of the first one the taps need
+
+  // lane-fixed parts of the staging: gy vector m = (channel gch, row, group); x vector m = (channel xch, row, group)
+  int gch[4], grow[4], gcol[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int idx = lane + 64 * m;
+    gch[m] = idx >> 4; grow[m] = (idx >> 3) & 1; gcol[m] = (idx & 7) * 4;
+  }
+  int xch[XM], xrow[XM], xcol[XM], xlds[XM];
+#pragma unroll
+  for (int m = 0; m < XM; ++m) {
+    const int idx = lane + 64 * m;
+    const int c = idx / XV, r = idx - c * XV;
+    xch[m] = c < 16 ? c : 15; xrow[m] = r / RV; xcol[m] = (r - xrow[m] * RV) * VX;
+    xlds[m] = c < 16 ? (wave * 16 + c) * PX + r * VX : -1;
+  }
+
+  f32x16 acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float db = 0.f;
+  const bool do_db = cbk == 0 && ct == 0 && ky == 0;
+
+  f32x4 rg[4];
+  xvec rx[XM];
+  bool g_ok[4], x_ok[XM];
+  auto issue_loads = [&](int tile) {
+    const int tx_ = tile % a.tiles_x;
+    const int t2 = tile / a.tiles_x;
+    const int ty_ = t2 % a.tiles_y;
+    const int n = t2 / a.tiles_y;
+    const int oy0 = ty_ * 2, ox0 = tx_ * 32;
+    const float* gn = a.gy + ((size_t)n * a.Cout + ob * 64 + wave * 16) * HWo;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int co = ob * 64 + wave * 16 + gch[m];
+      g_ok[m] = co < a.Cout && oy0 + grow[m] < a.Ho && ox0 + gcol[m] < a.Wo;
+      const size_t off = g_ok[m] ? (size_t)gch[m] * HWo + (size_t)(oy0 + grow[m]) * a.Wo + ox0 + gcol[m] : 0;
+      rg[m] = *reinterpret_cast<const f32x4*>(gn + off);
+    }
+    const int iy0 = oy0 - a.pad + ky, ix0 = ox0 - a.pad - shift;
+    const float* xn = a.x + (size_t)(n / a.x_bdiv) * a.x_bs + (size_t)(cbk * 64 + wave * 16) * HW;
+#pragma unroll
+    for (int m = 0; m < XM; ++m) {
+      const int ci = cbk * 64 + wave * 16 + xch[m];
+      const int gy_ = iy0 + xrow[m], gx_ = ix0 + xcol[m];
+      x_ok[m] = xlds[m] >= 0 && ci < a.Cin && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W;
+      const size_t off = x_ok[m] ? (size_t)xch[m] * HW + (size_t)gy_ * a.W + gx_ : 0;
+      rx[m] = *reinterpret_cast<const xvec*>(xn + off);
+    }
+  };
+  auto write_lds = [&](int buf) {
+    float* s_g = smem + buf * BUF;
+    float* s_x = s_g + 64 * GP;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 v = g_ok[m] ? rg[m] : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(s_g + (wave * 16 + gch[m]) * GP + grow[m] * 32 + gcol[m]) = v;
+    }
+#pragma unroll
+    for (int m = 0; m < XM; ++m) {
+      xvec v = rx[m];
+      if (!x_ok[m]) {
+#pragma unroll
+        for (int e = 0; e < VX; ++e) v[e] = 0.f;
+      }
+      if (xlds[m] >= 0) *reinterpret_cast<xvec*>(s_x + xlds[m]) = v;
+    }
+  };
+  auto mfma_fast = [&](int buf, auto k0c, auto k1c) {
+    constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
+    constexpr int D = KK >= 9 ? 1 : (KK >= 3 ? 2 : 6);
+    const float* ga = smem + buf * BUF + (ot * 32 + lo) * GP + hi;
+    const float* xb = smem + buf * BUF + 64 * GP + (ct * 32 + lo) * PX + hi + shift;
+    float av[D + 1], bv[D + 1][KK];
+    auto load = [&](auto kkc) {
+      constexpr int kk = decltype(kkc)::value;
+      constexpr int slot = (kk - K0) % (D + 1);
+      av[slot] = ga[2 * kk];
+#pragma unroll
+      for (int t = 0; t < KK; ++t) bv[slot][t] = xb[(kk >> 4) * WWIN + 2 * (kk & 15) + (t / KS) * WWIN + (t % KS)];
+    };
+    static_for<0, (D < K1 - K0 ? D : K1 - K0)>([&](auto i) { load(std::integral_constant<int, K0 + decltype(i)::value>{}); });
+    static_for<K0, K1>([&](auto kkc) {
+      constexpr int kk = decltype(kkc)::value;
+      constexpr int slot = (kk - K0) % (D + 1);
+      if constexpr (kk + D < K1) load(std::integral_constant<int, kk + D>{});
+      db += av[slot];
+#pragma unroll
+      for (int t = 0; t < KK; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[slot], bv[slot][t], acc[t], 0, 0, 0);
+    });
+  };
+
+  const WgSpan sp = wg_span(a, split);
+  int tile = sp.tile0;
+  if (tile < sp.tile_end) {
+    issue_loads(tile);
+    write_lds(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < sp.tile_end; tile += a.nsplit) {
+    const bool has_next = tile + a.nsplit < sp.tile_end;
+    if (has_next) issue_loads(tile + a.nsplit);
+    mfma_fast(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, 3 * NPX / 8>{});
+    if (has_next) write_lds(buf ^ 1);
+    mfma_fast(buf, std::integral_constant<int, 3 * NPX / 8>{}, std::integral_constant<int, NPX / 2>{});
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  const int OP = a.nob * 64, CP = a.ncb * 64;
+  const int slot = sp.slot;
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ob * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int c = cbk * 64 + ct * 32 + lo;
+      unsafeAtomicAdd(a.partial + (((size_t)slot * (KS * KS) + ky * KS + t) * OP + o) * CP + c, acc[t][r]);
+    }
   if (do_db) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + ob * 64 + ot * 32 + lo, db);
 }
 
