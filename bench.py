@@ -211,6 +211,9 @@ def inner_step_rate(dev, steps=60, h=176, w=320, frames_per_batch=16):
     ep = engine.get_estimator_plan((engine.MFDN, est.netE.nf, est.netE.in_nc, est.netE.scale, 5), K, h, w, grad_groups=K)
     launches = {"edvr_forward": gp.n_launches, "edvr_backward": gp.n_backward_launches,
                 "estimator_forward": ep.n_launches, "estimator_backward": ep.n_backward_launches}
+    # (a') BASELINE configs[2] takes 3 inner steps per frame: after the first one the copies have diverged and the batch runs
+    # on per-frame weight sets (dvsr_*_plan_create_ex)
+    ms3 = timed(lambda: fb.adapt(model, est, est_fixed, lqs_k, steps=3), max(3, steps // (3 * K))) / K
     del fb
     # (b) the per-frame loop, same content
     lq1 = {"LQs": lqs_k[:1].contiguous()}
@@ -250,6 +253,10 @@ def inner_step_rate(dev, steps=60, h=176, w=320, frames_per_batch=16):
                           "workload": "r01 / r02 protocol: one frame, no copy refresh, frozen estimator outside the loop "
                                       "(%.0f GFLOP executed)" % ((fl - f_mfdn(h, w)) / 1e9),
                           "roofline": roof(ms_step, fl - f_mfdn(h, w))},
+            "three_inner_steps": {"ms_per_frame": ms3, "frames_per_batch": K,
+                                  "workload": "adapt_iter = 3 (BASELINE configs[2]) on the same batch: steps 2 and 3 with per-frame "
+                                              "weight sets; %.0f GFLOP per frame" % ((3 * (fl - f_mfdn(h, w)) + f_mfdn(h, w)) / 1e9),
+                                  "roofline": roof(ms3, 3 * (fl - f_mfdn(h, w)) + f_mfdn(h, w))},
             "tape_ops_per_batch": launches,
             "target_clips_per_s": 50}
 

@@ -550,22 +550,24 @@ __device__ __forceinline__ void conv2d_wgrad_wide_item(const WgradK& a, const in
     const int ty_ = t2 % a.tiles_y;
     const int n = t2 / a.tiles_y;
     const int oy0 = ty_ * 2, ox0 = tx_ * 32;
-    const float* gn = a.gy + ((size_t)n * a.Cout + ob * 64 + wave * 16) * HWo;
+    // (an invalid vector reads the first one of the image instead: channels past Cout / Cin of a partly filled block
+    // would otherwise address memory behind the tensor)
+    const float* gn = a.gy + (size_t)n * a.Cout * HWo;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int co = ob * 64 + wave * 16 + gch[m];
       g_ok[m] = co < a.Cout && oy0 + grow[m] < a.Ho && ox0 + gcol[m] < a.Wo;
-      const size_t off = g_ok[m] ? (size_t)gch[m] * HWo + (size_t)(oy0 + grow[m]) * a.Wo + ox0 + gcol[m] : 0;
+      const size_t off = g_ok[m] ? (size_t)co * HWo + (size_t)(oy0 + grow[m]) * a.Wo + ox0 + gcol[m] : 0;
       rg[m] = *reinterpret_cast<const f32x4*>(gn + off);
     }
     const int iy0 = oy0 - a.pad + ky, ix0 = ox0 - a.pad - shift;
-    const float* xn = a.x + (size_t)(n / a.x_bdiv) * a.x_bs + (size_t)(cbk * 64 + wave * 16) * HW;
+    const float* xn = a.x + (size_t)(n / a.x_bdiv) * a.x_bs;
 #pragma unroll
     for (int m = 0; m < XM; ++m) {
       const int ci = cbk * 64 + wave * 16 + xch[m];
       const int gy_ = iy0 + xrow[m], gx_ = ix0 + xcol[m];
       x_ok[m] = xlds[m] >= 0 && ci < a.Cin && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W;
-      const size_t off = x_ok[m] ? (size_t)xch[m] * HW + (size_t)gy_ * a.W + gx_ : 0;
+      const size_t off = x_ok[m] ? (size_t)ci * HW + (size_t)gy_ * a.W + gx_ : 0;
       rx[m] = *reinterpret_cast<const xvec*>(xn + off);
     }
   };
