@@ -196,6 +196,9 @@ def test_tsa_gate_and_blend(ops):
 @pytest.mark.parametrize("cin,cout,ks,stride,h,w", [
     (64, 64, 3, 1, 12, 40), (3, 64, 3, 1, 9, 33), (64, 216, 3, 1, 7, 35), (64, 3, 3, 1, 8, 32),
     (64, 64, 3, 2, 12, 40), (64, 64, 1, 1, 9, 70), (320, 64, 1, 1, 8, 32), (16, 24, 3, 1, 5, 7),
+    # wide staging of the weight gradient (W % 4 == 0: float4 windows; W even: float2) incl. partly filled 64-channel
+    # blocks (100 = 64 + 36, 104 = 64 + 40: the second block runs the wide path with channels past the end masked)
+    (100, 104, 3, 1, 12, 40), (96, 100, 1, 1, 8, 32), (64, 64, 3, 1, 10, 34), (100, 64, 3, 1, 6, 38), (64, 64, 3, 1, 45, 80),
 ])
 def test_conv2d_backward(ops, cin, cout, ks, stride, h, w):
     x = rnd(2, cin, h, w, seed=1).requires_grad_()
