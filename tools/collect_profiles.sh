@@ -58,6 +58,12 @@ python tools/rocprof_summary.py $out/db9/r_results.db > $out/${tag}_inner_batch_
 python tools/trace_dump.py $out/db9/r_results.db l1_final > $out/${tag}_inner_batch_K8_timeline.txt; rm -rf $out/db9
 WGRAD_BENCH_BATCHED=1 python tools/wgrad_bench.py 20 2>&1 | grep wgrad > $out/${tag}_wgrad_kernel.txt
 python tools/wgrad_bench.py 20 2>&1 | grep wgrad >> $out/${tag}_wgrad_kernel.txt
+if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then   # staging ablations of the scalar-staged weight-gradient kernel (debug build)
+  for nf in 0 1 3 5 7; do
+    echo "== DVSR_WGRAD_WIDE=0 DVSR_WGRAD_NOFLUSH=$nf (bit 0: no flush, bit 1: no global loads, bit 2: no LDS writes; results wrong)" >> $out/${tag}_wgrad_ablation.txt
+    DVSR_WGRAD_WIDE=0 DVSR_WGRAD_NOFLUSH=$nf WGRAD_BENCH_BATCHED=1 DVSR_HIP_LIB=$PWD/dynavsr_amd/libdynavsr_hip_trace.so python tools/wgrad_bench.py 10 2>&1 | grep wgrad >> $out/${tag}_wgrad_ablation.txt
+  done
+fi
 python tools/dcn_bwd_bench.py 20 2>&1 | grep -v amdgpu > $out/${tag}_dcn_bwd.txt
 rocprofv3 --kernel-trace --stats -d $out/db9b -o r -- python tools/dcn_bwd_bench.py 20 > /dev/null 2>&1
 python tools/rocprof_summary.py $out/db9b/r_results.db | head -8 >> $out/${tag}_dcn_bwd.txt; rm -rf $out/db9b
