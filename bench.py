@@ -262,7 +262,7 @@ def inner_step_rate(dev, steps=60, h=176, w=320, frames_per_batch=16):
 
 
 # ---- per-frame pipeline (SURVEY §8d iii) ----------------------------------------------------------
-def per_frame_pipeline_rate(dev, clips=16, h=176, w=320, frames_per_batch=8):
+def per_frame_pipeline_rate(dev, clips=32, h=176, w=320, frames_per_batch=16):
     """test_dynavsr.py:197-283 per frame: un-adapted baseline forward, copies refreshed, one inner step, adapted
     forward -- adapt_video with the two full-size forwards on side streams under the next clip's adaptation."""
     from dynavsr_amd import synth
@@ -463,6 +463,51 @@ def edvr_l_rates(dev, steps=10):
                        "373.4 GFLOP forward; bf16 modes: 3x3 stride-1 convolutions (forward + data gradient) on "
                        "v_mfma_f32_32x32x16_bf16 with fp32 accumulate, everything else fp32; peak for bf16_split3 = "
                        "2500/6 TFLOP/s of fp32-equivalent work (six bf16 products per fp32 product)")
+    return out
+
+
+# ---- the other two video backbones behind define_G ---------------------------------------
+def backbone_rates(dev):
+    """TOFlow on 1x7x3x256x448 (it runs at the output resolution) and DUF-16L x4 on 1x7x3x64x112: eval forward and
+    training forward+backward, against the algorithmic FLOPs of their convolutions (tools/backbone_bench.py has all three
+    DUF depths)."""
+    from dynavsr_amd import hipops, synth
+    from dynavsr_amd.models.archs import DUF_arch, TOF_arch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import backbone_bench as bb      # conv_flops(): 2 * MAC of every convolution at the size it runs on
+    out = {}
+    tof = TOF_arch.TOFlow(adapt_official=True); tof.load_state_dict(synth.tof_state_dict(0))
+    duf = DUF_arch.DUF_16L(scale=4, adapt_official=True); duf.load_state_dict(synth.duf_state_dict(0, 16, 4))
+    for name, net, x, sc in (("toflow", tof, synth.clip(1, 1, 7, 256, 448, smooth=False), 1),
+                             ("duf_16l_x4", duf, synth.clip(2, 1, 7, 64, 112, smooth=False), 4)):
+        net, x = net.to(dev), x.to(dev)
+        tgt = torch.rand(1, 3, sc * x.shape[-2], sc * x.shape[-1], device=dev)
+        fl = bb.conv_flops(net, x)
+
+        def fwd():
+            with torch.no_grad():
+                net(x)
+
+        def fwd_bwd():
+            for p in net.parameters():
+                p.grad = None
+            hipops.charbonnier(net(x), tgt).backward()
+        res = {"clip": "x".join(map(str, x.shape)), "conv_gflop_forward": fl / 1e9}
+        for key, fn, mult, train in (("forward", fwd, 1.0, False), ("forward_backward", fwd_bwd, 3.0, True)):
+            net.train(train)
+            _warm(fn)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 5 * 1e3
+            ach = mult * fl / (ms * 1e-3) / 1e12
+            res[key] = {"ms": ms, "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None}}
+        out[name] = res
+        del net
+    out["workload"] = ("the two other backbones behind define_G (TOF_arch.py, DUF_arch.py): op-composed on the native conv / "
+                       "BatchNorm / warp / dynamic-filter kernels, fp32")
     return out
 
 
@@ -722,6 +767,10 @@ def main():
         if world == 1 and not args.no_split:
             line["experimental_bf16_split"] = split_mode_rate(cfg, h, w, x, y, args.steps, args.warmup)
             line["edvr_l_bf16"] = edvr_l_rates(dev)
+            try:
+                line["other_backbones"] = backbone_rates(dev)
+            except Exception as e:     # a side leg must not cost the line
+                line["other_backbones"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # The meta-training iteration comes AFTER the single-GPU legs: once the RCCL communicator exists, its helper threads
     # slow host-bound launch sequences down (EDVR-L bf16 forward+backward, ~700 launches in 10.5 ms, measured 14.1 ms
     # when this leg ran first; the GPU-bound legs do not move).

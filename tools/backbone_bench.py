@@ -70,10 +70,15 @@ def run(name, net, x, out_scale):
     print("%-10s %-18s %6.1f GFLOP fwd | %s" % (name, "x".join(map(str, x.shape)), fl / 1e9, " | ".join(res)))
 
 
-tof = TOF_arch.TOFlow(adapt_official=True)
-tof.load_state_dict(synth.tof_state_dict(0))
-run("TOFlow", tof, synth.clip(1, 1, 7, 256, 448, smooth=False), 1)
-for layers, cls in ((16, DUF_arch.DUF_16L), (28, DUF_arch.DUF_28L), (52, DUF_arch.DUF_52L)):
-    net = cls(scale=4, adapt_official=True)
-    net.load_state_dict(synth.duf_state_dict(0, layers, 4))
-    run("DUF-%dL x4" % layers, net, synth.clip(2, 1, 7, 64, 112, smooth=False), 4)
+def main():
+    tof = TOF_arch.TOFlow(adapt_official=True)
+    tof.load_state_dict(synth.tof_state_dict(0))
+    run("TOFlow", tof, synth.clip(1, 1, 7, 256, 448, smooth=False), 1)
+    for layers, cls in ((16, DUF_arch.DUF_16L), (28, DUF_arch.DUF_28L), (52, DUF_arch.DUF_52L)):
+        net = cls(scale=4, adapt_official=True)
+        net.load_state_dict(synth.duf_state_dict(0, layers, 4))
+        run("DUF-%dL x4" % layers, net, synth.clip(2, 1, 7, 64, 112, smooth=False), 4)
+
+
+if __name__ == "__main__":
+    main()
