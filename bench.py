@@ -457,6 +457,18 @@ def edvr_l_rates(dev, steps=10):
         peak = FP32_MFMA_PEAK_TFLOPS if mode == 0 else BF16_MFMA_PEAK_TFLOPS / (6.0 if mode == 2 else 1.0)
         res["roofline"] = {"bound": "mfma", "achieved": res["forward"]["tflops"], "peak": peak, "unit": "TFLOP/s",
                            "frac": res["forward"]["tflops"] / peak, "traffic": None}
+        # HBM-side bytes of one forward+backward step from the committed PMC passes (tools/collect_profiles.sh 7b): at this
+        # tile size the step moves ~10 GB in ~10 ms -- a tenth of the HBM rate: the leg is launch / latency bound, not HBM-bound
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                tj = json.load(f).get("edvr_l_fwd_bwd_mode%d" % mode)
+            if tj:
+                res["roofline"]["traffic"] = tj["bytes_per_step"]
+                res["roofline"]["traffic_scope"] = "one forward+backward step, all kernels (PMC FETCH_SIZE + WRITE_SIZE)"
+                res["hbm_gbs_forward_backward"] = tj["bytes_per_step"] / (res["forward_backward"]["ms"] * 1e-3) / 1e9
+                res["hbm_frac_forward_backward"] = res["hbm_gbs_forward_backward"] / HBM_PEAK_GBS
+        except (OSError, ValueError, KeyError):
+            pass
         out[name] = res
         del net
     out["workload"] = ("EDVR-L x4 (nf 128, 7 frames, 40 blocks) 1x7x3x64x64 -> 3x256x256 (BASELINE configs[4] tile), "

@@ -92,11 +92,18 @@ def test_edvr_forward_layerwise_vs_oracle():
         ("tsa_out", (b, c, h, w), taps["tsa_out"]),
         ("recon", (b, c, h, w), taps["recon"]),
     ]:
-        e = relerr(plan.tensor(ws, name, shape), ref_t)
-        report.append((name, e))
-    print("\n".join("%-12s %.3e" % r for r in report))
+        got = plan.tensor(ws, name, shape)
+        e = relerr(got, ref_t)
+        # kink flips: elements whose activation branch (the sign an (L)ReLU backward keys on) differs between the GPU's
+        # fp32 summation order and the oracle's -- what makes per-tensor GRADIENT bars looser than the forward's
+        flips = int(((got.cpu() > 0) != (ref_t > 0)).sum())
+        report.append((name, e, flips, ref_t.numel()))
+    print("\n".join("%-12s %.3e  sign flips %d / %d" % r for r in report))
     bad = [r for r in report if not r[1] < 2e-4]
     assert not bad, bad
+    # the flips are counted, not assumed: a handful of near-zero elements per million (they sit within ~1e-6 of the kink)
+    act_taps = [r for r in report if r[0] in ("L1_fea", "L2_fea", "L3_fea", "L3_offset", "L2_offset", "L1_offset", "aligned")]
+    assert sum(r[2] for r in act_taps) <= 2e-5 * sum(r[3] for r in act_taps), [(r[0], r[2], r[3]) for r in act_taps]
     assert relerr(y, ref) < 2e-4
 
 

@@ -41,6 +41,14 @@ rocprofv3 --kernel-trace --stats -d $out/db7 -o r -- python tools/edvr_l_step_pr
 python tools/rocprof_summary.py $out/db7/r_results.db >> $out/${tag}_edvr_l_bf16_step.txt; rm -rf $out/db7
 python tools/edvr_l_step_profile.py 1 20 2>&1 | grep EDVR-L >> $out/${tag}_edvr_l_bf16_step.txt
 python tools/edvr_l_step_profile.py 0 10 2>&1 | grep EDVR-L >> $out/${tag}_edvr_l_bf16_step.txt
+# 7b. HBM-side traffic of the EDVR-L forward+backward step per MFMA mode (merged into pmc_traffic.json for bench.py)
+for mode in 0 1 2; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    EDVR_L_EXACT_STEPS=1 rocprofv3 --pmc $c --kernel-trace -d $out/dbl_$c -o p -- python tools/edvr_l_step_profile.py $mode 6 > /dev/null 2>&1
+  done
+  echo "EDVR-L fwd+bwd bf16_mfma=$mode: $(python tools/pmc_total.py $out/dbl_FETCH_SIZE/p_results.db $out/dbl_WRITE_SIZE/p_results.db 8 --json $out/pmc_traffic.json edvr_l_fwd_bwd_mode$mode | head -1)" >> $out/${tag}_edvr_l_bf16_step.txt
+  rm -rf $out/dbl_FETCH_SIZE $out/dbl_WRITE_SIZE
+done
 # 8. micro-measurements behind DESIGN 3.1 / 3.2: what hides behind an fp32 MFMA; cycle stamps of the DCN forward (debug build)
 python tools/mfma_shadow.py 2>&1 | grep "cycles per" > $out/${tag}_mfma_shadow.txt
 if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
