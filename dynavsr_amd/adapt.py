@@ -203,6 +203,45 @@ def _meta_train_step_batched(opt, model, est_model, train_data, optimizer, group
             'loss_e': [le[b] for b in range(B)], 'batched': True}
 
 
+def _meta_train_step_copies_batched(opt, model, est_model, modelcp, est_modelcp, train_data, optimizer, group,
+                                    force_collective):
+    """inner='copies' (first-order MAML, the semantics of the reference's validation / test loops) with all B tasks as
+    batches: the B copies adapt together (FrameBatch: first step on the shared weights, later steps on per-task weight
+    sets), loss_q and loss_e are taken at the ADAPTED weights of every task in one forward each (per-task weight sets),
+    and the meta-gradient is the sum over the task slices of their first-order gradients."""
+    from . import dist as D
+    m = opt['train']['maml']
+    lqs, slq, gt = train_data['LQs'], train_data['SuperLQs'], train_data['GT']
+    B, center = lqs.size(0), lqs.size(1) // 2
+    optimizer.zero_grad()
+    fb = getattr(modelcp, '_meta_batch', None)
+    if fb is None or fb.k != B or fb.sig != FrameBatch.signature(opt, model.netG, est_model.netE):
+        fb = modelcp._meta_batch = FrameBatch(opt, model.netG, est_model.netE, B)
+    losses, _ = fb.adapt(model, est_model, None, lqs, slr_weight=1.0, steps=m['adapt_iter'], slr_ref=slq.to(lqs.device))
+    fb.inner.zero_grad()
+    sr_q = model.netG.forward_stacked(backbone_input(opt, lqs), fb.g_stack, per_slice=True)
+    l_q = model.l_pix_w * hipops.charbonnier_per_sample(sr_q, gt[:, center], model.cri_pix.eps)
+    est_model.feed_data({'LQs': lqs, 'SuperLQs': slq})
+    y = est_model.netE.forward_stacked(est_model.var_H, fb.e_stack, per_slice=True)
+    if est_model.mode != 'image':
+        slr = y.transpose(1, 2)
+    else:
+        b, t, c = lqs.shape[:3]
+        slr = y.reshape(b, t, c, y.shape[-2], y.shape[-1])
+    l_e = hipops.inner_loss_per_sample(torch.zeros_like(l_q), slr, slq.to(slr.device), 1.0)
+    (l_q.sum() / B + l_e.sum() / (B * 10)).backward()
+    for p, s_ in zip(model.netG.ordered_parameters(), fb.g_stack):       # :414-415 `param.grad += grads[j]` over the tasks
+        p.grad = s_.grad.sum(0)
+    for p, s_ in zip(est_model.netE.ordered_parameters(), fb.e_stack):
+        p.grad = s_.grad.sum(0)
+    modelcp.netG, est_modelcp.netE = fb.netG[B - 1], fb.netE[B - 1]     # the last task's adapted copies, like the loop leaves them
+    if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        D.allreduce_meta_gradients([model.netG, est_model.netE], average=True, group=group, force=force_collective)
+    optimizer.step()
+    return {'loss_q': float(l_q.detach().sum()) / B, 'loss_train': [l_[b] for b in range(B) for l_ in losses],
+            'loss_e': [l_e.detach()[b] for b in range(B)], 'batched': True}
+
+
 def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, optimizer, inner='reference',
                     group=None, force_collective=False, batched=True):
     """One outer (meta) iteration of the DynaVSR training driver, codes/train_dynavsr.py:265-438, over the
@@ -230,6 +269,11 @@ def meta_train_step(opt, model, est_model, modelcp, est_modelcp, train_data, opt
     loss and loss_e); batched=False keeps the task loop."""
     if batched and _meta_batchable(opt, model, est_model, inner):
         return _meta_train_step_batched(opt, model, est_model, train_data, optimizer, group, force_collective)
+    m_ = opt['train']['maml']
+    if (batched and inner == 'copies' and _meta_batchable(opt, model, est_model, 'reference') and FrameBatch.supported(opt, model, est_model)
+            and (m_['lr_alpha_est'] is None or m_['lr_alpha_est'] == m_['lr_alpha'])):
+        return _meta_train_step_copies_batched(opt, model, est_model, modelcp, est_modelcp, train_data, optimizer, group,
+                                               force_collective)
     from . import dist as D
     m = opt['train']['maml']
     steps = m['adapt_iter']
@@ -397,15 +441,20 @@ class FrameBatch:
             if e.training != netE.training:
                 e.train(netE.training)
 
-    def adapt(self, model, est_model, est_model_fixed, lqs, slr_weight=10.0, steps=1):
+    def adapt(self, model, est_model, est_model_fixed, lqs, slr_weight=10.0, steps=1, slr_ref=None):
         """lqs [K,N,3,H,W] -> (per-step list of per-frame losses [K], SLR clips [K,N,3,h,w]); afterwards slice k holds
-        frame k's adapted weights.  Same statements as adapt_frame's step loop, on the batch."""
+        frame k's adapted weights.  Same statements as adapt_frame's step loop, on the batch.  The SLR term's reference is
+        the frozen estimator's output (test time, test_dynavsr.py:264-274) or, with ``slr_ref``, a given clip (meta-training:
+        the dataset's SuperLQs with weight 1, train_dynavsr.py:393)."""
         assert lqs.size(0) == self.k
         self.refresh(model.netG, est_model.netE)
         center = lqs.size(1) // 2
-        est_model_fixed.feed_data({'LQs': lqs})
-        est_model_fixed.test()
-        slr_fixed = est_model_fixed.fake_L
+        if slr_ref is None:
+            est_model_fixed.feed_data({'LQs': lqs})
+            est_model_fixed.test()
+            slr_fixed = est_model_fixed.fake_L
+        else:
+            slr_fixed = slr_ref
         est_model.feed_data({'LQs': lqs})                 # the wrapper's own layout handling ('video' / 'image' mode)
         losses = []
         for step in range(steps):

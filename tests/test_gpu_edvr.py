@@ -582,6 +582,7 @@ def test_meta_train_step_first_order_maml_mode():
     opt["train"]["maml"]["lr_alpha"] = 1e-4
     optimizer = torch.optim.SGD(params, lr=0.0)                 # lr 0: the meta step must leave the parameters alone
     r = meta_train_step(opt, model, est, modelcp, estcp, data, optimizer, inner="copies")
+    gb = [p.grad.detach().clone() for p in list(model.netG.parameters()) + list(est.netE.parameters())]
     for k, v in model.netG.state_dict().items():
         assert torch.equal(v.cpu(), PG[k]), k                   # inner steps ran on the copies only
     moved = sum(float((a.detach() - b.detach()).abs().max()) > 0 for a, b in zip(modelcp.netG.parameters(), model.netG.parameters()))
@@ -591,6 +592,16 @@ def test_meta_train_step_first_order_maml_mode():
     gq = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.netG.parameters())))
     assert np.isfinite(gq) and gq > 0 and np.isfinite(r["loss_q"])
     assert r["loss_q"] != ref["loss_q"]                         # loss_q was taken at the ADAPTED weights
+    # the task loop and the batched form (FrameBatch + per-task weight sets) are the same computation
+    assert r.get("batched")
+    r2 = meta_train_step(opt, model, est, modelcp, estcp, data, torch.optim.SGD(params, lr=0.0), inner="copies", batched=False)
+    assert not r2.get("batched") and abs(r2["loss_q"] - r["loss_q"]) < 1e-5 * abs(r["loss_q"])
+    assert all(abs(float(a) - float(b)) < 1e-5 * abs(float(b)) for a, b in zip(r["loss_train"], r2["loss_train"]))
+    gl = [p.grad for p in list(model.netG.parameters()) + list(est.netE.parameters())]
+    na, nb = float(torch.sqrt(sum((g.double() ** 2).sum() for g in gb))), float(torch.sqrt(sum((g.double() ** 2).sum() for g in gl)))
+    assert abs(na - nb) < 2e-3 * nb
+    worst = max(relerr(a, b) for a, b in zip(gb, gl) if float(b.norm()) > 1e-8 * nb)
+    assert worst < 2e-2, worst
 
 
 def test_dcn_dropin_module_matches_engine_and_oracle():
