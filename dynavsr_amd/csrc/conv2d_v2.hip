@@ -81,7 +81,7 @@ int conv2_pch(int ks, int stride) {  // packed floats per (64-cout block, chunk)
 // wt = 1 (data gradient): this conv's (cin, cout, tap) = original (cout, cin slice, mirrored tap).
 __global__ void pack_weights_kernel(PackTable t) {
   const PackEntry& e = t.e[blockIdx.y];
-  if (e.bf) return;  // packed by pack_weights_bf16_kernel
+  if (e.bf || e.perm == 3) return;  // packed by pack_weights_bf16_kernel / pack_weights_wino_kernel
   const int kq4 = e.CC / 8;
   const size_t per_chunk = (size_t)e.pch;
   const size_t total = (size_t)e.ncb * e.nchunks * per_chunk;
@@ -147,8 +147,12 @@ __global__ void pack_weights_bf16_kernel(PackTable t) {
 
 int pack_weights_run(const PackTable& t, hipStream_t st) {
   if (t.n <= 0) return DVSR_OK;
-  bool any_f32 = false, any_bf = false;
-  for (int i = 0; i < t.n; ++i) (t.e[i].bf ? any_bf : any_f32) = true;
+  bool any_f32 = false, any_bf = false, any_wino = false;
+  for (int i = 0; i < t.n; ++i) (t.e[i].bf ? any_bf : (t.e[i].perm == 3 ? any_wino : any_f32)) = true;
+  if (any_wino) {
+    int rc = pack_weights_wino_run(t, st);
+    if (rc) return rc;
+  }
   if (any_f32) {
     hipLaunchKernelGGL(pack_weights_kernel, dim3(48, t.n), dim3(256), 0, st, t);
     int rc = check_launch("pack_weights_kernel");
@@ -984,6 +988,23 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
   }
   if (dma_on && (allow_ksplit & 2) && ks == 3 && stride == 1 && Wo % 4 == 0 && Ctot % 8 == 0) g.dma = 1;
   if (force >= 0) return g;
+  // Winograd F(2x2, 3x3) (conv2d_wino.hip): one workgroup per CU, 64 couts x 64 2x2-pixel tiles, 4/9 of the MFMAs plus the
+  // transforms.  Model: rounds over the 256 CUs x (MFMA cycles of a workgroup's chunks + transform / epilogue overhead)
+  // against the direct kernel's rounds x MFMA cycles at its measured 0.78 efficiency.  DVSR_CONV_WINO=0 disables,
+  // =2 takes it wherever it is eligible (A/B aid).
+  int wino_on = 1;   // (read per call: plans are built once, and the tests switch it at run time)
+  if (const char* v = getenv("DVSR_CONV_WINO")) wino_on = atoi(v);
+  if (wino_on && g.dma == 1 && (allow_ksplit & 4) && Cout >= 32 && Ctot >= 16) {
+    const int nch = Ctot / 8;
+    auto wino_cost = [&](int oh, int ow) {
+      const double wgs = (double)ceil_div(Wo, ow) * ceil_div(Ho, oh) * N * ceil_div(Cout, 64);
+      return ceil(wgs / 256.0) * (nch * 5100.0 + 12500.0) / 2.07;   // (measured: tools/wino_trace.py, 2.07 GHz under this kernel)
+    };
+    const double w4 = wino_cost(4, 64), w8 = wino_cost(8, 32);
+    const double direct = std::min(c42, c41) * nch / 0.78 / 2.4;
+    const double best = std::min(w4, w8);
+    if (wino_on == 2 || best < direct) return ConvGeo{8, w8 < w4 ? 8 : 4, 2, 0, 3};
+  }
   // Small grids (every workgroup resident at once) are bound by one memory latency per chunk, not by the
   // matrix pipe: 16-channel chunks halve the number of exposed latencies.  DVSR_CONV_CC16_BELOW=<workgroups>
   // moves the threshold (0 disables).
@@ -999,7 +1020,10 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
   return g;
 }
 
-int conv2_pch_cc(int ks, int cc, int bf) { return (bf == 2 ? 3 : 1) * 2 * ks * ks * (bf ? cc / 16 : cc / 8) * 2 * 32 * 4; }
+int conv2_pch_cc(int ks, int cc, int bf, int dma) {
+  if (dma == 3) return 16 * 2 * 64 * 4;   // Winograd image: 16 transformed taps x 8 channels x 64 couts
+  return (bf == 2 ? 3 : 1) * 2 * ks * ks * (bf ? cc / 16 : cc / 8) * 2 * 32 * 4;
+}
 
 // `wp` = weights packed by pack_weights_kernel for this (ks, wt, geo.cc) combination.
 #ifdef DVSR_CONV_TRACE
@@ -1057,6 +1081,9 @@ int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const Conv
                  DVSR_ERR_UNSUPPORTED, "conv2d_packed: the row-split DMA kernel needs 7x7 / 9x9, stride 1, pad ks/2, plain "
                  "16-byte aligned inputs and W %% 4 == 0 (W=%d c0=%d c1=%d)", d.W, d.c0, d.c1);
   } else if (geo.dma) {
+    DVSR_REQUIRE(geo.dma != 3 || d.c0 + d.c1 >= 16, DVSR_ERR_UNSUPPORTED, "conv2d_packed: the Winograd kernel needs two 8-channel chunks");
+    DVSR_REQUIRE(geo.dma != 3 || d.pixel_shuffle == 0 || (d.pixel_shuffle == 2 && d.Cout % 4 == 0 && !d.res && !ex.accum && !ex.gmask),
+                 DVSR_ERR_UNSUPPORTED, "conv2d_packed: the Winograd kernel stores plain or PixelShuffle(2) tiles (ps=%d)", d.pixel_shuffle);
     DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && d.pad == 1 && !ex.in_ps && !ex.in_dil && geo.cc == 8 && (geo.th == 4 || geo.th == 8) &&
                      d.W % 4 == 0 && d.c0 % 8 == 0 && d.c1 % 8 == 0 && k.x0_bs % 4 == 0 && k.x1_bs % 4 == 0 &&
                      ((uintptr_t)d.x0 & 15) == 0 && ((uintptr_t)d.x1 & 15) == 0,
@@ -1097,6 +1124,7 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
     if (geo.mt == 2) return launch_conv2<3, 1, 16, 4, 2, 1>(k, st);
     return launch_conv2<3, 1, 16, 4, 1, 1>(k, st);
   }
+  if (geo.dma == 3) return conv2d_wino_launch(k, geo.th, st);
   if (geo.dma == 2) {
     if (d.ks == 7) return geo.mt == 2 ? launch_dmarow<7, 4, 2>(k, st) : launch_dmarow<7, 4, 1>(k, st);
     return geo.mt == 2 ? launch_dmarow<9, 4, 2>(k, st) : launch_dmarow<9, 4, 1>(k, st);
@@ -1155,8 +1183,8 @@ OpPack op_pack(int ks, int stride, int pad, int N, int Ho, int Wo, int Cout, int
   using namespace dvsr;
   OpPack o;
   const bool k3 = ks == 3 && stride == 1 && pad == 1, kbig = (ks == 7 || ks == 9) && stride == 1 && pad == ks / 2;
-  o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, Ctot, (k3 && plain ? 1 : 0) | ((k3 || kbig) && aligned ? 2 : 0));
-  o.floats = (size_t)ceil_div(Cout, 64) * ceil_div(Ctot, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, 0);
+  o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, Ctot, (k3 && plain ? 1 : 0) | ((k3 || kbig) && aligned ? 2 : 0) | (k3 && aligned ? 4 : 0));
+  o.floats = (size_t)ceil_div(Cout, 64) * ceil_div(Ctot, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, 0, o.geo.dma);
   return o;
 }
 OpPack op_pack_for(const dvsr_conv2d_desc& d, int Cout, int Ctot) {
@@ -1181,7 +1209,7 @@ int op_run(const dvsr_conv2d_desc& d, const dvsr::ConvExtra& ex, int Cout, int C
   e.w = d.w; e.P = (float*)ws; e.Cout = Cout; e.Ctot = Ctot; e.KK = d.ks * d.ks; e.CC = o.geo.cc; e.wt = ex.wt;
   e.w_ctot = ex.w_ctot; e.w_coff = ex.w_coff; e.ncb = ceil_div(Cout, 64); e.nchunks = ceil_div(Ctot, e.CC); e.bf = 0;
   e.perm = o.geo.dma;
-  e.pch = conv2_pch_cc(d.ks, e.CC, 0);
+  e.pch = conv2_pch_cc(d.ks, e.CC, 0, o.geo.dma);
   int rc = pack_weights_run(t, st);
   if (rc) return rc;
   return conv2d_packed_run(d, (const float*)ws, ex, o.geo, st);

@@ -1,0 +1,448 @@
+// 3x3 / stride 1 / pad 1 convolution by Winograd's minimal filtering F(2x2, 3x3), fp32, on v_mfma_f32_32x32x2_f32.
+//
+// The dense 3x3 convolutions are ~90 % of EDVR's FLOPs (EDVR_arch.py:254-313) and the exact-fp32 matrix pipe tops
+// out at 157 TFLOP/s; conv2d_dma_kernel sits at 0.75-0.79 of that on the big layers and two rounds of work on its
+// pipeline moved it by a few percent.  This kernel spends 2.25x fewer multiplies instead: every 2x2 block of output
+// pixels ("tile") of a (cout, cin) pair costs 16 multiplies in the transformed domain instead of 36,
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A,      g: 3x3 filter, d: 4x4 input patch, Y: 2x2 outputs,
+// which turns the layer into SIXTEEN independent GEMMs (one per position xn = (xi, nu) of the 4x4 transformed patch),
+//     M[xn][cout][tile] = sum_cin U[xn][cout][cin] V[xn][cin][tile],
+// with U = G g G^T computed once per weight update (pack_weights_wino_kernel) and V = B^T d B computed here, per
+// 8-channel chunk, from the raw halo tile.  Same arithmetic class as the fp32 path of the vendor libraries the
+// reference runs on (cuDNN's WINOGRAD algorithms for the nn.Conv2d calls of EDVR_arch.py); the transforms of F(2x2, 3x3)
+// only add/subtract and halve, the result differs from the direct sum by a few fp32 ulps (tests: rel-L2 <= 2e-6 against
+// the direct kernel, the network-level goldens unchanged).
+//
+// Work split (one workgroup = 4 waves = one CU: 256 accumulator registers per lane leave room for nothing else):
+//   * workgroup tile = 64 couts x 64 tiles (TC tile columns x 64/TC tile rows: 4x64 or 8x32 output pixels);
+//   * wave (mh, tr) = 32 couts x 32 tiles x all 16 xn: acc[16] x f32x16 in AGPRs; per chunk and xn ONE ds_read_b128 for A
+//     (4 k-steps of U) and one for B (4 k-steps of V), then 4 dependent MFMAs (issue = dependent latency = 64 cycles);
+//     the output transform is then lane-local: a lane holds M[0..15] of its (cout, tile) pairs;
+//   * per chunk the workgroup moves U(k+1) (32 KB, the packed LDS image) and the raw halo of chunk k+2 global -> LDS by
+//     DMA (16 B per lane), transforms the raw halo of chunk k+1 into V (each thread: two channels of one tile as
+//     packed-fp32 pairs, 32 v_pk_add, 16 conflict-free ds_write_b64) and runs the 64 MFMAs of chunk k; one barrier.
+// LDS: 2 x (U 32 KB + V 32 KB + raw <= 13.5 KB) = 155 KB of the CU's 160 KB.
+// Epilogue: A^T M A in registers (24 adds per (cout, tile), packed over cout pairs), then bias / activation / residual /
+// accumulate / gradient mask / PixelShuffle(2) exactly as store_mfma_tile does for the direct kernels.
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+#include "small_grid.h"
+
+namespace dvsr {
+
+// measurement aid of the debug build (DVSR_CONV_ABLATE, results are WRONG when set): bit 0 no epilogue, bit 1 no input
+// transform, bit 2 no DMA, bit 3 operands read once per chunk, bit 4 no chunk barriers
+// (and tools/wino_trace.py: thread 0 of every workgroup stamps s_memtime at the phase boundaries)
+#ifdef DVSR_CONV_TRACE
+#define WINO_ABLATE(a) ((a).ablate)
+#define WINO_STAMP(i)                                                                                     \
+  do {                                                                                                    \
+    if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define WINO_ABLATE(a) 0
+#define WINO_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// P[cb][k][((xn*2 + hi)*64 + co_l)*4 + j] = (G g G^T)[xi][nu] of (cout = cb*64 + co_l, cin = k*8 + 2j + hi), xn = 4 xi + nu.
+__global__ void pack_weights_wino_kernel(PackTable t) {
+  const PackEntry& e = t.e[blockIdx.y];
+  if (e.perm != 3) return;
+  const size_t per_chunk = 8192;
+  const size_t total = (size_t)e.ncb * e.nchunks * per_chunk;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int r = (int)(i % per_chunk);
+    const size_t ck = i / per_chunk;
+    const int k = (int)(ck % e.nchunks), cb = (int)(ck / e.nchunks);
+    const int j = r & 3; r >>= 2;
+    const int col = r & 63; r >>= 6;
+    const int hi = r & 1; r >>= 1;
+    const int xi = r >> 2, nu = r & 3;
+    const int co = cb * 64 + col, ci = k * 8 + 2 * j + hi;
+    float v = 0.f;
+    if (co < e.Cout && ci < e.Ctot) {
+      float g[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const int tap = a * 3 + b;
+          g[a][b] = !e.wt ? e.w[((size_t)co * e.Ctot + ci) * 9 + tap]
+                          : e.w[((size_t)ci * e.w_ctot + e.w_coff + co) * 9 + (8 - tap)];
+        }
+      // row xi of G applied to the columns of g, then row nu of G to the result
+      float c[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        c[b] = xi == 0 ? g[0][b] : (xi == 3 ? g[2][b] : 0.5f * (xi == 1 ? (g[0][b] + g[1][b] + g[2][b]) : (g[0][b] - g[1][b] + g[2][b])));
+      }
+      v = nu == 0 ? c[0] : (nu == 3 ? c[2] : 0.5f * (nu == 1 ? (c[0] + c[1] + c[2]) : (c[0] - c[1] + c[2])));
+    }
+    e.P[i] = v;
+  }
+}
+
+int pack_weights_wino_run(const PackTable& t, hipStream_t st) {
+  hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(48, t.n), dim3(256), 0, st, t);
+  return check_launch("pack_weights_wino_kernel");
+}
+
+template <int TC>
+struct WinoShape {
+  static constexpr int CC = 8, NTILE = 64, TRW = NTILE / TC;
+  static constexpr int OH = 2 * TRW, OW = 2 * TC;      // output pixels of the workgroup tile
+  static constexpr int IH = OH + 2, RP = OW + 8, GR = RP / 4;
+  static constexpr int NG = CC * IH * GR;              // 16-byte groups of one chunk's raw halo image
+  static constexpr int NI = (NG + 511) / 512;
+  static constexpr int RAW_FLOATS = NG * 4;
+  static constexpr int UV = 16 * 2 * 64 * 4;           // floats of one U (or V) image
+  static constexpr size_t LDS_BYTES = (size_t)(4 * UV + 2 * RAW_FLOATS) * sizeof(float);
+};
+
+template <int TC>
+__global__ __launch_bounds__(512, 2) void conv2d_wino_kernel(ConvK2 a) {
+  using Sh = WinoShape<TC>;
+  constexpr int IH = Sh::IH, RP = Sh::RP, GR = Sh::GR, NI = Sh::NI, UV = Sh::UV;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const s_u0 = smem;
+  float* const s_v0 = smem + 2 * UV;
+  float* const s_r0 = smem + 4 * UV;
+
+  const int id = blockIdx.x;
+  const int q_ = id >> 3;  // XCD-aware order, as conv2d_pipe_item
+  const int cbi = q_ % a.ncb;
+  const int j_ = q_ / a.ncb;
+  const int tile = (id & 7) * a.tiles_per_xcd + j_;
+  if (j_ >= a.tiles_per_xcd || tile >= a.ntiles) return;
+  const int tx_ = tile % a.tiles_x;
+  const int t2 = tile / a.tiles_x;
+  const int ty_ = t2 % a.tiles_y;
+  const int n = t2 / a.tiles_y;
+  const int oy0 = ty_ * Sh::OH, ox0 = tx_ * Sh::OW;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int mh = wave & 1, tr = (wave >> 1) & 1, xh = wave >> 2;
+  const size_t HW = (size_t)a.H * a.W;
+  const float* x0n = a.x0 + (size_t)n * a.x0_bs;
+  const float* x1n = a.c1 ? a.x1 + (size_t)(n / a.x1_bdiv) * a.x1_bs : x0n;
+
+  // raw halo groups this lane moves: group L = 64 * (wave + 8 jj) + lane = (channel, row, column group)
+  unsigned hoff[NI];
+  bool hval[NI];
+#pragma unroll
+  for (int jj = 0; jj < NI; ++jj) {
+    const int L = 64 * (wave + 8 * jj) + lane;
+    const int c = L / (IH * GR), r = L - c * (IH * GR);
+    const int iy = r / GR, g = r - iy * GR;
+    const int gy = oy0 - 1 + iy, gx = ox0 - 4 + 4 * g;
+    const bool ok = L < Sh::NG && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    hoff[jj] = ok ? (unsigned)(((size_t)c * HW + (size_t)gy * a.W + gx) * 4) : 0u;
+    hval[jj] = ok;
+    if (L < Sh::NG && !ok) {
+      *reinterpret_cast<f32x4*>(s_r0 + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(s_r0 + Sh::RAW_FLOATS + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  f32x16 acc[8];   // xn = 8 xh + i (first written by the MFMAs of chunk 0)
+
+  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + (size_t)cbi * a.nchunks * UV;
+
+  auto issue_raw_piece = [&](int k, int buf, int jj) {
+    const int cbase = k * Sh::CC;
+    const bool second = cbase >= a.c0;  // only possible when c1 > 0; a chunk never straddles the two inputs
+    const float* b = second ? x1n : x0n;
+    const int ci = second ? cbase - a.c0 : cbase;
+    const char* p = reinterpret_cast<const char*>(b + (size_t)ci * HW);
+    float* dst = s_r0 + buf * Sh::RAW_FLOATS;
+    if (hval[jj])
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + hoff[jj]),
+                                       (__attribute__((address_space(3))) void*)(dst + 256 * (wave + 8 * jj)), 16, 0, 0);
+  };
+  auto issue_raw = [&](int k, int buf) {
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) issue_raw_piece(k, buf, jj);
+  };
+  auto issue_u_piece = [&](int k, int buf, int j) {   // j = 0..3: 8 KB each
+    const float* wsrc = wp_cb + (size_t)k * UV;
+    float* wdst = s_u0 + buf * UV;
+    const int piece = j * 8 + wave;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + piece * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(wdst + piece * 256), 16, 0, 0);
+  };
+  auto issue_u = [&](int k, int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_u_piece(k, buf, j);
+  };
+
+  // input transform: wave = channel of the chunk, lane = tile.  A patch row is read as three aligned 8-byte pairs (columns
+  // 2 tc + 2 .. 2 tc + 7 of the raw image, conflict-free; the patch is columns + 3 .. + 6), the row pass B^T d runs on the
+  // pairs, the column pass is scalar; V[xn][channel][tile] takes 4-byte stores, consecutive lanes consecutive words.
+  const int trow_t = lane / TC, tcol_t = lane - trow_t * TC;
+  const int roff = (wave * IH + 2 * trow_t) * RP + 2 * tcol_t + 2;
+  const int voff = wave * 64 + lane;
+  f32x2 td[4][3];
+  auto tf_load = [&](int rbuf) {
+    const float* ra = s_r0 + rbuf * Sh::RAW_FLOATS + roff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int p2 = 0; p2 < 3; ++p2) td[i][p2] = *reinterpret_cast<const f32x2*>(ra + i * RP + 2 * p2);
+  };
+  auto tf_rows = [&]() {
+#pragma unroll
+    for (int p2 = 0; p2 < 3; ++p2) {
+      const f32x2 d0 = td[0][p2], d1 = td[1][p2], d2 = td[2][p2], d3 = td[3][p2];
+      td[0][p2] = d0 - d2;
+      td[1][p2] = d1 + d2;
+      td[2][p2] = d2 - d1;
+      td[3][p2] = d1 - d3;
+    }
+  };
+  auto tf_cols = [&](int i, int vbuf) {   // row i of (B^T d) B -> V[4 i .. 4 i + 3]
+    float* v = s_v0 + vbuf * UV + voff;
+    const float c0 = td[i][0][1], c1 = td[i][1][0], c2 = td[i][1][1], c3 = td[i][2][0];
+    v[(i * 4 + 0) * 512] = c0 - c2;
+    v[(i * 4 + 1) * 512] = c1 + c2;
+    v[(i * 4 + 2) * 512] = c2 - c1;
+    v[(i * 4 + 3) * 512] = c1 - c3;
+  };
+  auto transform = [&](int rbuf, int vbuf) {
+    tf_load(rbuf);
+    tf_rows();
+    tf_cols(0, vbuf); tf_cols(1, vbuf); tf_cols(2, vbuf); tf_cols(3, vbuf);
+  };
+
+  // bias: every output of a tile receives M[1][1] with weight one (column 1 of A^T is (1, 1)), so the bias is the INITIAL value
+  // of xn = 5 (a wave of the xh = 0 half); the other accumulators start from the MFMA's inline zero
+  const int co_block = cbi * 64 + mh * 32;
+  f32x16 cinit5;
+  {
+    const float* bias = wset_ptr(a.bias, a.b_gs, n, a.wdiv);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co_block + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      cinit5[r] = (bias && xh == 0) ? bias[co < a.Cout ? co : a.Cout - 1] : 0.f;
+    }
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // One chunk = 4 steps of two xn (two independent accumulator chains alternate), the operands of the next pair in flight,
+  // one piece of the next chunk's weight DMA and one slice of the next chunk's input transform per step.
+  const int abase = xh * 8 * 512 + (hi * 64 + mh * 32 + lo) * 4;       // A: U[xn][hi][cout][j], one 16-byte read = 4 k-steps
+  const int bbase = xh * 8 * 512 + hi * 64 + tr * 32 + lo;              // B: V[xn][2 j + hi][tile], four 4-byte reads
+  auto block = [&](int k, auto has_next_tag, auto first_tag) {
+    constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int buf = k & 1;
+    const float* s_u = s_u0 + buf * UV + abase;
+    const float* s_v = s_v0 + buf * UV + bbase;
+    const bool raw2 = HAS_NEXT && k + 2 < a.nchunks;
+    f32x4 A[2][2];
+    float B[2][2][4];
+    auto load_pair = [&](int pp, int rb) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        A[rb][e] = *reinterpret_cast<const f32x4*>(s_u + (2 * pp + e) * 512);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) B[rb][e][j] = s_v[(2 * pp + e) * 512 + j * 128];
+      }
+    };
+    load_pair(0, 0);
+    static_for<0, 4>([&](auto p_) {
+      constexpr int p = decltype(p_)::value;
+      constexpr int rb = p & 1;
+      if (p + 1 < 4) load_pair(p + 1, rb ^ 1);
+      if (HAS_NEXT) {
+        if (p == 0) tf_load(buf ^ 1);
+        issue_u_piece(k + 1, buf ^ 1, p);
+        if (p >= 4 - NI && raw2) issue_raw_piece(k + 2, buf, p - (4 - NI));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int i = 2 * p + e;
+          if (FIRST && j == 0)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][e][j], B[rb][e][j], i == 5 ? cinit5 : zero16, 0, 0, 0);
+          else
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][e][j], B[rb][e][j], acc[i], 0, 0, 0);
+        }
+      if (HAS_NEXT) {
+        if (p == 1) tf_rows();
+        if (p == 2) { tf_cols(0, buf ^ 1); tf_cols(1, buf ^ 1); }
+        if (p == 3) { tf_cols(2, buf ^ 1); tf_cols(3, buf ^ 1); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (HAS_NEXT) __syncthreads();  // next U / V / raw complete (the barrier's vmcnt(0) covers the DMAs)
+  };
+
+  WINO_STAMP(0);
+#ifdef DVSR_CONV_TRACE
+  if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + 60] = __builtin_amdgcn_s_memrealtime();
+#endif
+  issue_u(0, 0);
+  issue_raw(0, 0);
+  issue_raw(1, 1);   // (at least two chunks: conv2d_packed_prepare)
+  __syncthreads();
+  WINO_STAMP(1);
+  transform(0, 0);
+  __syncthreads();
+  WINO_STAMP(2);
+  block(0, std::true_type{}, std::true_type{});
+  WINO_STAMP(3);
+  for (int k = 1; k + 1 < a.nchunks; ++k) {
+    block(k, std::true_type{}, std::false_type{});
+    if (k < 30) WINO_STAMP(3 + k);
+  }
+  block(a.nchunks - 1, std::false_type{}, std::false_type{});
+  WINO_STAMP(40);
+
+  // ---- epilogue.  Y = A^T M A is linear in the rows of M: this wave reduces ITS two rows (xi = 2 xh, 2 xh + 1) to a partial
+  // 2x2 output per (cout, tile), the two waves of a pair swap halves through LDS (the idle U / V buffers of the other
+  // parity: the last block reads buffer (nchunks - 1) & 1 only) and each finishes 8 of the 16 cout registers:
+  // activation / residual / accumulate / gradient mask / PixelShuffle(2) as store_mfma_tile does for the direct kernels.
+  const int ttw = tr * 32 + lo;                        // this lane's tile
+  const int orow = oy0 + 2 * (ttw / TC), ocol = ox0 + 2 * (ttw % TC);
+  const size_t HWo = (size_t)a.Ho * a.Wo;
+  const float slope = a.act == ACT_LRELU ? 0.1f : (a.act == ACT_RELU ? 0.f : 1.f);
+  const float neg = a.gmask_act == ACT_LRELU ? 0.1f : (a.gmask_act == ACT_RELU ? 0.f : 1.f);
+  const bool full = oy0 + Sh::OH <= a.Ho && ox0 + Sh::OW <= a.Wo && cbi * 64 + 64 <= a.Cout;
+  const int ob = ((a.nchunks - 1) & 1) ^ 1;
+  const int q = mh + 2 * tr;   // the pair
+  float* const xch = (q < 2 ? s_u0 + ob * UV : s_v0 + ob * UV) + (q & 1) * 4096 + lane * 4;   // slot [receiving half][rr][lane]
+  auto finish = [&](auto xh_) {   // (one instantiation per half: register indices stay compile-time constants)
+    constexpr int XH = decltype(xh_)::value;
+    f32x4 part[16];   // (y00, y01, y10, y11) of register r
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s0[4], s1[4];
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        const float ma = acc[nu][r], mb = acc[4 + nu][r];
+        // XH = 0: rows 0, 1 of M: s0 = M0 + M1, s1 = M1;  XH = 1: rows 2, 3: s0 = M2, s1 = -(M2 + M3)
+        s0[nu] = XH == 0 ? ma + mb : ma;
+        s1[nu] = XH == 0 ? mb : -(ma + mb);
+      }
+      part[r] = f32x4{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) *reinterpret_cast<f32x4*>(xch + ((XH ^ 1) * 8 + rr) * 256) = part[(XH ^ 1) * 8 + rr];
+    __syncthreads();
+    f32x4 o8[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const f32x4 v = part[XH * 8 + rr] + *reinterpret_cast<const f32x4*>(xch + (XH * 8 + rr) * 256);
+      o8[rr] = __builtin_elementwise_max(v, v * slope);
+    }
+    if (a.ps == 0) {
+      const bool plain = !a.res && !a.accum && !a.gmask;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const f32x4 o = o8[rr];
+        const int r = 8 * XH + rr;
+        const int co = co_block + (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {     // the two rows of the tile
+          f32x2 v = i == 0 ? f32x2{o[0], o[1]} : f32x2{o[2], o[3]};
+          const int oy = orow + i;
+          const size_t idx = ((size_t)n * a.Cout + co) * HWo + (size_t)oy * a.Wo + ocol;
+          if (full && plain) {
+            *reinterpret_cast<f32x2*>(a.y + idx) = v;
+            continue;
+          }
+          const bool ok0 = full || (co < a.Cout && oy < a.Ho && ocol < a.Wo);
+          const bool ok1 = full || (ok0 && ocol + 1 < a.Wo);
+          if (!ok0) continue;
+          if (ok1 && (idx & 1) == 0) {
+            if (a.res) v += *reinterpret_cast<const f32x2*>(a.res + idx);
+            if (a.accum) v += *reinterpret_cast<const f32x2*>(a.y + idx);
+            if (a.gmask) {
+              const f32x2 g = *reinterpret_cast<const f32x2*>(a.gmask + idx);
+              v = f32x2{v[0] * (g[0] > 0.f ? 1.f : neg), v[1] * (g[1] > 0.f ? 1.f : neg)};
+            }
+            *reinterpret_cast<f32x2*>(a.y + idx) = v;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              if (j == 1 && !ok1) continue;
+              float w = v[j];
+              if (a.res) w += a.res[idx + j];
+              if (a.accum) w += a.y[idx + j];
+              if (a.gmask) w *= a.gmask[idx + j] > 0.f ? 1.f : neg;
+              a.y[idx + j] = w;
+            }
+          }
+        }
+      }
+    } else {
+      // PixelShuffle(2): channels 4 cq .. 4 cq + 3 (registers 4 g .. 4 g + 3) are the 2x2 sub-pixels (dy, dx) of channel cq:
+      // one output row of a tile is 4 consecutive floats (x = 2 ocol .. 2 ocol + 3, dx interleaved) -> 16-byte stores
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const f32x4 c0 = o8[4 * gg], c1 = o8[4 * gg + 1], c2 = o8[4 * gg + 2], c3 = o8[4 * gg + 3];  // (dy, dx) = 00 01 10 11
+        const int co = co_block + 8 * (2 * XH + gg) + 4 * hi;
+        const int cq = co >> 2;
+        if (co >= a.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int oy = orow + i;
+          if (!full && (oy >= a.Ho || ocol >= a.Wo)) continue;
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            const f32x4& e0 = dy ? c2 : c0;   // dx = 0
+            const f32x4& e1 = dy ? c3 : c1;   // dx = 1
+            const f32x4 v = f32x4{e0[2 * i], e1[2 * i], e0[2 * i + 1], e1[2 * i + 1]};
+            float* dst = a.y + (((size_t)n * (a.Cout >> 2) + cq) * (2 * a.Ho) + (2 * oy + dy)) * (size_t)(2 * a.Wo) + 2 * ocol;
+            if (full || ocol + 1 < a.Wo) *reinterpret_cast<f32x4*>(dst) = v;
+            else *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
+          }
+        }
+      }
+    }
+  };
+  if (xh == 0) finish(std::integral_constant<int, 0>{});
+  else finish(std::integral_constant<int, 1>{});
+#ifdef DVSR_CONV_TRACE
+  WINO_STAMP(41);
+  __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged
+  WINO_STAMP(42);
+  if (a.trace && threadIdx.x == 0) {
+    a.trace[(size_t)blockIdx.x * 64 + 61] = __builtin_amdgcn_s_memrealtime();
+    a.trace[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_ID
+  }
+#endif
+}
+
+template <int TC>
+static int launch_wino(ConvK2 k, hipStream_t st) {
+  using Sh = WinoShape<TC>;
+  auto kern = conv2d_wino_kernel<TC>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
+    attr_done = true;
+  }
+  k.tiles_x = ceil_div(k.Wo, Sh::OW); k.tiles_y = ceil_div(k.Ho, Sh::OH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
+  k.ncb = ceil_div(k.Cout, 64);
+  k.tiles_per_xcd = ceil_div(k.ntiles, 8);
+  k.nitems = k.tiles_per_xcd * 8 * k.ncb;
+  hipLaunchKernelGGL(kern, dim3(k.nitems), dim3(512), Sh::LDS_BYTES, st, k);
+  return check_launch("conv2d_wino_kernel");
+}
+
+// th = 4: 4 x 64-pixel workgroup tiles (TC = 32), th = 8: 8 x 32 (TC = 16)
+int conv2d_wino_launch(const ConvK2& k, int th, hipStream_t st) {
+  return th == 8 ? launch_wino<16>(k, st) : launch_wino<32>(k, st);
+}
+
+}  // namespace dvsr

@@ -182,9 +182,11 @@ struct Builder {
       // the K-split small-grid kernel takes plain inputs with an explicit pad of 1 and 32-channel chunks
       // (bit 0), the DMA-halo kernel plain inputs in whole 8-channel chunks (bit 1)
       const bool plain = pad < 0 && !wmap && !p.cfg.bf16_mfma;
-      const int ks_ok = (plain && (c1 == 0 || c0 % 32 == 0) ? 1 : 0) | (plain && c0 % 8 == 0 && c1 % 8 == 0 ? 2 : 0);
-      o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1, ks_ok), Ho, Wo, Cout);
-      o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, o.geo.bf);
+      // ... and the Winograd kernel where the DMA-halo kernel could run (bit 2; its epilogue stores plain or
+      // PixelShuffle(2) tiles)
+      const int ks_ok = (plain && (c1 == 0 || c0 % 32 == 0) ? 1 : 0) | (plain && c0 % 8 == 0 && c1 % 8 == 0 ? 2 | 4 : 0);
+      o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1, (ps == 0 || (ps == 2 && !res.valid())) ? ks_ok : (ks_ok & ~4)), Ho, Wo, Cout);
+      o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, o.geo.bf, o.geo.dma);
       o.wp_off = alloc("", o.wp_floats * p.wsets).off;   // one pack per weight set, consecutive
       for (int which = 0; which < 2; ++which) {
         const int ci = which ? c1 : c0;
@@ -193,7 +195,7 @@ struct Builder {
         // (data gradient: the gradient tensor is the plain input unless it is pixel-shuffled or zero-dilated)
         o.dgeo[which] = as_bf(conv2_choose(ks, 1, N, H, W, ci, Cout, (!ps && stride == 1) ? ks_ok : 0), H, W, ci);
         o.dpk_floats[which] = (size_t)ceil_div(ci, 64) * ceil_div(Cout, o.dgeo[which].cc) *
-                              conv2_pch_cc(ks, o.dgeo[which].cc, o.dgeo[which].bf);
+                              conv2_pch_cc(ks, o.dgeo[which].cc, o.dgeo[which].bf, o.dgeo[which].dma);
         o.dpk_off[which] = p.dpack_floats;
         p.dpack_floats += o.dpk_floats[which] * p.wsets;
       }
@@ -840,7 +842,7 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
         PackEntry& e = t.e[t.n++];
         e.w = wsrc + ws * wnum; e.P = fwd_base + o.wp_off + (size_t)ws * o.wp_floats; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
         e.CC = o.geo.cc; e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
-        e.nchunks = ceil_div(ctot, e.CC); e.bf = o.geo.bf; e.perm = o.geo.dma; e.pch = conv2_pch_cc(o.ks, e.CC, e.bf);
+        e.nchunks = ceil_div(ctot, e.CC); e.bf = o.geo.bf; e.perm = o.geo.dma; e.pch = conv2_pch_cc(o.ks, e.CC, e.bf, o.geo.dma);
         if (t.n == 48) { int rc = flush(); if (rc) return rc; }
       }
       if (bwd_base) {
@@ -852,7 +854,7 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
           e.KK = KK;
           e.CC = o.dgeo[which].cc; e.wt = 1; e.w_ctot = ctot; e.w_coff = which ? o.c0 : 0;
           e.ncb = ceil_div(ci, 64); e.nchunks = ceil_div(o.Cout, e.CC); e.bf = o.dgeo[which].bf;
-          e.pch = conv2_pch_cc(o.ks, e.CC, e.bf); e.perm = o.dgeo[which].dma;
+          e.pch = conv2_pch_cc(o.ks, e.CC, e.bf, o.dgeo[which].dma); e.perm = o.dgeo[which].dma;
           if (t.n == 48) { int rc = flush(); if (rc) return rc; }
         }
       }
@@ -1165,7 +1167,7 @@ extern "C" int dvsr_edvr_op_info(const dvsr_edvr_plan* p, int index, char* kind,
   snprintf(kind, kind_cap, "%s", k);
   if (p->ops[index].type == OP_CONV)
     snprintf(name, name_cap, "%s[%d/%d/%d%s]", p->ops[index].name, p->ops[index].geo.cc, p->ops[index].geo.th,
-             p->ops[index].geo.mt, p->ops[index].geo.dma ? "d" : "");
+             p->ops[index].geo.mt, p->ops[index].geo.dma == 3 ? "w" : (p->ops[index].geo.dma ? "d" : ""));
   else
     snprintf(name, name_cap, "%s", p->ops[index].name);
   return DVSR_OK;

@@ -69,6 +69,7 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
                          size_t ws_bytes, hipStream_t st, int scratch_is_zero, int pad, WgradReduceEntry* defer,
                          WgradLaunch* out, int bf16 = 0, int groups = 1, long long dW_gs = 0, long long db_gs = 0);
 int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st);
+int conv2d_wino_launch(const ConvK2& k, int th, hipStream_t st);   // conv2d_wino.hip (ConvGeo::dma == 3)
 int conv2d_wgrad_bf16_launch(const WgradLaunch& l, hipStream_t st);
 
 // -------------------------------------------------------------------------------------------------

@@ -360,11 +360,13 @@ def test_native_optimizer_matches_torch(kind):
     (1, 64, 64, 180, 320, 2, False),   # the reconstruction trunk of the headline clip
     (2, 8, 64, 128, 128, 1, False),    # ONE chunk: prologue only, no steady state
 ])
-def test_conv3x3_dma_halo(n, cin, cout, h, w, act, res):
+def test_conv3x3_dma_halo(n, cin, cout, h, w, act, res, monkeypatch):
     """Forward and data gradient through dvsr_conv2d_forward_packed / _dgrad_packed on grids large enough for
-    the DMA-halo kernel, against fp64 torch on the CPU; dvsr_conv2d_packed_geometry confirms which kernel ran."""
+    the DMA-halo kernel, against fp64 torch on the CPU; dvsr_conv2d_packed_geometry confirms which kernel ran.
+    (DVSR_CONV_WINO=0: the Winograd kernel would take most of these shapes, test_conv3x3_winograd.)"""
     import ctypes
     from dynavsr_amd import _lib as L, tofops
+    monkeypatch.setenv("DVSR_CONV_WINO", "0")
     x = rnd(n, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=1 / np.sqrt(cin * 9))
     b = rnd(cout, seed=3, scale=0.1)
@@ -384,6 +386,54 @@ def test_conv3x3_dma_halo(n, cin, cout, h, w, act, res):
     got.backward(dev(gy))
     ref.backward(gy.double())
     assert relerr(xd.grad, x64.grad) < TOL
+
+
+# ---- Winograd F(2x2, 3x3) kernel (conv2d_wino_kernel): the large 3x3 / stride-1 layers ----------------------------------
+@pytest.mark.parametrize("n,c0,c1,cout,h,w,act,res,ps,force", [
+    (5, 64, 0, 64, 180, 320, 2, False, 0, False),   # fe_rb of the headline clip: 4x64-pixel tiles, all full
+    (2, 64, 64, 64, 96, 128, 1, True, 0, False),    # two inputs (16 chunks), residual
+    (1, 64, 0, 256, 90, 160, 1, False, 2, True),    # PixelShuffle(2) store, partial tile rows and columns
+    (3, 72, 0, 40, 90, 200, 0, False, 0, True),     # Cout % 32 != 0, nine chunks, ragged in both directions
+    (2, 8, 8, 64, 44, 80, 1, True, 0, True),        # two chunks: first and last block only
+])
+def test_conv3x3_winograd(n, c0, c1, cout, h, w, act, res, ps, force, monkeypatch):
+    """Forward (and data gradient for single plain inputs) on the Winograd kernel against fp64 torch; the geometry query
+    confirms the kernel.  force: DVSR_CONV_WINO=2 takes it wherever it is eligible (the cost model would keep the direct
+    kernel on these small grids)."""
+    import ctypes
+    from dynavsr_amd import _lib as L
+    if force:
+        monkeypatch.setenv("DVSR_CONV_WINO", "2")
+    cin = c0 + c1
+    x0 = rnd(n, c0, h, w, seed=1)
+    x1 = rnd(n, c1, h, w, seed=6) if c1 else None
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1 / np.sqrt(cin * 9))
+    b = rnd(cout, seed=3, scale=0.1)
+    r = rnd(n, cout, h, w, seed=4) if res else None
+    d0, d1, dw, db_, dr = dev(x0), (dev(x1) if c1 else None), dev(wt), dev(b), (dev(r) if res else None)
+    y = torch.empty((n, cout // 4, 2 * h, 2 * w) if ps else (n, cout, h, w), device="cuda")
+    d = L.Conv2dDesc(L.ptr(d0), L.ptr(d1), L.ptr(dw), L.ptr(db_), L.ptr(dr), L.ptr(y), n, c0, c1, h, w, cout, 3, 1, 1,
+                     act, ps, 1, 0, 0)
+    geo = (ctypes.c_int * 4)()
+    L.check(L.lib().dvsr_conv2d_packed_geometry(d, ctypes.byref(geo)), "dvsr_conv2d_packed_geometry")
+    assert list(geo)[3] == 3, "expected the Winograd kernel, got %s" % list(geo)
+    ws = torch.empty(max(int(L.lib().dvsr_conv2d_packed_workspace_bytes(d)), 16), dtype=torch.uint8, device="cuda")
+    L.check(L.lib().dvsr_conv2d_forward_packed(d, ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_forward_packed")
+    x = torch.cat([x0, x1], 1) if c1 else x0
+    ref = ACT[act](F.conv2d(x.double(), wt.double(), b.double(), 1, 1))
+    if res:
+        ref = ref + r.double()
+    if ps:
+        ref = F.pixel_shuffle(ref, 2)
+    assert relerr(y, ref) < 2e-6
+    if c1 == 0 and not ps:   # data gradient: the same kernel over the transposed, tap-mirrored weights
+        gy = rnd(n, cout, h, w, seed=5)
+        gx = torch.empty(n, c0, h, w, device="cuda")
+        dgy = dev(gy)
+        L.check(L.lib().dvsr_conv2d_dgrad_packed(d, L.ptr(dgy), L.ptr(gx), ws.data_ptr(), ws.numel(), L.stream()),
+                "dvsr_conv2d_dgrad_packed")
+        ref_g = torch.nn.grad.conv2d_input((n, c0, h, w), wt.double(), gy.double(), 1, 1)
+        assert relerr(gx, ref_g) < 2e-6
 
 
 def test_conv3x3_dma_halo_not_for_unaligned():
