@@ -83,7 +83,7 @@ def _opt():
 def _sources_digest():
     """Identity of the conv kernel sources the committed PMC traffic figure was collected on."""
     h = hashlib.sha256()
-    for f in ("conv2d_v2.hip", "small_grid.h", "common.h"):
+    for f in ("conv2d_v2.hip", "conv2d_wino.hip", "small_grid.h", "common.h"):
         with open(os.path.join(ROOT, "dynavsr_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -731,11 +731,15 @@ def main():
         out = torch.empty_like(y)
         info = plan.op_info()
         acc = {}
+        wino = {}   # per kind: [launches on the Winograd kernel, their algorithmic flops, their time]
         reps = max(3, min(10, args.steps))
         for _ in range(reps):
-            for (kind, _name, fl, by), t_ms in zip(info, plan.forward_timed(params, x, out, ws)):
+            for (kind, name, fl, by), t_ms in zip(info, plan.forward_timed(params, x, out, ws)):
                 a = acc.setdefault(kind, [0.0, 0.0, 0.0, 0])
                 a[0] += t_ms; a[1] += fl; a[2] += by; a[3] += 1
+                if name.endswith("w]"):   # launch geometry tag of dvsr_edvr_op_info: Winograd F(2x2, 3x3) kernel
+                    wv = wino.setdefault(kind, [0, 0.0, 0.0])
+                    wv[0] += 1; wv[1] += fl; wv[2] += t_ms
         dom = max(acc, key=lambda k: acc[k][0])
         t_ms, fl, by, cnt = acc[dom]
         total_ms = sum(a[0] for a in acc.values())
@@ -769,6 +773,18 @@ def main():
                                "passes after the timed region" % reps})
         if traffic_err:
             roof["traffic_error"] = traffic_err
+        if dom in wino:
+            # `achieved` counts ALGORITHMIC flops (2 x MACs of the direct 3x3 sum).  The launches on the Winograd
+            # kernel execute 16 multiplies per 2x2 output block and (cout, cin) pair instead of 36: the matrix pipe's own
+            # utilisation is reported next to it so that the two are not confused.
+            wn, wfl, wt = wino[dom]
+            executed = fl - wfl * (1.0 - 16.0 / 36.0)
+            roof["algorithm"] = ("%d of %d launches per step on the Winograd F(2x2,3x3) fp32 kernel (conv2d_wino.hip: same "
+                                 "result within fp32 round-off, 4/9 of the multiplies + transforms), the rest on the direct "
+                                 "implicit-GEMM kernels" % (wn // reps, cnt // reps))
+            roof["mfma_flops_executed_frac"] = executed / fl
+            roof["mfma_pipe_frac"] = executed / (t_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS
+            roof["winograd_launch_share_of_kernel_time"] = wt / t_ms
         line["roofline"] = roof
         line["kernel_breakdown_ms_per_step"] = {k: round(a[0] / reps, 4) for k, a in
                                                 sorted(acc.items(), key=lambda kv: -kv[1][0])}

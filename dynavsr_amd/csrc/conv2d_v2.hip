@@ -1223,7 +1223,10 @@ extern "C" size_t dvsr_conv2d_packed_workspace_bytes(const dvsr_conv2d_desc* d) 
   const size_t a = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, d->Cout, ctot, true).floats;
   const size_t b = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, ctot, d->Cout, true).floats;
   const size_t c = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, d->Cout, ctot, false).floats;
-  return (a > b ? (a > c ? a : c) : (b > c ? b : c)) * sizeof(float);
+  // (the Winograd image of a 3x3 layer: 16 transformed taps instead of 9)
+  const size_t w = d->ks == 3 ? (size_t)std::max(dvsr::ceil_div(d->Cout, 64) * dvsr::ceil_div(ctot, 8), dvsr::ceil_div(ctot, 64) * dvsr::ceil_div(d->Cout, 8)) *
+                                    dvsr::conv2_pch_cc(3, 8, 0, 3) : 0;
+  return std::max(std::max(a, b), std::max(c, w)) * sizeof(float);
 }
 
 extern "C" int dvsr_conv2d_packed_geometry(const dvsr_conv2d_desc* d, int geo[4]) {

@@ -33,7 +33,7 @@
 namespace dvsr {
 
 // measurement aid of the debug build (DVSR_CONV_ABLATE, results are WRONG when set): bit 0 no epilogue, bit 1 no input
-// transform, bit 2 no DMA, bit 3 operands read once per chunk, bit 4 no chunk barriers
+// transform, bit 2 no DMA, bit 3 operands read once, bit 4 no chunk barriers
 // (and tools/wino_trace.py: thread 0 of every workgroup stamps s_memtime at the phase boundaries)
 #ifdef DVSR_CONV_TRACE
 #define WINO_ABLATE(a) ((a).ablate)
@@ -91,6 +91,14 @@ __global__ void pack_weights_wino_kernel(PackTable t) {
 int pack_weights_wino_run(const PackTable& t, hipStream_t st) {
   hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(48, t.n), dim3(256), 0, st, t);
   return check_launch("pack_weights_wino_kernel");
+}
+
+// 16 bytes per lane global -> LDS: buffer load with the per-lane byte offset in a VGPR and everything that changes per chunk in
+// the scalar offset (no vector instruction per transfer).  A plain function: the builtin inside the kernel TEMPLATE makes the
+// host pass drop the kernel's stub.
+__device__ __forceinline__ void wino_dma16(const float* base, float* lds, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000),
+                                           (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
 template <int TC>
@@ -156,27 +164,30 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino_kernel(ConvK2 a) {
 
   const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + (size_t)cbi * a.nchunks * UV;
 
+  // DMA addressing: buffer loads take (resource, per-lane byte offset, scalar byte offset) -- the per-lane part is fixed
+  // for the life of the workgroup, the chunk / piece part is scalar arithmetic: no vector instruction per transfer.
+  const unsigned uoff = (unsigned)(lane * 16 + wave * 1024);
+  const unsigned chunk_bytes = (unsigned)(Sh::CC * HW * 4);
   auto issue_raw_piece = [&](int k, int buf, int jj) {
     const int cbase = k * Sh::CC;
     const bool second = cbase >= a.c0;  // only possible when c1 > 0; a chunk never straddles the two inputs
-    const float* b = second ? x1n : x0n;
-    const int ci = second ? cbase - a.c0 : cbase;
-    const char* p = reinterpret_cast<const char*>(b + (size_t)ci * HW);
+    const unsigned soff = (unsigned)((second ? k - a.c0 / Sh::CC : k)) * chunk_bytes;
     float* dst = s_r0 + buf * Sh::RAW_FLOATS;
-    if (hval[jj])
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + hoff[jj]),
-                                       (__attribute__((address_space(3))) void*)(dst + 256 * (wave + 8 * jj)), 16, 0, 0);
+    if (hval[jj]) {
+      if (second)
+        wino_dma16(x1n, dst + 256 * (wave + 8 * jj), hoff[jj], soff);
+      else
+        wino_dma16(x0n, dst + 256 * (wave + 8 * jj), hoff[jj], soff);
+    }
   };
   auto issue_raw = [&](int k, int buf) {
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj) issue_raw_piece(k, buf, jj);
   };
   auto issue_u_piece = [&](int k, int buf, int j) {   // j = 0..3: 8 KB each
-    const float* wsrc = wp_cb + (size_t)k * UV;
     float* wdst = s_u0 + buf * UV;
-    const int piece = j * 8 + wave;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + piece * 256 + lane * 4),
-                                     (__attribute__((address_space(3))) void*)(wdst + piece * 256), 16, 0, 0);
+    wino_dma16(wp_cb, wdst + (j * 8 + wave) * 256, uoff,
+                                             (unsigned)(k * (UV * 4) + j * 8192));
   };
   auto issue_u = [&](int k, int buf) {
 #pragma unroll
@@ -235,10 +246,22 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino_kernel(ConvK2 a) {
   }
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  // One chunk = 4 steps of two xn (two independent accumulator chains alternate), the operands of the next pair in flight,
-  // one piece of the next chunk's weight DMA and one slice of the next chunk's input transform per step.
+  // One chunk = 4 steps of two xn (two independent accumulator chains alternate), the operands of the next pair in flight.
+  // The next chunk's weight / halo DMA and its input transform are issued in steps 0..2; the chunk barrier sits BEFORE the
+  // last step, whose MFMAs then cover the LDS round trip of the next chunk's first operands (after the barrier no wave reads
+  // this chunk's buffers any more: the last pair's operands are already in registers).
   const int abase = xh * 8 * 512 + (hi * 64 + mh * 32 + lo) * 4;       // A: U[xn][hi][cout][j], one 16-byte read = 4 k-steps
   const int bbase = xh * 8 * 512 + hi * 64 + tr * 32 + lo;              // B: V[xn][2 j + hi][tile], four 4-byte reads
+  f32x4 A[2][2];
+  float B[2][2][4];
+  auto load_pair = [&](const float* s_u, const float* s_v, int pp, int rb) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      A[rb][e] = *reinterpret_cast<const f32x4*>(s_u + (2 * pp + e) * 512);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) B[rb][e][j] = s_v[(2 * pp + e) * 512 + j * 128];
+    }
+  };
   auto block = [&](int k, auto has_next_tag, auto first_tag) {
     constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;
@@ -246,25 +269,23 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino_kernel(ConvK2 a) {
     const float* s_u = s_u0 + buf * UV + abase;
     const float* s_v = s_v0 + buf * UV + bbase;
     const bool raw2 = HAS_NEXT && k + 2 < a.nchunks;
-    f32x4 A[2][2];
-    float B[2][2][4];
-    auto load_pair = [&](int pp, int rb) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        A[rb][e] = *reinterpret_cast<const f32x4*>(s_u + (2 * pp + e) * 512);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) B[rb][e][j] = s_v[(2 * pp + e) * 512 + j * 128];
-      }
-    };
-    load_pair(0, 0);
     static_for<0, 4>([&](auto p_) {
       constexpr int p = decltype(p_)::value;
       constexpr int rb = p & 1;
-      if (p + 1 < 4) load_pair(p + 1, rb ^ 1);
-      if (HAS_NEXT) {
+      if (p == 3 && HAS_NEXT) {
+        if (!(WINO_ABLATE(a) & 16)) __syncthreads();  // next U / V / raw complete (the barrier's vmcnt(0) covers the DMAs)
+        if (!(WINO_ABLATE(a) & 8)) load_pair(s_u0 + (buf ^ 1) * UV + abase, s_v0 + (buf ^ 1) * UV + bbase, 0, 0);
+      }
+      if (p + 1 < 4 && !(WINO_ABLATE(a) & 8)) load_pair(s_u, s_v, p + 1, rb ^ 1);
+      if (HAS_NEXT && !(WINO_ABLATE(a) & 2)) {
         if (p == 0) tf_load(buf ^ 1);
-        issue_u_piece(k + 1, buf ^ 1, p);
-        if (p >= 4 - NI && raw2) issue_raw_piece(k + 2, buf, p - (4 - NI));
+      }
+      if (HAS_NEXT && !(WINO_ABLATE(a) & 4)) {
+        if (p < 2) {
+          issue_u_piece(k + 1, buf ^ 1, 2 * p);
+          issue_u_piece(k + 1, buf ^ 1, 2 * p + 1);
+          if (raw2 && p < NI) issue_raw_piece(k + 2, buf, p);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -276,14 +297,13 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino_kernel(ConvK2 a) {
           else
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][e][j], B[rb][e][j], acc[i], 0, 0, 0);
         }
-      if (HAS_NEXT) {
-        if (p == 1) tf_rows();
-        if (p == 2) { tf_cols(0, buf ^ 1); tf_cols(1, buf ^ 1); }
-        if (p == 3) { tf_cols(2, buf ^ 1); tf_cols(3, buf ^ 1); }
+      if (HAS_NEXT && !(WINO_ABLATE(a) & 2)) {
+        if (p == 0) tf_rows();
+        if (p == 1) { tf_cols(0, buf ^ 1); tf_cols(1, buf ^ 1); }
+        if (p == 2) { tf_cols(2, buf ^ 1); tf_cols(3, buf ^ 1); }
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    if (HAS_NEXT) __syncthreads();  // next U / V / raw complete (the barrier's vmcnt(0) covers the DMAs)
   };
 
   WINO_STAMP(0);
@@ -297,6 +317,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino_kernel(ConvK2 a) {
   WINO_STAMP(1);
   transform(0, 0);
   __syncthreads();
+  load_pair(s_u0 + abase, s_v0 + bbase, 0, 0);
   WINO_STAMP(2);
   block(0, std::true_type{}, std::true_type{});
   WINO_STAMP(3);
@@ -320,58 +341,105 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino_kernel(ConvK2 a) {
   const int ob = ((a.nchunks - 1) & 1) ^ 1;
   const int q = mh + 2 * tr;   // the pair
   float* const xch = (q < 2 ? s_u0 + ob * UV : s_v0 + ob * UV) + (q & 1) * 4096 + lane * 4;   // slot [receiving half][rr][lane]
+  // full tiles: address = scalar base of (image, cout) + one per-lane byte offset
+  const char* const ybase = reinterpret_cast<const char*>(a.y + ((size_t)n * a.Cout + co_block) * HWo);
+  const unsigned lane_off = (unsigned)(((size_t)(4 * hi) * HWo + (size_t)orow * a.Wo + ocol) * 4);
   auto finish = [&](auto xh_) {   // (one instantiation per half: register indices stay compile-time constants)
     constexpr int XH = decltype(xh_)::value;
-    f32x4 part[16];   // (y00, y01, y10, y11) of register r
+    // pp[P] = (y00, y01, y10, y11) of the register PAIR (2P, 2P + 1) = output channels (co, co + 1), as packed pairs
+    f32x2 pp[8][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float s0[4], s1[4];
+    for (int P = 0; P < 8; ++P) {
+      f32x2 s0[4], s1[4];
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) {
-        const float ma = acc[nu][r], mb = acc[4 + nu][r];
-        // XH = 0: rows 0, 1 of M: s0 = M0 + M1, s1 = M1;  XH = 1: rows 2, 3: s0 = M2, s1 = -(M2 + M3)
+        const f32x2 ma = {acc[nu][2 * P], acc[nu][2 * P + 1]}, mb = {acc[4 + nu][2 * P], acc[4 + nu][2 * P + 1]};
+        // XH = 0: rows 0, 1 of M: s0 = M0 + M1, s1 = M1;  XH = 1: rows 2, 3: s0 = M2, s1 = -(M2 + M3) (sign applied below)
         s0[nu] = XH == 0 ? ma + mb : ma;
-        s1[nu] = XH == 0 ? mb : -(ma + mb);
+        s1[nu] = XH == 0 ? mb : ma + mb;
       }
-      part[r] = f32x4{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
+      pp[P][0] = s0[0] + s0[1] + s0[2];
+      pp[P][1] = s0[1] - s0[2] - s0[3];
+      if (XH == 0) {
+        pp[P][2] = s1[0] + s1[1] + s1[2];
+        pp[P][3] = s1[1] - s1[2] - s1[3];
+      } else {
+        pp[P][2] = -s1[0] - s1[1] - s1[2];
+        pp[P][3] = s1[2] + s1[3] - s1[1];
+      }
     }
+    // swap: the pairs of the OTHER half's registers go out (two 16-byte slots per pair), this half's come in
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) *reinterpret_cast<f32x4*>(xch + ((XH ^ 1) * 8 + rr) * 256) = part[(XH ^ 1) * 8 + rr];
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int P = (XH ^ 1) * 4 + q4;
+      *reinterpret_cast<f32x4*>(xch + (((XH ^ 1) * 4 + q4) * 2 + 0) * 256) = f32x4{pp[P][0][0], pp[P][0][1], pp[P][1][0], pp[P][1][1]};
+      *reinterpret_cast<f32x4*>(xch + (((XH ^ 1) * 4 + q4) * 2 + 1) * 256) = f32x4{pp[P][2][0], pp[P][2][1], pp[P][3][0], pp[P][3][1]};
+    }
+    // full tiles with a residual / accumulate / gradient mask: their loads go out before the swap's barrier
+    // (ex[q4][c][i] = value added after the activation, gm = multiplier of the result)
+    const bool plain = !a.res && !a.accum && !a.gmask;
+    f32x2 ex[4][2][2];
+    if (full && !plain && a.ps == 0) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int r = 8 * XH + 2 * q4;
+        const int rc = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const size_t sb = (((size_t)n * a.Cout + co_block + rc + c) * HWo + (size_t)i * a.Wo) * 4;   // scalar
+            f32x2 e = {0.f, 0.f};
+            if (a.res) e = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(a.res) + sb + lane_off);
+            if (a.accum) e += *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(a.y) + sb + lane_off);
+            ex[q4][c][i] = e;
+          }
+      }
+    }
     __syncthreads();
-    f32x4 o8[8];
+    f32x2 o[4][4];   // own pairs, activated
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const f32x4 v = part[XH * 8 + rr] + *reinterpret_cast<const f32x4*>(xch + (XH * 8 + rr) * 256);
-      o8[rr] = __builtin_elementwise_max(v, v * slope);
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int P = XH * 4 + q4;
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(xch + ((XH * 4 + q4) * 2 + 0) * 256);
+      const f32x4 r1 = *reinterpret_cast<const f32x4*>(xch + ((XH * 4 + q4) * 2 + 1) * 256);
+      const f32x2 in[4] = {f32x2{r0[0], r0[1]}, f32x2{r0[2], r0[3]}, f32x2{r1[0], r1[1]}, f32x2{r1[2], r1[3]}};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 v = pp[P][e] + in[e];
+        o[q4][e] = __builtin_elementwise_max(v, v * slope);
+      }
     }
     if (a.ps == 0) {
-      const bool plain = !a.res && !a.accum && !a.gmask;
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        const f32x4 o = o8[rr];
-        const int r = 8 * XH + rr;
-        const int co = co_block + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int r = 8 * XH + 2 * q4;                       // registers r, r + 1 = channels co, co + 1
+        const int rc = (r & 3) + 8 * (r >> 2);               // channel of register r relative to co_block + 4 hi
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {     // the two rows of the tile
-          f32x2 v = i == 0 ? f32x2{o[0], o[1]} : f32x2{o[2], o[3]};
-          const int oy = orow + i;
-          const size_t idx = ((size_t)n * a.Cout + co) * HWo + (size_t)oy * a.Wo + ocol;
-          if (full && plain) {
-            *reinterpret_cast<f32x2*>(a.y + idx) = v;
-            continue;
-          }
-          const bool ok0 = full || (co < a.Cout && oy < a.Ho && ocol < a.Wo);
-          const bool ok1 = full || (ok0 && ocol + 1 < a.Wo);
-          if (!ok0) continue;
-          if (ok1 && (idx & 1) == 0) {
-            if (a.res) v += *reinterpret_cast<const f32x2*>(a.res + idx);
-            if (a.accum) v += *reinterpret_cast<const f32x2*>(a.y + idx);
-            if (a.gmask) {
-              const f32x2 g = *reinterpret_cast<const f32x2*>(a.gmask + idx);
-              v = f32x2{v[0] * (g[0] > 0.f ? 1.f : neg), v[1] * (g[1] > 0.f ? 1.f : neg)};
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {     // the two rows of the tile
+            f32x2 v = {o[q4][2 * i][c], o[q4][2 * i + 1][c]};
+            if (full) {
+              const size_t sb = ((size_t)(rc + c) * HWo + (size_t)i * a.Wo) * 4;   // scalar
+              float* dst = reinterpret_cast<float*>(const_cast<char*>(ybase) + sb + lane_off);
+              if (!plain) {
+                v += ex[q4][c][i];
+                if (a.gmask) {   // (data-gradient launches: the activation mask of the producer, read late -- registers)
+                  const size_t sg = (((size_t)n * a.Cout + co_block + rc + c) * HWo + (size_t)i * a.Wo) * 4;
+                  const f32x2 m = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(a.gmask) + sg + lane_off);
+                  v = f32x2{v[0] * (m[0] > 0.f ? 1.f : neg), v[1] * (m[1] > 0.f ? 1.f : neg)};
+                }
+              }
+              *reinterpret_cast<f32x2*>(dst) = v;
+              continue;
             }
-            *reinterpret_cast<f32x2*>(a.y + idx) = v;
-          } else {
+            const int co = co_block + rc + c + 4 * hi;
+            const int oy = orow + i;
+            const size_t idx = ((size_t)n * a.Cout + co) * HWo + (size_t)oy * a.Wo + ocol;
+            const bool ok0 = co < a.Cout && oy < a.Ho && ocol < a.Wo;
+            const bool ok1 = ok0 && ocol + 1 < a.Wo;
+            if (!ok0) continue;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               if (j == 1 && !ok1) continue;
@@ -385,11 +453,11 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino_kernel(ConvK2 a) {
         }
       }
     } else {
-      // PixelShuffle(2): channels 4 cq .. 4 cq + 3 (registers 4 g .. 4 g + 3) are the 2x2 sub-pixels (dy, dx) of channel cq:
-      // one output row of a tile is 4 consecutive floats (x = 2 ocol .. 2 ocol + 3, dx interleaved) -> 16-byte stores
+      // PixelShuffle(2): channels 4 cq .. 4 cq + 3 (registers 4 g .. 4 g + 3) are the 2x2 sub-pixels (dy, dx) of channel cq;
+      // one output row of a tile is 4 consecutive floats (x = 2 ocol .. 2 ocol + 3, dx interleaved): the register pair
+      // (dx = 0, 1) of y_i0 followed by the pair of y_i1 -> 16-byte stores straight from the packed pairs
 #pragma unroll
       for (int gg = 0; gg < 2; ++gg) {
-        const f32x4 c0 = o8[4 * gg], c1 = o8[4 * gg + 1], c2 = o8[4 * gg + 2], c3 = o8[4 * gg + 3];  // (dy, dx) = 00 01 10 11
         const int co = co_block + 8 * (2 * XH + gg) + 4 * hi;
         const int cq = co >> 2;
         if (co >= a.Cout) continue;
@@ -399,9 +467,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino_kernel(ConvK2 a) {
           if (!full && (oy >= a.Ho || ocol >= a.Wo)) continue;
 #pragma unroll
           for (int dy = 0; dy < 2; ++dy) {
-            const f32x4& e0 = dy ? c2 : c0;   // dx = 0
-            const f32x4& e1 = dy ? c3 : c1;   // dx = 1
-            const f32x4 v = f32x4{e0[2 * i], e1[2 * i], e0[2 * i + 1], e1[2 * i + 1]};
+            const f32x2 e0 = o[2 * gg + dy][2 * i], e1 = o[2 * gg + dy][2 * i + 1];
+            const f32x4 v = f32x4{e0[0], e0[1], e1[0], e1[1]};
             float* dst = a.y + (((size_t)n * (a.Cout >> 2) + cq) * (2 * a.Ho) + (2 * oy + dy)) * (size_t)(2 * a.Wo) + 2 * ocol;
             if (full || ocol + 1 < a.Wo) *reinterpret_cast<f32x4*>(dst) = v;
             else *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};

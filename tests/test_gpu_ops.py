@@ -391,7 +391,7 @@ def test_conv3x3_dma_halo(n, cin, cout, h, w, act, res, monkeypatch):
 # ---- Winograd F(2x2, 3x3) kernel (conv2d_wino_kernel): the large 3x3 / stride-1 layers ----------------------------------
 @pytest.mark.parametrize("n,c0,c1,cout,h,w,act,res,ps,force", [
     (5, 64, 0, 64, 180, 320, 2, False, 0, False),   # fe_rb of the headline clip: 4x64-pixel tiles, all full
-    (2, 64, 64, 64, 96, 128, 1, True, 0, False),    # two inputs (16 chunks), residual
+    (4, 64, 64, 64, 96, 128, 1, True, 0, False),    # two inputs (16 chunks), residual
     (1, 64, 0, 256, 90, 160, 1, False, 2, True),    # PixelShuffle(2) store, partial tile rows and columns
     (3, 72, 0, 40, 90, 200, 0, False, 0, True),     # Cout % 32 != 0, nine chunks, ragged in both directions
     (2, 8, 8, 64, 44, 80, 1, True, 0, True),        # two chunks: first and last block only
