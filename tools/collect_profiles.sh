@@ -81,4 +81,16 @@ for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
 done
 python tools/pmc_mfma.py $out/dbi_SQ_VALU_MFMA_BUSY_CYCLES/p_results.db $out/dbi_GRBM_GUI_ACTIVE/p_results.db > $out/${tag}_pmc_mfma_util_inner_batch.txt
 rm -rf $out/dbi_SQ_VALU_MFMA_BUSY_CYCLES $out/dbi_GRBM_GUI_ACTIVE
+# 10. r03: Winograd F(2x2, 3x3) kernel against the direct DMA-halo kernel per layer shape (accuracy vs fp64, time per launch),
+#     its cycle-stamp timeline (debug build), and the forward with the kernel switched off
+DVSR_CONV_WINO=2 python tools/wino_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_wino_vs_direct.txt
+DVSR_CONV_WINO=0 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
+if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
+  python tools/wino_trace.py 2>&1 | grep -v amdgpu > $out/${tag}_wino_trace.txt
+  python tools/wino_trace.py 5 64 64 64 180 320 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
+fi
+echo "== forward 180x320 with DVSR_CONV_WINO=0 (direct kernels only)" >> $out/${tag}_wino_vs_direct.txt
+DVSR_CONV_WINO=0 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-inner-step --no-split --no-meta --no-validation 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'])" >> $out/${tag}_wino_vs_direct.txt
 du -sh gpurun_out

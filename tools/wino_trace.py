@@ -61,6 +61,9 @@ print("core clock (s_memtime / s_memrealtime): %.0f MHz; kernel wall span %.1f u
       (np.median((t[:, 42] - t[:, 0]) / np.maximum(rt, 1)) * 100.0, (t[:, 61].max() - t[:, 60].min()) / 100.0))
 stat("workgroup lifetime", t[:, 42] - t[:, 0])
 stat("prologue: first DMA landed", t[:, 1] - t[:, 0])
+if t[:, 44].any():   # persistent workgroups: the stamps are those of the LAST tile of each workgroup
+    stat("last tile: loop top before the barrier", t[:, 43] - t[:, 44])
+    stat("last tile: loop-top barrier (DMA wait)", t[:, 1] - t[:, 43])
 stat("prologue: first transform", t[:, 2] - t[:, 1])
 nch = (c0 + c1) // 8
 prev = t[:, 2]
