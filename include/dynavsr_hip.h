@@ -307,7 +307,10 @@ int dvsr_conv2d_dgrad_packed(const dvsr_conv2d_desc* d, const float* gy, float* 
  * tile rows (x 32 pixels), 32-output-channel halves per workgroup, 1 when the halo is staged by LDS-DMA
  * (conv2d_dma_kernel: 3x3 / stride 1, 16-byte aligned inputs, W % 4 == 0, channel counts % 8 == 0), 2 for the row-split
  * DMA kernel of 7x7 / 9x9 convolutions (conv2d_dmarow_kernel) -- for those sizes the packed entries exist ONLY when
- * geo[3] == 2, otherwise use dvsr_conv2d_forward / _backward.  32-channel chunks = the K-split small-grid kernel. */
+ * geo[3] == 2, otherwise use dvsr_conv2d_forward / _backward.  32-channel chunks = the K-split small-grid kernel.
+ * geo[3] == 3: the Winograd F(2x2, 3x3) kernel (conv2d_wino_kernel; the DMA-halo kernel's conditions and at least 16 input
+ * channels; geo[1] = 4: 4x64-pixel workgroup tiles, 8: 8x32), chosen per shape by a cost model; the environment variable
+ * DVSR_CONV_WINO=0 keeps the direct kernels, =2 takes it wherever it is eligible.  Same results within fp32 round-off. */
 int dvsr_conv2d_packed_geometry(const dvsr_conv2d_desc* d, int geo[4]);
 
 /* Weight / bias gradient of a single-input 3x3 stride-1 convolution with both operands rounded to bf16 on
