@@ -130,3 +130,25 @@ def test_psnr_golden():
     g = load_golden("psnr")
     gt = synth.clip(int(g["gtseed"]), 1, 1, 256, 256)[0, 0]
     assert abs(inner.psnr_uint8(g["img"], inner.tensor2img_rgb(gt)) - float(g["psnr"])) < 1e-12
+
+
+def test_winograd_f2x2_3x3_restatement_equals_correlation():
+    """oracle/winograd.py (the transforms conv2d_wino.hip uses) against a plain 3x3 / stride-1 / pad-1 correlation, in fp64
+    (identity up to round-off) and with the transformed-domain products rounded to fp32 (the kernel's arithmetic)."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle import winograd
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((2, 5, 8, 12))
+    w = rs.standard_normal((7, 5, 3, 3)) / np.sqrt(45.0)
+    b = rs.standard_normal(7)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, 1).numpy()
+    got = winograd.conv3x3_winograd(x, w, b)
+    assert np.abs(got - ref).max() < 1e-12
+    got32 = winograd.conv3x3_winograd(x, w, b, dtype=np.float32)
+    assert np.linalg.norm(got32 - ref) / np.linalg.norm(ref) < 2e-6
+    # the weight transform alone: U[0][0] = g[0][0], U[3][3] = g[2][2], U[1][1] = sum(g) / 4
+    U = winograd.weight_transform(w)
+    assert np.allclose(U[0, 0], w[:, :, 0, 0]) and np.allclose(U[3, 3], w[:, :, 2, 2])
+    assert np.allclose(U[1, 1], w.sum((2, 3)) / 4)
