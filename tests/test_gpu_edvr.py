@@ -778,6 +778,38 @@ def test_inner_step_size_forward_backward_vs_oracle():
     assert abs(gn(net.parameters()) - gn(PO.values())) / gn(PO.values()) < 5e-3
 
 
+def test_winograd_path_equals_direct_path_forward_and_backward(monkeypatch):
+    """The same clip through the tape with the large 3x3 convolutions on the Winograd kernel (default cost model: every
+    96x128 level-1 layer of this 5-frame clip takes it, forward and data gradient) and with DVSR_CONV_WINO=0 (direct
+    kernels): output, loss and every parameter gradient agree to fp32 round-off -- the two are different algorithms for
+    the same sums, kink flips bound the gradients."""
+    from dynavsr_amd import engine, hipops
+    x = synth.clip(5, 1, 5, 96, 128)
+    tgt = synth.clip(6, 1, 1, 384, 512)[:, 0]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DVSR_CONV_WINO", mode)
+        engine._plans.clear()          # geometry is chosen when a plan is built
+        net = make_net(0)
+        plan = engine.get_plan(net._cfg(), 1, 96, 128)
+        tags = [nm for (_k, nm, _f, _b) in plan.op_info()]
+        nw = sum(1 for t in tags if t.endswith("w]"))
+        assert (nw > 20) if mode == "1" else (nw == 0), (mode, nw)
+        xg = x.cuda().requires_grad_(True)
+        y = net(xg)
+        loss = hipops.charbonnier(y, tgt.cuda())
+        loss.backward()
+        res[mode] = (y.detach().cpu(), float(loss.detach()), xg.grad.cpu(), [p.grad.detach().cpu() for p in net.parameters()])
+    engine._plans.clear()
+    (y1, l1, gx1, g1), (y0, l0, gx0, g0) = res["1"], res["0"]
+    assert relerr(y1, y0) < 5e-6 and abs(l1 - l0) / abs(l0) < 1e-6
+    assert relerr(gx1, gx0) < 5e-3
+    gn = lambda gs: float(torch.sqrt(sum((g.double() ** 2).sum() for g in gs)))
+    assert abs(gn(g1) - gn(g0)) / gn(g0) < 5e-3
+    worst = max(relerr(a, b) for a, b in zip(g1, g0))
+    assert worst < 5e-2, worst
+
+
 # ---- BASELINE.json configs[4]: EDVR-L x4 (nf 128, 7 frames, 40 blocks) on 1x7x3x64x64 (256x256 HR tiles) -----------
 EDVR_L = dict(nf=128, nframes=7, groups=8, front_RBs=5, back_RBs=40, scale=4)
 _edvr_l_cache = {}
