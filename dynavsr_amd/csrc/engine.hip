@@ -820,6 +820,7 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
     if (o.type == OP_DCN && fwd_base && o.wp_floats) {
       for (int ws = 0; ws < S; ++ws) {
         PackEntry& e = t.e[t.n++];
+        e = PackEntry{};   // (slots are reused after a flush: no field may keep the previous occupant's value -- perm!)
         e.w = P[o.pw] + (size_t)ws * o.Cout * o.c0 * 9; e.P = fwd_base + o.wp_off + (size_t)ws * o.wp_floats;
         e.Cout = o.Cout; e.Ctot = o.c0; e.KK = 9; e.CC = 8; e.wt = 0;
         e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64); e.nchunks = o.c0 / 8; e.pch = conv2_pch(3, 1); e.bf = 0;
@@ -840,6 +841,7 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
     for (int ws = 0; ws < S; ++ws) {
       if (fwd_base) {
         PackEntry& e = t.e[t.n++];
+        e = PackEntry{};
         e.w = wsrc + ws * wnum; e.P = fwd_base + o.wp_off + (size_t)ws * o.wp_floats; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
         e.CC = o.geo.cc; e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
         e.nchunks = ceil_div(ctot, e.CC); e.bf = o.geo.bf; e.perm = o.geo.dma; e.pch = conv2_pch_cc(o.ks, e.CC, e.bf, o.geo.dma);
@@ -850,6 +852,7 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
           const int ci = which ? o.c1 : o.c0;
           if (!ci) continue;
           PackEntry& e = t.e[t.n++];
+          e = PackEntry{};
           e.w = wsrc + ws * wnum; e.P = bwd_base + o.dpk_off[which] + (size_t)ws * o.dpk_floats[which]; e.Cout = ci; e.Ctot = o.Cout;
           e.KK = KK;
           e.CC = o.dgeo[which].cc; e.wt = 1; e.w_ctot = ctot; e.w_coff = which ? o.c0 : 0;

@@ -950,7 +950,7 @@ def test_edvr_stacked_tape_gives_per_clip_gradients(k, h, w):
         engine.EdvrStackedFunction.apply(x, net._cfg(), False, *[s[:1] for s in stacked])
 
 
-@pytest.mark.parametrize("k,h,w", [(3, 16, 24), (2, 44, 80)])
+@pytest.mark.parametrize("k,h,w", [(3, 16, 24), (2, 44, 80), (2, 96, 128)])   # (96x128: the level-1 layers on the Winograd kernel)
 def test_edvr_stacked_tape_per_slice_weights(k, h, w):
     """dvsr_edvr_plan_create_ex with weight_sets = K: clip k is convolved with ITS OWN copy of the weights (the private
     copies of K frames after they have diverged: later inner steps, adapted forwards).  Every slice is a differently
