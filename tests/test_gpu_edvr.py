@@ -913,7 +913,7 @@ def _stack(params, k):
     return [p.detach().unsqueeze(0).repeat((k,) + (1,) * p.dim()).contiguous().requires_grad_() for p in params]
 
 
-@pytest.mark.parametrize("k,h,w", [(3, 16, 24), (2, 44, 80)])
+@pytest.mark.parametrize("k,h,w", [(3, 16, 24), (2, 44, 80), (2, 96, 128)])   # (96x128: DMA-halo / Winograd / FAST wgrad kernels)
 def test_edvr_stacked_tape_gives_per_clip_gradients(k, h, w):
     """EdvrStackedFunction: K clips as one batch, parameters stacked [K, ...] with equal slices; slice k of every gradient
     must be what a B = 1 pass over clip k alone produces (same kernels; launch geometry and atomic order may differ:
@@ -1049,6 +1049,34 @@ def test_adapt_video_batched_frames_equal_the_per_frame_loop(optimizer, overlap)
     opt["train"]["maml"]["use_patch"] = True
     assert not FrameBatch.supported(opt, model, est)
     opt["train"]["maml"]["use_patch"] = False
+
+
+def test_adapt_video_batched_at_the_north_star_size():
+    """The batched pipeline at the size bench.py measures it on (LR 176x320, SLR 44x80; four frames per batch -> 20-image
+    launches: the large-grid kernels -- DMA-halo, Winograd, FAST weight gradient, per-frame weight sets in the adapted
+    forwards) against the per-frame loop: same baselines, losses, SLR clips and adapted frames."""
+    from dynavsr_amd.adapt import adapt_frame, adapt_video
+    from dynavsr_amd.models import create_model
+    opt = _gpu_opt("Adam")
+    model, est = create_model(opt)
+    modelcp, estcp = create_model(opt)
+    _, est_fixed = create_model(opt)
+    model.netG.load_state_dict(synth.edvr_state_dict(0)); est.netE.load_state_dict(synth.mfdn_state_dict(0))
+    est_fixed.netE.load_state_dict(synth.mfdn_state_dict(1))
+    clips = [{"LQs": synth.clip(70 + i, 1, 5, 176, 320).cuda()} for i in range(4)]
+    want = []
+    for c in clips:
+        model.feed_data(c, need_GT=False); model.test()
+        base = model.fake_H.clone()
+        r = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, c)
+        want.append((base.cpu(), r["sr"].cpu(), float(r["losses"][0]), r["slr"].cpu()))
+    got = list(adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips, frames_per_batch=4))
+    assert len(got) == 4
+    for (base, r), w_ in zip(got, want):
+        assert relerr(base.cpu(), w_[0]) < 1e-6
+        assert abs(float(r["losses"][0]) - w_[2]) <= 2e-6 * abs(w_[2])
+        assert relerr(r["slr"].cpu(), w_[3]) < 1e-6
+        assert relerr(r["sr"].cpu(), w_[1]) < 1e-4
 
 
 def test_validate_video_psnr_vectors_match_the_host_definition():

@@ -121,7 +121,7 @@ def test_estimator_rejects_input_grad_and_bad_shapes():
         net(synth.clip(1, 1, 5, 18, 16).transpose(1, 2).contiguous().cuda())
 
 
-@pytest.mark.parametrize("scale,k,t,h,w", [(4, 3, 5, 32, 48), (2, 2, 3, 24, 40)])
+@pytest.mark.parametrize("scale,k,t,h,w", [(4, 3, 5, 32, 48), (2, 2, 3, 24, 40), (4, 2, 5, 176, 320)])   # (+ the bench size)
 def test_mfdn_stacked_tape_gives_per_clip_gradients(scale, k, t, h, w):
     """EstimatorStackedFunction (dvsr_estimator_plan_create_grouped): K clips as one batch, per-clip parameter
     gradients in the slices of the stacked parameters == K separate B = 1 passes (incl. the re-laid-out 4x4 stride-2
@@ -144,7 +144,7 @@ def test_mfdn_stacked_tape_gives_per_clip_gradients(scale, k, t, h, w):
         assert not bad, (i, bad)
 
 
-@pytest.mark.parametrize("scale,k,t,h,w", [(4, 3, 5, 32, 48), (2, 2, 3, 24, 40)])
+@pytest.mark.parametrize("scale,k,t,h,w", [(4, 3, 5, 32, 48), (2, 2, 3, 24, 40), (4, 2, 5, 176, 320)])   # (+ the bench size)
 def test_mfdn_stacked_tape_per_slice_weights(scale, k, t, h, w):
     """dvsr_estimator_plan_create_ex with weight_sets = K: clip k runs on slice k of the stacked parameters (copies that
     have diverged), output and slice k of every gradient == a B = 1 pass through a network holding slice k."""
