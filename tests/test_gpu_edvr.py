@@ -1077,6 +1077,16 @@ def test_adapt_video_batched_at_the_north_star_size():
         assert abs(float(r["losses"][0]) - w_[2]) <= 2e-6 * abs(w_[2])
         assert relerr(r["slr"].cpu(), w_[3]) < 1e-6
         assert relerr(r["sr"].cpu(), w_[1]) < 1e-4
+    # three inner steps (BASELINE configs[2]): steps 2 and 3 and the adapted forwards run on per-frame weight sets
+    opt["train"]["maml"]["adapt_iter"] = 3
+    want3 = []
+    for c in clips[:2]:
+        r = adapt_frame(opt, model, est, modelcp, estcp, est_fixed, c)
+        want3.append((r["sr"].cpu(), [float(v) for v in r["losses"]]))
+    got3 = list(adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips[:2], frames_per_batch=2))
+    for (base, r), (sr_w, l_w) in zip(got3, want3):
+        assert all(abs(float(a) - b) <= 1e-5 * abs(b) for a, b in zip(r["losses"], l_w)), (r["losses"], l_w)
+        assert relerr(r["sr"].cpu(), sr_w) < 2e-4
 
 
 def test_validate_video_psnr_vectors_match_the_host_definition():
