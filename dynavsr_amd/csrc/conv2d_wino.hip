@@ -51,46 +51,47 @@ namespace dvsr {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // P[cb][k][((xn*2 + hi)*64 + co_l)*4 + j] = (G g G^T)[xi][nu] of (cout = cb*64 + co_l, cin = k*8 + 2j + hi), xn = 4 xi + nu.
+// One thread = one (cout, cin) pair: nine contiguous weights in, sixteen transformed values out (a wave = 8 couts x 8
+// channels writes two 128-byte runs per xn).
 __global__ void pack_weights_wino_kernel(PackTable t) {
   const PackEntry& e = t.e[blockIdx.y];
   if (e.perm != 3) return;
-  const size_t per_chunk = 8192;
-  const size_t total = (size_t)e.ncb * e.nchunks * per_chunk;
+  const size_t total = (size_t)e.ncb * e.nchunks * 512;   // (cout, cin) pairs incl. padding
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    int r = (int)(i % per_chunk);
-    const size_t ck = i / per_chunk;
+    const int c8 = (int)(i & 7), col = (int)((i >> 3) & 63);
+    const size_t ck = i >> 9;
     const int k = (int)(ck % e.nchunks), cb = (int)(ck / e.nchunks);
-    const int j = r & 3; r >>= 2;
-    const int col = r & 63; r >>= 6;
-    const int hi = r & 1; r >>= 1;
-    const int xi = r >> 2, nu = r & 3;
-    const int co = cb * 64 + col, ci = k * 8 + 2 * j + hi;
-    float v = 0.f;
-    if (co < e.Cout && ci < e.Ctot) {
-      float g[3][3];
+    const int co = cb * 64 + col, ci = k * 8 + c8;
+    float g[3][3];
+    const bool ok = co < e.Cout && ci < e.Ctot;
+    const float* src = !e.wt ? e.w + ((size_t)co * e.Ctot + ci) * 9 : e.w + ((size_t)ci * e.w_ctot + e.w_coff + co) * 9;
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const int tap = a * 3 + b;
-          g[a][b] = !e.wt ? e.w[((size_t)co * e.Ctot + ci) * 9 + tap]
-                          : e.w[((size_t)ci * e.w_ctot + e.w_coff + co) * 9 + (8 - tap)];
-        }
-      // row xi of G applied to the columns of g, then row nu of G to the result
-      float c[3];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        c[b] = xi == 0 ? g[0][b] : (xi == 3 ? g[2][b] : 0.5f * (xi == 1 ? (g[0][b] + g[1][b] + g[2][b]) : (g[0][b] - g[1][b] + g[2][b])));
-      }
-      v = nu == 0 ? c[0] : (nu == 3 ? c[2] : 0.5f * (nu == 1 ? (c[0] + c[1] + c[2]) : (c[0] - c[1] + c[2])));
+    for (int tap = 0; tap < 9; ++tap) {
+      const float v = ok ? src[e.wt ? 8 - tap : tap] : 0.f;
+      g[tap / 3][tap % 3] = v;
     }
-    e.P[i] = v;
+    // rows of G on the columns of g (c[xi][b]), then on the rows of the result: same operation order as before
+    float c[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      c[0][b] = g[0][b];
+      c[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+      c[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+      c[3][b] = g[2][b];
+    }
+    float* dst = e.P + ck * 8192 + ((size_t)(c8 & 1) * 64 + col) * 4 + (c8 >> 1);
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      dst[(xi * 4 + 0) * 512] = c[xi][0];
+      dst[(xi * 4 + 1) * 512] = 0.5f * (c[xi][0] + c[xi][1] + c[xi][2]);
+      dst[(xi * 4 + 2) * 512] = 0.5f * (c[xi][0] - c[xi][1] + c[xi][2]);
+      dst[(xi * 4 + 3) * 512] = c[xi][2];
+    }
   }
 }
 
 int pack_weights_wino_run(const PackTable& t, hipStream_t st) {
-  // (one entry = 16 x Cout x Ctot outputs of nine loads each: latency-bound, so many blocks per entry -- 61 -> 20 us per launch)
-  hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(256, t.n), dim3(256), 0, st, t);
+  hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(64, t.n), dim3(256), 0, st, t);
   return check_launch("pack_weights_wino_kernel");
 }
 
