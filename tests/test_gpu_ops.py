@@ -395,6 +395,7 @@ def test_conv3x3_dma_halo(n, cin, cout, h, w, act, res, monkeypatch):
     (1, 64, 0, 256, 90, 160, 1, False, 2, True),    # PixelShuffle(2) store, partial tile rows and columns
     (3, 72, 0, 40, 90, 200, 0, False, 0, True),     # Cout % 32 != 0, nine chunks, ragged in both directions
     (2, 8, 8, 64, 44, 80, 1, True, 0, True),        # two chunks: first and last block only
+    (2, 64, 0, 216, 96, 128, 0, False, 0, True),    # the offset / mask conv: the last 64-cout block holds 24 (its upper-half waves idle)
 ])
 def test_conv3x3_winograd(n, c0, c1, cout, h, w, act, res, ps, force, monkeypatch):
     """Forward (and data gradient for single plain inputs) on the Winograd kernel against fp64 torch; the geometry query
