@@ -1001,7 +1001,11 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
       return ceil(wgs / 256.0) * (nch * 5100.0 + 12500.0) / 2.07;   // (measured: tools/wino_trace.py, 2.07 GHz under this kernel)
     };
     const double w4 = wino_cost(4, 64), w8 = wino_cost(8, 32);
-    const double direct = std::min(c42, c41) * nch / 0.78 / 2.4;
+    // (the direct kernels reach 0.78 of their MFMA time only over many rounds of workgroups; on grids of a few rounds their
+    // prologue / epilogue is exposed: L2_fea 5x64->64 @90x160 measures 0.60 -- profiles/r03_c_per_launch_fwd180x320.txt)
+    const double dcyc = std::min(c42, c41);
+    const double drounds = dcyc / (64.0 * 9 * 4 * (c41 < 0.97 * c42 ? 1 : 2));
+    const double direct = dcyc * nch / (drounds <= 6.0 ? 0.60 : 0.78) / 2.4;
     const double best = std::min(w4, w8);
     if (wino_on == 2 || best < direct) return ConvGeo{8, w8 < w4 ? 8 : 4, 2, 0, 3};
   }
