@@ -13,17 +13,23 @@
 // only add/subtract and halve, the result differs from the direct sum by a few fp32 ulps (tests: rel-L2 <= 2e-6 against
 // the direct kernel, the network-level goldens unchanged).
 //
-// Work split (one workgroup = 4 waves = one CU: 256 accumulator registers per lane leave room for nothing else):
+// Work split (one workgroup = 8 waves = one CU; the accumulators are the whole register file: 16 xn x 64 couts x 64 tiles):
 //   * workgroup tile = 64 couts x 64 tiles (TC tile columns x 64/TC tile rows: 4x64 or 8x32 output pixels);
-//   * wave (mh, tr) = 32 couts x 32 tiles x all 16 xn: acc[16] x f32x16 in AGPRs; per chunk and xn ONE ds_read_b128 for A
-//     (4 k-steps of U) and one for B (4 k-steps of V), then 4 dependent MFMAs (issue = dependent latency = 64 cycles);
-//     the output transform is then lane-local: a lane holds M[0..15] of its (cout, tile) pairs;
+//   * wave (mh, tr, xh) = 32 couts x 32 tiles x EIGHT xn (rows xi in {0,1} or {2,3} of the transformed patch): acc[8] x
+//     f32x16, two waves per SIMD.  (Four waves x 16 xn was built first: with ONE wave on a SIMD every dependent VALU chain
+//     and LDS round trip of the transforms stalls the MFMA stream -- 174 us on a layer this design does in 132.)
+//     Per chunk and pair of xn: one ds_read_b128 of U per xn (4 k-steps) and four 4-byte reads of V (ds_read2st64_b32),
+//     two independent accumulator chains alternating, operands one pair ahead;
 //   * per chunk the workgroup moves U(k+1) (32 KB, the packed LDS image) and the raw halo of chunk k+2 global -> LDS by
-//     DMA (16 B per lane), transforms the raw halo of chunk k+1 into V (each thread: two channels of one tile as
-//     packed-fp32 pairs, 32 v_pk_add, 16 conflict-free ds_write_b64) and runs the 64 MFMAs of chunk k; one barrier.
+//     buffer-load DMA (16 B per lane; per-lane offset fixed, chunk offsets scalar), transforms the raw halo of chunk k+1
+//     into V (wave = channel, lane = tile: three aligned 8-byte reads per patch row, 32 adds, sixteen conflict-free 4-byte
+//     stores into V[xn][channel][tile]) and runs its 32 MFMAs; ONE barrier per chunk, in front of the last MFMA pair, whose
+//     MFMAs cover the LDS round trip of the next chunk's first operands.
 // LDS: 2 x (U 32 KB + V 32 KB + raw <= 13.5 KB) = 155 KB of the CU's 160 KB.
-// Epilogue: A^T M A in registers (24 adds per (cout, tile), packed over cout pairs), then bias / activation / residual /
-// accumulate / gradient mask / PixelShuffle(2) exactly as store_mfma_tile does for the direct kernels.
+// Epilogue: Y = A^T M A is linear in the rows of M: each wave reduces its two rows to a partial 2x2 output per (cout,
+// tile) in registers (packed over cout pairs), the two waves of a pair swap halves through the idle LDS buffers and each
+// finishes 8 of the 16 cout registers: bias / activation / residual / accumulate / gradient mask / PixelShuffle(2) exactly
+// as store_mfma_tile does for the direct kernels.  Design notes and measurements: DESIGN.md 3.1e.
 #include <type_traits>
 
 #include "common.h"
