@@ -785,6 +785,10 @@ def main():
             roof["mfma_flops_executed_frac"] = executed / fl
             roof["mfma_pipe_frac"] = executed / (t_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS
             roof["winograd_launch_share_of_kernel_time"] = wt / t_ms
+            roof["note"] = ("frac = ALGORITHMIC FLOPs / time / peak as the bench contract defines it; it can exceed 1 because the "
+                            "Winograd launches issue 4/9 of the algorithmic multiplies -- mfma_pipe_frac is the pipe's own "
+                            "utilisation (PMC SQ_VALU_MFMA_BUSY_CYCLES agrees: profiles/*_pmc_mfma_util.txt); with "
+                            "DVSR_CONV_WINO=0 the direct kernels measure frac 0.70 (profiles/*_wino_vs_direct.txt)")
         line["roofline"] = roof
         line["kernel_breakdown_ms_per_step"] = {k: round(a[0] / reps, 4) for k, a in
                                                 sorted(acc.items(), key=lambda kv: -kv[1][0])}
