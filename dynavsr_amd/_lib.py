@@ -143,6 +143,8 @@ def _declare(lib):
         "dvsr_debug_mfma_peak": (LL, [P, I, I, I, I, P]),
         "dvsr_debug_mfma_shadow": (I, [P, P, I, I, I, I, I, P]),
         "dvsr_edvr_tensor_info": (I, [P, c_char_p, POINTER(LL), POINTER(LL)]),
+        "dvsr_edvr_plan_work": (I, [P, POINTER(ctypes.c_double * 4)]),
+        "dvsr_estimator_plan_work": (I, [P, POINTER(ctypes.c_double * 4)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -346,7 +346,8 @@ def validate_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed,
     super-resolves the frames range(rank, len(clips), world) (adapt_video), PSNR of the un-adapted ('start') and of the
     adapted ('final') output against ``gts[i]`` [3,sH,sW] with the reference's uint8 definition, computed on the device
     (utils.util.frame_metrics, no per-frame host sync); the two vectors are reduced to rank 0 (dist.validate_sharded).
-    Returns {'psnr_start', 'psnr_final'} as float64 tensors of length len(clips) (complete on rank 0) and 'frames'."""
+    Returns {'psnr_start', 'psnr_final'} as float64 tensors of length len(clips) (complete on rank 0; NaN where this rank
+    holds no result; +inf for an exact match, as util.calculate_psnr), 'evaluated' (bool mask) and 'frames'."""
     from . import dist as D
     from .utils import util
     dev = next(model.netG.parameters()).device
@@ -356,12 +357,18 @@ def validate_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed,
         for i, (base, r) in zip(indices, adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, mine,
                                                      overlap=overlap, frames_per_batch=frames_per_batch)):
             gt = gts[i].to(dev)
-            yield (util.frame_metrics(base[0], gt, need_img=None)[0], util.frame_metrics(r['sr'][0], gt, need_img=None)[0])
-    mse_s, mse_f = D.validate_sharded(len(clips), run, rank, world, group, dev)
-    # (entries of other ranks' frames are 0 before the reduction and stay 0 off rank 0: PSNR is taken where mse > 0 ...
-    # an exact match would read as "not evaluated", as in the reference's `(v != 0).sum()`, :735-737)
-    psnr = lambda m: torch.where(m > 0, 20 * torch.log10(255.0 / torch.sqrt(m.clamp_min(1e-300))), torch.zeros_like(m))
-    return {'psnr_start': psnr(mse_s), 'psnr_final': psnr(mse_f), 'frames': D.shard_indices(len(clips), rank, world)}
+            yield (util.frame_metrics(base[0], gt, need_img=None)[0], util.frame_metrics(r['sr'][0], gt, need_img=None)[0], 1.0)
+    mse_s, mse_f, seen = D.validate_sharded(len(clips), run, rank, world, group, dev, n_metrics=3)
+    # A separate 'evaluated' vector travels with the two MSE vectors (all zero-initialised, summed to rank 0): an exact match
+    # (mse == 0) is +inf dB like util.calculate_psnr, an entry this rank does not hold (other ranks' frames off rank 0) is NaN.
+    seen = seen > 0
+    inf, nan = float('inf'), float('nan')
+
+    def psnr(m):
+        v = torch.where(m > 0, 20 * torch.log10(255.0 / torch.sqrt(m.clamp_min(1e-300))), torch.full_like(m, inf))
+        return torch.where(seen, v, torch.full_like(m, nan))
+    return {'psnr_start': psnr(mse_s), 'psnr_final': psnr(mse_f), 'evaluated': seen,
+            'frames': D.shard_indices(len(clips), rank, world)}
 
 
 class FrameBatch:
@@ -413,10 +420,19 @@ class FrameBatch:
         """What the batched step covers; everything else takes the per-frame loop."""
         m = opt['train']['maml']
         from .models.loss import CharbonnierLoss
-        return (m['adapt_iter'] >= 1 and not m['use_patch'] and not opt['train']['use_real']
-                and hasattr(model.netG, 'forward_stacked') and hasattr(est_model.netE, 'forward_stacked')
-                and isinstance(model.cri_pix, CharbonnierLoss) and next(model.netG.parameters()).is_cuda
-                and not list(model.netG.buffers()) and not list(est_model.netE.buffers()))
+        ok = (m['adapt_iter'] >= 1 and not m['use_patch'] and not opt['train']['use_real']
+              and hasattr(model.netG, 'forward_stacked') and hasattr(est_model.netE, 'forward_stacked')
+              and isinstance(model.cri_pix, CharbonnierLoss) and next(model.netG.parameters()).is_cuda
+              and not list(model.netG.buffers()) and not list(est_model.netE.buffers()))
+        if not ok:
+            return False
+        # what the per-sample weight sets of the native tapes need (dvsr_edvr_plan_create_ex: whole 8-channel deformable
+        # groups; the fused DCN backward: whole 64-cout blocks; no DVSR_CONV_V1 A/B kernel) -- anything else would raise
+        # DVSR_ERR_UNSUPPORTED in the middle of a batch instead of taking the per-frame loop
+        import os
+        nf, groups = int(model.netG.nf), int(model.netG.groups)
+        return (nf % 64 == 0 and groups > 0 and nf % groups == 0 and (nf // groups) % 8 == 0
+                and os.environ.get("DVSR_CONV_V1", "0") in ("", "0"))
 
     def refresh(self, netG, netE):
         """Every slice = the un-adapted weights (the per-frame deepcopy), fresh optimiser state."""

@@ -222,6 +222,33 @@ __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT]
   }
 }
 
+// Compute units of the current device (cached per ordinal; 256 on MI355X).
+inline int device_cus() {
+  static int cus[64] = {};
+  int d = 0;
+  (void)hipGetDevice(&d);
+  d &= 63;
+  if (!cus[d]) {
+    hipDeviceProp_t prop;
+    cus[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cus[d];
+}
+
+// hipFuncSetAttribute (the dynamic-LDS limit of a kernel) applies to the CURRENT device only: a launcher keeps one flag per
+// device ordinal, so a process that drives several GPUs (or rebuilds plans after hipSetDevice) sets it on each of them.
+struct PerDeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    if (done[d]) return false;
+    done[d] = true;   // (benign race: the attribute call is idempotent)
+    return true;
+  }
+};
+
 // Store modes carried in TileOut::ps beyond 0 (plain) and 2 (PixelShuffle(2)): the tile goes STRAIGHT into the
 // explicitly padded tensor the next convolution of the estimator reads (LRimg_estimator.py:82-86: ReflectionPad2d(1) in
 // front of every 2-D conv), so that no pad kernel re-reads and re-writes the whole activation (r03):
@@ -247,8 +274,11 @@ __device__ __forceinline__ void store_mfma_tile_padded(const f32x16 (&acc)[MT][N
     return s2d ? (size_t)(2 * (py & 1) + (px & 1)) * plane + (size_t)(py >> 1) * Ws + (px >> 1) : (size_t)py * Ws + px;
   };
   const bool col_ok = ox < t.Wo;
-  const int pxm = ox == 1 ? 0 : (ox == t.Wo - 2 ? Wp - 1 : -1);       // this lane's column also feeds the ring
-  const bool col_ring = __builtin_amdgcn_ballot_w64(pxm >= 0 && col_ok) != 0;
+  // this lane's column also feeds the ring: column 1 -> padded column 0, column Wo - 2 -> padded column Wp - 1 (two
+  // independent mirrors, like the rows: with Wo == 3 column 1 feeds BOTH)
+  const int pxm[2] = {ox == 1 ? 0 : -1, ox == t.Wo - 2 ? Wp - 1 : -1};
+  const bool col_ring[2] = {__builtin_amdgcn_ballot_w64(pxm[0] >= 0 && col_ok) != 0,
+                            __builtin_amdgcn_ballot_w64(pxm[1] >= 0 && col_ok) != 0};
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     float v[NT][16];
@@ -269,9 +299,9 @@ __device__ __forceinline__ void store_mfma_tile_padded(const f32x16 (&acc)[MT][N
       for (int a = 0; a < 3; ++a) {
         if (pys[a] < 0) continue;                                      // wave-uniform
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if (b == 1 && !col_ring) continue;                           // wave-uniform
-          const int px = b == 0 ? ox + 1 : pxm;
+        for (int b = 0; b < 3; ++b) {
+          if (b >= 1 && !col_ring[b - 1]) continue;                    // wave-uniform
+          const int px = b == 0 ? ox + 1 : pxm[b - 1];
           const bool ok = col_ok && px >= 0;
           const size_t lo_ = ok ? loff(pys[a], px) : 0;
 #pragma unroll

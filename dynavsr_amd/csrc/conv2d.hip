@@ -159,11 +159,10 @@ template <int KS, int S, int CC, int MT = 2>
 static int launch_conv(const ConvK& k, hipStream_t st) {
   using Sh = ConvShape<KS, S, CC>;
   auto kern = conv2d_mfma_kernel<KS, S, CC, MT>;
-  static bool attr_done = false;  // benign race: idempotent
-  if (!attr_done) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)Sh::LDS_BYTES);
-    attr_done = true;
   }
   const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Sh::LDS_BYTES, st, k);

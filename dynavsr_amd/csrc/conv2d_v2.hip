@@ -81,7 +81,7 @@ int conv2_pch(int ks, int stride) {  // packed floats per (64-cout block, chunk)
 // wt = 1 (data gradient): this conv's (cin, cout, tap) = original (cout, cin slice, mirrored tap).
 __global__ void pack_weights_kernel(PackTable t) {
   const PackEntry& e = t.e[blockIdx.y];
-  if (e.bf || e.perm == 3) return;  // packed by pack_weights_bf16_kernel / pack_weights_wino_kernel
+  if (e.bf || e.perm >= 3) return;  // packed by pack_weights_bf16_kernel / pack_weights_wino(3)_kernel
   const int kq4 = e.CC / 8;
   const size_t per_chunk = (size_t)e.pch;
   const size_t total = (size_t)e.ncb * e.nchunks * per_chunk;
@@ -147,10 +147,14 @@ __global__ void pack_weights_bf16_kernel(PackTable t) {
 
 int pack_weights_run(const PackTable& t, hipStream_t st) {
   if (t.n <= 0) return DVSR_OK;
-  bool any_f32 = false, any_bf = false, any_wino = false;
-  for (int i = 0; i < t.n; ++i) (t.e[i].bf ? any_bf : (t.e[i].perm == 3 ? any_wino : any_f32)) = true;
+  bool any_f32 = false, any_bf = false, any_wino = false, any_wino3 = false;
+  for (int i = 0; i < t.n; ++i) (t.e[i].bf ? any_bf : (t.e[i].perm == 3 ? any_wino : (t.e[i].perm == 4 ? any_wino3 : any_f32))) = true;
   if (any_wino) {
     int rc = pack_weights_wino_run(t, st);
+    if (rc) return rc;
+  }
+  if (any_wino3) {
+    int rc = pack_weights_wino3_run(t, st);
     if (rc) return rc;
   }
   if (any_f32) {
@@ -500,15 +504,14 @@ template <int KS, int S, int CC, int TH, int MT, int BF = 0>
 static int launch_conv2(ConvK2 k, hipStream_t st) {
   using Sh = Conv2Shape<KS, S, CC, TH, MT, BF>;
   auto kern = conv2d_pipe_kernel<KS, S, CC, TH, MT, BF>;
-  static bool attr_done = false;
+  static PerDeviceOnce attr_once;
   size_t lds = Sh::LDS_BYTES;
 #ifdef DVSR_CONV_TRACE
   // debug: DVSR_CONV_LDS=<bytes> inflates the LDS request to force fewer workgroups per CU
   if (const char* e = getenv("DVSR_CONV_LDS")) lds = std::max(lds, (size_t)atol(e));
 #endif
-  if (!attr_done) {
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
   }
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 32 * MT);
@@ -693,10 +696,9 @@ template <int TH, int MT>
 static int launch_dma(ConvK2 k, hipStream_t st) {
   using Sh = DmaShape<TH, MT>;
   auto kern = conv2d_dma_kernel<TH, MT>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
-    attr_done = true;
   }
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 32 * MT);
@@ -876,10 +878,9 @@ template <int KS, int TH, int MT>
 static int launch_dmarow(ConvK2 k, hipStream_t st) {
   using Sh = RowShape<KS, TH, MT>;
   auto kern = conv2d_dmarow_kernel<KS, TH, MT>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
-    attr_done = true;
   }
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 32 * MT);
@@ -899,10 +900,9 @@ template <int MT, int NT>
 static int launch_ksplit(ConvK2 k, hipStream_t st) {
   using Sh = KsShape<MT, NT>;
   auto kern = conv2d_ksplit_kernel<MT, NT>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
-    attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(k.nitems), dim3(256), Sh::LDS_BYTES, st, k);  // tiles: conv2d_packed_prepare
   return check_launch("conv2d_ksplit_kernel");
@@ -996,9 +996,12 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
   if (const char* v = getenv("DVSR_CONV_WINO")) wino_on = atoi(v);
   if (wino_on && g.dma == 1 && (allow_ksplit & 4) && Cout >= 32 && Ctot >= 16) {
     const int nch = Ctot / 8;
+    // (one workgroup per CU: rounds over the device's CUs; cycle figures measured on MI355X: tools/wino_trace.py, 2.07 GHz
+    // under this kernel)
+    const double cus = (double)device_cus();
     auto wino_cost = [&](int oh, int ow) {
       const double wgs = (double)ceil_div(Wo, ow) * ceil_div(Ho, oh) * N * ceil_div(Cout, 64);
-      return ceil(wgs / 256.0) * (nch * 5100.0 + 12500.0) / 2.07;   // (measured: tools/wino_trace.py, 2.07 GHz under this kernel)
+      return ceil(wgs / cus) * (nch * 5100.0 + 12500.0) / 2.07;
     };
     const double w4 = wino_cost(4, 64), w8 = wino_cost(8, 32);
     // (the direct kernels reach 0.78 of their MFMA time only over many rounds of workgroups; on grids of a few rounds their
@@ -1007,7 +1010,10 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
     const double drounds = dcyc / (64.0 * 9 * 4 * (c41 < 0.97 * c42 ? 1 : 2));
     const double direct = dcyc * nch / (drounds <= 6.0 ? 0.60 : 0.78) / 2.4;
     const double best = std::min(w4, w8);
-    if (wino_on == 2 || best < direct) return ConvGeo{8, w8 < w4 ? 8 : 4, 2, 0, 3};
+    // DVSR_CONV_WINO3 (default 1): the same GEMMs on the bf16 pipe with the exact 3-way operand split (conv2d_wino3.hip)
+    int wino3_on = 1;
+    if (const char* v = getenv("DVSR_CONV_WINO3")) wino3_on = atoi(v);
+    if (wino_on == 2 || best < direct) return ConvGeo{8, w8 < w4 ? 8 : 4, 2, 0, wino3_on ? 4 : 3};
   }
   // Small grids (every workgroup resident at once) are bound by one memory latency per chunk, not by the
   // matrix pipe: 16-channel chunks halve the number of exposed latencies.  DVSR_CONV_CC16_BELOW=<workgroups>
@@ -1026,6 +1032,7 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
 
 int conv2_pch_cc(int ks, int cc, int bf, int dma) {
   if (dma == 3) return 16 * 2 * 64 * 4;   // Winograd image: 16 transformed taps x 8 channels x 64 couts
+  if (dma == 4) return 2 * 6144;          // the same as three bf16 pieces: 2 phases x 24 KB
   return (bf == 2 ? 3 : 1) * 2 * ks * ks * (bf ? cc / 16 : cc / 8) * 2 * 32 * 4;
 }
 
@@ -1085,8 +1092,8 @@ int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const Conv
                  DVSR_ERR_UNSUPPORTED, "conv2d_packed: the row-split DMA kernel needs 7x7 / 9x9, stride 1, pad ks/2, plain "
                  "16-byte aligned inputs and W %% 4 == 0 (W=%d c0=%d c1=%d)", d.W, d.c0, d.c1);
   } else if (geo.dma) {
-    DVSR_REQUIRE(geo.dma != 3 || d.c0 + d.c1 >= 16, DVSR_ERR_UNSUPPORTED, "conv2d_packed: the Winograd kernel needs two 8-channel chunks");
-    DVSR_REQUIRE(geo.dma != 3 || d.pixel_shuffle == 0 || (d.pixel_shuffle == 2 && d.Cout % 4 == 0 && !d.res && !ex.accum && !ex.gmask),
+    DVSR_REQUIRE(geo.dma < 3 || d.c0 + d.c1 >= 16, DVSR_ERR_UNSUPPORTED, "conv2d_packed: the Winograd kernel needs two 8-channel chunks");
+    DVSR_REQUIRE(geo.dma < 3 || d.pixel_shuffle == 0 || (d.pixel_shuffle == 2 && d.Cout % 4 == 0 && !d.res && !ex.accum && !ex.gmask),
                  DVSR_ERR_UNSUPPORTED, "conv2d_packed: the Winograd kernel stores plain or PixelShuffle(2) tiles (ps=%d)", d.pixel_shuffle);
     DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && d.pad == 1 && !ex.in_ps && !ex.in_dil && geo.cc == 8 && (geo.th == 4 || geo.th == 8) &&
                      d.W % 4 == 0 && d.c0 % 8 == 0 && d.c1 % 8 == 0 && k.x0_bs % 4 == 0 && k.x1_bs % 4 == 0 &&
@@ -1129,6 +1136,7 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
     return launch_conv2<3, 1, 16, 4, 1, 1>(k, st);
   }
   if (geo.dma == 3) return conv2d_wino_launch(k, geo.th, st);
+  if (geo.dma == 4) return conv2d_wino3_launch(k, geo.th, st);
   if (geo.dma == 2) {
     if (d.ks == 7) return geo.mt == 2 ? launch_dmarow<7, 4, 2>(k, st) : launch_dmarow<7, 4, 1>(k, st);
     return geo.mt == 2 ? launch_dmarow<9, 4, 2>(k, st) : launch_dmarow<9, 4, 1>(k, st);
@@ -1229,7 +1237,7 @@ extern "C" size_t dvsr_conv2d_packed_workspace_bytes(const dvsr_conv2d_desc* d) 
   const size_t c = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, d->Cout, ctot, false).floats;
   // (the Winograd image of a 3x3 layer: 16 transformed taps instead of 9)
   const size_t w = d->ks == 3 ? (size_t)std::max(dvsr::ceil_div(d->Cout, 64) * dvsr::ceil_div(ctot, 8), dvsr::ceil_div(ctot, 64) * dvsr::ceil_div(d->Cout, 8)) *
-                                    dvsr::conv2_pch_cc(3, 8, 0, 3) : 0;
+                                    dvsr::conv2_pch_cc(3, 8, 0, 4) : 0;
   return std::max(std::max(a, b), std::max(c, w)) * sizeof(float);
 }
 

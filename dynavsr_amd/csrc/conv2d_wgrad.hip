@@ -237,10 +237,9 @@ template <int KS, int S>
 static void launch_wgrad(const WgradK& k, dim3 grid, hipStream_t st) {
   using Sh = WgShape<KS, S>;
   auto kern = conv2d_wgrad_kernel<KS, S>;
-  static bool done = false;
-  if (!done) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
-    done = true;
   }
   const size_t lds = Sh::LDS_BYTES;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
@@ -399,11 +398,10 @@ int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st) {
       constexpr size_t lds_b = KS_ <= 3 ? (WgWideShape<KS_, KYS_, 4>::LDS_BYTES > WgWideShape<KS_, KYS_, 2>::LDS_BYTES
                                                ? WgWideShape<KS_, KYS_, 4>::LDS_BYTES : WgWideShape<KS_, KYS_, 2>::LDS_BYTES) : 0;
       constexpr size_t lds = lds_a > lds_b ? lds_a : lds_b;
-      static bool done = false;
-      if (!done) {
+      static PerDeviceOnce attr_once;
+      if (attr_once.first()) {
         hipFuncSetAttribute((const void*)conv2d_wgrad_pipe_kernel<KS_, KYS_>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-        done = true;
       }
       hipLaunchKernelGGL((conv2d_wgrad_pipe_kernel<KS_, KYS_>), grid, dim3(256), lds, st, k);
     };

@@ -187,10 +187,9 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_bf16_kernel(WgradK a) {
 }
 
 int conv2d_wgrad_bf16_launch(const WgradLaunch& l, hipStream_t st) {
-  static bool done = false;
-  if (!done) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)conv2d_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS_BYTES);
-    done = true;
   }
   hipLaunchKernelGGL(conv2d_wgrad_bf16_kernel, l.grid, dim3(256), WB_LDS_BYTES, st, l.k);
   return check_launch("conv2d_wgrad_bf16_kernel");

@@ -502,10 +502,9 @@ template <int TC>
 static int launch_wino(ConvK2 k, hipStream_t st) {
   using Sh = WinoShape<TC>;
   auto kern = conv2d_wino_kernel<TC>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
-    attr_done = true;
   }
   k.tiles_x = ceil_div(k.Wo, Sh::OW); k.tiles_y = ceil_div(k.Ho, Sh::OH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 64);

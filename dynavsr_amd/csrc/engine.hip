@@ -1170,9 +1170,46 @@ extern "C" int dvsr_edvr_op_info(const dvsr_edvr_plan* p, int index, char* kind,
   snprintf(kind, kind_cap, "%s", k);
   if (p->ops[index].type == OP_CONV)
     snprintf(name, name_cap, "%s[%d/%d/%d%s]", p->ops[index].name, p->ops[index].geo.cc, p->ops[index].geo.th,
-             p->ops[index].geo.mt, p->ops[index].geo.dma == 3 ? "w" : (p->ops[index].geo.dma ? "d" : ""));
+             p->ops[index].geo.mt, p->ops[index].geo.dma >= 3 ? "w" : (p->ops[index].geo.dma ? "d" : ""));
   else
     snprintf(name, name_cap, "%s", p->ops[index].name);
+  return DVSR_OK;
+}
+
+// Contraction work of a whole plan, forward and backward tapes: out[0] / out[2] = algorithmic FLOPs (2 x MACs of the direct
+// sums: convolutions and the DCN contraction; weight + data gradients for the backward), out[1] / out[3] = the FLOPs the
+// matrix pipe actually issues -- launches on the Winograd F(2x2, 3x3) kernel (geo.dma == 3) issue 16/36 of theirs.
+// bench.py prices every roofline fraction with the executed figure.
+extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out4) {
+  DVSR_REQUIRE(p && out4, DVSR_ERR_INVALID, "edvr_plan_work: null argument");
+  double fa = 0, fe = 0, ba = 0, be = 0;
+  auto conv_part = [](const Op& o, int ci) {
+    return 2.0 * (double)o.N * conv_out(o, o.H) * conv_out(o, o.W) * o.Cout * ci * o.ks * o.ks;
+  };
+  for (const Op& o : p->ops) {
+    if (o.type == OP_CONV) {
+      const double f = conv_part(o, o.c0 + o.c1);
+      fa += f; fe += o.geo.dma >= 3 ? f * (16.0 / 36.0) : f;
+    } else if (o.type == OP_DCN) {
+      const double f = 2.0 * (double)o.N * o.H * o.W * o.Cout * o.c0 * 9;
+      fa += f; fe += f;
+    }
+  }
+  for (const BOp& b : p->bops) {
+    if (b.fwd < 0) continue;
+    const Op& o = p->ops[b.fwd];
+    if (b.type == B_WGRAD) {
+      const double f = conv_part(o, b.which ? o.c1 : o.c0);
+      ba += f; be += f;
+    } else if (b.type == B_DGRAD) {
+      const double f = conv_part(o, b.which ? o.c1 : o.c0);
+      ba += f; be += o.dgeo[b.which].dma >= 3 ? f * (16.0 / 36.0) : f;
+    } else if (b.type == B_DCN) {
+      const double f = 2.0 * 2.0 * (double)o.N * o.H * o.W * o.Cout * o.c0 * 9;   // dcol + dW
+      ba += f; be += f;
+    }
+  }
+  out4[0] = fa; out4[1] = fe; out4[2] = ba; out4[3] = be;
   return DVSR_OK;
 }
 
@@ -1377,6 +1414,11 @@ extern "C" int dvsr_estimator_num_params(const dvsr_estimator_plan* ep) { return
 extern "C" int dvsr_estimator_num_launches(const dvsr_estimator_plan* ep, int backward) {
   if (!ep) return -1;
   return backward ? (int)ep->core.bops.size() : (int)ep->core.ops.size();
+}
+
+extern "C" int dvsr_estimator_plan_work(const dvsr_estimator_plan* ep, double* out4) {
+  DVSR_REQUIRE(ep, DVSR_ERR_INVALID, "estimator_plan_work: null plan");
+  return dvsr_edvr_plan_work(&ep->core, out4);
 }
 
 extern "C" size_t dvsr_estimator_workspace_bytes(const dvsr_estimator_plan* ep, int need_grad) {

@@ -722,11 +722,10 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
     }
     // LDS: input window + max(gradient window, W^T operands); the weight-gradient phase re-uses it ([64 + 72][129] floats)
     const size_t lds = (size_t)std::max(8 * XPX + std::max(16 * XPX, 3 * (Cout / 2) * 64), (64 + 72) * 129) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
       hipFuncSetAttribute((const void*)mdcn_bwd_fused_kernel<HALO>, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(std::max(8 * XPX + std::max(16 * XPX, 3 * 64 * 64), (64 + 72) * 129) * sizeof(float)));
-      attr_done = true;
     }
 #ifdef DVSR_CONV_TRACE
     f.trace = (g_dcnb_countdown == 0) ? g_dcnb_trace : nullptr;

@@ -70,6 +70,7 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
                          WgradLaunch* out, int bf16 = 0, int groups = 1, long long dW_gs = 0, long long db_gs = 0);
 int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st);
 int conv2d_wino_launch(const ConvK2& k, int th, hipStream_t st);   // conv2d_wino.hip (ConvGeo::dma == 3)
+int conv2d_wino3_launch(const ConvK2& k, int th, hipStream_t st);  // conv2d_wino3.hip (ConvGeo::dma == 4)
 int conv2d_wgrad_bf16_launch(const WgradLaunch& l, hipStream_t st);
 
 // -------------------------------------------------------------------------------------------------

@@ -13,6 +13,15 @@ import torch
 from . import _lib as L
 
 _plans = {}
+# Environment switches that the native plan builder reads when it chooses kernels (conv2_choose, build_backward): they are
+# part of the plan-cache key, so a plan built under one setting is never handed out under another.
+_GEOMETRY_ENV = ("DVSR_CONV_WINO", "DVSR_CONV_WINO3", "DVSR_CONV_V1", "DVSR_CONV_DMA", "DVSR_CONV_TILE",
+                 "DVSR_CONV_KSPLIT_BELOW", "DVSR_DCN_BWD", "DVSR_EST_FUSE_PAD", "DVSR_FUSE_ACT_BWD", "DVSR_BWD_STREAMS")
+
+
+def _env_key():
+    import os
+    return tuple(os.environ.get(k) for k in _GEOMETRY_ENV)
 
 
 class Plan:
@@ -55,6 +64,13 @@ class Plan:
                 "dvsr_edvr_forward_timed")
         return list(ms)
 
+    def work(self):
+        """Contraction FLOPs of the two tapes: {'fwd_algorithmic', 'fwd_executed', 'bwd_algorithmic', 'bwd_executed'}
+        (launches on the Winograd kernel issue 16/36 of their algorithmic multiplies)."""
+        out = (ctypes.c_double * 4)()
+        L.check(L.lib().dvsr_edvr_plan_work(self._h, ctypes.byref(out)), "dvsr_edvr_plan_work")
+        return dict(zip(("fwd_algorithmic", "fwd_executed", "bwd_algorithmic", "bwd_executed"), out))
+
     def op_info(self):
         """[(kind, name, flops, bytes)] per launch."""
         out = []
@@ -88,7 +104,7 @@ def get_plan(cfg, b, h, w, device=None, grad_groups=1, weight_sets=1):
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     # ... and per HIP stream: the plan's side stream and fork / join events belong to ONE in-flight backward, so two
     # clips adapted concurrently on two streams (adapt_video(concurrency=2)) must not share them
-    key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream, grad_groups, weight_sets)
+    key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream, grad_groups, weight_sets, _env_key())
     p = _plans.get(key)
     if p is None:
         p = _plans[key] = Plan(tuple(cfg), b, h, w, grad_groups, weight_sets)
@@ -239,6 +255,12 @@ class EstimatorPlan:
                                                 ws.numel() * ws.element_size(), L.stream()),
                 "dvsr_estimator_backward")
 
+    def work(self):
+        """As Plan.work(), for the estimator's tapes."""
+        out = (ctypes.c_double * 4)()
+        L.check(L.lib().dvsr_estimator_plan_work(self._h, ctypes.byref(out)), "dvsr_estimator_plan_work")
+        return dict(zip(("fwd_algorithmic", "fwd_executed", "bwd_algorithmic", "bwd_executed"), out))
+
     def __del__(self):
         try:
             if self._h:
@@ -249,7 +271,7 @@ class EstimatorPlan:
 
 def get_estimator_plan(cfg, b, h, w, device=None, grad_groups=1, weight_sets=1):
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream, grad_groups, weight_sets)
+    key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream, grad_groups, weight_sets, _env_key())
     p = _eplans.get(key)
     if p is None:
         p = _eplans[key] = EstimatorPlan(tuple(cfg), b, h, w, grad_groups, weight_sets)

@@ -72,7 +72,10 @@ int dvsr_mdcn_forward_fast(const float* x, const float* offset, const float* mas
 /* Replaces modulated_deform_conv_cuda_backward (deform_conv_cuda.cpp:566-679).  grad_out = gradient
  * w.r.t. the op's output (act = NONE).  gx is ACCUMULATED into with fp32 atomics (zero it first, the
  * reference's caller does: deform_conv.py:128); goffset/gmask/gw/gb are overwritten; gx/gw/gb may
- * be NULL.  Workspace holds the [C*9, Ho*Wo] column buffer + weight-gradient partials. */
+ * be NULL.  Workspace: the EDVR configuration (3x3, stride / pad / dilation 1, 8 channels per group) runs the fused
+ * kernel, whose only scratch is the per-workgroup [Cout][72] weight-gradient partials (no column buffer: dcol and the
+ * sampled columns stay on chip); other configurations take the three-kernel path, which also needs the [C*9, Ho*Wo]
+ * column buffer.  dvsr_mdcn_backward_workspace_bytes() returns the larger of the two. */
 size_t dvsr_mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int kh, int kw, int stride,
                                           int pad, int dil);
 int dvsr_mdcn_backward(const float* x, const float* offset, const float* mask, const float* w,
@@ -207,6 +210,10 @@ int dvsr_edvr_num_backward_launches(const dvsr_edvr_plan* plan);
  * synchronises, and returns per-launch milliseconds in op_ms[dvsr_edvr_num_launches()]. */
 int dvsr_edvr_op_info(const dvsr_edvr_plan* plan, int index, char* kind, int kind_cap, char* name,
                       int name_cap, double* flops, double* bytes);
+/* Contraction work of the plan's two tapes: out4 = {forward algorithmic FLOPs, forward FLOPs issued to the matrix pipe,
+ * backward algorithmic, backward issued}.  Algorithmic = 2 x MACs of the direct sums; launches on the
+ * Winograd F(2x2,3x3) kernel issue 16/36 of theirs.  bench.py's roofline fractions use the issued figure. */
+int dvsr_edvr_plan_work(const dvsr_edvr_plan* plan, double* out4);
 int dvsr_edvr_forward_timed(const dvsr_edvr_plan* plan, const float* const* params, const float* x,
                             float* out, void* workspace, size_t workspace_bytes,
                             dvsr_stream_t stream, float* op_ms);
@@ -255,6 +262,7 @@ int dvsr_estimator_num_params(const dvsr_estimator_plan* plan);
 /* tape length: forward ops (backward = 0) or backward ops (backward = 1); a measurement aid like
  * dvsr_edvr_num_launches / dvsr_edvr_num_backward_launches */
 int dvsr_estimator_num_launches(const dvsr_estimator_plan* plan, int backward);
+int dvsr_estimator_plan_work(const dvsr_estimator_plan* plan, double* out4);   /* as dvsr_edvr_plan_work */
 size_t dvsr_estimator_workspace_bytes(const dvsr_estimator_plan* plan, int need_grad);
 int dvsr_estimator_forward(const dvsr_estimator_plan* plan, const float* const* params, const float* x, float* out,
                            void* workspace, size_t workspace_bytes, dvsr_stream_t stream);

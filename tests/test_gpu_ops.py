@@ -397,14 +397,18 @@ def test_conv3x3_dma_halo(n, cin, cout, h, w, act, res, monkeypatch):
     (2, 8, 8, 64, 44, 80, 1, True, 0, True),        # two chunks: first and last block only
     (2, 64, 0, 216, 96, 128, 0, False, 0, True),    # the offset / mask conv: the last 64-cout block holds 24 (its upper-half waves idle)
 ])
-def test_conv3x3_winograd(n, c0, c1, cout, h, w, act, res, ps, force, monkeypatch):
-    """Forward (and data gradient for single plain inputs) on the Winograd kernel against fp64 torch; the geometry query
+@pytest.mark.parametrize("pipe", ["bf16x3", "fp32"])
+def test_conv3x3_winograd(n, c0, c1, cout, h, w, act, res, ps, force, pipe, monkeypatch):
+    """Forward (and data gradient for single plain inputs) on the Winograd kernels against fp64 torch; the geometry query
     confirms the kernel.  force: DVSR_CONV_WINO=2 takes it wherever it is eligible (the cost model would keep the direct
-    kernel on these small grids)."""
+    kernel on these small grids).  pipe: the sixteen GEMMs on the bf16 matrix pipe with the exact 3-way operand split
+    (conv2d_wino3.hip, the default: geometry code 4) or on the fp32 MFMA (conv2d_wino.hip, DVSR_CONV_WINO3=0: code 3) --
+    both are held to the same fp32 bar."""
     import ctypes
     from dynavsr_amd import _lib as L
     if force:
         monkeypatch.setenv("DVSR_CONV_WINO", "2")
+    monkeypatch.setenv("DVSR_CONV_WINO3", "1" if pipe == "bf16x3" else "0")
     cin = c0 + c1
     x0 = rnd(n, c0, h, w, seed=1)
     x1 = rnd(n, c1, h, w, seed=6) if c1 else None
@@ -417,7 +421,7 @@ def test_conv3x3_winograd(n, c0, c1, cout, h, w, act, res, ps, force, monkeypatc
                      act, ps, 1, 0, 0)
     geo = (ctypes.c_int * 4)()
     L.check(L.lib().dvsr_conv2d_packed_geometry(d, ctypes.byref(geo)), "dvsr_conv2d_packed_geometry")
-    assert list(geo)[3] == 3, "expected the Winograd kernel, got %s" % list(geo)
+    assert list(geo)[3] == (4 if pipe == "bf16x3" else 3), "expected the Winograd kernel, got %s" % list(geo)
     ws = torch.empty(max(int(L.lib().dvsr_conv2d_packed_workspace_bytes(d)), 16), dtype=torch.uint8, device="cuda")
     L.check(L.lib().dvsr_conv2d_forward_packed(d, ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_forward_packed")
     x = torch.cat([x0, x1], 1) if c1 else x0
