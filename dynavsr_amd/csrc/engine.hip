@@ -1242,6 +1242,22 @@ extern "C" int dvsr_edvr_forward_timed(const dvsr_edvr_plan* p, const float* con
   return rc;
 }
 
+// Where launch `index` of the forward tape leaves its result: which = 0 the output, 1 the second output of the two-output
+// launches (pool: the average plane; TSA gate: the gated features).  *in_arena = 1: offset_floats counts from the start of
+// the workspace; 0: the launch writes the network's output tensor (conv_last).  Test aid: every saved activation of a
+// need_grad forward can be read back, launch by launch (tests/test_gpu_edvr.py: the kink-free gradient check).
+extern "C" int dvsr_edvr_op_output(const dvsr_edvr_plan* p, int index, int which, int* in_arena, long long* offset_floats,
+                                   long long* numel) {
+  DVSR_REQUIRE(p && in_arena && offset_floats && numel && index >= 0 && index < (int)p->ops.size() && (which == 0 || which == 1),
+               DVSR_ERR_INVALID, "edvr_op_output: bad argument");
+  const T& t = which ? p->ops[index].y2 : p->ops[index].y;
+  DVSR_REQUIRE(t.valid(), DVSR_ERR_INVALID, "edvr_op_output: launch %d has no output %d", index, which);
+  *in_arena = t.space == SP_ARENA;
+  *offset_floats = (long long)t.off;
+  *numel = (long long)t.numel;
+  return DVSR_OK;
+}
+
 extern "C" int dvsr_edvr_tensor_info(const dvsr_edvr_plan* p, const char* name, long long* offset_floats,
                                      long long* numel) {
   DVSR_REQUIRE(p && name && offset_floats && numel, DVSR_ERR_INVALID, "edvr_tensor_info: null argument");

@@ -71,6 +71,15 @@ class Plan:
         L.check(L.lib().dvsr_edvr_plan_work(self._h, ctypes.byref(out)), "dvsr_edvr_plan_work")
         return dict(zip(("fwd_algorithmic", "fwd_executed", "bwd_algorithmic", "bwd_executed"), out))
 
+    def op_output(self, ws, index, which=0):
+        """Flat view of what launch `index` wrote into the workspace (None when it writes the output tensor)."""
+        ia, off, n = ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong()
+        L.check(L.lib().dvsr_edvr_op_output(self._h, index, which, ctypes.byref(ia), ctypes.byref(off), ctypes.byref(n)),
+                "dvsr_edvr_op_output")
+        if not ia.value:
+            return None
+        return ws.view(torch.float32)[off.value:off.value + n.value]
+
     def op_info(self):
         """[(kind, name, flops, bytes)] per launch."""
         out = []

@@ -214,6 +214,11 @@ int dvsr_edvr_op_info(const dvsr_edvr_plan* plan, int index, char* kind, int kin
  * backward algorithmic, backward issued}.  Algorithmic = 2 x MACs of the direct sums; launches on the
  * Winograd F(2x2,3x3) kernel issue 16/36 of theirs.  bench.py's roofline fractions use the issued figure. */
 int dvsr_edvr_plan_work(const dvsr_edvr_plan* plan, double* out4);
+/* Test aid: where launch `index` of the forward tape leaves its result (which = 0; 1 = the second output of the pool /
+ * TSA-gate launches).  *in_arena = 1: offset_floats counts from the start of the workspace (every activation of a
+ * need_grad forward stays there); 0: the launch writes the output tensor. */
+int dvsr_edvr_op_output(const dvsr_edvr_plan* plan, int index, int which, int* in_arena, long long* offset_floats,
+                        long long* numel);
 int dvsr_edvr_forward_timed(const dvsr_edvr_plan* plan, const float* const* params, const float* x,
                             float* out, void* workspace, size_t workspace_bytes,
                             dvsr_stream_t stream, float* op_ms);

@@ -1110,3 +1110,79 @@ def test_validate_video_psnr_vectors_match_the_host_definition():
         hr = util.tensor2img(gts[i], mode="rgb")
         assert abs(float(r["psnr_start"][i]) - util.calculate_psnr(util.tensor2img(base[0], mode="rgb"), hr)) < 1e-9   # same call path
         assert abs(float(r["psnr_final"][i]) - util.calculate_psnr(util.tensor2img(res["sr"][0], mode="rgb"), hr)) < 2e-3
+
+
+# ---- gradient parity that kink flips cannot loosen (r04) -------------------------------------------------------------
+def _kink_free_gradient_check(cfg, seed, b, h, w, xseed, tseed):
+    """dvsr_edvr_backward against the fp64 oracle evaluated ON THE GPU'S OWN ACTIVATIONS (oracle/edvr_tape.py: every launch
+    output of the GPU forward is teacher-forced into the oracle, (L)ReLU backwards key on the sign of the GPU's stored
+    outputs, pools / the deformable sampler decide on the GPU's values): what is compared is the exact linearisation of the
+    forward the GPU ran, so only summation-order round-off separates the two -- every parameter gradient is held to 1e-4
+    rel-L2 (observed worst: 1.8e-5, EDVR-M and EDVR-L, Winograd and direct kernels alike) and the input gradient, which
+    has passed through every layer's data gradient and the deformable sampler's fixed-point window sums, to 5e-4 (observed
+    4e-5 .. 1.2e-4) -- where the unforced comparisons need 1e-2 .. 5e-2 for the flips."""
+    from dynavsr_amd import hipops
+    from oracle import edvr as oedvr
+    from oracle import edvr_tape
+    net = make_net(seed, **cfg)
+    net._debug_ws = []
+    s = cfg.get("scale", 4)
+    x = synth.clip(xseed, b, cfg.get("nframes", 5), h, w)
+    tgt = synth.clip(tseed, b, 1, s * h, s * w)[:, 0]
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    plan, ws = net._debug_ws[-1]
+    names = [nm.split("[")[0] for (_k, nm, _f, _b) in plan.op_info()]
+    two = ("tsa_gate", "tsa_pool1", "tsa_pool2")
+    outs = []
+    for i, nm in enumerate(names):     # read back BEFORE the backward runs over the workspace
+        o0 = plan.op_output(ws, i, 0)
+        o1 = plan.op_output(ws, i, 1) if nm in two else None
+        outs.append((None if o0 is None else o0.detach().cpu().clone(), None if o1 is None else o1.detach().cpu().clone()))
+    y_cpu = y.detach().cpu()
+    loss = hipops.charbonnier(y, tgt.cuda())
+    loss.backward()
+
+    def force(i, name, which, v):
+        assert names[i] == name, (i, names[i], name)
+        f = outs[i][which]
+        if f is None:
+            assert name == "conv_last"
+            f = y_cpu
+        assert f.numel() == v.numel(), (name, f.numel(), tuple(v.shape))
+        return f.view(v.shape)
+    P = synth.edvr_state_dict(seed, **cfg)
+    Pd = OrderedDict((k, v.double().clone().requires_grad_(True)) for k, v in P.items())
+    xd = x.double().clone().requires_grad_(True)
+    yo, onames = edvr_tape.edvr_forward_tape(Pd, xd, force=force, **cfg)
+    assert onames == names
+    lo = oedvr.charbonnier(yo, tgt.double())
+    lo.backward()
+    assert abs(float(loss.detach()) - float(lo.detach())) < 1e-6 * abs(float(lo.detach()))
+    worst = ("", 0.0)
+    bad = []
+    for name, p in zip(net._names, net.ordered_parameters()):
+        e = relerr(p.grad, Pd[name].grad)
+        if e > worst[1]:
+            worst = (name, e)
+        if not e < 1e-4:
+            bad.append((name, e))
+    ex = relerr(xg.grad, xd.grad)
+    print("kink-free gradient check %s B=%d %dx%d: worst parameter gradient %s %.2e, input gradient %.2e"
+          % (cfg or "EDVR-M", b, h, w, worst[0], worst[1], ex))
+    assert not bad, bad[:8]
+    assert ex < 5e-4, ex
+
+
+@pytest.mark.parametrize("wino", ["1", "0"])
+@pytest.mark.parametrize("b,h,w", [(1, 32, 48), (2, 44, 80)])
+def test_edvr_backward_kink_free_all_144_gradients(b, h, w, wino, monkeypatch):
+    """EDVR-M x4, every one of the 144 parameter gradients and the input gradient, on the default tape (the large 3x3 layers of
+    the 44x80 batch on the Winograd kernels) and on the direct kernels (DVSR_CONV_WINO=0)."""
+    monkeypatch.setenv("DVSR_CONV_WINO", wino)
+    _kink_free_gradient_check({}, 0, b, h, w, 21, 22)
+
+
+def test_edvr_l_backward_kink_free_all_264_gradients():
+    """BASELINE configs[4]'s network (EDVR-L x4: nf 128, 7 frames, 40 blocks) on its 1x7x3x64x64 tile."""
+    _kink_free_gradient_check(dict(EDVR_L), 8, 1, 64, 64, 31, 32)
