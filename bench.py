@@ -347,10 +347,11 @@ def per_frame_pipeline_rate(dev, clips=32, h=176, w=320, frames_per_batch=16):
 
 
 # ---- configs[3]: one outer meta-training iteration with the RCCL exchange -----------------------------
-def meta_step_rate(dev, world, dist, tasks_per_rank=2, iters=4):
+def meta_step_rate(dev, world, dist, group=None, cpu_group=False, tasks_per_rank=2, iters=4):
     """Every rank: adapt.meta_train_step on its own `tasks_per_rank` tasks at the training YAML's shapes (LR 5x3x64x64,
     SLR 16x16, HR 256x256; train_dynavsr.py:265-438), with the meta-gradient all-reduce over the process group.
-    The collective alone is timed separately on the same flat buffer."""
+    The collective alone is timed separately on the same flat buffer.  `group`: the RCCL group the gradients travel over;
+    `cpu_group`: the default group is the gloo one (barriers and the MAX of the times use CPU tensors on it)."""
     from dynavsr_amd import dist as D, synth
     from dynavsr_amd.adapt import meta_train_step
     from dynavsr_amd.models import create_model
@@ -368,7 +369,7 @@ def meta_step_rate(dev, world, dist, tasks_per_rank=2, iters=4):
     force = dist is not None
 
     def it():
-        return meta_train_step(opt, model, est, modelcp, estcp, data, optimizer, inner="reference",
+        return meta_train_step(opt, model, est, modelcp, estcp, data, optimizer, inner="reference", group=group,
                                force_collective=force)
     for _ in range(6):          # (a fixed count: every rank must run the same number of collectives)
         it()
@@ -387,14 +388,14 @@ def meta_step_rate(dev, world, dist, tasks_per_rank=2, iters=4):
     nbytes, ar_ms = None, None
     if dist is not None:
         for _ in range(2):
-            nbytes = D.allreduce_meta_gradients([model.netG, est.netE], average=True, force=True)
+            nbytes = D.allreduce_meta_gradients([model.netG, est.netE], average=True, group=group, force=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):
-            D.allreduce_meta_gradients([model.netG, est.netE], average=True, force=True)
+            D.allreduce_meta_gradients([model.netG, est.netE], average=True, group=group, force=True)
         torch.cuda.synchronize()
         ar_ms = (time.perf_counter() - t0) / 10 * 1e3
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if cpu_group else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     return {"value": world * B / dt, "unit": "tasks/s (all ranks)", "tasks_per_s_per_gpu": B / dt,
@@ -408,7 +409,7 @@ def meta_step_rate(dev, world, dist, tasks_per_rank=2, iters=4):
 
 
 # ---- distributed validation: frames sharded round-robin over the ranks -----------------------------------
-def validation_rate(dev, world, dist, frames_per_rank=8, h=176, w=320, frames_per_batch=8):
+def validation_rate(dev, world, dist, group=None, frames_per_rank=8, h=176, w=320, frames_per_batch=8):
     """train_dynavsr.py:500-728 / the test driver's frame loop on N ranks: the frames range(rank, n, world) are adapted
     and super-resolved on each rank (adapt.validate_video: baseline forward, inner step, adapted forward, PSNR of both on
     the device), the PSNR vectors are reduced to rank 0.  Weak scaling: `frames_per_rank` per rank."""
@@ -429,7 +430,8 @@ def validation_rate(dev, world, dist, frames_per_rank=8, h=176, w=320, frames_pe
     gts = [synth.clip(500 + i, 1, 1, 4 * h, 4 * w, smooth=True)[0, 0].to(dev) if i in mine else None for i in range(n)]
 
     def run():
-        return validate_video(opt, model, est, modelcp, estcp, est_fixed, clips, gts, rank, world, frames_per_batch=frames_per_batch)
+        return validate_video(opt, model, est, modelcp, estcp, est_fixed, clips, gts, rank, world, group=group,
+                              frames_per_batch=frames_per_batch)
     run()
     torch.cuda.synchronize()
     if dist is not None:
@@ -441,7 +443,7 @@ def validation_rate(dev, world, dist, frames_per_rank=8, h=176, w=320, frames_pe
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64)   # (the default group is the gloo one)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     ps, pf, seen = r["psnr_start"], r["psnr_final"], r["evaluated"]
@@ -595,6 +597,30 @@ def split_mode_rate(cfg, h, w, x, y_fp32, steps, warmup):
             "note": "opt-in (bf16_mfma = 2), held to the fp32 parity bars by tests/test_gpu_edvr.py"}
 
 
+def _merge_rank_leg(per_rank, value_key="value"):
+    """A leg every rank ran on its own frames (independent work, no collective): rank 0's full object, with `value` = the SUM
+    over the ranks and the per-rank figures beside it (the driver derives scaling efficiency from its own N = 1 run)."""
+    legs = [x for x in per_rank if x is not None]
+    if not legs:
+        return None
+    out = dict(legs[0])
+    vals = [float(x[value_key]) for x in legs]
+    out[value_key] = sum(vals)
+    out["ranks"] = len(legs)
+    out["per_rank_value"] = vals
+    out["min_rank_value"], out["max_rank_value"] = min(vals), max(vals)
+    return out
+
+
+def _gather_objects(dist, obj, world):
+    """Every rank's object on rank 0 (list in rank order; [obj] without a process group)."""
+    if dist is None or world == 1:
+        return [obj]
+    box = [None] * world
+    dist.all_gather_object(box, obj)
+    return box
+
+
 def _spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: re-run this file under torch.distributed.run with N local ranks
     (rendezvous on 127.0.0.1, a free port) and hand its exit code back."""
@@ -609,17 +635,21 @@ def _spawn_ranks(n, argv):
 
 
 def _dry_run(rank, world, args):
-    """The N-rank skeleton of the bench with no kernels: gloo process group on the CPU, the barrier-bracketed timed loop,
-    the MAX-over-ranks reduction of the elapsed time, the flat meta-gradient all-reduce (dist.allreduce_meta_gradients on a
-    tensor list of the real size: 15.0 MB for EDVR-M + MFDN) and the round-robin frame shards with their metric reduction
-    (dist.shard_indices / reduce_metric_vectors).  Rank 0 returns the JSON line."""
+    """The N-rank skeleton of the bench with no kernels, through the SAME plumbing as the GPU run: the gloo process group
+    (barriers, MAX of the elapsed time, gathering of the per-rank legs: _gather_objects / _merge_rank_leg), a second group
+    where the GPU run creates the RCCL one (here gloo as well) for the flat meta-gradient all-reduce
+    (dist.allreduce_meta_gradients on a tensor list of the real size: 15.0 MB for EDVR-M + MFDN) and the round-robin frame
+    shards with their metric reduction (dist.shard_indices / reduce_metric_vectors).  Rank 0 returns a JSON line with the key
+    set of the GPU line at the same world size (tests/test_host_logic.py compares it with a recorded GPU line)."""
     import torch.distributed as tdist
     from dynavsr_amd import dist as D
+    dist, coll = None, None
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         tdist.init_process_group("gloo", rank=rank, world_size=world)
-    grouped = tdist.is_initialized()
+        dist = tdist
+    grouped = dist is not None
 
     def barrier():
         if grouped:
@@ -637,32 +667,44 @@ def _dry_run(rank, world, args):
     if grouped:
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
     elapsed = float(t)
+    # the legs every rank runs on its own frames: stand-ins with the rank in their value (sum = world (world + 1) / 2)
+    mine = ({"value": float(rank + 1), "unit": "clips/s", "ms_per_step": None},
+            {"value": float(rank + 1), "unit": "frames/s", "ms_per_frame": None})
+    both = _gather_objects(dist, mine, world)
+    if grouped:
+        coll = tdist.new_group(backend="gloo")    # (the GPU run: backend "nccl" = RCCL, created after the single-GPU legs)
     # the one exchange step of the method, on parameters of the real sizes (values: rank + 1, averaged -> (world + 1) / 2)
     holder = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(n)) for n in (3_300_131, 452_291)])
     for p in holder:
         p.grad = torch.full_like(p, float(rank + 1))
-    nbytes = D.allreduce_meta_gradients([holder], average=True, force=grouped)
+    nbytes = D.allreduce_meta_gradients([holder], average=True, group=coll, force=grouped)
     ok = all(bool((p.grad == (world + 1) / 2.0).all()) for p in holder)
     # distributed validation: frames range(rank, n, world), per-frame metric vector reduced to rank 0
     frames = 10
     vec = torch.zeros(frames, dtype=torch.float64)
     for i in D.shard_indices(frames, rank, world):
         vec[i] = 30.0 + i
-    D.reduce_metric_vectors([vec])
+    D.reduce_metric_vectors([vec], group=coll)
     if grouped:
         tdist.barrier()
         tdist.destroy_process_group()
     if rank != 0:
         return None
-    return {"metric": "dry run: launcher and process-group plumbing only (gloo, CPU, no kernels)", "value": None,
+    line = {"metric": "dry run: launcher and process-group plumbing only (gloo, CPU, no kernels)", "value": None,
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
             "config": {"workload": "none (dry run)", "clips_per_step": world},
+            "roofline": None, "kernel_breakdown_ms_per_step": None, "end_to_end_tflops": None,
+            "inner_step": _merge_rank_leg([b_[0] for b_ in both]),
+            "per_frame_pipeline": _merge_rank_leg([b_[1] for b_ in both]),
             "meta_step": {"ranks": world, "allreduce": {"backend": "gloo", "bytes": nbytes, "executed": grouped,
                                                          "averaged_correctly": ok}},
             "validation": {"frames": frames, "sharding": "range(rank, frames, world)",
                            "psnr_vector_complete": bool((vec == torch.arange(frames, dtype=torch.float64) + 30.0).all())}}
+    if world == 1:   # legs of the one-GPU line only
+        line.update({"experimental_bf16_split": None, "edvr_l_bf16": None, "other_backbones": None, "cpu_baseline": None})
+    return line
 
 
 def main():
@@ -709,23 +751,18 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist, dist_err = None, None
-    try:
-        import torch.distributed as tdist
-        if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with 1 rank)
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
-            tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        elif not args.no_meta:                  # plain `python bench.py`: a one-rank RCCL group for the meta_step leg
-            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-            tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
-                                     device_id=dev)
-        if tdist.is_initialized():
-            dist = tdist
-    except Exception as e:   # only the optional one-rank group may fail softly
-        if world > 1:
-            raise
-        dist_err = "%s: %s" % (type(e).__name__, e)
+    # Two process groups.  `dist` (gloo, CPU) carries the barriers, the MAX of the elapsed times and the gathering of the
+    # per-rank legs: it owns no GPU stream or helper thread, so the host-bound launch sequences of the single-GPU legs run as
+    # they do without a launcher (an initialised RCCL communicator slows them by 25-35 %: tools/rccl_effect.py).  The RCCL
+    # group (`rccl`, backend "nccl") is created AFTER those legs, for the two legs that move data between GPUs: the
+    # meta-gradient all-reduce and the reduction of the validation metrics.
+    dist, rccl, dist_err = None, None, None
+    import torch.distributed as tdist
+    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with 1 rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        tdist.init_process_group("gloo", rank=rank, world_size=world)
+        dist = tdist
 
     from dynavsr_amd import engine, synth
     from dynavsr_amd.models.archs.EDVR_arch import EDVR
@@ -753,7 +790,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     assert torch.isfinite(y).all()
@@ -849,9 +886,6 @@ def main():
         line["kernel_breakdown_ms_per_step"] = {k: round(a[0] / reps, 4) for k, a in
                                                 sorted(acc.items(), key=lambda kv: -kv[1][0])}
         line["end_to_end_tflops"] = sum(a[1] for a in acc.values()) / reps / (ms * 1e-3) / 1e12
-        if world == 1 and not args.no_inner_step:
-            line["inner_step"] = inner_step_rate(dev)
-            line["per_frame_pipeline"] = per_frame_pipeline_rate(dev)
         if world == 1 and not args.no_split:
             line["experimental_bf16_split"] = split_mode_rate(cfg, h, w, x, y, args.steps, args.warmup)
             line["edvr_l_bf16"] = edvr_l_rates(dev)
@@ -859,13 +893,35 @@ def main():
                 line["other_backbones"] = backbone_rates(dev)
             except Exception as e:     # a side leg must not cost the line
                 line["other_backbones"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    # The meta-training iteration comes AFTER the single-GPU legs: once the RCCL communicator exists, its helper threads
-    # slow host-bound launch sequences down (EDVR-L bf16 forward+backward, ~700 launches in 10.5 ms, measured 14.1 ms
-    # when this leg ran first; the GPU-bound legs do not move).
+    # The legs the metric is named after run on EVERY rank, each on its own frames (independent work items, no collective:
+    # north_star asks for the inner step at 1/2/4/8 GPUs): rank 0 reports the sum and the per-rank figures.
+    if not args.no_inner_step:
+        barrier()
+        mine = (inner_step_rate(dev), per_frame_pipeline_rate(dev))
+        barrier()
+        both = _gather_objects(dist, mine, world)
+        if rank == 0:
+            line["inner_step"] = _merge_rank_leg([b_[0] for b_ in both])
+            line["per_frame_pipeline"] = _merge_rank_leg([b_[1] for b_ in both])
+    # The RCCL communicator is created only now: once it exists, its helper threads slow host-bound launch sequences down
+    # (EDVR-L bf16 forward+backward, ~700 launches in 10.5 ms, measured 14.1 ms when the meta leg ran first; the inner-step
+    # per-frame loop 8.2 -> 10.0 ms; the GPU-bound legs do not move).
+    if not (args.no_meta and args.no_validation):
+        try:
+            if dist is not None:
+                rccl = tdist.new_group(backend="nccl")
+            elif not args.no_meta:            # plain `python bench.py`: a one-rank RCCL group for the meta_step leg
+                s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+                tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+                rccl = tdist.group.WORLD
+        except Exception as e:   # only the optional one-rank group may fail softly
+            if world > 1:
+                raise
+            dist_err = "%s: %s" % (type(e).__name__, e)
     meta = None
     if not args.no_meta:   # every rank takes part (the collective)
         try:
-            meta = meta_step_rate(dev, world, dist)
+            meta = meta_step_rate(dev, world, tdist if rccl is not None else None, rccl, cpu_group=dist is not None)
         except Exception as e:
             if world > 1:
                 raise
@@ -875,7 +931,7 @@ def main():
     val = None
     if not args.no_validation:   # every rank takes part (its shard of the frames, the metric reduction)
         try:
-            val = validation_rate(dev, world, dist if world > 1 else None)
+            val = validation_rate(dev, world, tdist if (world > 1 and rccl is not None) else None, rccl)
         except Exception as e:
             if world > 1:
                 raise
@@ -888,9 +944,9 @@ def main():
             line["validation"] = val
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, h, w, 0, y)   # same clip (seed 1 + rank 0), same weights
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if tdist.is_initialized():
+        tdist.barrier(group=None if dist is not None else rccl)
+        tdist.destroy_process_group()
     if line is not None:
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
 

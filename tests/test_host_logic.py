@@ -363,6 +363,20 @@ def test_bench_two_ranks_dry_run(launcher):
     assert line["meta_step"]["ranks"] == 2 and line["meta_step"]["allreduce"]["executed"]
     assert line["meta_step"]["allreduce"]["averaged_correctly"] and line["meta_step"]["allreduce"]["bytes"] == 4 * (3300131 + 452291)
     assert line["validation"]["psnr_vector_complete"]
+    # the legs every rank runs on its own frames arrive on rank 0 as sum + per-rank figures (stand-in values: rank + 1)
+    for leg in ("inner_step", "per_frame_pipeline"):
+        assert line[leg]["ranks"] == 2 and line[leg]["per_rank_value"] == [1.0, 2.0] and line[leg]["value"] == 3.0
+        assert line[leg]["min_rank_value"] == 1.0 and line[leg]["max_rank_value"] == 2.0
+    # ... and the line has the key set of a GPU line (recorded on one MI355X: profiles/r04_bench_line.json) minus the legs
+    # that only the one-GPU line carries
+    rec_path = os.path.join(root, "profiles", "r04_bench_line.json")
+    if os.path.exists(rec_path):
+        with open(rec_path) as f:
+            rec = json.loads(f.read().strip().splitlines()[-1])
+        one_gpu_only = {"experimental_bf16_split", "edvr_l_bf16", "other_backbones", "cpu_baseline"}
+        assert set(line) - {"dry_run"} == set(rec) - one_gpu_only, (sorted(set(line) ^ set(rec)))
+        for leg in ("inner_step", "per_frame_pipeline"):
+            assert {"value", "unit", "ranks", "per_rank_value", "min_rank_value", "max_rank_value"} <= set(rec[leg]) & set(line[leg])
 
 
 def _val_worker(rank, world, port, q):
