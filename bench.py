@@ -105,7 +105,7 @@ def _opt():
 def _sources_digest():
     """Identity of the conv kernel sources the committed PMC traffic figure was collected on."""
     h = hashlib.sha256()
-    for f in ("conv2d_v2.hip", "conv2d_wino.hip", "small_grid.h", "common.h"):
+    for f in ("conv2d_v2.hip", "conv2d_wino.hip", "conv2d_wino3.hip", "small_grid.h", "common.h"):
         with open(os.path.join(ROOT, "dynavsr_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -272,9 +272,13 @@ def inner_step_rate(dev, steps=60, h=176, w=320, frames_per_batch=16):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             tj = json.load(f).get("inner_step_batched")
         if tj and tj.get("frames_per_batch") == K and (tj.get("h"), tj.get("w")) == (h, w):
+            # algorithmic bytes of the same step: every launch's distinct inputs once + outputs once over the forward tapes
+            # (EDVR on the SLR batch, MFDN twice: adapted + frozen), the backward tapes counted as twice their forward
+            alg_bytes = (3.0 * gk["fwd_bytes"] + 4.0 * ek["fwd_bytes"]) / K
             traffic = {"traffic": tj["bytes_per_frame_step"], "traffic_source": tj["source"],
                        "traffic_scope": "all kernels of one batched inner step / K (PMC FETCH_SIZE + WRITE_SIZE)",
-                       "algorithmic_bytes_per_frame_step": tj.get("algorithmic_bytes_per_frame_step")}
+                       "algorithmic_bytes_per_frame_step": alg_bytes,
+                       "hbm_gbs": tj["bytes_per_frame_step"] / (ms * 1e-3) / 1e9}
     except (OSError, ValueError):
         pass
 

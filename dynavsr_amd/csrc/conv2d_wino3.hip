@@ -40,10 +40,19 @@ namespace dvsr {
   do {                                                                                                    \
     if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
+// stamps INSIDE one phase (s == 6), by lane 0 of waves 0 and 4 (the two waves of one SIMD): slots 20 + i / 30 + i
+#define W3_FINE(i)                                                                                                      \
+  do {                                                                                                                  \
+    if (a.trace && s == 6 && lane == 0 && (wave & 3) == 0)                                                              \
+      a.trace[(size_t)blockIdx.x * 64 + (wave ? 30 : 20) + (i)] = __builtin_readcyclecounter();                          \
+  } while (0)
 #else
 #define W3_ABLATE(a) 0
 #define W3_STAMP(i) \
   do {              \
+  } while (0)
+#define W3_FINE(i) \
+  do {             \
   } while (0)
 #endif
 
@@ -219,10 +228,12 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino3_kernel(ConvK2 a) {
           w3_dma16(x0n, dst + 256 * (wave + 8 * jj), hoff[jj], soff);
       }
   };
-  auto issue_u = [&](int s, int ub) {   // phase image s (24 KB = 3 x 8 KB) -> U buffer ub
-    float* wdst = s_ub + ub * SUB;
+  auto issue_u_piece = [&](int s, int ub, int j) {   // piece j (8 KB) of phase image s (24 KB) -> U buffer ub
+    w3_dma16(wp_cb, s_ub + ub * SUB + (j * 8 + wave) * 256, uoff, (unsigned)(s * (SUB * 4) + j * 8192));
+  };
+  auto issue_u = [&](int s, int ub) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) w3_dma16(wp_cb, wdst + (j * 8 + wave) * 256, uoff, (unsigned)(s * (SUB * 4) + j * 8192));
+    for (int j = 0; j < 3; ++j) issue_u_piece(s, ub, j);
   };
 
   // ---- input transform of one phase: lane = tile, channels 2 tq and 2 tq + 1, row xi = 2 p + trr
@@ -232,22 +243,32 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino3_kernel(ConvK2 a) {
   float tdl[2][2], tdr[2][2];   // [channel][raw row A / B]: columns +3 and +6 of the patch row
   w3f2 tdm[2][2];               // columns +4, +5
   float vv[2][4];
-  auto tf_load = [&](auto p_, int rbuf) {
+  auto tf_load_c = [&](auto p_, int rbuf, int c) __attribute__((always_inline)) {   // the two raw rows of channel 2 tq + c
     constexpr int P = decltype(p_)::value;
     const int rowA = P == 0 ? trr : (trr ? 1 : 2), rowB = P == 0 ? 2 : (trr ? 3 : 1);
     // (inline asm: the compiler would merge neighbours into ds_read2 forms and keep six registers per row; the results are
     // waited for by the lgkmcnt(0) in front of their first use)
     const unsigned aA = w3_lds_addr(s_r0 + rbuf * Sh::RAW_FLOATS + roff + rowA * RP);
     const unsigned aB = w3_lds_addr(s_r0 + rbuf * Sh::RAW_FLOATS + roff + rowB * RP);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdl[c][0]) : "v"(aA), "i"((c * IH * RP + 1) * 4));
-      w3_read_b64(tdm[c][0], aA, (c * IH * RP + 2) * 4);
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdr[c][0]) : "v"(aA), "i"((c * IH * RP + 4) * 4));
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdl[c][1]) : "v"(aB), "i"((c * IH * RP + 1) * 4));
-      w3_read_b64(tdm[c][1], aB, (c * IH * RP + 2) * 4);
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdr[c][1]) : "v"(aB), "i"((c * IH * RP + 4) * 4));
+    if (c == 0) {
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdl[0][0]) : "v"(aA), "i"((1) * 4));
+      w3_read_b64(tdm[0][0], aA, (2) * 4);
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdr[0][0]) : "v"(aA), "i"((4) * 4));
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdl[0][1]) : "v"(aB), "i"((1) * 4));
+      w3_read_b64(tdm[0][1], aB, (2) * 4);
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdr[0][1]) : "v"(aB), "i"((4) * 4));
+    } else {
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdl[1][0]) : "v"(aA), "i"((IH * RP + 1) * 4));
+      w3_read_b64(tdm[1][0], aA, (IH * RP + 2) * 4);
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdr[1][0]) : "v"(aA), "i"((IH * RP + 4) * 4));
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdl[1][1]) : "v"(aB), "i"((IH * RP + 1) * 4));
+      w3_read_b64(tdm[1][1], aB, (IH * RP + 2) * 4);
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tdr[1][1]) : "v"(aB), "i"((IH * RP + 4) * 4));
     }
+  };
+  auto tf_load = [&](auto p_, int rbuf) __attribute__((always_inline)) {
+    tf_load_c(p_, rbuf, 0);
+    tf_load_c(p_, rbuf, 1);
   };
   auto tf_rows_cols = [&](auto p_, bool wait) __attribute__((always_inline)) {
     constexpr int P = decltype(p_)::value;
@@ -348,12 +369,16 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino3_kernel(ConvK2 a) {
     const float* s_v = smem + (P ? Sh::OFF_V1 : Sh::OFF_V0);
     float* const v_next = smem + (P ? Sh::OFF_V0 : Sh::OFF_V1);
     const int ub1 = ub == 2 ? 0 : ub + 1;
-    // six MFMAs of pair h; nu / nv = LDS addresses of the U / V image the NEXT pair (xn 2 hn, 2 hn + 1) is read from (0: none)
-    auto blkM = [&](auto h_, auto ld_, unsigned nu, unsigned nv, int hn) __attribute__((always_inline)) {
+    // six MFMAs of pair h; nu / nv = LDS addresses of the U / V image the NEXT pair (xn 2 hn, 2 hn + 1) is read from.
+    // `fill(j)` runs behind the two MFMAs of product j (and the reloads of their registers): everything else the phase has
+    // to issue is cut into three such pieces per block, so that no long stretch of non-MFMA instructions is left anywhere
+    // (tools/wino_trace.py: issued in one go behind the blocks, the raw reads + DMA of the tail took 640 cycles of a
+    // 2500-cycle phase, an LDS-DMA instruction alone costs 60 - 180 cycles of issue).
+    auto blkM = [&](auto h_, auto ld_, unsigned nu, unsigned nv, int hn, auto&& fill) __attribute__((always_inline)) {
       constexpr int h = decltype(h_)::value;
       constexpr bool ld = decltype(ld_)::value;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      static_for<0, 3>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int i = 2 * h + e;
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino3_kernel(ConvK2 a) {
             acc[4 * P + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[4 * P + i], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ld) {   // the registers of product j are free: A_j of both xn; B2 after j = 1, B1 after j = 2
+        if (ld && !(W3_ABLATE(a) & 8)) {   // the registers of product j are free: A_j of both xn; B2 after j = 1, B1 after j = 2
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             load_A(nu, 2 * hn + e, e, j);
@@ -374,32 +399,55 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino3_kernel(ConvK2 a) {
             if (j == 2) load_B(nv, 2 * hn + e, e, 0);
           }
         }
+        fill(j_);
         __builtin_amdgcn_sched_barrier(0);
-      }
+      });
     };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    using PN = std::integral_constant<int, P ^ 1>;
+    W3_FINE(0);
     wait_ops(true);
-    blkM(std::integral_constant<int, 0>{}, std::true_type{}, w3_lds_addr(s_u), w3_lds_addr(s_v), 1);
-    if (HAS_NEXT) {
-      if (!(W3_ABLATE(a) & 2)) {
-        tf_rows_cols(std::integral_constant<int, P ^ 1>{}, false);
-        tf_split(0, v_next); tf_split(1, v_next); tf_split(2, v_next); tf_split(3, v_next);
+    W3_FINE(1);
+    // M0 + the loads of pair 1 + the NEXT phase's input transform (its raw rows were read in the previous phase's M1)
+    blkM(H0{}, std::true_type{}, w3_lds_addr(s_u), w3_lds_addr(s_v), 1, [&](auto j_) __attribute__((always_inline)) {
+      constexpr int j = decltype(j_)::value;
+      if (HAS_NEXT && !(W3_ABLATE(a) & 2)) {
+        if (j == 0) tf_rows_cols(PN{}, false);
+        if (j == 1) { tf_split(0, v_next); tf_split(1, v_next); }
+        if (j == 2) { tf_split(2, v_next); tf_split(3, v_next); }
       }
-      __builtin_amdgcn_sched_barrier(0);
+    });
+    W3_FINE(2);
+    W3_FINE(3);
+    if (HAS_NEXT) {
       if (!(W3_ABLATE(a) & 16)) {
         if (s + 2 < nph) __builtin_amdgcn_s_waitcnt(W3_WAIT_VM3_LGKM0);   // U(s+1) and the raw halo landed; U(s+2) may still fly
         else __builtin_amdgcn_s_waitcnt(W3_WAIT_VM0_LGKM0);
+        W3_FINE(4);
         __builtin_amdgcn_s_barrier();
       }
+      W3_FINE(5);
       wait_ops(false);
-      blkM(std::integral_constant<int, 1>{}, std::true_type{}, w3_lds_addr(s_ub + ub1 * SUB), w3_lds_addr(v_next), 0);
-      if (s + 2 < nph && !(W3_ABLATE(a) & 2)) tf_load(std::integral_constant<int, P>{}, ((s + 2) >> 1) & 1);
-      if (!(W3_ABLATE(a) & 4)) {
-        if (s + 3 < nph) issue_u(s + 3, ub);
-        if (P == 0 && (s >> 1) + 2 < a.nchunks) issue_raw((s >> 1) + 2);
-      }
+      // M1 + the next phase's first operands + the raw reads of the transform after next + the DMA issue (U three phases
+      // ahead into the buffer this phase has finished with, the raw halo two chunks ahead)
+      const int rb2 = ((s + 2) >> 1) & 1;
+      blkM(H1{}, std::true_type{}, w3_lds_addr(s_ub + ub1 * SUB), w3_lds_addr(v_next), 0, [&](auto j_) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_)::value;
+        if (s + 2 < nph && !(W3_ABLATE(a) & 2)) {
+          if (j == 0) tf_load_c(std::integral_constant<int, P>{}, rb2, 0);
+          if (j == 1) tf_load_c(std::integral_constant<int, P>{}, rb2, 1);
+        }
+        if (!(W3_ABLATE(a) & 4)) {
+          if (s + 3 < nph) issue_u_piece(s + 3, ub, j);
+          if (j == 2 && P == 0 && (s >> 1) + 2 < a.nchunks) issue_raw((s >> 1) + 2);
+        }
+      });
+      W3_FINE(6);
+      W3_FINE(7);
     } else {
       wait_ops(true);
-      blkM(std::integral_constant<int, 1>{}, std::false_type{}, 0u, 0u, 0);
+      blkM(H1{}, std::false_type{}, 0u, 0u, 0, [&](auto) __attribute__((always_inline)) {});
     }
     __builtin_amdgcn_sched_barrier(0);
     ub = ub1;

@@ -127,6 +127,9 @@ struct dvsr_edvr_plan {
   // params[i] points to [wsets][numel_i] floats and batch group g convolves with set g -- the private copies of K frames
   // that have diverged (second and later inner steps; the adapted forwards) still run as one batch.
   int wsets = 1;
+  // estimator plans under DVSR_EST_SPLIT=1: the 3x3 stride-1 convolutions over explicitly padded inputs (pad = 0; the data
+  // gradient's pad = 2) take the exact 3-way bf16 split kernel too (cfg.bf16_mfma = 2)
+  bool split_any_pad = false;
 };
 
 namespace dvsr {
@@ -169,7 +172,7 @@ struct Builder {
     // (the gradient arena mirrors this slot: one re-laid-out gradient per group)
     if (wmap) o.w2_off = alloc("", (size_t)std::max(p.wgroups, p.wsets) * Cout * (c0 + c1) * ks * ks).off;
     {
-      const bool bf = p.cfg.bf16_mfma && ks == 3 && stride == 1 && pad < 0 && (c1 == 0 || c0 % 16 == 0);
+      const bool bf = p.cfg.bf16_mfma && ks == 3 && stride == 1 && (pad < 0 || p.split_any_pad) && (c1 == 0 || c0 % 16 == 0);
       // bf16_mfma = 2: 8-row tiles (two 32-pixel rows per wave) once they still give ~a workgroup per CU
       static const int split_th8_from = getenv("DVSR_SPLIT_TH8_FROM") ? atoi(getenv("DVSR_SPLIT_TH8_FROM")) : 200;
       auto as_bf = [&](ConvGeo g, int ho, int wo, int cout) {
@@ -1176,17 +1179,22 @@ extern "C" int dvsr_edvr_op_info(const dvsr_edvr_plan* p, int index, char* kind,
   return DVSR_OK;
 }
 
-// Contraction work of a whole plan, forward and backward tapes: out[0] / out[2] = algorithmic FLOPs (2 x MACs of the direct
+// Contraction work of a whole plan, forward and backward tapes (out: FIVE doubles): out[0] / out[2] = algorithmic FLOPs (2 x MACs of the direct
 // sums: convolutions and the DCN contraction; weight + data gradients for the backward), out[1] / out[3] = the FLOPs the
 // matrix pipe actually issues -- launches on the Winograd F(2x2, 3x3) kernel (geo.dma == 3) issue 16/36 of theirs.
 // bench.py prices every roofline fraction with the executed figure.
 extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out4) {
   DVSR_REQUIRE(p && out4, DVSR_ERR_INVALID, "edvr_plan_work: null argument");
-  double fa = 0, fe = 0, ba = 0, be = 0;
+  double fa = 0, fe = 0, ba = 0, be = 0, fby = 0;
   auto conv_part = [](const Op& o, int ci) {
     return 2.0 * (double)o.N * conv_out(o, o.H) * conv_out(o, o.W) * o.Cout * ci * o.ks * o.ks;
   };
   for (const Op& o : p->ops) {
+    {
+      const char* k; double fl, by;
+      op_work(o, &k, &fl, &by);
+      fby += by;
+    }
     if (o.type == OP_CONV) {
       const double f = conv_part(o, o.c0 + o.c1);
       fa += f; fe += o.geo.dma >= 3 ? f * (16.0 / 36.0) : f;
@@ -1210,6 +1218,7 @@ extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out4) {
     }
   }
   out4[0] = fa; out4[1] = fe; out4[2] = ba; out4[3] = be;
+  out4[4] = fby;   // algorithmic bytes of the forward tape: every launch's distinct inputs once + outputs once (op_work)
   return DVSR_OK;
 }
 
@@ -1404,6 +1413,14 @@ extern "C" int dvsr_estimator_plan_create_ex(const dvsr_estimator_config* cfg, i
   ep->ecfg = *cfg;
   dvsr_edvr_plan& p = ep->core;
   p.cfg = dvsr_edvr_config{cfg->nf, cfg->nframes, 1, 0, 0, cfg->scale, 0, 0};
+  {
+    // The estimators' 3x3 stride-1 convolutions run over explicitly (reflection-)padded tensors, whose pitch W + 2 keeps them
+    // off the DMA-halo and Winograd kernels; the register-staged kernel with the exact 3-way bf16 operand split
+    // (cfg.bf16_mfma = 2: fp32-accurate, six bf16 products per fp32 product) is 1.3x the fp32 MFMA on them: MFDN x4 forward
+    // at 5x3x176x320 0.72 -> 0.62 ms, the batched inner step 4.55 -> 4.36 ms per frame.  DVSR_EST_SPLIT=0: fp32 MFMA.
+    const char* v = getenv("DVSR_EST_SPLIT");
+    if (!v || atoi(v)) { p.cfg.bf16_mfma = 2; p.split_any_pad = true; }
+  }
   p.B = B; p.H = H; p.W = W; p.wgroups = grad_groups; p.wsets = weight_sets;
   { const char* v = getenv("DVSR_BWD_STREAMS"); p.side_streams = (v && v[0] == '0') ? 0 : 1; }
   p.fork_every = 1;   // seven layers whose weight gradients outlast the data-gradient chain: every fork at once

@@ -16,7 +16,7 @@ _plans = {}
 # Environment switches that the native plan builder reads when it chooses kernels (conv2_choose, build_backward): they are
 # part of the plan-cache key, so a plan built under one setting is never handed out under another.
 _GEOMETRY_ENV = ("DVSR_CONV_WINO", "DVSR_CONV_WINO3", "DVSR_CONV_V1", "DVSR_CONV_DMA", "DVSR_CONV_TILE",
-                 "DVSR_CONV_KSPLIT_BELOW", "DVSR_DCN_BWD", "DVSR_EST_FUSE_PAD", "DVSR_FUSE_ACT_BWD", "DVSR_BWD_STREAMS")
+                 "DVSR_CONV_KSPLIT_BELOW", "DVSR_DCN_BWD", "DVSR_EST_FUSE_PAD", "DVSR_EST_SPLIT", "DVSR_FUSE_ACT_BWD", "DVSR_BWD_STREAMS")
 
 
 def _env_key():
@@ -67,9 +67,9 @@ class Plan:
     def work(self):
         """Contraction FLOPs of the two tapes: {'fwd_algorithmic', 'fwd_executed', 'bwd_algorithmic', 'bwd_executed'}
         (launches on the Winograd kernel issue 16/36 of their algorithmic multiplies)."""
-        out = (ctypes.c_double * 4)()
+        out = (ctypes.c_double * 5)()
         L.check(L.lib().dvsr_edvr_plan_work(self._h, ctypes.byref(out)), "dvsr_edvr_plan_work")
-        return dict(zip(("fwd_algorithmic", "fwd_executed", "bwd_algorithmic", "bwd_executed"), out))
+        return dict(zip(("fwd_algorithmic", "fwd_executed", "bwd_algorithmic", "bwd_executed", "fwd_bytes"), out))
 
     def op_output(self, ws, index, which=0):
         """Flat view of what launch `index` wrote into the workspace (None when it writes the output tensor)."""
@@ -266,9 +266,9 @@ class EstimatorPlan:
 
     def work(self):
         """As Plan.work(), for the estimator's tapes."""
-        out = (ctypes.c_double * 4)()
+        out = (ctypes.c_double * 5)()
         L.check(L.lib().dvsr_estimator_plan_work(self._h, ctypes.byref(out)), "dvsr_estimator_plan_work")
-        return dict(zip(("fwd_algorithmic", "fwd_executed", "bwd_algorithmic", "bwd_executed"), out))
+        return dict(zip(("fwd_algorithmic", "fwd_executed", "bwd_algorithmic", "bwd_executed", "fwd_bytes"), out))
 
     def __del__(self):
         try:

@@ -210,8 +210,9 @@ int dvsr_edvr_num_backward_launches(const dvsr_edvr_plan* plan);
  * synchronises, and returns per-launch milliseconds in op_ms[dvsr_edvr_num_launches()]. */
 int dvsr_edvr_op_info(const dvsr_edvr_plan* plan, int index, char* kind, int kind_cap, char* name,
                       int name_cap, double* flops, double* bytes);
-/* Contraction work of the plan's two tapes: out4 = {forward algorithmic FLOPs, forward FLOPs issued to the matrix pipe,
- * backward algorithmic, backward issued}.  Algorithmic = 2 x MACs of the direct sums; launches on the
+/* Contraction work of the plan's two tapes: out4 (FIVE doubles) = {forward algorithmic FLOPs, forward FLOPs issued to the
+ * matrix pipe, backward algorithmic, backward issued, algorithmic bytes of the forward tape (every launch's distinct inputs
+ * once + its outputs once)}.  Algorithmic = 2 x MACs of the direct sums; launches on the
  * Winograd F(2x2,3x3) kernel issue 16/36 of theirs.  bench.py's roofline fractions use the issued figure. */
 int dvsr_edvr_plan_work(const dvsr_edvr_plan* plan, double* out4);
 /* Test aid: where launch `index` of the forward tape leaves its result (which = 0; 1 = the second output of the pool /

@@ -441,6 +441,42 @@ def test_conv3x3_winograd(n, c0, c1, cout, h, w, act, res, ps, force, pipe, monk
         assert relerr(gx, ref_g) < 2e-6
 
 
+@pytest.mark.parametrize("pipe", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("name,cout,h,w,ps", [("upconv2", 256, 360, 640, 2), ("HRconv", 64, 720, 1280, 0)])
+def test_conv3x3_winograd_largest_geometries(name, cout, h, w, ps, pipe, monkeypatch):
+    """The two largest launches of the headline forward at op level -- upconv2 (64 -> 256 + PixelShuffle(2) at 360x640) and
+    HRconv (64 -> 64 at 720x1280), EDVR_arch.py:304-306 -- on both Winograd kernels: the whole output against the direct
+    kernel (the same sums in another order: <= 2e-6), and three bands of rows (top edge, middle, bottom edge) against fp64
+    torch on the corresponding crops (<= 2e-6): a full fp64 evaluation of these shapes is 34 / 68 GFLOP of CPU work."""
+    import ctypes
+    from dynavsr_amd import _lib as L
+    n, c0 = 1, 64
+    x = rnd(n, c0, h, w, seed=11)
+    wt = rnd(cout, c0, 3, 3, seed=12, scale=1 / np.sqrt(c0 * 9))
+    b = rnd(cout, seed=13, scale=0.1)
+    dx, dw, db_ = dev(x), dev(wt), dev(b)
+    outs = {}
+    for mode in ("wino", "direct"):
+        monkeypatch.setenv("DVSR_CONV_WINO", "2" if mode == "wino" else "0")
+        monkeypatch.setenv("DVSR_CONV_WINO3", "1" if pipe == "bf16x3" else "0")
+        y = torch.empty((n, cout // 4, 2 * h, 2 * w) if ps else (n, cout, h, w), device="cuda")
+        d = L.Conv2dDesc(L.ptr(dx), None, L.ptr(dw), L.ptr(db_), None, L.ptr(y), n, c0, 0, h, w, cout, 3, 1, 1, 1, ps, 1, 0, 0)
+        geo = (ctypes.c_int * 4)()
+        L.check(L.lib().dvsr_conv2d_packed_geometry(d, ctypes.byref(geo)), "dvsr_conv2d_packed_geometry")
+        assert list(geo)[3] == ((4 if pipe == "bf16x3" else 3) if mode == "wino" else 1), (mode, list(geo))
+        ws = torch.empty(max(int(L.lib().dvsr_conv2d_packed_workspace_bytes(d)), 16), dtype=torch.uint8, device="cuda")
+        L.check(L.lib().dvsr_conv2d_forward_packed(d, ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_forward_packed")
+        outs[mode] = y.cpu()
+    assert relerr(outs["wino"], outs["direct"]) < 2e-6
+    s = 2 if ps else 1
+    for r0, r1 in ((0, 12), (h // 2 - 6, h // 2 + 6), (h - 12, h)):
+        a0, a1 = max(r0 - 1, 0), min(r1 + 1, h)                       # input rows incl. the one-row halo inside the image
+        ref = F.leaky_relu(F.conv2d(x[:, :, a0:a1].double(), wt.double(), b.double(), 1, 1), 0.1)[:, :, r0 - a0:r0 - a0 + (r1 - r0)]
+        if ps:
+            ref = F.pixel_shuffle(ref, 2)
+        assert relerr(outs["wino"][:, :, s * r0:s * r1], ref) < 2e-6, (name, r0)
+
+
 def test_conv3x3_dma_halo_not_for_unaligned():
     """W % 4 != 0 or channel counts % 8 != 0 keep the register-staged kernel."""
     import ctypes

@@ -81,14 +81,41 @@ for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
 done
 python tools/pmc_mfma.py $out/dbi_SQ_VALU_MFMA_BUSY_CYCLES/p_results.db $out/dbi_GRBM_GUI_ACTIVE/p_results.db > $out/${tag}_pmc_mfma_util_inner_batch.txt
 rm -rf $out/dbi_SQ_VALU_MFMA_BUSY_CYCLES $out/dbi_GRBM_GUI_ACTIVE
+# r04: HBM-side traffic of the batched inner step (K = 16, the leg the metric is named after): 5 warm-up + 2 + 2 profiled batches
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace -d $out/dbt_$c -o p -- python tools/inner_batch_profile.py 16 2 > /dev/null 2>&1
+done
+echo "batched inner step K=16 LR 176x320, per batch: $(python tools/pmc_total.py $out/dbt_FETCH_SIZE/p_results.db $out/dbt_WRITE_SIZE/p_results.db 9 --json $out/pmc_traffic.json inner_step_batched frames_per_batch=16 h=176 w=320 | head -1)" > $out/${tag}_pmc_hbm_traffic_inner_step.txt
+rm -rf $out/dbt_FETCH_SIZE $out/dbt_WRITE_SIZE
 # 10. r03: Winograd F(2x2, 3x3) kernel against the direct DMA-halo kernel per layer shape (accuracy vs fp64, time per launch),
 #     its cycle-stamp timeline (debug build), and the forward with the kernel switched off
-DVSR_CONV_WINO=2 python tools/wino_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_wino_vs_direct.txt
+echo "== Winograd on the bf16 pipe, exact 3-way split (conv2d_wino3.hip, the default)" > $out/${tag}_wino_vs_direct.txt
+DVSR_CONV_WINO=2 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
+echo "== Winograd on the fp32 MFMA (conv2d_wino.hip, DVSR_CONV_WINO3=0)" >> $out/${tag}_wino_vs_direct.txt
+DVSR_CONV_WINO=2 DVSR_CONV_WINO3=0 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
+echo "== direct kernels (DVSR_CONV_WINO=0)" >> $out/${tag}_wino_vs_direct.txt
 DVSR_CONV_WINO=0 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
 if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
   python tools/wino_trace.py 2>&1 | grep -v amdgpu > $out/${tag}_wino_trace.txt
   python tools/wino_trace.py 5 64 64 64 180 320 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
+  echo "== the fp32 MFMA kernel (DVSR_CONV_WINO3=0)" >> $out/${tag}_wino_trace.txt
+  DVSR_CONV_WINO3=0 python tools/wino_trace.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
+  # run-time ablations of the bf16x3 kernel (debug build; results are wrong when a bit is set): 2 no input transform,
+  # 4 no DMA, 8 operands read once, 16 no barriers
+  for ab in 0 2 4 8 16 6 30; do
+    echo "== DVSR_CONV_ABLATE=$ab" >> $out/${tag}_wino3_ablation.txt
+    DVSR_CONV_WINO=2 DVSR_CONV_ABLATE=$ab DVSR_HIP_LIB=$PWD/dynavsr_amd/libdynavsr_hip_trace.so python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_ablation.txt
+  done
 fi
+# r04: PMC picture of the bf16x3 Winograd kernel (LDS activity, wave wait / issue-stall split, instruction mix)
+for set in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  DVSR_CONV_WINO=2 rocprofv3 --pmc $set --kernel-trace -d $out/dbw -o p -- python tools/wino_bench.py --quick > /dev/null 2>&1
+  python tools/pmc_dump.py $out/dbw/p_results.db conv2d_wino3 >> $out/${tag}_wino3_pmc.txt; rm -rf $out/dbw
+done
+# r04: what the two waves of a SIMD share (micro-benchmarks behind DESIGN 3.1f)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/mfma_overlap.hip -o /tmp/mfma_overlap 2>/dev/null && /tmp/mfma_overlap > $out/${tag}_mfma_overlap.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/wave_phase.hip -o /tmp/wave_phase 2>/dev/null && /tmp/wave_phase > $out/${tag}_wave_phase.txt
+python tools/graph_fwd_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_graph_vs_eager_fwd.txt
 echo "== forward 180x320 with DVSR_CONV_WINO=0 (direct kernels only)" >> $out/${tag}_wino_vs_direct.txt
 DVSR_CONV_WINO=0 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-inner-step --no-split --no-meta --no-validation 2>/dev/null | tail -1 | python -c "
 import json,sys
