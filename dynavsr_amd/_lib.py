@@ -112,6 +112,7 @@ def _declare(lib):
         "dvsr_conv2d_dgrad_packed": (I, [POINTER(Conv2dDesc), P, P, P, c_size_t, P]),
         "dvsr_conv2d_packed_geometry": (I, [POINTER(Conv2dDesc), POINTER(ctypes.c_int * 4)]),
         "dvsr_conv2d_wgrad_bf16": (I, [POINTER(Conv2dDesc), P, P, P, P, c_size_t, P]),
+        "dvsr_conv2d_wgrad_split3": (I, [POINTER(Conv2dDesc), P, P, P, P, c_size_t, P]),
         "dvsr_flow_warp_forward": (I, [P, P, P, I, I, I, I, LL, P]),
         "dvsr_flow_warp_backward": (I, [P, P, P, P, P, I, I, I, I, LL, P]),
         "dvsr_avgpool2_forward": (I, [P, P, LL, I, I, P]),

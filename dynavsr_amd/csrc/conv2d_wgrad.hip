@@ -327,7 +327,7 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
     s = groups > 1 ? s / groups : s;
     return s > k.gtiles ? k.gtiles : (s < 1 ? 1 : s);
   };
-  out->bf = bf16 && ks == 3 && stride == 1;
+  out->bf = (bf16 && ks == 3 && stride == 1) ? bf16 : 0;
   if (out->bf) {
     // the bf16 kernel is staging- and flush-bound (36 MFMAs per tile): fewer workgroups, each with more tiles, keep the
     // 147 KB-per-workgroup atomic flush small.  DVSR_WGRAD_BF_WGS=<workgroups per launch to aim for>.
@@ -358,7 +358,7 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
   {
     static const bool wide = [] { const char* v = getenv("DVSR_WGRAD_WIDE"); return !(v && v[0] == '0'); }();
     const bool gy_ok = !gy_ps && k.Wo % 4 == 0 && ((uintptr_t)gy & 15) == 0;
-    if (wide && gy_ok && stride == 1 && ks <= 3 && !out->bf) {
+    if (wide && gy_ok && stride == 1 && ks <= 3 && out->bf != 1) {   // (bf == 2: the split kernel has the same two vector forms)
       if (W % 4 == 0 && k.x_bs % 4 == 0 && ((uintptr_t)x & 15) == 0) k.vx = 4;
       else if (W % 2 == 0 && k.x_bs % 2 == 0 && ((uintptr_t)x & 7) == 0) k.vx = 2;
     }
@@ -381,6 +381,7 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
 }
 
 int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st) {
+  if (l.bf == 2) return conv2d_wgrad_split3_launch(l, st);
   if (l.bf) return conv2d_wgrad_bf16_launch(l, st);
   const WgradK& k = l.k;
   const dim3 grid = l.grid;
@@ -491,8 +492,8 @@ extern "C" int dvsr_conv2d_backward(const dvsr_conv2d_desc* d, const float* gy, 
 // Weight / bias gradient of a single-input 3x3 stride-1 conv with bf16 operands on the bf16 MFMA (fp32 accumulate):
 // the op-level face of conv2d_wgrad_bf16.hip (the EDVR plan uses it when network_G.bf16_mfma = 1).  Workspace:
 // dvsr_conv2d_backward_workspace_bytes.
-extern "C" int dvsr_conv2d_wgrad_bf16(const dvsr_conv2d_desc* d, const float* gy, float* gw, float* gb, void* workspace,
-                                      size_t workspace_bytes, dvsr_stream_t stream) {
+static int wgrad_bf_mode(const dvsr_conv2d_desc* d, const float* gy, float* gw, float* gb, void* workspace,
+                         size_t workspace_bytes, dvsr_stream_t stream, int mode) {
   using namespace dvsr;
   DVSR_REQUIRE(d && gy && gw && d->x0, DVSR_ERR_INVALID, "conv2d_wgrad_bf16: null argument");
   DVSR_REQUIRE(d->ks == 3 && d->stride == 1 && d->c1 == 0 && d->pixel_shuffle == 0, DVSR_ERR_UNSUPPORTED,
@@ -500,7 +501,7 @@ extern "C" int dvsr_conv2d_wgrad_bf16(const dvsr_conv2d_desc* d, const float* gy
   hipStream_t st = (hipStream_t)stream;
   WgradLaunch l;
   int rc = conv2d_wgrad_prepare(d->x0, d->x0_bstride, 1, gy, 0, gw, gb, d->N, d->c0, d->H, d->W, d->Cout, d->c0, 0, 3, 1,
-                                workspace, workspace_bytes, st, 0, d->pad, nullptr, &l, 1);
+                                workspace, workspace_bytes, st, 0, d->pad, nullptr, &l, mode);
   if (rc) return rc;
   rc = conv2d_wgrad_launch(l, st);
   if (rc) return rc;
@@ -509,5 +510,17 @@ extern "C" int dvsr_conv2d_wgrad_bf16(const dvsr_conv2d_desc* d, const float* gy
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, k.partial, k.dbp, gw, gb, k.nslot, 9,
                      k.nob * 64, k.ncb * 64, d->Cout, d->c0, d->c0, 0, 0LL, 0LL);
   return check_launch("wgrad_reduce_kernel");
+}
+
+extern "C" int dvsr_conv2d_wgrad_bf16(const dvsr_conv2d_desc* d, const float* gy, float* gw, float* gb, void* workspace,
+                                      size_t workspace_bytes, dvsr_stream_t stream) {
+  return wgrad_bf_mode(d, gy, gw, gb, workspace, workspace_bytes, stream, 1);
+}
+
+// The same on the exact 3-way bf16 split of both operands (fp32 accuracy; what the plans run for their 3x3 stride-1 weight
+// gradients unless DVSR_WGRAD_SPLIT3=0).
+extern "C" int dvsr_conv2d_wgrad_split3(const dvsr_conv2d_desc* d, const float* gy, float* gw, float* gb, void* workspace,
+                                        size_t workspace_bytes, dvsr_stream_t stream) {
+  return wgrad_bf_mode(d, gy, gw, gb, workspace, workspace_bytes, stream, 2);
 }
 

@@ -23,6 +23,7 @@
 namespace dvsr {
 
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WB_GROW = 72;            // bf16 per gy row: 64 pixels + 8 pad (144 B)
 constexpr int WB_XCH = 136;            // bf16 per channel of one x copy: 4 rows x 32 + 8 pad (272 B)
@@ -184,6 +185,330 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_bf16_kernel(WgradK a) {
     }
   // lane (lo, hi) summed gy[o = ot*32 + lo] over the pixel blocks of half hi
   if (cbk == 0 && ct == 0) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + ob * 64 + ot * 32 + lo, db);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same weight gradient at fp32 ACCURACY on the bf16 pipe (r04): both operands are split exactly into three bf16 pieces
+// (x = hi + mid + lo, 8 + 8 + 8 significand bits) as they are staged, and the six partial products above 2^-24
+// (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) are accumulated in fp32 -- the arithmetic of the forward's split kernels
+// (conv2d_v2.hip BF = 2, conv2d_wino3.hip).  Per (tap, 16-pixel block) six v_mfma_f32_32x32x16_bf16 (192 cycles) take the
+// place of eight v_mfma_f32_32x32x2_f32 (512 cycles); 216 MFMAs per tile and wave instead of 288 at half the cycles each.
+// Why: the fp32 kernel (conv2d_wgrad_pipe_kernel) is the largest item of the batched inner MAML step (22 % of its kernel
+// time, matrix pipe 57 % busy) and its pipe has no faster exact mode.
+//   * LDS: ONE copy of the x tile per piece (4 rows x 34 columns per channel, rows padded to 40, channels to 168 bf16: 16-byte
+//     operand reads conflict-free across the 32 channels of a lane group); the column shift of a tap is made in registers
+//     (tx = 1: four v_alignbit over the 16-byte operand and the next pixel pair; tx = 2: the dwords one further) instead of by
+//     three shifted copies -- 3 x (9.2 + 21.5) KB = 90 KB;
+//   * per 16-pixel block and kernel row: 3 + 3 LDS reads per piece set, 18 MFMAs on three accumulators (the three taps of
+//     the row) so that no MFMA waits for its predecessor;
+//   * the bias gradient is the fp32 sum of the three pieces of gy, i.e. of the exact values.
+constexpr int S3_GROW = 72;                  // bf16 per gy row: 64 pixels + 8 pad (144 B)
+constexpr int S3_GP = 64 * S3_GROW;          // one piece of the gy tile
+constexpr int S3_XROW = 40;                  // bf16 per x row: 34 columns + 6 pad (80 B)
+constexpr int S3_XCH = 4 * S3_XROW + 8;      // 168 bf16 (336 B) per channel
+constexpr int S3_XP = 64 * S3_XCH;           // one piece of the x tile
+constexpr size_t S3_LDS_BYTES = (size_t)(3 * S3_GP + 3 * S3_XP) * 2;
+
+// exact 3-way split of a pair: words {bf16(a) | bf16(b) << 16} of the hi / mid / lo pieces
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+  const float r0 = a - __builtin_bit_cast(float, h << 16), r1 = b - __builtin_bit_cast(float, h & 0xffff0000u);
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m) : "v"(r0), "v"(r1));
+  const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l) : "v"(q0), "v"(q1));
+}
+
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+
+// VX = 0: scalar staging (any geometry: pixel-shuffled gy, odd widths).  VX = 4 / 2: the x window as float4 / float2 vectors
+// and the gy rows as float4 -- the window starts SHIFT = (VX - pad % VX) % VX columns left of the first column the taps need,
+// so that every vector is aligned and lies entirely inside or outside the image (as conv2d_wgrad_wide_item does for the fp32
+// kernel): 14 / 22 vector loads and 42 / 66 8-byte (4-byte) LDS stores per lane and tile instead of 50 + 99.
+template <int VX, int SHIFT>
+__global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  __bf16* const s_g = smem16;
+  __bf16* const s_x = smem16 + 3 * S3_GP;
+  constexpr int WWIN = VX ? ((34 + 2 * (VX - 1)) / VX) * VX : 34;   // window columns per row (40 / 36 / 34)
+  constexpr int RV = VX ? WWIN / VX : 1, XV = 4 * RV;                // vectors per row / per channel
+  constexpr int XM = VX ? (16 * XV + 63) / 64 : 1;                   // x vectors per lane and tile (16 channels per wave)
+  typedef float xvec __attribute__((ext_vector_type(VX ? VX : 1)));
+
+  const int split = blockIdx.x, ob = blockIdx.y, cbk = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int ot = wave >> 1, ct = wave & 1;
+  const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float db = 0.f;
+
+  // ---- scalar staging (VX = 0)
+  const int gpy = lane >> 5, gpx = lane & 31;  // gy tile: lane = pixel
+  const unsigned g_lane = a.gy_ps ? (unsigned)((2 * gpy) * (2 * a.Wo) + 2 * gpx) : (unsigned)(gpy * a.Wo + gpx);
+  const int xrow = lane >> 4, xp = lane & 15;       // x tile: lane = (row, column pair)
+  const int trow = lane & 3, tch = lane >> 2;       // halo pair (columns 32, 33): lane = (channel of the wave, row)
+  float rg[VX ? 1 : 16];
+  float2 rx[VX ? 1 : 16], rt;
+  bool g_ok, x_ok0, x_ok1, t_ok0, t_ok1;
+  // ---- vector staging (VX = 2, 4): lane-fixed (channel, row, column) of its vectors
+  int gch[4], grow[4], gcol[4], xch[XM], xrw[XM], xcol[XM], xlds[XM];
+  f32x4 vg[4];
+  xvec vx[XM];
+  bool vg_ok[4], vx_ok[XM];
+  if (VX) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int idx = lane + 64 * m;
+      gch[m] = idx >> 4; grow[m] = (idx >> 3) & 1; gcol[m] = (idx & 7) * 4;
+    }
+#pragma unroll
+    for (int m = 0; m < XM; ++m) {
+      const int idx = lane + 64 * m;
+      const int c = idx / XV, r = idx - c * XV;
+      xch[m] = c < 16 ? c : 15; xrw[m] = r / RV; xcol[m] = (r - xrw[m] * RV) * VX;
+      xlds[m] = c < 16 ? (wave * 16 + c) * S3_XCH + xrw[m] * S3_XROW + xcol[m] : -1;
+    }
+  }
+
+  auto issue_loads = [&](int tile) {
+    const int tx_ = tile % a.tiles_x;
+    const int t2 = tile / a.tiles_x;
+    const int ty_ = t2 % a.tiles_y;
+    const int n = t2 / a.tiles_y;
+    const int oy0 = ty_ * 2, ox0 = tx_ * 32;
+    if constexpr (VX != 0) {
+      // (an invalid vector reads the first one of the image instead: channels past Cout / Cin of a partly filled block
+      // would otherwise address memory behind the tensor)
+      const float* gn = a.gy + (size_t)n * a.Cout * HWo;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int co = ob * 64 + wave * 16 + gch[m];
+        vg_ok[m] = co < a.Cout && oy0 + grow[m] < a.Ho && ox0 + gcol[m] < a.Wo;
+        const size_t off = vg_ok[m] ? (size_t)co * HWo + (size_t)(oy0 + grow[m]) * a.Wo + ox0 + gcol[m] : 0;
+        vg[m] = *reinterpret_cast<const f32x4*>(gn + off);
+      }
+      const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad - SHIFT;
+      const float* xn = a.x + (size_t)(n / a.x_bdiv) * a.x_bs;
+#pragma unroll
+      for (int m = 0; m < XM; ++m) {
+        const int ci = cbk * 64 + wave * 16 + xch[m];
+        const int gy_ = iy0 + xrw[m], gx_ = ix0 + xcol[m];
+        vx_ok[m] = xlds[m] >= 0 && ci < a.Cin && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W;
+        const size_t off = vx_ok[m] ? (size_t)ci * HW + (size_t)gy_ * a.W + gx_ : 0;
+        vx[m] = *reinterpret_cast<const xvec*>(xn + off);
+      }
+    } else {
+    g_ok = oy0 + gpy < a.Ho && ox0 + gpx < a.Wo;
+    const unsigned g_off = g_ok ? g_lane * 4u : 0u;
+    {
+      const int co0 = ob * 64 + wave * 16;
+      const int cc = co0 < a.Cout ? co0 : a.Cout - 1;
+      const char* p;
+      if (a.gy_ps)
+        p = reinterpret_cast<const char*>(a.gy + (((size_t)n * (a.Cout >> 2) + (cc >> 2)) * (2 * a.Ho) + 2 * oy0 + ((cc >> 1) & 1)) *
+                                                     (size_t)(2 * a.Wo) + 2 * ox0 + (cc & 1));
+      else
+        p = reinterpret_cast<const char*>(a.gy + ((size_t)n * a.Cout + cc) * HWo + (size_t)oy0 * a.Wo + ox0);
+      const size_t inc0 = a.gy_ps ? 4 : HWo * 4;
+      const size_t inc1 = a.gy_ps ? ((size_t)2 * a.Wo - 1) * 4 : HWo * 4;
+      const size_t inc3 = a.gy_ps ? ((size_t)4 * HWo - 2 * a.Wo - 1) * 4 : HWo * 4;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        rg[j] = *reinterpret_cast<const float*>(p + g_off);
+        const size_t inc = (j & 1) == 0 ? inc0 : ((j & 3) == 1 ? inc1 : inc3);   // (co0 is a multiple of 16)
+        p += (co0 + j + 1 < a.Cout) ? inc : 0;
+      }
+    }
+    const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
+    const float* xn = a.x + (size_t)(n / a.x_bdiv) * a.x_bs;
+    {
+      const int gy_ = iy0 + xrow, gx_ = ix0 + 2 * xp;
+      const bool rok = (unsigned)gy_ < (unsigned)a.H;
+      x_ok0 = rok && (unsigned)gx_ < (unsigned)a.W;
+      x_ok1 = rok && (unsigned)(gx_ + 1) < (unsigned)a.W;
+      const unsigned o0 = x_ok0 ? (unsigned)(gy_ * a.W + gx_) * 4u : 0u, o1 = x_ok1 ? (unsigned)(gy_ * a.W + gx_ + 1) * 4u : 0u;
+      const int ci0 = cbk * 64 + wave * 16;
+      const char* base = reinterpret_cast<const char*>(xn + (size_t)(ci0 < a.Cin ? ci0 : a.Cin - 1) * HW);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        rx[j].x = *reinterpret_cast<const float*>(base + o0);
+        rx[j].y = *reinterpret_cast<const float*>(base + o1);
+        base += (ci0 + j + 1 < a.Cin) ? HW * 4 : 0;
+      }
+    }
+    {
+      const int gy_ = iy0 + trow, gx_ = ix0 + 32;
+      int ci = cbk * 64 + wave * 16 + tch;
+      ci = ci < a.Cin ? ci : a.Cin - 1;
+      const bool rok = (unsigned)gy_ < (unsigned)a.H;
+      t_ok0 = rok && (unsigned)gx_ < (unsigned)a.W;
+      t_ok1 = rok && (unsigned)(gx_ + 1) < (unsigned)a.W;
+      const float* base = xn + (size_t)ci * HW;
+      rt.x = base[t_ok0 ? (size_t)gy_ * a.W + gx_ : 0];
+      rt.y = base[t_ok1 ? (size_t)gy_ * a.W + gx_ + 1 : 0];
+    }
+    }
+  };
+  auto write_lds = [&]() {
+    if constexpr (VX != 0) {
+      // four pixels of one channel: two pairs -> 8 bytes per piece
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const f32x4 v = vg_ok[m] ? vg[m] : f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned w0[3], w1[3];
+        split3_pair(v[0], v[1], w0[0], w0[1], w0[2]);
+        split3_pair(v[2], v[3], w1[0], w1[1], w1[2]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          *reinterpret_cast<wbf16x4*>(s_g + q * S3_GP + (wave * 16 + gch[m]) * S3_GROW + grow[m] * 32 + gcol[m]) =
+              __builtin_bit_cast(wbf16x4, uint2{w0[q], w1[q]});
+      }
+#pragma unroll
+      for (int m = 0; m < XM; ++m) {
+        xvec v = vx[m];
+        if (!vx_ok[m]) {
+#pragma unroll
+          for (int e = 0; e < VX; ++e) v[e] = 0.f;
+        }
+        if (xlds[m] < 0) continue;
+        unsigned w0[3], w1[3];
+        split3_pair(v[0], v[1], w0[0], w0[1], w0[2]);
+        if (VX == 4) split3_pair(v[VX - 2], v[VX - 1], w1[0], w1[1], w1[2]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          if (VX == 4) *reinterpret_cast<wbf16x4*>(s_x + q * S3_XP + xlds[m]) = __builtin_bit_cast(wbf16x4, uint2{w0[q], w1[q]});
+          else *reinterpret_cast<wbf16x2*>(s_x + q * S3_XP + xlds[m]) = __builtin_bit_cast(wbf16x2, w0[q]);
+        }
+      }
+    } else {
+    // gy: channels in pairs (one v_cvt_pk per piece and pair), 2-byte stores at [piece][o][pixel]
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+      const int o = wave * 16 + j;
+      const float v0 = (g_ok && ob * 64 + o < a.Cout) ? rg[j] : 0.f, v1 = (g_ok && ob * 64 + o + 1 < a.Cout) ? rg[j + 1] : 0.f;
+      unsigned w[3];
+      split3_pair(v0, v1, w[0], w[1], w[2]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const wbf16x2 pr = __builtin_bit_cast(wbf16x2, w[q]);
+        __bf16* d = s_g + q * S3_GP + o * S3_GROW + lane;
+        d[0] = pr[0];
+        d[S3_GROW] = pr[1];
+      }
+    }
+    // x: the column pair of (row, p) as one word per piece; the halo pair (columns 32, 33) of (channel tch, row trow)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = wave * 16 + j;
+      const bool cok = cbk * 64 + c < a.Cin;
+      const float v0 = (x_ok0 && cok) ? rx[j].x : 0.f, v1 = (x_ok1 && cok) ? rx[j].y : 0.f;
+      unsigned w[3];
+      split3_pair(v0, v1, w[0], w[1], w[2]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        reinterpret_cast<wbf16x2*>(s_x + q * S3_XP + c * S3_XCH + xrow * S3_XROW)[xp] = __builtin_bit_cast(wbf16x2, w[q]);
+    }
+    {
+      const int c = wave * 16 + tch;
+      const bool cok = cbk * 64 + c < a.Cin;
+      unsigned w[3];
+      split3_pair((t_ok0 && cok) ? rt.x : 0.f, (t_ok1 && cok) ? rt.y : 0.f, w[0], w[1], w[2]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        reinterpret_cast<wbf16x2*>(s_x + q * S3_XP + c * S3_XCH + trow * S3_XROW)[16] = __builtin_bit_cast(wbf16x2, w[q]);
+    }
+    }
+  };
+
+  const WgSpan sp = wg_span(a, split);
+  int tile = sp.tile0;
+  if (tile < sp.tile_end) issue_loads(tile);
+  for (; tile < sp.tile_end; tile += a.nsplit) {
+    write_lds();
+    if (tile + a.nsplit < sp.tile_end) issue_loads(tile + a.nsplit);  // in flight under the MFMAs below
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int py = kb >> 1, px0 = (kb & 1) * 16 + 8 * hi;
+      wbf16x8 A[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        A[q] = *reinterpret_cast<const wbf16x8*>(s_g + q * S3_GP + (ot * 32 + lo) * S3_GROW + 16 * kb + 8 * hi);
+      if (ct == 0) {  // bias gradient: the three pieces of the operand this wave reads anyway sum to the exact fp32 values
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) db += (float)A[q][i];
+      }
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        wbf16x8 B[3][3];   // [piece][tx]
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const __bf16* bp = s_x + q * S3_XP + (ct * 32 + lo) * S3_XCH + (py + ty) * S3_XROW + px0;
+          const wbf16x8 r0 = *reinterpret_cast<const wbf16x8*>(bp);        // window columns px0 .. px0 + 7
+          if constexpr (VX != 0) {
+            const wbf16x8 r1 = *reinterpret_cast<const wbf16x8*>(bp + 8); // px0 + 8 .. px0 + 15
+            // tap tx reads the window columns px0 + SHIFT + tx .. + 7 (element shuffles: v_alignbit / v_perm / moves)
+            B[q][0] = __builtin_shufflevector(r0, r1, SHIFT, SHIFT + 1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7);
+            B[q][1] = __builtin_shufflevector(r0, r1, SHIFT + 1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7, SHIFT + 8);
+            B[q][2] = __builtin_shufflevector(r0, r1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7, SHIFT + 8, SHIFT + 9);
+          } else {
+            const wbf16x2 r4 = *reinterpret_cast<const wbf16x2*>(bp + 8);   // px0 + 8, px0 + 9
+            B[q][0] = r0;
+            B[q][1] = wbf16x8{r0[1], r0[2], r0[3], r0[4], r0[5], r0[6], r0[7], r4[0]};
+            B[q][2] = wbf16x8{r0[2], r0[3], r0[4], r0[5], r0[6], r0[7], r4[0], r4[1]};
+          }
+        }
+        // hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the three taps of the row alternate (independent accumulators)
+        constexpr int QA[6] = {0, 0, 1, 0, 2, 1}, QB[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx)
+            acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[QA[pr]], B[QB[pr]][tx], acc[ty * 3 + tx], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- partial[slot][tap][o][c], as conv2d_wgrad_pipe_kernel
+  const int OP = a.nob * 64, CP = a.ncb * 64;
+  const int slot = sp.slot;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ob * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int c = cbk * 64 + ct * 32 + lo;
+      unsafeAtomicAdd(a.partial + (((size_t)slot * 9 + t) * OP + o) * CP + c, acc[t][r]);
+    }
+  if (cbk == 0 && ct == 0) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + ob * 64 + ot * 32 + lo, db);
+}
+
+template <int VX, int SHIFT>
+static int launch_split3(const WgradLaunch& l, hipStream_t st) {
+  auto kern = conv2d_wgrad_split3_kernel<VX, SHIFT>;
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
+  hipLaunchKernelGGL(kern, l.grid, dim3(256), S3_LDS_BYTES, st, l.k);
+  return check_launch("conv2d_wgrad_split3_kernel");
+}
+
+int conv2d_wgrad_split3_launch(const WgradLaunch& l, hipStream_t st) {
+  // l.k.vx (conv2d_wgrad_prepare): 4 / 2 when gy rows are float4-loadable and the x rows float4 / float2-loadable
+  const int pad = l.k.pad;
+  if (l.k.vx == 4 && pad == 1) return launch_split3<4, 3>(l, st);
+  if (l.k.vx == 4 && pad == 0) return launch_split3<4, 0>(l, st);
+  if (l.k.vx == 2 && pad == 1) return launch_split3<2, 1>(l, st);
+  if (l.k.vx == 2 && pad == 0) return launch_split3<2, 0>(l, st);
+  return launch_split3<0, 0>(l, st);
 }
 
 int conv2d_wgrad_bf16_launch(const WgradLaunch& l, hipStream_t st) {

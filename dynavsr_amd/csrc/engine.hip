@@ -666,6 +666,13 @@ struct BBases {
   }
 };
 
+// DVSR_WGRAD_SPLIT3=0: the 3x3 stride-1 weight gradients stay on the fp32 MFMA kernel (A/B aid); default: the exact 3-way
+// bf16 split kernel (conv2d_wgrad_bf16.hip)
+static bool wgrad_split3_on() {
+  static const bool on = [] { const char* v = getenv("DVSR_WGRAD_SPLIT3"); return !(v && v[0] == '0'); }();
+  return on;
+}
+
 // Argument marshalling of the two gradient launches of a conv, shared by the separate and the fused paths.
 static int prep_wgrad(const dvsr_edvr_plan& p, const BOp& b, float* const* GP, const BBases& bs, void* scratch,
                       size_t scratch_bytes, hipStream_t st, WgradReduceEntry* defer, WgradLaunch* out) {
@@ -675,7 +682,7 @@ static int prep_wgrad(const dvsr_edvr_plan& p, const BOp& b, float* const* GP, c
   return conv2d_wgrad_prepare(bs.at(b.a), b.which ? o->x1_bs : o->x0_bs, b.which ? o->x1_bdiv : 1, bs.at(b.b), o->ps, dW,
                               b.which ? nullptr : GP[o->pb], o->N, ci, o->H, o->W, o->Cout, o->c0 + o->c1,
                               b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st, 1, conv_pad(*o), defer, out,
-                              p.cfg.bf16_mfma == 1 && !o->wmap, p.wgroups,
+                              o->wmap ? 0 : (p.cfg.bf16_mfma == 1 ? 1 : wgrad_split3_on() ? 2 : 0), p.wgroups,
                               (long long)o->Cout * (o->c0 + o->c1) * o->ks * o->ks, o->Cout);
 }
 

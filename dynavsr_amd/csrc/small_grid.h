@@ -62,7 +62,8 @@ struct WgradLaunch {
   WgradK k;
   dim3 grid;
   int ks, stride, kys;
-  int bf = 0;  // 1: bf16 operands on v_mfma_f32_32x32x16_bf16 (conv2d_wgrad_bf16.hip; 3x3 stride 1 only)
+  int bf = 0;  // 1: bf16 operands on v_mfma_f32_32x32x16_bf16 (conv2d_wgrad_bf16.hip; 3x3 stride 1 only); 2: the exact
+               // 3-way split of both operands on the same pipe (fp32 accuracy)
 };
 int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float* gy, int gy_ps, float* dW, float* db,
                          int N, int Cin, int H, int W, int Cout, int Ctot, int c_off, int ks, int stride, void* ws,
@@ -72,6 +73,7 @@ int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st);
 int conv2d_wino_launch(const ConvK2& k, int th, hipStream_t st);   // conv2d_wino.hip (ConvGeo::dma == 3)
 int conv2d_wino3_launch(const ConvK2& k, int th, hipStream_t st);  // conv2d_wino3.hip (ConvGeo::dma == 4)
 int conv2d_wgrad_bf16_launch(const WgradLaunch& l, hipStream_t st);
+int conv2d_wgrad_split3_launch(const WgradLaunch& l, hipStream_t st);   // bf = 2: exact 3-way bf16 split (fp32 accuracy)
 
 // -------------------------------------------------------------------------------------------------
 // K-split variant for SMALL grids (the 44x80 / 22x40 / 11x20 levels of the inner MAML step).

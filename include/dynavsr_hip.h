@@ -333,6 +333,10 @@ int dvsr_conv2d_packed_geometry(const dvsr_conv2d_desc* d, int geo[4]);
  * Workspace: dvsr_conv2d_backward_workspace_bytes(d). */
 int dvsr_conv2d_wgrad_bf16(const dvsr_conv2d_desc* d, const float* gy, float* gw, float* gb, void* workspace,
                            size_t workspace_bytes, dvsr_stream_t stream);
+/* The same weight gradient at fp32 accuracy on the bf16 pipe: both operands split exactly into three bf16 pieces, six
+ * partial products per fp32 product (what the plans run for 3x3 stride-1 layers; arguments as dvsr_conv2d_wgrad_bf16). */
+int dvsr_conv2d_wgrad_split3(const dvsr_conv2d_desc* d, const float* gy, float* gw, float* gb, void* workspace,
+                             size_t workspace_bytes, dvsr_stream_t stream);
 
 /* ---- TOFlow backbone ops (codes/models/archs/TOF_arch.py:25-140, arch_util.py:55-79) --------
  * The convolutions of SpyNet (7x7) and of the TOFlow head (9x9, 1x1) go through dvsr_conv2d_forward / _backward

@@ -306,6 +306,29 @@ def test_conv3x3_wgrad_bf16(ops, n, cin, cout, h, w):
     assert relerr(gb, gy.double().sum(dim=(0, 2, 3))) < 5e-3
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,pad", [(2, 64, 64, 12, 40, 1), (1, 128, 128, 9, 33, 1), (3, 24, 72, 7, 20, 1),
+                                                (1, 64, 216, 16, 32, 1), (5, 64, 64, 46, 82, 0), (8, 64, 64, 44, 80, 1)])
+def test_conv3x3_wgrad_split3(ops, n, cin, cout, h, w, pad):
+    """Weight / bias gradient on the bf16 pipe with the exact 3-way split of both operands (conv2d_wgrad_split3_kernel, what
+    the plans run for their 3x3 stride-1 layers): against the fp64 gradient at the fp32 kernels' bar (2e-6: the six products
+    kept cover 2^-24 of every fp32 product), the bias gradient to fp32 summation round-off; ragged tiles, channel counts off
+    the 64-blocks, an explicitly padded input (pad = 0: the estimators' layers), a batch of frames."""
+    import torch.nn.functional as F
+    from dynavsr_amd import _lib as L
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    x, gy = rnd(n, cin, h, w, seed=1), rnd(n, cout, ho, wo, seed=2)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (gw_exact,) = torch.autograd.grad(F.conv2d(x.double(), wt, padding=pad), wt, gy.double())
+    xg, gg = dev(x), dev(gy)
+    gw, gb = torch.empty(cout, cin, 3, 3, device="cuda"), torch.empty(cout, device="cuda")
+    d = L.Conv2dDesc(L.ptr(xg), None, None, None, None, None, n, cin, 0, h, w, cout, 3, 1, pad, 0, 0, 1, 0, 0)
+    ws = torch.empty(max(int(L.lib().dvsr_conv2d_backward_workspace_bytes(d)), 16), dtype=torch.uint8, device="cuda")
+    L.check(L.lib().dvsr_conv2d_wgrad_split3(d, L.ptr(gg), L.ptr(gw), L.ptr(gb), ws.data_ptr(), ws.numel(), L.stream()),
+            "dvsr_conv2d_wgrad_split3")
+    assert relerr(gw, gw_exact) < 2e-6, relerr(gw, gw_exact)
+    assert relerr(gb, gy.double().sum(dim=(0, 2, 3))) < 2e-6
+
+
 def test_inner_loss_tail(ops):
     """loss_pix + 10 * F.l1_loss(SLR, SLR_fixed) (test_dynavsr.py:264-274) as one native reduction: value, the
     pass-through gradient of the pixel loss, the sign gradient of the L1 term (sign(0) = 0 like torch), ragged
