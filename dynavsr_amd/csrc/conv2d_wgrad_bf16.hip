@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
   float2 rx[VX ? 1 : 16], rt;
   bool g_ok, x_ok0, x_ok1, t_ok0, t_ok1;
   // ---- vector staging (VX = 2, 4): lane-fixed (channel, row, column) of its vectors
-  int gch[4], grow[4], gcol[4], xch[XM], xrw[XM], xcol[XM], xlds[XM];
+  int gch[4], grow[4], gcol[4], xpk[XM], xlds[XM];   // xpk = channel | row << 4 | column << 8 of x vector m
   f32x4 vg[4];
   xvec vx[XM];
   bool vg_ok[4], vx_ok[XM];
@@ -271,8 +271,9 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
     for (int m = 0; m < XM; ++m) {
       const int idx = lane + 64 * m;
       const int c = idx / XV, r = idx - c * XV;
-      xch[m] = c < 16 ? c : 15; xrw[m] = r / RV; xcol[m] = (r - xrw[m] * RV) * VX;
-      xlds[m] = c < 16 ? (wave * 16 + c) * S3_XCH + xrw[m] * S3_XROW + xcol[m] : -1;
+      const int xr = r / RV, xc = (r - xr * RV) * VX;
+      xpk[m] = (c < 16 ? c : 15) | (xr << 4) | (xc << 8);
+      xlds[m] = c < 16 ? (wave * 16 + c) * S3_XCH + xr * S3_XROW + xc : -1;
     }
   }
 
@@ -297,8 +298,8 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
       const float* xn = a.x + (size_t)(n / a.x_bdiv) * a.x_bs;
 #pragma unroll
       for (int m = 0; m < XM; ++m) {
-        const int ci = cbk * 64 + wave * 16 + xch[m];
-        const int gy_ = iy0 + xrw[m], gx_ = ix0 + xcol[m];
+        const int ci = cbk * 64 + wave * 16 + (xpk[m] & 15);
+        const int gy_ = iy0 + ((xpk[m] >> 4) & 15), gx_ = ix0 + (xpk[m] >> 8);
         vx_ok[m] = xlds[m] >= 0 && ci < a.Cin && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W;
         const size_t off = vx_ok[m] ? (size_t)ci * HW + (size_t)gy_ * a.W + gx_ : 0;
         vx[m] = *reinterpret_cast<const xvec*>(xn + off);
@@ -356,37 +357,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
     }
   };
   auto write_lds = [&]() {
-    if constexpr (VX != 0) {
-      // four pixels of one channel: two pairs -> 8 bytes per piece
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const f32x4 v = vg_ok[m] ? vg[m] : f32x4{0.f, 0.f, 0.f, 0.f};
-        unsigned w0[3], w1[3];
-        split3_pair(v[0], v[1], w0[0], w0[1], w0[2]);
-        split3_pair(v[2], v[3], w1[0], w1[1], w1[2]);
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          *reinterpret_cast<wbf16x4*>(s_g + q * S3_GP + (wave * 16 + gch[m]) * S3_GROW + grow[m] * 32 + gcol[m]) =
-              __builtin_bit_cast(wbf16x4, uint2{w0[q], w1[q]});
-      }
-#pragma unroll
-      for (int m = 0; m < XM; ++m) {
-        xvec v = vx[m];
-        if (!vx_ok[m]) {
-#pragma unroll
-          for (int e = 0; e < VX; ++e) v[e] = 0.f;
-        }
-        if (xlds[m] < 0) continue;
-        unsigned w0[3], w1[3];
-        split3_pair(v[0], v[1], w0[0], w0[1], w0[2]);
-        if (VX == 4) split3_pair(v[VX - 2], v[VX - 1], w1[0], w1[1], w1[2]);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          if (VX == 4) *reinterpret_cast<wbf16x4*>(s_x + q * S3_XP + xlds[m]) = __builtin_bit_cast(wbf16x4, uint2{w0[q], w1[q]});
-          else *reinterpret_cast<wbf16x2*>(s_x + q * S3_XP + xlds[m]) = __builtin_bit_cast(wbf16x2, w0[q]);
-        }
-      }
-    } else {
+    if constexpr (VX == 0) {
     // gy: channels in pairs (one v_cvt_pk per piece and pair), 2-byte stores at [piece][o][pixel]
 #pragma unroll
     for (int j = 0; j < 16; j += 2) {
@@ -426,56 +397,142 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
     }
   };
 
-  const WgSpan sp = wg_span(a, split);
-  int tile = sp.tile0;
-  if (tile < sp.tile_end) issue_loads(tile);
-  for (; tile < sp.tile_end; tile += a.nsplit) {
-    write_lds();
-    if (tile + a.nsplit < sp.tile_end) issue_loads(tile + a.nsplit);  // in flight under the MFMAs below
-    __syncthreads();
+  // ---- vector staging: the conversion of the NEXT tile (its loads were issued before this tile's MFMAs) is cut into pieces
+  // that sit between the MFMA steps; only the LDS stores of the finished words are left for the gap between two tiles
+  unsigned wg0[4][3], wg1[4][3], wx0[XM][3], wx1[XM][3];
+  float dbl[4] = {0.f, 0.f, 0.f, 0.f};   // bias gradient: fp32 sums of the staged gy vectors (cbk == 0 workgroups)
+  auto convert_g = [&](int m) {
+    const f32x4 v = vg_ok[m] ? vg[m] : f32x4{0.f, 0.f, 0.f, 0.f};
+    dbl[m] += (v[0] + v[1]) + (v[2] + v[3]);
+    split3_pair(v[0], v[1], wg0[m][0], wg0[m][1], wg0[m][2]);
+    split3_pair(v[2], v[3], wg1[m][0], wg1[m][1], wg1[m][2]);
+  };
+  auto convert_x = [&](int m) {
+    xvec v = vx[m];
+    if (!vx_ok[m]) {
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int py = kb >> 1, px0 = (kb & 1) * 16 + 8 * hi;
-      wbf16x8 A[3];
+      for (int e = 0; e < (VX ? VX : 1); ++e) v[e] = 0.f;
+    }
+    split3_pair(v[0], v[VX ? 1 : 0], wx0[m][0], wx0[m][1], wx0[m][2]);
+    if (VX == 4) split3_pair(v[VX == 4 ? 2 : 0], v[VX == 4 ? 3 : 0], wx1[m][0], wx1[m][1], wx1[m][2]);
+  };
+  auto store_words = [&]() {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int q = 0; q < 3; ++q)
-        A[q] = *reinterpret_cast<const wbf16x8*>(s_g + q * S3_GP + (ot * 32 + lo) * S3_GROW + 16 * kb + 8 * hi);
-      if (ct == 0) {  // bias gradient: the three pieces of the operand this wave reads anyway sum to the exact fp32 values
+        *reinterpret_cast<wbf16x4*>(s_g + q * S3_GP + (wave * 16 + gch[m]) * S3_GROW + grow[m] * 32 + gcol[m]) =
+            __builtin_bit_cast(wbf16x4, uint2{wg0[m][q], wg1[m][q]});
+#pragma unroll
+    for (int m = 0; m < XM; ++m) {
+      if (xlds[m] < 0) continue;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (VX == 4) *reinterpret_cast<wbf16x4*>(s_x + q * S3_XP + xlds[m]) = __builtin_bit_cast(wbf16x4, uint2{wx0[m][q], wx1[m][q]});
+        else *reinterpret_cast<wbf16x2*>(s_x + q * S3_XP + xlds[m]) = __builtin_bit_cast(wbf16x2, wx0[m][q]);
+      }
+    }
+  };
+
+  // ---- MFMA loop of one tile: 12 steps (16-pixel block kb, kernel row ty) of 18 MFMAs; the operands of step i + 1 are read
+  // from LDS before the MFMAs of step i (two register sets), `fill(i)` is the piece of other work placed behind step i
+  wbf16x8 A[2][3], R0[2][3], R1[2][3];
+  wbf16x2 R4[2][3];
+  auto load_step = [&](int st, int rb) {
+    const int kb = st / 3, ty = st - kb * 3;
+    const int py = kb >> 1, px0 = (kb & 1) * 16 + 8 * hi;
+    if (ty == 0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        A[kb & 1][q] = *reinterpret_cast<const wbf16x8*>(s_g + q * S3_GP + (ot * 32 + lo) * S3_GROW + 16 * kb + 8 * hi);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const __bf16* bp = s_x + q * S3_XP + (ct * 32 + lo) * S3_XCH + (py + ty) * S3_XROW + px0;
+      R0[rb][q] = *reinterpret_cast<const wbf16x8*>(bp);
+      if (VX != 0) R1[rb][q] = *reinterpret_cast<const wbf16x8*>(bp + 8);
+      else R4[rb][q] = *reinterpret_cast<const wbf16x2*>(bp + 8);
+    }
+  };
+  auto mfma_tile = [&](auto&& fill) __attribute__((always_inline)) {
+    load_step(0, 0);
+    static_for<0, 12>([&](auto st_) {
+      constexpr int st = decltype(st_)::value;
+      constexpr int kb = st / 3, ty = st - kb * 3, rb = st & 1;
+      if (st + 1 < 12) load_step(st + 1, rb ^ 1);
+      if (VX == 0 && ct == 0 && ty == 0) {  // (scalar staging: the bias gradient from the A operands, whose pieces sum to the exact values)
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) db += (float)A[q][i];
+          for (int i = 0; i < 8; ++i) db += (float)A[kb & 1][q][i];
       }
+      wbf16x8 B[3][3];   // [piece][tx]
 #pragma unroll
-      for (int ty = 0; ty < 3; ++ty) {
-        wbf16x8 B[3][3];   // [piece][tx]
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const __bf16* bp = s_x + q * S3_XP + (ct * 32 + lo) * S3_XCH + (py + ty) * S3_XROW + px0;
-          const wbf16x8 r0 = *reinterpret_cast<const wbf16x8*>(bp);        // window columns px0 .. px0 + 7
-          if constexpr (VX != 0) {
-            const wbf16x8 r1 = *reinterpret_cast<const wbf16x8*>(bp + 8); // px0 + 8 .. px0 + 15
-            // tap tx reads the window columns px0 + SHIFT + tx .. + 7 (element shuffles: v_alignbit / v_perm / moves)
-            B[q][0] = __builtin_shufflevector(r0, r1, SHIFT, SHIFT + 1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7);
-            B[q][1] = __builtin_shufflevector(r0, r1, SHIFT + 1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7, SHIFT + 8);
-            B[q][2] = __builtin_shufflevector(r0, r1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7, SHIFT + 8, SHIFT + 9);
-          } else {
-            const wbf16x2 r4 = *reinterpret_cast<const wbf16x2*>(bp + 8);   // px0 + 8, px0 + 9
-            B[q][0] = r0;
-            B[q][1] = wbf16x8{r0[1], r0[2], r0[3], r0[4], r0[5], r0[6], r0[7], r4[0]};
-            B[q][2] = wbf16x8{r0[2], r0[3], r0[4], r0[5], r0[6], r0[7], r4[0], r4[1]};
-          }
+      for (int q = 0; q < 3; ++q) {
+        const wbf16x8 r0 = R0[rb][q];
+        if constexpr (VX != 0) {
+          const wbf16x8 r1 = R1[rb][q];
+          // tap tx reads the window columns px0 + SHIFT + tx .. + 7 (element shuffles: v_alignbit / v_perm / moves)
+          B[q][0] = __builtin_shufflevector(r0, r1, SHIFT, SHIFT + 1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7);
+          B[q][1] = __builtin_shufflevector(r0, r1, SHIFT + 1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7, SHIFT + 8);
+          B[q][2] = __builtin_shufflevector(r0, r1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7, SHIFT + 8, SHIFT + 9);
+        } else {
+          const wbf16x2 r4 = R4[rb][q];
+          B[q][0] = r0;
+          B[q][1] = wbf16x8{r0[1], r0[2], r0[3], r0[4], r0[5], r0[6], r0[7], r4[0]};
+          B[q][2] = wbf16x8{r0[2], r0[3], r0[4], r0[5], r0[6], r0[7], r4[0], r4[1]};
         }
-        // hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the three taps of the row alternate (independent accumulators)
-        constexpr int QA[6] = {0, 0, 1, 0, 2, 1}, QB[6] = {0, 1, 0, 2, 0, 1};
-#pragma unroll
-        for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-          for (int tx = 0; tx < 3; ++tx)
-            acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[QA[pr]], B[QB[pr]][tx], acc[ty * 3 + tx], 0, 0, 0);
       }
+      // hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the three taps of the row alternate (independent accumulators)
+      constexpr int QA[6] = {0, 0, 1, 0, 2, 1}, QB[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+          acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[kb & 1][QA[pr]], B[QB[pr]][tx], acc[ty * 3 + tx], 0, 0, 0);
+      fill(st_);
+    });
+  };
+
+  const WgSpan sp = wg_span(a, split);
+  int tile = sp.tile0;
+  if constexpr (VX != 0) {
+    if (tile < sp.tile_end) {
+      issue_loads(tile);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) convert_g(m);
+#pragma unroll
+      for (int m = 0; m < XM; ++m) convert_x(m);
     }
-    __syncthreads();
+    for (; tile < sp.tile_end; tile += a.nsplit) {
+      store_words();
+      const bool has_next = tile + a.nsplit < sp.tile_end;
+      if (has_next) issue_loads(tile + a.nsplit);  // in flight under the first MFMA steps below
+      __syncthreads();
+      mfma_tile([&](auto st_) __attribute__((always_inline)) {
+        constexpr int st = decltype(st_)::value;
+        // steps 4 .. 11: the next tile's vectors have landed long ago -- convert them (registers only)
+        if (has_next && st >= 4) {
+          constexpr int j = st - 4;   // 0 .. 7
+          if (j < 4) convert_g(j);
+          constexpr int per = (XM + 7) / 8;
+#pragma unroll
+          for (int u = 0; u < per; ++u)
+            if (j * per + u < XM) convert_x(j * per + u);
+        }
+      });
+      __syncthreads();
+    }
+    if (cbk != 0) { dbl[0] = dbl[1] = dbl[2] = dbl[3] = 0.f; }
+  } else {
+    if (tile < sp.tile_end) issue_loads(tile);
+    for (; tile < sp.tile_end; tile += a.nsplit) {
+      write_lds();
+      if (tile + a.nsplit < sp.tile_end) issue_loads(tile + a.nsplit);  // in flight under the MFMAs below
+      __syncthreads();
+      mfma_tile([&](auto) __attribute__((always_inline)) {});
+      __syncthreads();
+    }
   }
 
   // ---- partial[slot][tap][o][c], as conv2d_wgrad_pipe_kernel
@@ -489,7 +546,19 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
       const int c = cbk * 64 + ct * 32 + lo;
       unsafeAtomicAdd(a.partial + (((size_t)slot * 9 + t) * OP + o) * CP + c, acc[t][r]);
     }
-  if (cbk == 0 && ct == 0) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + ob * 64 + ot * 32 + lo, db);
+  if constexpr (VX != 0) {
+    if (cbk == 0) {   // lanes 16 k .. 16 k + 15 staged channel (lane >> 4) + 4 m of this wave's 16
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float v = dbl[m];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+        const int co = ob * 64 + wave * 16 + gch[m];
+        if ((lane & 15) == 0 && co < OP) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + co, v);
+      }
+    }
+  } else {
+    if (cbk == 0 && ct == 0) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + ob * 64 + ot * 32 + lo, db);
+  }
 }
 
 template <int VX, int SHIFT>
