@@ -327,7 +327,7 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
     s = groups > 1 ? s / groups : s;
     return s > k.gtiles ? k.gtiles : (s < 1 ? 1 : s);
   };
-  out->bf = (bf16 && ks == 3 && stride == 1) ? bf16 : 0;
+  out->bf = (bf16 && stride == 1 && (ks == 3 || (ks == 2 && bf16 == 2))) ? bf16 : 0;   // (the split kernel also has a 2x2 form)
   if (out->bf) {
     // the bf16 kernel is staging- and flush-bound (36 MFMAs per tile): fewer workgroups, each with more tiles, keep the
     // 147 KB-per-workgroup atomic flush small.  DVSR_WGRAD_BF_WGS=<workgroups per launch to aim for>.

@@ -224,13 +224,16 @@ typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
 // and the gy rows as float4 -- the window starts SHIFT = (VX - pad % VX) % VX columns left of the first column the taps need,
 // so that every vector is aligned and lies entirely inside or outside the image (as conv2d_wgrad_wide_item does for the fp32
 // kernel): 14 / 22 vector loads and 42 / 66 8-byte (4-byte) LDS stores per lane and tile instead of 50 + 99.
-template <int VX, int SHIFT>
+// KS = 3: the 3x3 stride-1 layers; KS = 2: the estimators' 4x4 stride-2 convolutions, re-expressed as 2x2 stride-1 over the
+// space-to-depth input (engine.hip: conv4s2).
+template <int KS, int VX, int SHIFT>
 __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
+  constexpr int NT = KS * KS, XR = 1 + KS, XC = 31 + KS;   // taps; rows / columns of x a 2 x 32-pixel tile needs
   extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
   __bf16* const s_g = smem16;
   __bf16* const s_x = smem16 + 3 * S3_GP;
-  constexpr int WWIN = VX ? ((34 + 2 * (VX - 1)) / VX) * VX : 34;   // window columns per row (40 / 36 / 34)
-  constexpr int RV = VX ? WWIN / VX : 1, XV = 4 * RV;                // vectors per row / per channel
+  constexpr int WWIN = VX ? ((XC + 2 * (VX - 1)) / VX) * VX : XC;   // window columns per row (3x3: 40 / 36 / 34)
+  constexpr int RV = VX ? WWIN / VX : 1, XV = XR * RV;               // vectors per row / per channel
   constexpr int XM = VX ? (16 * XV + 63) / 64 : 1;                   // x vectors per lane and tile (16 channels per wave)
   typedef float xvec __attribute__((ext_vector_type(VX ? VX : 1)));
 
@@ -241,9 +244,9 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
   const int ot = wave >> 1, ct = wave & 1;
   const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
 
-  f32x16 acc[9];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float db = 0.f;
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
     const float* xn = a.x + (size_t)(n / a.x_bdiv) * a.x_bs;
     {
       const int gy_ = iy0 + xrow, gx_ = ix0 + 2 * xp;
-      const bool rok = (unsigned)gy_ < (unsigned)a.H;
+      const bool rok = (unsigned)gy_ < (unsigned)a.H && xrow < XR;
       x_ok0 = rok && (unsigned)gx_ < (unsigned)a.W;
       x_ok1 = rok && (unsigned)(gx_ + 1) < (unsigned)a.W;
       const unsigned o0 = x_ok0 ? (unsigned)(gy_ * a.W + gx_) * 4u : 0u, o1 = x_ok1 ? (unsigned)(gy_ * a.W + gx_ + 1) * 4u : 0u;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
       const int gy_ = iy0 + trow, gx_ = ix0 + 32;
       int ci = cbk * 64 + wave * 16 + tch;
       ci = ci < a.Cin ? ci : a.Cin - 1;
-      const bool rok = (unsigned)gy_ < (unsigned)a.H;
+      const bool rok = (unsigned)gy_ < (unsigned)a.H && trow < XR;
       t_ok0 = rok && (unsigned)gx_ < (unsigned)a.W;
       t_ok1 = rok && (unsigned)(gx_ + 1) < (unsigned)a.W;
       const float* base = xn + (size_t)ci * HW;
@@ -434,12 +437,12 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
     }
   };
 
-  // ---- MFMA loop of one tile: 12 steps (16-pixel block kb, kernel row ty) of 18 MFMAs; the operands of step i + 1 are read
+  // ---- MFMA loop of one tile: 4 KS steps (16-pixel block kb, kernel row ty) of 6 KS MFMAs; the operands of step i + 1 are read
   // from LDS before the MFMAs of step i (two register sets), `fill(i)` is the piece of other work placed behind step i
   wbf16x8 A[2][3], R0[2][3], R1[2][3];
   wbf16x2 R4[2][3];
   auto load_step = [&](int st, int rb) {
-    const int kb = st / 3, ty = st - kb * 3;
+    const int kb = st / KS, ty = st - kb * KS;
     const int py = kb >> 1, px0 = (kb & 1) * 16 + 8 * hi;
     if (ty == 0) {
 #pragma unroll
@@ -456,10 +459,10 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
   };
   auto mfma_tile = [&](auto&& fill) __attribute__((always_inline)) {
     load_step(0, 0);
-    static_for<0, 12>([&](auto st_) {
+    static_for<0, 4 * KS>([&](auto st_) {
       constexpr int st = decltype(st_)::value;
-      constexpr int kb = st / 3, ty = st - kb * 3, rb = st & 1;
-      if (st + 1 < 12) load_step(st + 1, rb ^ 1);
+      constexpr int kb = st / KS, ty = st - kb * KS, rb = st & 1;
+      if (st + 1 < 4 * KS) load_step(st + 1, rb ^ 1);
       if (VX == 0 && ct == 0 && ty == 0) {  // (scalar staging: the bias gradient from the A operands, whose pieces sum to the exact values)
 #pragma unroll
         for (int q = 0; q < 3; ++q)
@@ -488,8 +491,8 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
 #pragma unroll
       for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
-        for (int tx = 0; tx < 3; ++tx)
-          acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[kb & 1][QA[pr]], B[QB[pr]][tx], acc[ty * 3 + tx], 0, 0, 0);
+        for (int tx = 0; tx < KS; ++tx)
+          acc[ty * KS + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[kb & 1][QA[pr]], B[QB[pr]][tx], acc[ty * KS + tx], 0, 0, 0);
       fill(st_);
     });
   };
@@ -511,9 +514,9 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
       __syncthreads();
       mfma_tile([&](auto st_) __attribute__((always_inline)) {
         constexpr int st = decltype(st_)::value;
-        // steps 4 .. 11: the next tile's vectors have landed long ago -- convert them (registers only)
-        if (has_next && st >= 4) {
-          constexpr int j = st - 4;   // 0 .. 7
+        // the last eight steps: the next tile's vectors have landed long ago -- convert them (registers only)
+        if (has_next && st >= 4 * KS - 8) {
+          constexpr int j = st - (4 * KS - 8);   // 0 .. 7
           if (j < 4) convert_g(j);
           constexpr int per = (XM + 7) / 8;
 #pragma unroll
@@ -539,12 +542,12 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
   const int OP = a.nob * 64, CP = a.ncb * 64;
   const int slot = sp.slot;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = ob * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const int c = cbk * 64 + ct * 32 + lo;
-      unsafeAtomicAdd(a.partial + (((size_t)slot * 9 + t) * OP + o) * CP + c, acc[t][r]);
+      unsafeAtomicAdd(a.partial + (((size_t)slot * NT + t) * OP + o) * CP + c, acc[t][r]);
     }
   if constexpr (VX != 0) {
     if (cbk == 0) {   // lanes 16 k .. 16 k + 15 staged channel (lane >> 4) + 4 m of this wave's 16
@@ -561,9 +564,9 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
   }
 }
 
-template <int VX, int SHIFT>
+template <int KS, int VX, int SHIFT>
 static int launch_split3(const WgradLaunch& l, hipStream_t st) {
-  auto kern = conv2d_wgrad_split3_kernel<VX, SHIFT>;
+  auto kern = conv2d_wgrad_split3_kernel<KS, VX, SHIFT>;
   static PerDeviceOnce attr_once;
   if (attr_once.first()) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
   hipLaunchKernelGGL(kern, l.grid, dim3(256), S3_LDS_BYTES, st, l.k);
@@ -573,11 +576,16 @@ static int launch_split3(const WgradLaunch& l, hipStream_t st) {
 int conv2d_wgrad_split3_launch(const WgradLaunch& l, hipStream_t st) {
   // l.k.vx (conv2d_wgrad_prepare): 4 / 2 when gy rows are float4-loadable and the x rows float4 / float2-loadable
   const int pad = l.k.pad;
-  if (l.k.vx == 4 && pad == 1) return launch_split3<4, 3>(l, st);
-  if (l.k.vx == 4 && pad == 0) return launch_split3<4, 0>(l, st);
-  if (l.k.vx == 2 && pad == 1) return launch_split3<2, 1>(l, st);
-  if (l.k.vx == 2 && pad == 0) return launch_split3<2, 0>(l, st);
-  return launch_split3<0, 0>(l, st);
+  if (l.ks == 2) {   // (pad 0 or 1: the forward of the space-to-depth form / nothing else; other pads take the scalar staging)
+    if (l.k.vx == 4 && pad == 0) return launch_split3<2, 4, 0>(l, st);
+    if (l.k.vx == 2 && pad == 0) return launch_split3<2, 2, 0>(l, st);
+    return launch_split3<2, 0, 0>(l, st);
+  }
+  if (l.k.vx == 4 && pad == 1) return launch_split3<3, 4, 3>(l, st);
+  if (l.k.vx == 4 && pad == 0) return launch_split3<3, 4, 0>(l, st);
+  if (l.k.vx == 2 && pad == 1) return launch_split3<3, 2, 1>(l, st);
+  if (l.k.vx == 2 && pad == 0) return launch_split3<3, 2, 0>(l, st);
+  return launch_split3<3, 0, 0>(l, st);
 }
 
 int conv2d_wgrad_bf16_launch(const WgradLaunch& l, hipStream_t st) {

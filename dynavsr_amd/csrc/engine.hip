@@ -682,7 +682,7 @@ static int prep_wgrad(const dvsr_edvr_plan& p, const BOp& b, float* const* GP, c
   return conv2d_wgrad_prepare(bs.at(b.a), b.which ? o->x1_bs : o->x0_bs, b.which ? o->x1_bdiv : 1, bs.at(b.b), o->ps, dW,
                               b.which ? nullptr : GP[o->pb], o->N, ci, o->H, o->W, o->Cout, o->c0 + o->c1,
                               b.which ? o->c0 : 0, o->ks, o->stride, scratch, scratch_bytes, st, 1, conv_pad(*o), defer, out,
-                              o->wmap ? 0 : (p.cfg.bf16_mfma == 1 ? 1 : wgrad_split3_on() ? 2 : 0), p.wgroups,
+                              (p.cfg.bf16_mfma == 1 && !o->wmap) ? 1 : (wgrad_split3_on() ? 2 : 0), p.wgroups,
                               (long long)o->Cout * (o->c0 + o->c1) * o->ks * o->ks, o->Cout);
 }
 
