@@ -340,13 +340,16 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
   //   end              : one barrier
   constexpr int NSTEP = KK * KQ4;
   constexpr int SPLIT = (3 * NSTEP) / 4;
-  static_assert(!Sh::AG || (NSTEP % 3 == 0 && KQ4 == 1), "the register ring of the global-A path needs NSTEP % 3 == 0");
+  // (register ring of the global-A path: three sets where the step count divides by three -- 3x3: nine steps --, two
+  // otherwise -- 2x2: four steps --; the prefetch distance is one step either way, the slot index stays static across chunks)
+  constexpr int RING = NSTEP % 3 == 0 ? 3 : 2;
+  static_assert(!Sh::AG || (NSTEP % RING == 0 && KQ4 == 1), "the register ring of the global-A path needs NSTEP % RING == 0");
   // BF == 2: the weight operands never touch LDS.  Every lane reads its 16 B of each (piece, 32-cout half) of
   // one tap straight from the packed image (1 KiB per wave instruction, the four waves of a workgroup read the
   // same lines: L1 hits), two steps ahead of their use.  LDS then holds only the three halo pieces, which
   // leaves room for two workgroups per CU, and its read port only serves the B operands.
   constexpr int AD = 1;  // prefetch distance in steps
-  f32x4 Ag[Sh::AG ? 3 : 1][MT][PIECES];
+  f32x4 Ag[Sh::AG ? RING : 1][MT][PIECES];
   auto load_a = [&](int k, int tap, int slot) {
     const float* b = wp_cb + (size_t)k * (PIECES * 2 * Sh::HALF) + tap * 256 + lane * 4;
 #pragma unroll
@@ -405,8 +408,8 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
         // chunks).  The halo loads of the next chunk go out right behind the first one: vmcnt retires in
         // order, so the weights of steps 1 and 2 (issued earlier) never wait for them, and by step 3 the halo
         // has had three steps of MFMAs to arrive.
-        if (step + AD < NSTEP) load_a(k, step + AD, (step + AD) % 3);
-        else if (HAS_NEXT) load_a(k + 1, step + AD - NSTEP, (step + AD) % 3);
+        if (step + AD < NSTEP) load_a(k, step + AD, (step + AD) % RING);
+        else if (HAS_NEXT) load_a(k + 1, step + AD - NSTEP, (step + AD) % RING);
         if (HAS_NEXT && step == 0) issue_halo(k + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -429,7 +432,7 @@ __device__ __forceinline__ void conv2d_pipe_item(const ConvK2& a, const int id, 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                  __builtin_bit_cast(bf16x8, Ag[step % 3][mt][pa]), __builtin_bit_cast(bf16x8, Bv[0][nt][pb]),
+                  __builtin_bit_cast(bf16x8, Ag[step % RING][mt][pa]), __builtin_bit_cast(bf16x8, Bv[0][nt][pb]),
                   acc[mt][nt], 0, 0, 0);
         };
         mm(0, 2);
@@ -1121,9 +1124,17 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
   if (rc) return rc;
   const int code = geo.cc * 100 + geo.th * 10 + geo.mt;
   if (geo.bf) {
-    DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && geo.cc == 16 && (geo.th == 4 || (geo.bf == 2 && geo.th == 8)),
+    DVSR_REQUIRE((d.ks == 3 || (d.ks == 2 && geo.bf == 2)) && d.stride == 1 && geo.cc == 16 && (geo.th == 4 || (geo.bf == 2 && geo.th == 8)),
                  DVSR_ERR_UNSUPPORTED,
-                 "conv2d_packed: the bf16 kernel exists for 3x3 stride-1 convs with 16-channel chunks");
+                 "conv2d_packed: the bf16 kernel exists for 3x3 (split: also 2x2) stride-1 convs with 16-channel chunks");
+    if (geo.bf == 2 && d.ks == 2) {   // the estimators' 4x4 stride-2 convolutions in their 2x2 space-to-depth form
+      if (geo.th == 8) {
+        if (geo.mt == 2) return launch_conv2<2, 1, 16, 8, 2, 2>(k, st);
+        return launch_conv2<2, 1, 16, 8, 1, 2>(k, st);
+      }
+      if (geo.mt == 2) return launch_conv2<2, 1, 16, 4, 2, 2>(k, st);
+      return launch_conv2<2, 1, 16, 4, 1, 2>(k, st);
+    }
     if (geo.bf == 2) {
       if (geo.th == 8) {
         if (geo.mt == 2) return launch_conv2<3, 1, 16, 8, 2, 2>(k, st);

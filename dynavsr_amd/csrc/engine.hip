@@ -172,11 +172,18 @@ struct Builder {
     // (the gradient arena mirrors this slot: one re-laid-out gradient per group)
     if (wmap) o.w2_off = alloc("", (size_t)std::max(p.wgroups, p.wsets) * Cout * (c0 + c1) * ks * ks).off;
     {
-      const bool bf = p.cfg.bf16_mfma && ks == 3 && stride == 1 && (pad < 0 || p.split_any_pad) && (c1 == 0 || c0 % 16 == 0);
+      // (estimator plans: also the 2x2 space-to-depth form of the 4x4 stride-2 convolutions, DVSR_EST_SPLIT2=0 keeps those
+      // on the fp32 MFMA)
+      const char* s2 = getenv("DVSR_EST_SPLIT2");
+      const int split2 = s2 ? atoi(s2) : 1;   // (read per plan build, as DVSR_EST_SPLIT is; 2: forward launches only)
+      const bool bf = p.cfg.bf16_mfma && (ks == 3 || (ks == 2 && p.split_any_pad && p.cfg.bf16_mfma == 2 && split2 && c0 % 16 == 0)) &&
+                      stride == 1 && (pad < 0 || p.split_any_pad) && (c1 == 0 || c0 % 16 == 0);
       // bf16_mfma = 2: 8-row tiles (two 32-pixel rows per wave) once they still give ~a workgroup per CU
       static const int split_th8_from = getenv("DVSR_SPLIT_TH8_FROM") ? atoi(getenv("DVSR_SPLIT_TH8_FROM")) : 200;
-      auto as_bf = [&](ConvGeo g, int ho, int wo, int cout) {
-        if (!bf) return g;
+      auto as_bf = [&](ConvGeo g, int ho, int wo, int cout, bool dgrad = false) {
+        if (!bf || (ks == 2 && split2 == 2 && dgrad)) return g;
+        // the 2x2 form only where it pays (launches of at least a workgroup per CU): small launches stay on the fp32 kernel
+        if (ks == 2 && (long long)ceil_div(wo, 32) * ceil_div(ho, 4) * N * ceil_div(cout, 64) < 256) return g;
         g.cc = 16; g.th = 4; g.bf = p.cfg.bf16_mfma == 2 ? 2 : 1;
         if (g.bf == 2 && (long long)ceil_div(wo, 32) * ceil_div(ho, 8) * N * ceil_div(cout, 32 * g.mt) >= split_th8_from)
           g.th = 8;
@@ -196,7 +203,7 @@ struct Builder {
         if (!ci) continue;
         // dgrad = stride-1 conv over the input grid with Cout' = ci, Ctot' = Cout
         // (data gradient: the gradient tensor is the plain input unless it is pixel-shuffled or zero-dilated)
-        o.dgeo[which] = as_bf(conv2_choose(ks, 1, N, H, W, ci, Cout, (!ps && stride == 1) ? ks_ok : 0), H, W, ci);
+        o.dgeo[which] = as_bf(conv2_choose(ks, 1, N, H, W, ci, Cout, (!ps && stride == 1) ? ks_ok : 0), H, W, ci, true);
         o.dpk_floats[which] = (size_t)ceil_div(ci, 64) * ceil_div(Cout, o.dgeo[which].cc) *
                               conv2_pch_cc(ks, o.dgeo[which].cc, o.dgeo[which].bf, o.dgeo[which].dma);
         o.dpk_off[which] = p.dpack_floats;

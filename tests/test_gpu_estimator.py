@@ -109,7 +109,29 @@ def test_mfdn_x4_vs_oracle_shapes(b, t, h, w):
         net(lq.transpose(1, 2).contiguous().cuda()).transpose(1, 2).backward(gg.cuda())
         grads.append([p.grad.clone() for p in net.parameters()])
     for (k, _), a, b_, c in zip(net.named_parameters(), g1, grads[0], grads[1]):
-        assert relerr(a + b_, c) < 1e-5, k
+        assert relerr(a + b_, c) < 2e-5, k   # 1.3e-5 observed with the 2x2 data gradient on the bf16 3-way split
+
+
+def test_mfdn_split_2x2_form_matches_fp32_kernels(monkeypatch):
+    """The 2x2 space-to-depth form of the 4x4 stride-2 convolutions on the bf16 3-way operand split (engine.hip
+    Builder::conv, DVSR_EST_SPLIT2; taken from a workgroup per CU upwards, hence 2 x 5 x 176 x 320) against the same tape
+    with those launches on the fp32 MFMA kernel: output to fp32 round-off, every parameter gradient within the kink-flip
+    budget of two fp32 evaluations (see test_mfdn_x4_vs_oracle_shapes)."""
+    sd = synth.mfdn_state_dict(5)
+    x = synth.clip(31, 2, 5, 176, 320, smooth=False).transpose(1, 2).contiguous().cuda()
+    go = None
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DVSR_EST_SPLIT2", mode)
+        net = _mfdn(sd, nf=64, in_nc=3, scale=4)
+        y = net(x)
+        go = _go(32, y.shape).cuda() if go is None else go
+        y.backward(go)
+        res[mode] = (y.detach().clone(), OrderedDict((k, p.grad.clone()) for k, p in net.named_parameters()))
+    assert not torch.equal(res["0"][0], res["1"][0])          # (the switch did change the kernels)
+    assert relerr(res["1"][0], res["0"][0]) < 2e-6
+    for k in res["0"][1]:
+        assert relerr(res["1"][1][k], res["0"][1][k]) < 5e-3, k
 
 
 def test_estimator_rejects_input_grad_and_bad_shapes():
