@@ -57,23 +57,41 @@ def f_inner(h, w):
     return 3 * f_edvr(h // 4, w // 4) + 4 * f_mfdn(h, w)
 
 
+def pipe_mix(f32_flops, bf16_flops, t_s):
+    """Roofline fields of work issued to BOTH matrix pipes (fp32: v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense; bf16:
+    v_mfma_f32_32x32x16_bf16, 2500): frac = the share of the time the pipes need at their dense peaks for exactly this
+    instruction mix (what PMC's SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES measures), achieved = all issued FLOPs / time,
+    peak = achieved / frac (the rate of this mix on always-busy pipes)."""
+    pipe_s = f32_flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) + bf16_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+    issued = f32_flops + bf16_flops
+    frac = pipe_s / t_s
+    ach = issued / t_s / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": (ach / frac) if frac > 0 else FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": frac, "issued_flops_f32_pipe": f32_flops, "issued_flops_bf16_pipe": bf16_flops,
+            "peak_f32_pipe": FP32_MFMA_PEAK_TFLOPS, "peak_bf16_pipe": BF16_MFMA_PEAK_TFLOPS}
+
+
 def mfma_roof(t_ms, alg_flops, tapes, what, extra=None):
-    """Roofline object of a whole leg on the fp32 matrix pipe.  `tapes` = [(plan.work() dict, forward passes, backward
-    passes)] of everything the leg runs: their issued / algorithmic ratio prices SURVEY 8d's algorithmic FLOP figure down to
-    what the pipe executes (launches on the Winograd kernel issue 16/36 of their multiplies), so `frac` is a fraction of the
-    hardware ceiling (<= 1) and the algorithmic rate is reported beside it."""
-    alg = sum(wk["fwd_algorithmic"] * nf + wk["bwd_algorithmic"] * nb for wk, nf, nb in tapes)
-    exe = sum(wk["fwd_executed"] * nf + wk["bwd_executed"] * nb for wk, nf, nb in tapes)
-    share = exe / alg if alg else 1.0
-    executed = alg_flops * share
-    ach = executed / (t_ms * 1e-3) / 1e12
-    r = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-         "executed_flops": executed, "algorithmic_flops": alg_flops,
-         "algorithmic_tflops": alg_flops / (t_ms * 1e-3) / 1e12, "mfma_flops_executed_frac": share,
-         "note": "%s: achieved = FLOPs ISSUED to the fp32 matrix pipe / time (algorithmic FLOPs of SURVEY 8d x the "
-                 "issued share of the leg's launch tapes: Winograd F(2x2,3x3) launches issue 4/9 of theirs); "
-                 "algorithmic_tflops = the same time priced with the direct sums" % what}
+    """Roofline object of a whole leg on the matrix pipes.  `tapes` = [(plan.work() dict, forward passes, backward
+    passes)] of everything the leg runs: the tapes' issued / algorithmic ratios price SURVEY 8d's algorithmic FLOP figure down
+    to what either pipe is issued (launches on the Winograd kernels do 16/36 of their multiplies; launches on the exact 3-way
+    bf16 operand split issue six bf16 products per fp32 product), so `frac` is a fraction of a hardware ceiling (<= 1) and
+    the algorithmic rate is reported beside it."""
+    def tot(kf, kb):
+        return sum(wk[kf] * nf + wk[kb] * nb for wk, nf, nb in tapes)
+    alg = tot("fwd_algorithmic", "bwd_algorithmic")
+    k = alg_flops / alg if alg else 1.0          # (SURVEY's figure also counts the few non-contraction FLOPs)
+    exe = tot("fwd_executed", "bwd_executed") * k
+    r = pipe_mix(tot("fwd_f32_pipe", "bwd_f32_pipe") * k, tot("fwd_bf16_pipe", "bwd_bf16_pipe") * k, t_ms * 1e-3)
+    r.update({"traffic": None, "executed_flops": exe, "algorithmic_flops": alg_flops,
+              "algorithmic_tflops": alg_flops / (t_ms * 1e-3) / 1e12, "mfma_flops_executed_frac": exe / alg_flops,
+              "fp32_products_tflops": exe / (t_ms * 1e-3) / 1e12,
+              "note": "%s: frac = time the two matrix pipes need at their dense peaks for the FLOPs ISSUED to them / time "
+                      "(issued = SURVEY 8d's algorithmic FLOPs x the issued share of the leg's launch tapes: Winograd "
+                      "F(2x2,3x3) launches do 4/9 of their multiplies, launches on the exact 3-way bf16 split issue six "
+                      "bf16 products per fp32 product); achieved = issued FLOPs / time, peak = achieved / frac; "
+                      "executed_flops / fp32_products_tflops = the fp32 products behind them (r03's `achieved`); "
+                      "algorithmic_tflops = the same time priced with the direct sums" % what})
     if extra:
         r.update(extra)
     return r
@@ -699,7 +717,7 @@ def _dry_run(rank, world, args):
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
             "config": {"workload": "none (dry run)", "clips_per_step": world},
-            "roofline": None, "kernel_breakdown_ms_per_step": None, "end_to_end_tflops": None,
+            "one_clip_in_flight": None, "roofline": None, "kernel_breakdown_ms_per_step": None, "end_to_end_tflops": None,
             "inner_step": _merge_rank_leg([b_[0] for b_ in both]),
             "per_frame_pipeline": _merge_rank_leg([b_[1] for b_ in both]),
             "meta_step": {"ranks": world, "allreduce": {"backend": "gloo", "bytes": nbytes, "executed": grouped,
@@ -723,6 +741,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--height", type=int, default=180)
     ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--clips-in-flight", type=int, default=2,
+                    help="clips of the forward leg on the GPU at a time, one HIP stream each (1: one clip per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inner-step", action="store_true", help="skip the inner-step and per-frame-pipeline legs")
     ap.add_argument("--no-split", action="store_true", help="skip the bf16 legs (split-mode forward, EDVR-L)")
@@ -784,15 +804,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            y = net(x)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            y = net(x)
-        barrier()
-        elapsed = time.perf_counter() - t0
+    # One step = `in_flight` clips, one per HIP stream (adapt.super_resolve_video: every clip runs the launches it would run
+    # alone; the second queue fills the tail rounds and the gaps between the 85 dependent launches of a forward).
+    from itertools import repeat
+    from dynavsr_amd.adapt import super_resolve_video
+    S = max(1, args.clips_in_flight)
+    opt_fwd = _opt()
+
+    def run_clips(n, in_flight):
+        y_ = None
+        for y_ in super_resolve_video(opt_fwd, net, repeat(x, n), in_flight=in_flight):
+            pass
+        return y_
+
+    run_clips(S * args.warmup, S)
+    barrier()
+    t0 = time.perf_counter()
+    y = run_clips(S * args.steps, S)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # ... and the same clips one at a time on one stream (the figure of rounds 1-3), rank-local
+    run_clips(max(3, args.warmup // 2), 1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run_clips(args.steps, 1)
+    torch.cuda.synchronize()
+    ms_one = 1e3 * (time.perf_counter() - t1) / args.steps
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -805,13 +842,18 @@ def main():
         line = {
             "metric": "inner-loop frames/sec/GPU (EDVR-M x4, 5x3x180x320): forward leg = BASELINE.json configs[1]; "
                       "the inner MAML step and the per-frame pipeline are `inner_step` / `per_frame_pipeline`",
-            "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world,
+            "value": world * S * args.steps / elapsed, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "EDVR-M x4 forward (PCD deformable alignment + TSA fusion + "
-                                   "reconstruction), 1 clip 1x5x3x%dx%d -> 3x%dx%d per GPU per step "
-                                   "(BASELINE.json configs[1])" % (h, w, 4 * h, 4 * w),
-                       "clips_per_step": world, "sharding": "independent clips per rank, no collective"},
+                                   "reconstruction), clips of 1x5x3x%dx%d -> 3x%dx%d (BASELINE.json configs[1]); one step = "
+                                   "%d clip(s) per GPU, one per HIP stream (adapt.super_resolve_video)"
+                                   % (h, w, 4 * h, 4 * w, S),
+                       "clips_per_step": world * S, "clips_in_flight_per_gpu": S,
+                       "sharding": "independent clips per rank, no collective"},
+            "one_clip_in_flight": {"value": 1e3 / ms_one, "unit": "frames/s", "ms_per_clip": ms_one,
+                                   "note": "the same clips one at a time on one stream (rank 0): the protocol of rounds 1-3 "
+                                           "and the latency of one forward"},
         }
         # ---- roofline of the dominant kernel: separate pass, hipEvents around every launch
         plan = engine.get_plan(net._cfg(), 1, h, w)
@@ -826,9 +868,11 @@ def main():
             for (kind, name, fl, by), t_ms in zip(info, plan.forward_timed(params, x, out, ws)):
                 a = acc.setdefault(kind, [0.0, 0.0, 0.0, 0])
                 a[0] += t_ms; a[1] += fl; a[2] += by; a[3] += 1
-                if name.endswith("w]"):   # launch geometry tag of dvsr_edvr_op_info: Winograd F(2x2, 3x3) kernel
-                    wv = wino.setdefault(kind, [0, 0.0, 0.0])
-                    wv[0] += 1; wv[1] += fl; wv[2] += t_ms
+                tag = name[name.rfind("/"):]
+                if tag.endswith("w]") or tag.endswith("w3]"):   # launch geometry tag of dvsr_edvr_op_info: Winograd F(2x2, 3x3)
+                    wv = wino.setdefault(kind, [0, 0.0, 0.0, 0, 0.0, 0.0])   # (fp32 kernel | bf16x3 kernel): n, flops, ms
+                    o3 = 3 if tag.endswith("w3]") else 0
+                    wv[o3] += 1; wv[o3 + 1] += fl; wv[o3 + 2] += t_ms
         dom = max(acc, key=lambda k: acc[k][0])
         t_ms, fl, by, cnt = acc[dom]
         total_ms = sum(a[0] for a in acc.values())
@@ -867,29 +911,47 @@ def main():
         if roof["bound"] == "mfma":
             roof["algorithmic_tflops"] = roof["achieved"]
         if dom in wino:
-            # The launches on the Winograd kernel issue 16 multiplies per 2x2 output block and (cout, cin) pair instead of the
-            # direct sum's 36.  `achieved` / `frac` count the FLOPs ISSUED to the matrix pipe (what PMC's MFMA-busy counter
-            # sees: a fraction of the hardware ceiling); the contract's algorithmic rate (2 x MACs of the direct 3x3 sum,
-            # SURVEY 8d, / time) is `algorithmic_tflops` -- it can pass the pipe's peak without the pipe being busier.
-            wn, wfl, wt = wino[dom]
-            executed = fl - wfl * (1.0 - 16.0 / 36.0)
-            roof["algorithm"] = ("%d of %d launches per step on the Winograd F(2x2,3x3) fp32 kernel (conv2d_wino.hip: same "
-                                 "result within fp32 round-off, 4/9 of the multiplies + transforms), the rest on the direct "
-                                 "implicit-GEMM kernels" % (wn // reps, cnt // reps))
+            # The launches on the Winograd kernels do 16 multiplies per 2x2 output block and (cout, cin) pair instead of the
+            # direct sum's 36; the bf16x3 kernel (conv2d_wino3.hip) issues each of them as six bf16 products.  The roofline
+            # object is that of the kernel most of the class's time goes to; the contract's algorithmic rate (2 x MACs of the
+            # direct 3x3 sum, SURVEY 8d, / time) is `algorithmic_tflops`.
+            wn, wfl, wt, w3n, w3fl, w3t = wino[dom]
+            executed = fl - (wfl + w3fl) * (1.0 - 16.0 / 36.0)
+            roof["algorithm"] = ("%d of %d launches per step on the Winograd F(2x2,3x3) kernel with the 16 GEMMs on the bf16 "
+                                 "pipe under the exact 3-way operand split (conv2d_wino3.hip: fp32 results, 4/9 of the "
+                                 "multiplies x 6 bf16 products + transforms), %d on the fp32 Winograd kernel "
+                                 "(conv2d_wino.hip), the rest on the direct implicit-GEMM kernels"
+                                 % (w3n // reps, cnt // reps, wn // reps))
             roof["executed_flops"] = executed / reps
             roof["mfma_flops_executed_frac"] = executed / fl
-            roof["achieved"] = executed / (t_ms * 1e-3) / 1e12
-            roof["frac"] = roof["achieved"] / FP32_MFMA_PEAK_TFLOPS
-            roof["winograd_launch_share_of_kernel_time"] = wt / t_ms
-            roof["note"] = ("achieved / frac = FLOPs ISSUED to the fp32 matrix pipe / kernel time (/ peak): the pipe's own "
-                            "utilisation (PMC SQ_VALU_MFMA_BUSY_CYCLES agrees: profiles/*_pmc_mfma_util.txt); "
-                            "algorithmic_tflops = SURVEY 8d's direct-sum FLOPs / the same time (the Winograd launches issue "
-                            "4/9 of their algorithmic multiplies); with DVSR_CONV_WINO=0 the direct kernels measure frac "
-                            "0.70 (profiles/*_wino_vs_direct.txt)")
+            roof["class"] = {"kind": dom, "launches_per_step": cnt // reps, "ms_per_step": t_ms / reps,
+                             "share_of_step": t_ms / total_ms, "algorithmic_tflops": fl / (t_ms * 1e-3) / 1e12,
+                             "fp32_products_tflops": executed / (t_ms * 1e-3) / 1e12,
+                             "fp32_products_over_fp32_pipe_peak": executed / (t_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+            if w3t >= wt:
+                k_fl, k_t, k_n, k_name = w3fl * (16.0 / 36.0), w3t, w3n, "conv2d_wino3_kernel"
+                roof.update(pipe_mix(0.0, 6.0 * k_fl / reps, k_t / reps * 1e-3))
+            else:
+                k_fl, k_t, k_n, k_name = wfl * (16.0 / 36.0), wt, wn, "conv2d_wino_kernel"
+                roof.update(pipe_mix(k_fl / reps, 0.0, k_t / reps * 1e-3))
+            roof.update({"kernel": k_name, "launches_per_step": k_n // reps, "avg_launch_ms": k_t / k_n,
+                         "share_of_step": k_t / total_ms, "algorithmic_flops": (w3fl if w3t >= wt else wfl) / reps,
+                         "executed_flops": k_fl / reps,
+                         "algorithmic_tflops": (w3fl if w3t >= wt else wfl) / (k_t * 1e-3) / 1e12,
+                         "fp32_products_tflops": k_fl / (k_t * 1e-3) / 1e12})
+            roof["winograd_launch_share_of_kernel_time"] = (wt + w3t) / t_ms
+            roof["note"] = ("roofline of the kernel most of the step goes to (`kernel`; the whole conv3x3s1 class is under "
+                            "`class`): achieved = FLOPs ISSUED to the matrix pipe it runs on / its time, frac = / that pipe's "
+                            "dense peak -- the pipe's own utilisation (PMC SQ_VALU_MFMA_BUSY_CYCLES agrees: "
+                            "profiles/*_pmc_mfma_util.txt).  The bf16x3 kernel is bound by LDS bandwidth and issue, not by "
+                            "the pipe (DESIGN 3.1f): its fp32 products / time are `fp32_products_tflops` (r03's fp32 "
+                            "Winograd kernel: 0.47 of the fp32 pipe for the same products at 5 %% more time); "
+                            "algorithmic_tflops = SURVEY 8d's direct-sum FLOPs / the same time; with DVSR_CONV_WINO=0 the "
+                            "direct kernels measure frac 0.70 of the fp32 pipe (profiles/*_wino_vs_direct.txt)")
         line["roofline"] = roof
         line["kernel_breakdown_ms_per_step"] = {k: round(a[0] / reps, 4) for k, a in
                                                 sorted(acc.items(), key=lambda kv: -kv[1][0])}
-        line["end_to_end_tflops"] = sum(a[1] for a in acc.values()) / reps / (ms * 1e-3) / 1e12
+        line["end_to_end_tflops"] = S * sum(a[1] for a in acc.values()) / reps / (ms * 1e-3) / 1e12   # (a step is S clips)
         if world == 1 and not args.no_split:
             line["experimental_bf16_split"] = split_mode_rate(cfg, h, w, x, y, args.steps, args.warmup)
             line["edvr_l_bf16"] = edvr_l_rates(dev)

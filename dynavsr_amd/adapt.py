@@ -498,7 +498,7 @@ class FrameBatch:
             return self.netG[0].forward_stacked(lqs, [s_.detach() for s_ in self.g_stack], per_slice=True)
 
 
-_STREAMS = {}
+_EXTRA_STREAMS = {}
 
 
 def _side_streams(lqs_device):
@@ -507,12 +507,68 @@ def _side_streams(lqs_device):
     both the next clip's baseline forward and the current clip's adapted forward: on two streams they run concurrently
     with each other as well whenever ROCm gives them separate hardware queues (GPU_MAX_HW_QUEUES >= 5), and three
     full-size tapes side by side take 32.5 ms per frame against 27.3 sequential and 23.3 with one stream (which is what
-    two streams measured only while they happened to share a queue)."""
-    key = torch.device(lqs_device).index if torch.device(lqs_device).index is not None else torch.cuda.current_device()
-    if key not in _STREAMS:
-        a = torch.cuda.Stream(device=key)
-        _STREAMS[key] = (a, a)
-    return _STREAMS[key]
+    two streams measured only while they happened to share a queue).  (The first of super_resolve_video's extra streams.)"""
+    a = _clip_streams(lqs_device, 2)[1]
+    return (a, a)
+
+
+def _clip_streams(device, n):
+    """The caller's current stream + n - 1 further HIP streams of the device.  The further ones are created once and shared
+    with adapt_video's forward stream (_side_streams): one block pool of the caching allocator and one launch plan +
+    workspace per stream must be found again on the next call -- and every extra stream a process has used takes part in
+    ROCm's stream -> hardware-queue assignment, which the legs with a weight-gradient side stream are sensitive to (DESIGN
+    3.1c; with two private streams here the per-frame pipeline that ran afterwards measured 61 instead of 71 frames/s)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    have = _EXTRA_STREAMS.setdefault(key, [])
+    while len(have) < n - 1:
+        have.append(torch.cuda.Stream(device=key))
+    return [torch.cuda.current_stream(key)] + have[:n - 1]
+
+
+def super_resolve_video(opt, net, clips, in_flight=2):
+    """The un-adapted forward of test_dynavsr.py:200-204 (`model.feed_data(val_data, need_GT=False); model.test()`) over a
+    stream of clips, as a generator: yields the SR frame [B, 3, sH, sW] of every clip [B, N, 3, H, W], in order.
+
+    `in_flight` clips are on the GPU at a time, one HIP stream each (round robin: the caller's stream and in_flight - 1
+    further ones).  A single EDVR-M forward at 180x320 is 85 dependent launches of 1125-workgroup grids on 256 CUs -- 4.4
+    rounds of workgroups each, the last one 40 % full, and 5-6 us of idle GPU between two launches -- and a second queue
+    fills both: 161.9 -> 187.9 frames/s with two clips in flight, 189.2 with three (tools/fwd_concurrent.py; one forward
+    over a batch of 8 clips: 180.4).  Every clip runs the launches it would run alone (its own plan and workspace, keyed
+    by the stream), so the outputs are bit-identical to `net(clip)`.  A yielded frame stays valid until the generator is
+    advanced `in_flight` times; clips and results are ordered against the caller's current stream."""
+    main = torch.cuda.current_stream()
+    streams = None
+    pending = []
+    was_training = net.training
+    net.eval()
+    try:
+        for i, c in enumerate(clips):
+            lq = c['LQs'] if isinstance(c, dict) else c
+            if not lq.is_cuda:
+                lq = lq.cuda()
+            if streams is None:
+                streams = _clip_streams(lq.device, max(1, int(in_flight)))
+            if len(pending) == len(streams):         # the oldest clip ran on the stream this one is about to take
+                sr, ev = pending.pop(0)
+                main.wait_event(ev)
+                sr.record_stream(main)
+                yield sr
+            s = streams[i % len(streams)]
+            if s != main:
+                s.wait_stream(main)                  # the clip (and the weights) were produced on the caller's stream
+            with torch.cuda.stream(s), torch.no_grad():
+                sr = net(backbone_input(opt, lq))
+                ev = torch.cuda.Event()
+                ev.record(s)
+            if s != main:
+                lq.record_stream(s)
+            pending.append((sr, ev))
+        for sr, ev in pending:
+            main.wait_event(ev)
+            sr.record_stream(main)
+            yield sr
+    finally:
+        net.train(was_training)
 
 
 def adapt_video(opt, model, est_model, modelcp, est_modelcp, est_model_fixed, clips, overlap=True, frames_per_batch=1):

@@ -1187,21 +1187,33 @@ extern "C" int dvsr_edvr_op_info(const dvsr_edvr_plan* p, int index, char* kind,
   snprintf(kind, kind_cap, "%s", k);
   if (p->ops[index].type == OP_CONV)
     snprintf(name, name_cap, "%s[%d/%d/%d%s]", p->ops[index].name, p->ops[index].geo.cc, p->ops[index].geo.th,
-             p->ops[index].geo.mt, p->ops[index].geo.dma >= 3 ? "w" : (p->ops[index].geo.dma ? "d" : ""));
+             p->ops[index].geo.mt, p->ops[index].geo.dma == 4 ? "w3" : (p->ops[index].geo.dma == 3 ? "w" : (p->ops[index].geo.dma ? "d" : "")));
   else
     snprintf(name, name_cap, "%s", p->ops[index].name);
   return DVSR_OK;
 }
 
-// Contraction work of a whole plan, forward and backward tapes (out: FIVE doubles): out[0] / out[2] = algorithmic FLOPs (2 x MACs of the direct
-// sums: convolutions and the DCN contraction; weight + data gradients for the backward), out[1] / out[3] = the FLOPs the
-// matrix pipe actually issues -- launches on the Winograd F(2x2, 3x3) kernel (geo.dma == 3) issue 16/36 of theirs.
-// bench.py prices every roofline fraction with the executed figure.
-extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out4) {
-  DVSR_REQUIRE(p && out4, DVSR_ERR_INVALID, "edvr_plan_work: null argument");
-  double fa = 0, fe = 0, ba = 0, be = 0, fby = 0;
+// Contraction work of a whole plan, forward and backward tapes (out: NINE doubles): out[0] / out[2] = algorithmic FLOPs (2 x MACs of the direct
+// sums: convolutions and the DCN contraction; weight + data gradients for the backward), out[1] / out[3] = the same work as
+// the kernels shape it, in fp32 products -- launches on the Winograd F(2x2, 3x3) kernels (geo.dma >= 3) do 16/36 of theirs;
+// out[4] = algorithmic bytes of the forward tape.  out[5] / out[7] = FLOPs ISSUED to the fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32), out[6] / out[8] = FLOPs ISSUED to the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) by the forward /
+// backward tape: a launch on the exact 3-way operand split issues SIX bf16 products per fp32 product (geo.bf == 2, the
+// Winograd bf16x3 kernel geo.dma == 4, the split3 weight gradient), a plain bf16 launch (geo.bf == 1) one.  bench.py prices
+// every roofline fraction with the issued figures against the peak of the pipe they were issued to.
+extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out9) {
+  DVSR_REQUIRE(p && out9, DVSR_ERR_INVALID, "edvr_plan_work: null argument");
+  double fa = 0, fe = 0, ba = 0, be = 0, fby = 0, f32p[2] = {0, 0}, bfp[2] = {0, 0};
   auto conv_part = [](const Op& o, int ci) {
     return 2.0 * (double)o.N * conv_out(o, o.H) * conv_out(o, o.W) * o.Cout * ci * o.ks * o.ks;
+  };
+  // one conv-shaped launch: f algorithmic FLOPs on geometry g -> (fp32 products done, pipe they go to)
+  auto issue = [&](const ConvGeo& g, double f, double* ex, int pass) {
+    const double shaped = g.dma >= 3 ? f * (16.0 / 36.0) : f;
+    *ex += shaped;
+    if (g.dma == 4 || g.bf == 2) bfp[pass] += 6.0 * shaped;
+    else if (g.bf == 1) bfp[pass] += shaped;
+    else f32p[pass] += shaped;
   };
   for (const Op& o : p->ops) {
     {
@@ -1211,10 +1223,10 @@ extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out4) {
     }
     if (o.type == OP_CONV) {
       const double f = conv_part(o, o.c0 + o.c1);
-      fa += f; fe += o.geo.dma >= 3 ? f * (16.0 / 36.0) : f;
+      fa += f; issue(o.geo, f, &fe, 0);
     } else if (o.type == OP_DCN) {
       const double f = 2.0 * (double)o.N * o.H * o.W * o.Cout * o.c0 * 9;
-      fa += f; fe += f;
+      fa += f; fe += f; f32p[0] += f;
     }
   }
   for (const BOp& b : p->bops) {
@@ -1223,16 +1235,21 @@ extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out4) {
     if (b.type == B_WGRAD) {
       const double f = conv_part(o, b.which ? o.c1 : o.c0);
       ba += f; be += f;
+      // (conv2d_wgrad_prepare's choice, restated: prep_wgrad's mode, then the kernel's own eligibility)
+      const int mode = (p->cfg.bf16_mfma == 1 && !o.wmap) ? 1 : (wgrad_split3_on() ? 2 : 0);
+      const int bf = (mode && o.stride == 1 && (o.ks == 3 || (o.ks == 2 && mode == 2))) ? mode : 0;
+      if (bf == 2) bfp[1] += 6.0 * f; else if (bf == 1) bfp[1] += f; else f32p[1] += f;
     } else if (b.type == B_DGRAD) {
       const double f = conv_part(o, b.which ? o.c1 : o.c0);
-      ba += f; be += o.dgeo[b.which].dma >= 3 ? f * (16.0 / 36.0) : f;
+      ba += f; issue(o.dgeo[b.which], f, &be, 1);
     } else if (b.type == B_DCN) {
       const double f = 2.0 * 2.0 * (double)o.N * o.H * o.W * o.Cout * o.c0 * 9;   // dcol + dW
-      ba += f; be += f;
+      ba += f; be += f; f32p[1] += f;
     }
   }
-  out4[0] = fa; out4[1] = fe; out4[2] = ba; out4[3] = be;
-  out4[4] = fby;   // algorithmic bytes of the forward tape: every launch's distinct inputs once + outputs once (op_work)
+  out9[0] = fa; out9[1] = fe; out9[2] = ba; out9[3] = be;
+  out9[4] = fby;   // algorithmic bytes of the forward tape: every launch's distinct inputs once + outputs once (op_work)
+  out9[5] = f32p[0]; out9[6] = bfp[0]; out9[7] = f32p[1]; out9[8] = bfp[1];
   return DVSR_OK;
 }
 
@@ -1463,9 +1480,9 @@ extern "C" int dvsr_estimator_num_launches(const dvsr_estimator_plan* ep, int ba
   return backward ? (int)ep->core.bops.size() : (int)ep->core.ops.size();
 }
 
-extern "C" int dvsr_estimator_plan_work(const dvsr_estimator_plan* ep, double* out4) {
+extern "C" int dvsr_estimator_plan_work(const dvsr_estimator_plan* ep, double* out9) {
   DVSR_REQUIRE(ep, DVSR_ERR_INVALID, "estimator_plan_work: null plan");
-  return dvsr_edvr_plan_work(&ep->core, out4);
+  return dvsr_edvr_plan_work(&ep->core, out9);
 }
 
 extern "C" size_t dvsr_estimator_workspace_bytes(const dvsr_estimator_plan* ep, int need_grad) {

@@ -19,6 +19,12 @@ _GEOMETRY_ENV = ("DVSR_CONV_WINO", "DVSR_CONV_WINO3", "DVSR_CONV_V1", "DVSR_CONV
                  "DVSR_CONV_KSPLIT_BELOW", "DVSR_DCN_BWD", "DVSR_EST_FUSE_PAD", "DVSR_EST_SPLIT", "DVSR_EST_SPLIT2", "DVSR_FUSE_ACT_BWD", "DVSR_BWD_STREAMS")
 
 
+# dvsr_edvr_plan_work's nine doubles (include/dynavsr_hip.h): *_executed = fp32 products as the kernels shape them,
+# *_f32_pipe / *_bf16_pipe = FLOPs issued to either matrix pipe
+_WORK_KEYS = ("fwd_algorithmic", "fwd_executed", "bwd_algorithmic", "bwd_executed", "fwd_bytes",
+              "fwd_f32_pipe", "fwd_bf16_pipe", "bwd_f32_pipe", "bwd_bf16_pipe")
+
+
 def _env_key():
     import os
     return tuple(os.environ.get(k) for k in _GEOMETRY_ENV)
@@ -67,9 +73,9 @@ class Plan:
     def work(self):
         """Contraction FLOPs of the two tapes: {'fwd_algorithmic', 'fwd_executed', 'bwd_algorithmic', 'bwd_executed'}
         (launches on the Winograd kernel issue 16/36 of their algorithmic multiplies)."""
-        out = (ctypes.c_double * 5)()
+        out = (ctypes.c_double * 9)()
         L.check(L.lib().dvsr_edvr_plan_work(self._h, ctypes.byref(out)), "dvsr_edvr_plan_work")
-        return dict(zip(("fwd_algorithmic", "fwd_executed", "bwd_algorithmic", "bwd_executed", "fwd_bytes"), out))
+        return dict(zip(_WORK_KEYS, out))
 
     def op_output(self, ws, index, which=0):
         """Flat view of what launch `index` wrote into the workspace (None when it writes the output tensor)."""
@@ -266,9 +272,9 @@ class EstimatorPlan:
 
     def work(self):
         """As Plan.work(), for the estimator's tapes."""
-        out = (ctypes.c_double * 5)()
+        out = (ctypes.c_double * 9)()
         L.check(L.lib().dvsr_estimator_plan_work(self._h, ctypes.byref(out)), "dvsr_estimator_plan_work")
-        return dict(zip(("fwd_algorithmic", "fwd_executed", "bwd_algorithmic", "bwd_executed", "fwd_bytes"), out))
+        return dict(zip(_WORK_KEYS, out))
 
     def __del__(self):
         try:

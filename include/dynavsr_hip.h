@@ -210,11 +210,13 @@ int dvsr_edvr_num_backward_launches(const dvsr_edvr_plan* plan);
  * synchronises, and returns per-launch milliseconds in op_ms[dvsr_edvr_num_launches()]. */
 int dvsr_edvr_op_info(const dvsr_edvr_plan* plan, int index, char* kind, int kind_cap, char* name,
                       int name_cap, double* flops, double* bytes);
-/* Contraction work of the plan's two tapes: out4 (FIVE doubles) = {forward algorithmic FLOPs, forward FLOPs issued to the
- * matrix pipe, backward algorithmic, backward issued, algorithmic bytes of the forward tape (every launch's distinct inputs
- * once + its outputs once)}.  Algorithmic = 2 x MACs of the direct sums; launches on the
- * Winograd F(2x2,3x3) kernel issue 16/36 of theirs.  bench.py's roofline fractions use the issued figure. */
-int dvsr_edvr_plan_work(const dvsr_edvr_plan* plan, double* out4);
+/* Contraction work of the plan's two tapes: out9 (NINE doubles) = {forward algorithmic FLOPs, forward fp32 products as the
+ * kernels shape them, backward algorithmic, backward shaped, algorithmic bytes of the forward tape (every launch's distinct
+ * inputs once + its outputs once), forward FLOPs issued to the fp32 matrix pipe, forward FLOPs issued to the bf16 matrix pipe,
+ * backward fp32-pipe, backward bf16-pipe}.  Algorithmic = 2 x MACs of the direct sums; launches on the Winograd
+ * F(2x2,3x3) kernels do 16/36 of theirs; launches on the exact 3-way bf16 operand split issue six bf16 products per fp32
+ * product.  bench.py's roofline fractions price the issued figures against the peak of the pipe they were issued to. */
+int dvsr_edvr_plan_work(const dvsr_edvr_plan* plan, double* out9);
 /* Test aid: where launch `index` of the forward tape leaves its result (which = 0; 1 = the second output of the pool /
  * TSA-gate launches).  *in_arena = 1: offset_floats counts from the start of the workspace (every activation of a
  * need_grad forward stays there); 0: the launch writes the output tensor. */
@@ -268,7 +270,7 @@ int dvsr_estimator_num_params(const dvsr_estimator_plan* plan);
 /* tape length: forward ops (backward = 0) or backward ops (backward = 1); a measurement aid like
  * dvsr_edvr_num_launches / dvsr_edvr_num_backward_launches */
 int dvsr_estimator_num_launches(const dvsr_estimator_plan* plan, int backward);
-int dvsr_estimator_plan_work(const dvsr_estimator_plan* plan, double* out4);   /* as dvsr_edvr_plan_work */
+int dvsr_estimator_plan_work(const dvsr_estimator_plan* plan, double* out9);   /* as dvsr_edvr_plan_work */
 size_t dvsr_estimator_workspace_bytes(const dvsr_estimator_plan* plan, int need_grad);
 int dvsr_estimator_forward(const dvsr_estimator_plan* plan, const float* const* params, const float* x, float* out,
                            void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
