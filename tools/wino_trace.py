@@ -72,6 +72,12 @@ for k in range(nch):
     stat("chunk %d block" % k, cur - prev)
     prev = cur
 stat("epilogue arithmetic + store issue", t[:, 41] - t[:, 40])
+if t[:, 50].any():   # the 2 x 2-block kernel: the epilogue's two exchange rounds
+    for nm, i0, i1 in (("epilogue: C_i in place", 40, 50), ("epilogue: first barrier", 50, 51), ("round 0: LDS writes (+ residual loads)", 51, 52),
+                       ("round 0: barrier", 52, 53), ("round 0: LDS reads + sums", 53, 54), ("barrier (reads done)", 54, 55),
+                       ("round 1: LDS writes", 55, 56), ("round 0: activation + stores issued", 56, 57),
+                       ("round 1: barrier + LDS reads + sums", 57, 58), ("round 1: activation + stores issued", 58, 41)):
+        stat(nm, t[:, i1] - t[:, i0])
 stat("store acknowledge", t[:, 42] - t[:, 41])
 # workgroups per CU over time: rounds
 hw = t[:, 63]
