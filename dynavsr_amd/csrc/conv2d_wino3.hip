@@ -873,6 +873,9 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino3_kernel(ConvK2 a) {
         const float* const v_nx = P ? v_img((kc + 1) & 1, 0) : v_img(kc & 1, 1);   // V(s + 1)
         asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");   // (only the B2 reads in flight)
         if (HAS_NEXT) gldA(P ^ 1, s + 1);                       // the set the previous phase has finished with
+        // the raw halo two chunks ahead, into the buffer whose rows were last read before the previous chunk's barrier: two
+        // phases to land (the input of the 720p layers comes from HBM, not from the last-level cache)
+        if (P == 0 && kc + 2 < a.nchunks) issue_raw(kc + 2);
         pinB(0);
         if (TF) pinT();
         fence();
@@ -915,8 +918,6 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino3_kernel(ConvK2 a) {
           if (s + 3 < nph) tf_load_c(PN{}, rb3, 1);
           fence();
           mm(PP{}, I1{}, I0{}, I1{}, NZ{});
-          if (P == 0 && kc + 2 < a.nchunks) issue_raw(kc + 2);
-          fence();
           mm(PP{}, I1{}, I1{}, I1{}, NZ{});
           ldB(vn, 0, 1); ldB(vn, 1, 1);
           fence();
