@@ -464,6 +464,22 @@ def test_conv3x3_winograd(n, c0, c1, cout, h, w, act, res, ps, force, pipe, monk
         assert relerr(gx, ref_g) < 2e-6
 
 
+@pytest.mark.parametrize("blk", ["0", "1", "2"])
+def test_conv3x3_winograd_bf16x3_other_forms(blk):
+    """The A/B forms of conv2d_wino3_kernel (DVSR_CONV_WINO3_BLK: 0 four xn per wave, 1 one xn per wave with U through the
+    LDS, 2 + U fragments from global; the default, 3, adds the one-barrier-per-chunk pipeline and is what every other test
+    runs) hold the same bars: the launcher reads the switch once per process, so each form runs the bf16x3 cases of
+    test_conv3x3_winograd in a child."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DVSR_CONV_WINO3_BLK=blk)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_conv3x3_winograd and bf16x3 and not other_forms"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("pipe", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("name,cout,h,w,ps", [("upconv2", 256, 360, 640, 2), ("HRconv", 64, 720, 1280, 0)])
 def test_conv3x3_winograd_largest_geometries(name, cout, h, w, ps, pipe, monkeypatch):

@@ -91,6 +91,12 @@ rm -rf $out/dbt_FETCH_SIZE $out/dbt_WRITE_SIZE
 #     its cycle-stamp timeline (debug build), and the forward with the kernel switched off
 echo "== Winograd on the bf16 pipe, exact 3-way split (conv2d_wino3.hip, the default)" > $out/${tag}_wino_vs_direct.txt
 DVSR_CONV_WINO=2 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
+# r04: the forms of the bf16x3 kernel: 3 (default) one xn per wave + U fragments from global + one barrier per chunk,
+#      2 the same with a barrier per phase, 1 one xn per wave with U through the LDS, 0 four xn per wave (one block each)
+for b in 3 2 1 0; do
+  echo "== DVSR_CONV_WINO3_BLK=$b" >> $out/${tag}_wino3_variants.txt
+  DVSR_CONV_WINO=2 DVSR_CONV_WINO3_BLK=$b python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_variants.txt
+done
 echo "== Winograd on the fp32 MFMA (conv2d_wino.hip, DVSR_CONV_WINO3=0)" >> $out/${tag}_wino_vs_direct.txt
 DVSR_CONV_WINO=2 DVSR_CONV_WINO3=0 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
 echo "== direct kernels (DVSR_CONV_WINO=0)" >> $out/${tag}_wino_vs_direct.txt
@@ -100,11 +106,13 @@ if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
   python tools/wino_trace.py 5 64 64 64 180 320 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
   echo "== the fp32 MFMA kernel (DVSR_CONV_WINO3=0)" >> $out/${tag}_wino_trace.txt
   DVSR_CONV_WINO3=0 python tools/wino_trace.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
-  # run-time ablations of the bf16x3 kernel (debug build; results are wrong when a bit is set): 2 no input transform,
-  # 4 no DMA, 8 operands read once, 16 no barriers
+  echo "== the four-xn-per-wave form (DVSR_CONV_WINO3_BLK=0), with the stamps inside a phase" >> $out/${tag}_wino_trace.txt
+  DVSR_CONV_WINO3_BLK=0 python tools/wino_trace.py 5 64 64 64 180 320 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
+  # run-time ablations of the bf16x3 kernel's four-xn-per-wave form (debug build; results are wrong when a bit is set):
+  # 2 no input transform, 4 no DMA, 8 operands read once, 16 no barriers
   for ab in 0 2 4 8 16 6 30; do
-    echo "== DVSR_CONV_ABLATE=$ab" >> $out/${tag}_wino3_ablation.txt
-    DVSR_CONV_WINO=2 DVSR_CONV_ABLATE=$ab DVSR_HIP_LIB=$PWD/dynavsr_amd/libdynavsr_hip_trace.so python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_ablation.txt
+    echo "== DVSR_CONV_WINO3_BLK=0 DVSR_CONV_ABLATE=$ab" >> $out/${tag}_wino3_ablation.txt
+    DVSR_CONV_WINO=2 DVSR_CONV_WINO3_BLK=0 DVSR_CONV_ABLATE=$ab DVSR_HIP_LIB=$PWD/dynavsr_amd/libdynavsr_hip_trace.so python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_ablation.txt
   done
 fi
 # r04: PMC picture of the bf16x3 Winograd kernel (LDS activity, wave wait / issue-stall split, instruction mix)
