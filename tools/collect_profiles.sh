@@ -128,4 +128,9 @@ echo "== forward 180x320 with DVSR_CONV_WINO=0 (direct kernels only)" >> $out/${
 DVSR_CONV_WINO=0 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-inner-step --no-split --no-meta --no-validation 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'])" >> $out/${tag}_wino_vs_direct.txt
+# r04: clips in flight on HIP streams against one clip at a time and against one forward over a batch of clips
+for cfg in "2 1" "3 1" "1 8" "2 4"; do
+  python tools/fwd_concurrent.py 180 320 20 $cfg 2>&1 | grep -E "stream|diff" >> $out/${tag}_fwd_clips_in_flight.txt
+done
+python tools/inner_two_streams.py 16 2 2>&1 | grep "inner step" >> $out/${tag}_fwd_clips_in_flight.txt
 du -sh gpurun_out
