@@ -235,6 +235,21 @@ inline int device_cus() {
   return cus[d];
 }
 
+// Largest dynamic LDS a workgroup of the current device may ask for (cached per ordinal; 160 KB on MI355X): the Winograd
+// kernels need 147 - 155 KB and are only chosen where that exists.
+inline size_t device_lds_optin() {
+  static size_t lds[64] = {};
+  int d = 0;
+  (void)hipGetDevice(&d);
+  d &= 63;
+  if (!lds[d]) {
+    hipDeviceProp_t prop;
+    lds[d] = hipGetDeviceProperties(&prop, d) == hipSuccess ? (size_t)prop.sharedMemPerBlockOptin : 0;
+    if (!lds[d]) lds[d] = 65536;
+  }
+  return lds[d];
+}
+
 // hipFuncSetAttribute (the dynamic-LDS limit of a kernel) applies to the CURRENT device only: a launcher keeps one flag per
 // device ordinal, so a process that drives several GPUs (or rebuilds plans after hipSetDevice) sets it on each of them.
 struct PerDeviceOnce {

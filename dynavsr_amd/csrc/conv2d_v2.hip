@@ -1016,7 +1016,9 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
     // DVSR_CONV_WINO3 (default 1): the same GEMMs on the bf16 pipe with the exact 3-way operand split (conv2d_wino3.hip)
     int wino3_on = 1;
     if (const char* v = getenv("DVSR_CONV_WINO3")) wino3_on = atoi(v);
-    if (wino_on == 2 || best < direct) return ConvGeo{8, w8 < w4 ? 8 : 4, 2, 0, wino3_on ? 4 : 3};
+    // (both Winograd kernels hold a workgroup's whole working set in ~150 KB of LDS: gfx950's 160 KB, checked, not assumed)
+    if ((wino_on == 2 || best < direct) && device_lds_optin() >= (size_t)155 * 1024)
+      return ConvGeo{8, w8 < w4 ? 8 : 4, 2, 0, wino3_on ? 4 : 3};
   }
   // Small grids (every workgroup resident at once) are bound by one memory latency per chunk, not by the
   // matrix pipe: 16-channel chunks halve the number of exposed latencies.  DVSR_CONV_CC16_BELOW=<workgroups>
