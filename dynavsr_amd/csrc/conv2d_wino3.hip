@@ -8,7 +8,13 @@
 // at half of the pipe (r03: 49 % busy).  The bf16 pipe retires the six products of 8 channels x 32 x 32 in 3 x 32 cycles
 // instead of 4 x 64, and VALU / LDS instructions issue beside it.
 //
-// Work split (one workgroup = 8 waves = one CU):
+// FOUR FORMS of the kernel body share the prologue below (template parameter BLK, DVSR_CONV_WINO3_BLK; DESIGN 3.1f has the
+// measurements): 0 -- the first one, described next; 1 -- one xn per wave and phase with 2 x 2 MFMA blocks (every operand
+// fragment feeds two MFMAs; the epilogue becomes an all-to-all through the LDS); 2 -- 1 + the U fragments straight from global
+// memory into a second register set (no other wave reads them); 3, THE DEFAULT -- 2 + the V images of two chunks in the LDS U
+// no longer needs and one barrier per chunk.
+//
+// Work split of form 0 (one workgroup = 8 waves = one CU):
 //   * workgroup tile = 64 couts x 64 tiles of 2x2 output pixels (TC tile columns: 4x64 or 8x32 pixels), K loop over chunks
 //     of 8 input channels; a chunk is processed as TWO phases p = 0, 1 = the transformed-patch rows xi in {2p, 2p+1} (8 of
 //     the 16 xn): the U and V images of a phase are 24 KB each, so U (three buffers: fetched two phases ahead), V (two) and
