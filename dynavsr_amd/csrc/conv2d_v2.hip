@@ -1012,13 +1012,17 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
     const double dcyc = std::min(c42, c41);
     const double drounds = dcyc / (64.0 * 9 * 4 * (c41 < 0.97 * c42 ? 1 : 2));
     const double direct = dcyc * nch / (drounds <= 6.0 ? 0.60 : 0.78) / 2.4;
-    const double best = std::min(w4, w8);
     // DVSR_CONV_WINO3 (default 1): the same GEMMs on the bf16 pipe with the exact 3-way operand split (conv2d_wino3.hip)
     int wino3_on = 1;
     if (const char* v = getenv("DVSR_CONV_WINO3")) wino3_on = atoi(v);
+    // ... which also has a 16 x 16-pixel tile (th = 16): the 44x80 levels of the batched inner step fill 92 % of its tiles
+    // against 72 % of the 8 x 32 ones (DVSR_CONV_WINO_T16=0: off)
+    static const bool t16_on = [] { const char* v = getenv("DVSR_CONV_WINO_T16"); return !(v && v[0] == '0'); }();
+    const double w16 = (wino3_on && t16_on) ? wino_cost(16, 16) : 1e300;
+    const double best = std::min(std::min(w4, w8), w16);
     // (both Winograd kernels hold a workgroup's whole working set in ~150 KB of LDS: gfx950's 160 KB, checked, not assumed)
     if ((wino_on == 2 || best < direct) && device_lds_optin() >= (size_t)155 * 1024)
-      return ConvGeo{8, w8 < w4 ? 8 : 4, 2, 0, wino3_on ? 4 : 3};
+      return ConvGeo{8, (w16 < w4 && w16 < w8) ? 16 : (w8 < w4 ? 8 : 4), 2, 0, wino3_on ? 4 : 3};
   }
   // Small grids (every workgroup resident at once) are bound by one memory latency per chunk, not by the
   // matrix pipe: 16-channel chunks halve the number of exposed latencies.  DVSR_CONV_CC16_BELOW=<workgroups>
@@ -1100,7 +1104,7 @@ int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const Conv
     DVSR_REQUIRE(geo.dma < 3 || d.c0 + d.c1 >= 16, DVSR_ERR_UNSUPPORTED, "conv2d_packed: the Winograd kernel needs two 8-channel chunks");
     DVSR_REQUIRE(geo.dma < 3 || d.pixel_shuffle == 0 || (d.pixel_shuffle == 2 && d.Cout % 4 == 0 && !d.res && !ex.accum && !ex.gmask),
                  DVSR_ERR_UNSUPPORTED, "conv2d_packed: the Winograd kernel stores plain or PixelShuffle(2) tiles (ps=%d)", d.pixel_shuffle);
-    DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && d.pad == 1 && !ex.in_ps && !ex.in_dil && geo.cc == 8 && (geo.th == 4 || geo.th == 8) &&
+    DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && d.pad == 1 && !ex.in_ps && !ex.in_dil && geo.cc == 8 && (geo.th == 4 || geo.th == 8 || (geo.th == 16 && geo.dma == 4)) &&
                      d.W % 4 == 0 && d.c0 % 8 == 0 && d.c1 % 8 == 0 && k.x0_bs % 4 == 0 && k.x1_bs % 4 == 0 &&
                      ((uintptr_t)d.x0 & 15) == 0 && ((uintptr_t)d.x1 & 15) == 0,
                  DVSR_ERR_UNSUPPORTED, "conv2d_packed: the DMA-halo kernel needs 3x3/s1/pad 1, plain 16-byte aligned inputs, "

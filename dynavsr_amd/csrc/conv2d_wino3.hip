@@ -1168,10 +1168,16 @@ static int launch_wino3(ConvK2 k, hipStream_t st) {
   return check_launch("conv2d_wino3_kernel");
 }
 
-// th = 4: 4 x 64-pixel workgroup tiles (TC = 32), th = 8: 8 x 32 (TC = 16)
+// th = 4: 4 x 64-pixel workgroup tiles (TC = 32), th = 8: 8 x 32 (TC = 16), th = 16: 16 x 16 (TC = 8)
 // DVSR_CONV_WINO3_BLK=0: the four-xn-per-wave form (one 32 x 32 block per xn; A/B aid)
 int conv2d_wino3_launch(const ConvK2& k, int th, hipStream_t st) {
   static const int blk = [] { const char* v = getenv("DVSR_CONV_WINO3_BLK"); return v ? atoi(v) : 3; }();
+  if (th == 16) {   // 16 x 16-pixel tiles (TC = 8)
+    if (blk == 0) return launch_wino3<8, 0>(k, st);
+    if (blk == 1) return launch_wino3<8, 1>(k, st);
+    if (blk == 2) return launch_wino3<8, 2>(k, st);
+    return launch_wino3<8, 3>(k, st);
+  }
   if (blk == 0) return th == 8 ? launch_wino3<16, 0>(k, st) : launch_wino3<32, 0>(k, st);
   if (blk == 2) return th == 8 ? launch_wino3<16, 2>(k, st) : launch_wino3<32, 2>(k, st);
   if (blk == 3) return th == 8 ? launch_wino3<16, 3>(k, st) : launch_wino3<32, 3>(k, st);

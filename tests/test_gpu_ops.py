@@ -422,6 +422,23 @@ def test_conv3x3_dma_halo(n, cin, cout, h, w, act, res, monkeypatch):
 ])
 @pytest.mark.parametrize("pipe", ["bf16x3", "fp32"])
 def test_conv3x3_winograd(n, c0, c1, cout, h, w, act, res, ps, force, pipe, monkeypatch):
+    _winograd_case(n, c0, c1, cout, h, w, act, res, ps, force, pipe, monkeypatch)
+
+
+@pytest.mark.parametrize("n,c0,c1,cout,h,w,act,res,ps", [
+    (16, 64, 0, 64, 44, 80, 2, False, 0),    # the trunk of a batched inner step: 240 tiles of 16x16 pixels, last tile row ragged
+    (16, 64, 0, 64, 44, 80, 0, True, 0),     # ... with the residual
+    (80, 64, 64, 64, 44, 80, 1, False, 0),   # 16 frames x 5: two inputs, five rounds instead of six
+    (16, 64, 0, 256, 44, 80, 1, False, 2),   # PixelShuffle(2) store
+])
+def test_conv3x3_winograd_16x16_tiles(n, c0, c1, cout, h, w, act, res, ps, monkeypatch):
+    """The bf16x3 kernel's third tile shape (TC = 8: 16 x 16 pixels), which the cost model takes where it saves a round of
+    workgroups: the 44x80 levels of the batched inner step."""
+    geo = _winograd_case(n, c0, c1, cout, h, w, act, res, ps, True, "bf16x3", monkeypatch)
+    assert geo[1] == 16, geo
+
+
+def _winograd_case(n, c0, c1, cout, h, w, act, res, ps, force, pipe, monkeypatch):
     """Forward (and data gradient for single plain inputs) on the Winograd kernels against fp64 torch; the geometry query
     confirms the kernel.  force: DVSR_CONV_WINO=2 takes it wherever it is eligible (the cost model would keep the direct
     kernel on these small grids).  pipe: the sixteen GEMMs on the bf16 matrix pipe with the exact 3-way operand split
@@ -462,6 +479,7 @@ def test_conv3x3_winograd(n, c0, c1, cout, h, w, act, res, ps, force, pipe, monk
                 "dvsr_conv2d_dgrad_packed")
         ref_g = torch.nn.grad.conv2d_input((n, c0, h, w), wt.double(), gy.double(), 1, 1)
         assert relerr(gx, ref_g) < 2e-6
+    return list(geo)
 
 
 @pytest.mark.parametrize("blk", ["0", "1", "2"])
