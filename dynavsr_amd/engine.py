@@ -15,7 +15,7 @@ from . import _lib as L
 _plans = {}
 # Environment switches that the native plan builder reads when it chooses kernels (conv2_choose, build_backward): they are
 # part of the plan-cache key, so a plan built under one setting is never handed out under another.
-_GEOMETRY_ENV = ("DVSR_CONV_WINO", "DVSR_CONV_WINO3", "DVSR_CONV_V1", "DVSR_CONV_DMA", "DVSR_CONV_TILE",
+_GEOMETRY_ENV = ("DVSR_CONV_WINO", "DVSR_CONV_WINO3", "DVSR_CONV_WINO_T16", "DVSR_CONV_V1", "DVSR_CONV_DMA", "DVSR_CONV_TILE",
                  "DVSR_CONV_KSPLIT_BELOW", "DVSR_DCN_BWD", "DVSR_EST_FUSE_PAD", "DVSR_EST_SPLIT", "DVSR_EST_SPLIT2", "DVSR_FUSE_ACT_BWD", "DVSR_BWD_STREAMS")
 
 
