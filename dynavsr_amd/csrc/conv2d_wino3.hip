@@ -719,6 +719,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino3_kernel(ConvK2 a) {
     auto mm = [&](auto p_, auto mh_, auto tr_, auto j_, auto zero_) __attribute__((always_inline)) {
       constexpr int P = decltype(p_)::value, MH = decltype(mh_)::value, TR = decltype(tr_)::value, J = decltype(j_)::value;
       constexpr bool Z = decltype(zero_)::value;
+      if (W3_ABLATE(a) & 32) return;
       const w3bf8 av = __builtin_bit_cast(w3bf8, A[GA ? P : 0][MH][J]);
       const w3bf8 bv = __builtin_bit_cast(w3bf8, B[TR][J == 1 ? 1 : 0]);
       if (Z) acc[4 * P + 2 * MH + TR] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, zero16, 0, 0, 0);
@@ -869,7 +870,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino3_kernel(ConvK2 a) {
       auto v_img = [&](int set, int par) { return smem + (set ? Sh::OFF_U + par * SUB : (par ? Sh::OFF_V1 : Sh::OFF_V0)); };
       auto phase = [&](int s, auto p_, auto first_, auto next_, auto tf_) __attribute__((always_inline)) {
         constexpr int P = decltype(p_)::value;
-        constexpr bool FIRST = decltype(first_)::value, HAS_NEXT = decltype(next_)::value, TF = decltype(tf_)::value;
+        constexpr bool FIRST = decltype(first_)::value, HAS_NEXT = decltype(next_)::value;
+        // (debug-build ablations, results wrong: 2 no input transform, 4 no global loads (U fragments, raw halo), 8 no V operand
+        // reads, 16 no barrier, 32 no MFMAs; W3_ABLATE is the constant 0 in the product build)
+        const bool TF = decltype(tf_)::value && !(W3_ABLATE(a) & 2);
         using PP = std::integral_constant<int, P>;
         using PN = std::integral_constant<int, P ^ 1>;
         using Z = std::integral_constant<bool, FIRST>;
@@ -878,10 +882,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino3_kernel(ConvK2 a) {
         float* const v_wr = v_img((kc + 1) & 1, P);                      // V(s + 2)
         const float* const v_nx = P ? v_img((kc + 1) & 1, 0) : v_img(kc & 1, 1);   // V(s + 1)
         asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");   // (only the B2 reads in flight)
-        if (HAS_NEXT) gldA(P ^ 1, s + 1);                       // the set the previous phase has finished with
+        if (HAS_NEXT && !(W3_ABLATE(a) & 4)) gldA(P ^ 1, s + 1);   // the set the previous phase has finished with
         // the raw halo two chunks ahead, into the buffer whose rows were last read before the previous chunk's barrier: two
         // phases to land (the input of the 720p layers comes from HBM, not from the last-level cache)
-        if (P == 0 && kc + 2 < a.nchunks) issue_raw(kc + 2);
+        if (P == 0 && kc + 2 < a.nchunks && !(W3_ABLATE(a) & 4)) issue_raw(kc + 2);
         pinB(0);
         if (TF) pinT();
         fence();
@@ -907,25 +911,25 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino3_kernel(ConvK2 a) {
           // the raw halo issued in the phase before this one has landed (only the six A loads of this phase's top may still
           // fly), this wave's V words are written
           __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0)
-          __builtin_amdgcn_s_barrier();
+          if (!(W3_ABLATE(a) & 16)) __builtin_amdgcn_s_barrier();
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         pinB(1);
         if (HAS_NEXT) {
           const unsigned vn = w3_lds_addr(v_nx);
-          ldB(vn, 0, 0); ldB(vn, 1, 0);
+          if (!(W3_ABLATE(a) & 8)) { ldB(vn, 0, 0); ldB(vn, 1, 0); }
           fence();
           const int rb3 = ((s + 3) >> 1) & 1;
           mm(PP{}, I0{}, I0{}, I1{}, NZ{});
-          if (s + 3 < nph) tf_load_c(PN{}, rb3, 0);
+          if (s + 3 < nph && !(W3_ABLATE(a) & 2)) tf_load_c(PN{}, rb3, 0);
           fence();
           mm(PP{}, I0{}, I1{}, I1{}, NZ{});
-          if (s + 3 < nph) tf_load_c(PN{}, rb3, 1);
+          if (s + 3 < nph && !(W3_ABLATE(a) & 2)) tf_load_c(PN{}, rb3, 1);
           fence();
           mm(PP{}, I1{}, I0{}, I1{}, NZ{});
           mm(PP{}, I1{}, I1{}, I1{}, NZ{});
-          ldB(vn, 0, 1); ldB(vn, 1, 1);
+          if (!(W3_ABLATE(a) & 8)) { ldB(vn, 0, 1); ldB(vn, 1, 1); }
           fence();
         } else {
           fence();

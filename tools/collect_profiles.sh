@@ -114,6 +114,12 @@ if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
     echo "== DVSR_CONV_WINO3_BLK=0 DVSR_CONV_ABLATE=$ab" >> $out/${tag}_wino3_ablation.txt
     DVSR_CONV_WINO=2 DVSR_CONV_WINO3_BLK=0 DVSR_CONV_ABLATE=$ab DVSR_HIP_LIB=$PWD/dynavsr_amd/libdynavsr_hip_trace.so python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_ablation.txt
   done
+  # ... and of the default form: 2 no input transform, 4 no global loads (U fragments, raw halo), 8 no V operand reads,
+  # 16 no barrier, 32 no MFMAs
+  for ab in 0 2 4 8 16 32 30 62; do
+    echo "== default form, DVSR_CONV_ABLATE=$ab" >> $out/${tag}_wino3_ablation.txt
+    DVSR_CONV_WINO=2 DVSR_CONV_ABLATE=$ab DVSR_HIP_LIB=$PWD/dynavsr_amd/libdynavsr_hip_trace.so python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_ablation.txt
+  done
 fi
 # r04: PMC picture of the bf16x3 Winograd kernel (LDS activity, wave wait / issue-stall split, instruction mix)
 for set in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
