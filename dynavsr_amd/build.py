@@ -66,6 +66,12 @@ def build(force=False, verbose=False):
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode:
             raise RuntimeError("link failed:\n" + r.stdout)
+        # a kernel template whose host stub was not instantiated links fine and fails at dlopen: check here, not on the GPU box
+        import ctypes
+        try:
+            ctypes.CDLL(SO)
+        except OSError as e:
+            raise RuntimeError("libdynavsr_hip.so does not load: %s" % e)
     return SO
 
 

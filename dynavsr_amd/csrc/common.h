@@ -254,15 +254,24 @@ inline size_t device_lds_optin() {
 // device ordinal, so a process that drives several GPUs (or rebuilds plans after hipSetDevice) sets it on each of them.
 struct PerDeviceOnce {
   bool done[64] = {};
-  bool first() {
+  static int slot() {
     int d = 0;
     (void)hipGetDevice(&d);
-    d &= 63;
-    if (done[d]) return false;
-    done[d] = true;   // (benign race: the attribute call is idempotent)
-    return true;
+    return (d >= 0 && d < 64) ? d : 63;   // (devices past the table share its last slot: the call is merely repeated)
   }
+  // needs(): the per-device action has not been COMPLETED on this device yet; mark(): it has (call it after the action
+  // succeeded).  Two host threads may both run the action -- it is idempotent (hipFuncSetAttribute) -- but none can launch
+  // before one of them has finished it, which the earlier set-then-act order allowed.
+  bool needs() const { return !__atomic_load_n(&done[slot()], __ATOMIC_ACQUIRE); }
+  void mark() { __atomic_store_n(&done[slot()], true, __ATOMIC_RELEASE); }
 };
+// Raises the dynamic-LDS limit of a kernel once per device.  The flag is set only after the call SUCCEEDED: a failure is
+// retried by the next launch, and that launch fails loudly (check_launch) instead of running with a stale limit.
+inline void set_dyn_lds_once(PerDeviceOnce& once, const void* kern, size_t bytes) {
+  if (!once.needs()) return;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) once.mark();
+  else (void)hipGetLastError();
+}
 
 // Store modes carried in TileOut::ps beyond 0 (plain) and 2 (PixelShuffle(2)): the tile goes STRAIGHT into the
 // explicitly padded tensor the next convolution of the estimator reads (LRimg_estimator.py:82-86: ReflectionPad2d(1) in

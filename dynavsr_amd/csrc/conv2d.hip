@@ -160,10 +160,7 @@ static int launch_conv(const ConvK& k, hipStream_t st) {
   using Sh = ConvShape<KS, S, CC>;
   auto kern = conv2d_mfma_kernel<KS, S, CC, MT>;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)Sh::LDS_BYTES);
-  }
+  set_dyn_lds_once(attr_once, (const void*)kern, Sh::LDS_BYTES);
   const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Sh::LDS_BYTES, st, k);
   return check_launch("conv2d_mfma_kernel");

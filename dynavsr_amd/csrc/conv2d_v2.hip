@@ -513,9 +513,7 @@ static int launch_conv2(ConvK2 k, hipStream_t st) {
   // debug: DVSR_CONV_LDS=<bytes> inflates the LDS request to force fewer workgroups per CU
   if (const char* e = getenv("DVSR_CONV_LDS")) lds = std::max(lds, (size_t)atol(e));
 #endif
-  if (attr_once.first()) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
+  set_dyn_lds_once(attr_once, (const void*)kern, lds);
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 32 * MT);
   k.tiles_per_xcd = ceil_div(k.ntiles, 8);
@@ -700,9 +698,7 @@ static int launch_dma(ConvK2 k, hipStream_t st) {
   using Sh = DmaShape<TH, MT>;
   auto kern = conv2d_dma_kernel<TH, MT>;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
-  }
+  set_dyn_lds_once(attr_once, (const void*)kern, Sh::LDS_BYTES);
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 32 * MT);
   k.tiles_per_xcd = ceil_div(k.ntiles, 8);
@@ -882,9 +878,7 @@ static int launch_dmarow(ConvK2 k, hipStream_t st) {
   using Sh = RowShape<KS, TH, MT>;
   auto kern = conv2d_dmarow_kernel<KS, TH, MT>;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
-  }
+  set_dyn_lds_once(attr_once, (const void*)kern, Sh::LDS_BYTES);
   k.tiles_x = ceil_div(k.Wo, 32); k.tiles_y = ceil_div(k.Ho, TH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 32 * MT);
   k.tiles_per_xcd = ceil_div(k.ntiles, 8);
@@ -904,9 +898,7 @@ static int launch_ksplit(ConvK2 k, hipStream_t st) {
   using Sh = KsShape<MT, NT>;
   auto kern = conv2d_ksplit_kernel<MT, NT>;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
-  }
+  set_dyn_lds_once(attr_once, (const void*)kern, Sh::LDS_BYTES);
   hipLaunchKernelGGL(kern, dim3(k.nitems), dim3(256), Sh::LDS_BYTES, st, k);  // tiles: conv2d_packed_prepare
   return check_launch("conv2d_ksplit_kernel");
 }

@@ -238,9 +238,7 @@ static void launch_wgrad(const WgradK& k, dim3 grid, hipStream_t st) {
   using Sh = WgShape<KS, S>;
   auto kern = conv2d_wgrad_kernel<KS, S>;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
-  }
+  set_dyn_lds_once(attr_once, (const void*)kern, Sh::LDS_BYTES);
   const size_t lds = Sh::LDS_BYTES;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
 }
@@ -400,10 +398,7 @@ int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st) {
                                                ? WgWideShape<KS_, KYS_, 4>::LDS_BYTES : WgWideShape<KS_, KYS_, 2>::LDS_BYTES) : 0;
       constexpr size_t lds = lds_a > lds_b ? lds_a : lds_b;
       static PerDeviceOnce attr_once;
-      if (attr_once.first()) {
-        hipFuncSetAttribute((const void*)conv2d_wgrad_pipe_kernel<KS_, KYS_>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-      }
+      set_dyn_lds_once(attr_once, (const void*)conv2d_wgrad_pipe_kernel<KS_, KYS_>, lds);
       hipLaunchKernelGGL((conv2d_wgrad_pipe_kernel<KS_, KYS_>), grid, dim3(256), lds, st, k);
     };
     if (ks == 7) launch_pipe(std::integral_constant<int, 7>{}, std::true_type{});

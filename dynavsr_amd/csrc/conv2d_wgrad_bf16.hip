@@ -568,8 +568,7 @@ template <int KS, int VX, int SHIFT>
 static int launch_split3(const WgradLaunch& l, hipStream_t st) {
   auto kern = conv2d_wgrad_split3_kernel<KS, VX, SHIFT>;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
-  hipLaunchKernelGGL(kern, l.grid, dim3(256), S3_LDS_BYTES, st, l.k);
+  set_dyn_lds_once(attr_once, (const void*)kern, S3_LDS_BYTES);hipLaunchKernelGGL(kern, l.grid, dim3(256), S3_LDS_BYTES, st, l.k);
   return check_launch("conv2d_wgrad_split3_kernel");
 }
 
@@ -590,9 +589,7 @@ int conv2d_wgrad_split3_launch(const WgradLaunch& l, hipStream_t st) {
 
 int conv2d_wgrad_bf16_launch(const WgradLaunch& l, hipStream_t st) {
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
-    hipFuncSetAttribute((const void*)conv2d_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS_BYTES);
-  }
+  set_dyn_lds_once(attr_once, (const void*)conv2d_wgrad_bf16_kernel, WB_LDS_BYTES);
   hipLaunchKernelGGL(conv2d_wgrad_bf16_kernel, l.grid, dim3(256), WB_LDS_BYTES, st, l.k);
   return check_launch("conv2d_wgrad_bf16_kernel");
 }

@@ -503,9 +503,7 @@ static int launch_wino(ConvK2 k, hipStream_t st) {
   using Sh = WinoShape<TC>;
   auto kern = conv2d_wino_kernel<TC>;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
-  }
+  set_dyn_lds_once(attr_once, (const void*)kern, Sh::LDS_BYTES);
   k.tiles_x = ceil_div(k.Wo, Sh::OW); k.tiles_y = ceil_div(k.Ho, Sh::OH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 64);
   k.tiles_per_xcd = ceil_div(k.ntiles, 8);

@@ -1163,8 +1163,7 @@ static int launch_wino3(ConvK2 k, hipStream_t st) {
   using Sh = Wino3Shape<TC>;
   auto kern = conv2d_wino3_kernel<TC, BLK>;
   static PerDeviceOnce attr_once;
-  if (attr_once.first()) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sh::LDS_BYTES);
-  k.tiles_x = ceil_div(k.Wo, Sh::OW); k.tiles_y = ceil_div(k.Ho, Sh::OH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
+  set_dyn_lds_once(attr_once, (const void*)kern, Sh::LDS_BYTES);k.tiles_x = ceil_div(k.Wo, Sh::OW); k.tiles_y = ceil_div(k.Ho, Sh::OH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 64);
   k.tiles_per_xcd = ceil_div(k.ntiles, 8);
   k.nitems = k.tiles_per_xcd * 8 * k.ncb;
@@ -1173,9 +1172,11 @@ static int launch_wino3(ConvK2 k, hipStream_t st) {
 }
 
 // th = 4: 4 x 64-pixel workgroup tiles (TC = 32), th = 8: 8 x 32 (TC = 16), th = 16: 16 x 16 (TC = 8)
-// DVSR_CONV_WINO3_BLK=0: the four-xn-per-wave form (one 32 x 32 block per xn; A/B aid)
+// DVSR_CONV_WINO3_BLK: 4 (default, round 5) the B operand built in registers (conv2d_wino4.hip); 0-3 the forms of this file
+// (A/B aids: 0 four xn per wave, 1 one xn per wave, 2 + U from global, 3 + one barrier per chunk = the round-4 default)
 int conv2d_wino3_launch(const ConvK2& k, int th, hipStream_t st) {
-  static const int blk = [] { const char* v = getenv("DVSR_CONV_WINO3_BLK"); return v ? atoi(v) : 3; }();
+  static const int blk = [] { const char* v = getenv("DVSR_CONV_WINO3_BLK"); return v ? atoi(v) : 4; }();
+  if (blk == 4) return conv2d_wino4_launch(k, th, st);   // conv2d_wino4.hip: the B operand built in registers
   if (th == 16) {   // 16 x 16-pixel tiles (TC = 8)
     if (blk == 0) return launch_wino3<8, 0>(k, st);
     if (blk == 1) return launch_wino3<8, 1>(k, st);

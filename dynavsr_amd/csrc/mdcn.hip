@@ -1027,11 +1027,9 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
   const bool aligned = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)off | (uintptr_t)msk) & 15) == 0 && off_bs % 4 == 0 &&
                        msk_bs % 4 == 0;
   if (variant == 0 && aligned) {
-    static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-      hipFuncSetAttribute((const void*)mdcn_fwd_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DcnDmaShape::LDS_BYTES);
-      hipFuncSetAttribute((const void*)mdcn_fwd_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DcnDmaShape::LDS_BYTES);
-    }
+    static PerDeviceOnce attr_once_t, attr_once_f;
+    set_dyn_lds_once(attr_once_t, (const void*)mdcn_fwd_dma_kernel<true>, DcnDmaShape::LDS_BYTES);
+    set_dyn_lds_once(attr_once_f, (const void*)mdcn_fwd_dma_kernel<false>, DcnDmaShape::LDS_BYTES);
     if (mask_logit) hipLaunchKernelGGL(mdcn_fwd_dma_kernel<true>, dim3(grid), dim3(256), DcnDmaShape::LDS_BYTES, st, k);
     else hipLaunchKernelGGL(mdcn_fwd_dma_kernel<false>, dim3(grid), dim3(256), DcnDmaShape::LDS_BYTES, st, k);
     return check_launch("mdcn_fwd_dma_kernel");

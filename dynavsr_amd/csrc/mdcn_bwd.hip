@@ -723,10 +723,7 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
     // LDS: input window + max(gradient window, W^T operands); the weight-gradient phase re-uses it ([64 + 72][129] floats)
     const size_t lds = (size_t)std::max(8 * XPX + std::max(16 * XPX, 3 * (Cout / 2) * 64), (64 + 72) * 129) * sizeof(float);
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-      hipFuncSetAttribute((const void*)mdcn_bwd_fused_kernel<HALO>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)(std::max(8 * XPX + std::max(16 * XPX, 3 * 64 * 64), (64 + 72) * 129) * sizeof(float)));
-    }
+    set_dyn_lds_once(attr_once, (const void*)mdcn_bwd_fused_kernel<HALO>, (std::max(8 * XPX + std::max(16 * XPX, 3 * 64 * 64), (64 + 72) * 129) * sizeof(float)));
 #ifdef DVSR_CONV_TRACE
     f.trace = (g_dcnb_countdown == 0) ? g_dcnb_trace : nullptr;
     if (g_dcnb_countdown >= 0) --g_dcnb_countdown;

@@ -72,6 +72,7 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
 int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st);
 int conv2d_wino_launch(const ConvK2& k, int th, hipStream_t st);   // conv2d_wino.hip (ConvGeo::dma == 3)
 int conv2d_wino3_launch(const ConvK2& k, int th, hipStream_t st);  // conv2d_wino3.hip (ConvGeo::dma == 4)
+int conv2d_wino4_launch(const ConvK2& k, int th, hipStream_t st);  // conv2d_wino4.hip (the same image, B operand in registers)
 int conv2d_wgrad_bf16_launch(const WgradLaunch& l, hipStream_t st);
 int conv2d_wgrad_split3_launch(const WgradLaunch& l, hipStream_t st);   // bf = 2: exact 3-way bf16 split (fp32 accuracy)
 

@@ -482,11 +482,11 @@ def _winograd_case(n, c0, c1, cout, h, w, act, res, ps, force, pipe, monkeypatch
     return list(geo)
 
 
-@pytest.mark.parametrize("blk", ["0", "1", "2"])
+@pytest.mark.parametrize("blk", ["0", "1", "2", "3"])
 def test_conv3x3_winograd_bf16x3_other_forms(blk):
     """The A/B forms of conv2d_wino3_kernel (DVSR_CONV_WINO3_BLK: 0 four xn per wave, 1 one xn per wave with U through the
-    LDS, 2 + U fragments from global; the default, 3, adds the one-barrier-per-chunk pipeline and is what every other test
-    runs) hold the same bars: the launcher reads the switch once per process, so each form runs the bf16x3 cases of
+    LDS, 2 + U fragments from global, 3 + the one-barrier-per-chunk pipeline = the round-4 default; the default since round
+    5, 4 = conv2d_wino4_kernel, builds the B operand in registers and is what every other test runs) hold the same bars: the launcher reads the switch once per process, so each form runs the bf16x3 cases of
     test_conv3x3_winograd in a child."""
     import os
     import subprocess
