@@ -14,6 +14,9 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 SO = os.path.join(HERE, "libdynavsr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# per-file flags.  conv2d_wino4.hip: the SLP vectoriser turns the split's residual subtractions into v_pk_add_f32 on register
+# pairs it has to assemble with moves (36 v_mov per chunk) -- and packed fp32 is slower beside MFMAs anyway (MI355X guide).
+EXTRA = {"conv2d_wino4.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():
@@ -30,7 +33,7 @@ def build_trace():
     """Debug library with the conv pipeline's cycle stamps compiled in (tools/conv_trace.py)."""
     so = os.path.join(HERE, "libdynavsr_hip_trace.so")
     srcs = [os.path.join(CSRC, s) for s in _sources()]
-    r = subprocess.run([HIPCC] + FLAGS + ["-DDVSR_CONV_TRACE", "-shared", "-o", so] + srcs,
+    r = subprocess.run([HIPCC] + FLAGS + ["-fno-slp-vectorize", "-DDVSR_CONV_TRACE", "-shared", "-o", so] + srcs,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode:
         raise RuntimeError("trace build failed:\n" + r.stdout)
@@ -49,7 +52,7 @@ def build(force=False, verbose=False):
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode:
             raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stdout))

@@ -25,8 +25,8 @@
 // A fragments (the packed transformed weights, conv2d_wino3.hip's image) come straight from global memory as before, each
 // reloaded with the next chunk's right behind its last MFMA.  Per chunk a wave issues 24 MFMAs (slot 0: A1 B1, A3 B1,
 // A2 B2 on the four 32 x 32 blocks; then slot 1), ~165 VALU, 48 LDS reads, 12 global loads and its share of the raw halo
-// DMA: no LDS write, no V image, ONE loose barrier per chunk (it only hands the raw halo over).  LDS: two raw chunks
-// (2 x 16 KB) during the loop; the epilogue's exchange (128 KB) reuses it.
+// DMA: no LDS write, no V image, ONE loose barrier per chunk (it only hands the raw halo over).  LDS: three raw chunks
+// (3 x 16 KB) during the loop; the epilogue's exchange (128 KB) reuses it.
 //
 // The halo DMA is UNCONDITIONAL: lanes whose 16-byte group lies outside the image carry a byte offset beyond the buffer
 // resource's num_records (the hardware drops the access; the group was zeroed once in the prologue), so every wave issues
@@ -44,6 +44,27 @@
 
 namespace dvsr {
 
+#ifdef DVSR_CONV_TRACE
+// cycle stamps of the debug build (tools/wino_trace.py): thread 0 of every workgroup, slots as in conv2d_wino3.hip; W4_FINE:
+// lane 0 of waves 0 and 4 (the two waves of one SIMD) inside chunk 3, slots 20 + i / 30 + i
+#define W4_STAMP(i)                                                                                       \
+  do {                                                                                                    \
+    if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#define W4_FINE(i)                                                                                                      \
+  do {                                                                                                                  \
+    if (a.trace && k == 3 && lane == 0 && (wave & 3) == 0)                                                              \
+      a.trace[(size_t)blockIdx.x * 64 + (wave ? 30 : 20) + (i)] = __builtin_readcyclecounter();                          \
+  } while (0)
+#else
+#define W4_STAMP(i) \
+  do {              \
+  } while (0)
+#define W4_FINE(i) \
+  do {             \
+  } while (0)
+#endif
+
 typedef float w4f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 w4bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned w4u4 __attribute__((ext_vector_type(4)));
@@ -57,7 +78,8 @@ struct Wino4Shape {
   static constexpr int NI = (NG + 511) / 512;
   static constexpr int RAWPAD = NI * 512 * 4;          // floats of one raw buffer (every lane of every DMA has a slot)
   static constexpr int XCH = 32768;                    // floats of the epilogue's exchange image (128 KB)
-  static constexpr size_t LDS_BYTES = (size_t)(2 * RAWPAD > XCH ? 2 * RAWPAD : XCH) * sizeof(float);
+  static constexpr int NBUF = 3;                       // raw chunks in the LDS: being read, landed for the next chunk, in flight
+  static constexpr size_t LDS_BYTES = (size_t)(NBUF * RAWPAD > XCH ? NBUF * RAWPAD : XCH) * sizeof(float);
 };
 
 // s_waitcnt immediate (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14]); lgkm = 15: no wait
@@ -66,11 +88,12 @@ constexpr int w4_waitcnt(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgk
 __device__ __forceinline__ unsigned w4_lds_addr(const float* p) {
   return (unsigned)(size_t)((__attribute__((address_space(3))) const float*)p);
 }
-// v_cvt_pk_bf16_f32: {bf16(a) (round to nearest even) in bits 15:0, bf16(b) in bits 31:16}
+// v_cvt_pk_bf16_f32: {bf16(a) (round to nearest even) in bits 15:0, bf16(b) in bits 31:16}.  (As a vector conversion, not
+// inline asm: behind an asm the compiler pads every dependent use with an s_nop -- 24 per chunk in conv2d_wino3.hip -- because it
+// cannot see which hazards the instruction has; this form it schedules itself.)
+typedef __bf16 w4bf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned w4_cvt_pk(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(w4f2{a, b}, w4bf2));
 }
 
 // one LDS-DMA instruction: 64 lanes x 16 bytes at lds + 16 lane (in a function of its own: used directly inside the kernel
@@ -121,23 +144,30 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
     const int gy = oy0 - 1 + iy, gx = ox0 - 4 + 4 * g;
     const bool ok = L < Sh::NG && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     hoff[jj] = ok ? (unsigned)(((size_t)c * HW + (size_t)gy * a.W + gx) * 4) : 0x80000000u;
-    if (L < Sh::NG && !ok) {
-      *reinterpret_cast<f32x4*>(smem + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(smem + Sh::RAWPAD + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef W4_NOZERO
+    if (L < Sh::NG && !ok)
+#else
+    if (false)   // (probe build: does the LDS-DMA write zeros for lanes the buffer resource rejects?)
+#endif
+    {
+#pragma unroll
+      for (int bb = 0; bb < Sh::NBUF; ++bb) *reinterpret_cast<f32x4*>(smem + bb * Sh::RAWPAD + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   const unsigned chunk_bytes = (unsigned)(Sh::CC * HW * 4);
   // (the resource is SELECTED, not branched on -- second input; past the last chunk an empty one: nothing is read -- so that
   // every path issues the same NI instructions and the compiler's own vmcnt bookkeeping for the A fragments stays exact)
+  int dbuf = 0;   // buffer of the next raw chunk to be fetched (chunk k lives in buffer k % NBUF)
   auto issue_raw = [&](int k) __attribute__((always_inline)) {
     const bool live = k < a.nchunks;
     const bool second = k * Sh::CC >= a.c0;  // only possible when c1 > 0; a chunk never straddles the two inputs
     const unsigned soff = live ? (unsigned)(second ? k - a.c0 / Sh::CC : k) * chunk_bytes : 0u;
     const __amdgpu_buffer_rsrc_t rs = w4_rsrc(second ? x1n : x0n, live ? 0x7fffffff : 0);
-    float* dst = smem + (k & 1) * Sh::RAWPAD;
+    float* dst = smem + dbuf * Sh::RAWPAD;
 #pragma unroll
     for (int jj = 0; jj < NI; ++jj)
       w4_dma16(rs, dst + 256 * (wave + 8 * jj), hoff[jj], soff);
+    dbuf = dbuf == Sh::NBUF - 1 ? 0 : dbuf + 1;
   };
 
   // ---- A fragments: packed image P16[cb][k][p][piece][xl][cout 64][8 ch] bf16 (pack_weights_wino3_kernel).  Lane halves read
@@ -169,14 +199,25 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
   // slot 0 reads X at +0 and Y at +8 bytes of these (np 0: c0, c2; np 1: c1, c3); slot 1 reads the aligned pair (c1, c2)
   unsigned aA0 = lbase + (unsigned)((pb + ra * RP + (np ? 1 : 0)) * 4), aB0 = lbase + (unsigned)((pb + rb * RP + (np ? 1 : 0)) * 4);
   unsigned aAp = lbase + (unsigned)((pb + ra * RP + 1) * 4), aBp = lbase + (unsigned)((pb + rb * RP + 1) * 4);
-  int hdelta = Sh::RAWPAD * 4, ldelta = Sh::RAWPAD * 4;   // the next raw buffer of the slot-0 / slot-1 reads
+  int hbuf = 0, lbuf = 0;   // the raw buffer the slot-0 / slot-1 reads point into
+  auto rotate = [&](unsigned& x0, unsigned& x1, int& buf) __attribute__((always_inline)) {   // on to the next chunk's buffer
+    const int d = buf == Sh::NBUF - 1 ? -(Sh::NBUF - 1) * Sh::RAWPAD * 4 : Sh::RAWPAD * 4;
+    x0 += d; x1 += d;
+    buf = buf == Sh::NBUF - 1 ? 0 : buf + 1;
+  };
 
   // B fragments of the two slots: after `finalize`, Bh = B1[tr 0], Bm = B1[tr 1], Bc = B2[tr 0], Bl = B2[tr 1]
   unsigned Bh[2][4], Bm[2][4], Bl[2][4], Bc[2][4];
   float t[8];        // raw values of one channel pair, slot 0: [c][XA, YA, XB, YB]
   w4f2 tp[4];        // slot 1: [c][(P, Q) of row a, (P, Q) of row b]
-  // (inline asm: single ds_read_b32 / ds_read_b64 with immediate channel offsets into ONE recycled register set; their
-  // results are waited for by the lgkmcnt(0) in front of the combine -- these are the only LDS operations of the chunk loop)
+  // (inline asm: single ds_read_b32 / ds_read_b64 with immediate channel offsets into ONE recycled register set.  Their
+  // results are waited for by `wait_lds` -- an lgkmcnt(0) CLOSED BY A SCHEDULING FENCE, so that no consumer can move above it;
+  // no "+v" pins on the registers: behind an asm that defines a register the compiler pads the first use with an s_nop.
+  // These are the only LDS operations of the chunk loop.)
+  auto wait_lds = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
   // (non-generic lambdas: clang rejects asm operands that name captured arrays inside a generic lambda)
   auto load0 = [&](int P) __attribute__((always_inline)) {   // slot 0, channel pair P
 #pragma unroll
@@ -197,11 +238,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
   // the pair's two V values -> three exact bf16 pieces each, packed per piece (channel 2 P in the low half)
   auto comb_split = [&](auto e_, auto p_) __attribute__((always_inline)) {
     constexpr int E = decltype(e_)::value, P = decltype(p_)::value;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float v[2];
     if constexpr (E == 0) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(t[i]));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const float fx = __builtin_fmaf(sg, t[4 * c + 2], t[4 * c + 0]);   // column X of row xi
@@ -209,8 +247,6 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
         v[c] = fx - fy;
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(tp[i]));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const float fp = __builtin_fmaf(sg, tp[2 * c + 1][0], tp[2 * c + 0][0]);   // column c1 of row xi
@@ -283,21 +319,21 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
       if constexpr (E == 0) load1(p); else load0(p);
     };
     mm(EE{}, I0{}, I0{}, I0{}, Z{});
-    if (build) { comb_split(EN{}, I0{}); ld(1); }
+    if (build) { wait_lds(); comb_split(EN{}, I0{}); ld(1); }
     fence();
     mm(EE{}, I0{}, I1{}, I0{}, Z{});
     mm(EE{}, I1{}, I0{}, I0{}, Z{});
-    if (build) { comb_split(EN{}, I1{}); ld(2); }
+    if (build) { wait_lds(); comb_split(EN{}, I1{}); ld(2); }
     fence();
     mm(EE{}, I1{}, I1{}, I0{}, Z{});
     if (anext) gldA(EE{}, I0{}, k + 1);
     fence();
     mm(EE{}, I0{}, I0{}, I2{}, NZ{});
-    if (build) { comb_split(EN{}, I2{}); ld(3); }
+    if (build) { wait_lds(); comb_split(EN{}, I2{}); ld(3); }
     fence();
     mm(EE{}, I0{}, I1{}, I2{}, NZ{});
     mm(EE{}, I1{}, I0{}, I2{}, NZ{});
-    if (build) comb_split(EN{}, I3{});
+    if (build) { wait_lds(); comb_split(EN{}, I3{}); }
     fence();
     mm(EE{}, I1{}, I1{}, I2{}, NZ{});
     if (anext) gldA(EE{}, I2{}, k + 1);
@@ -313,30 +349,44 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
     if (anext) gldA(EE{}, I1{}, k + 1);
     fence();
   };
-  // One chunk.  Mid-chunk: raw(k + 1) has landed (this wave's share: everything but the six newest loads -- the A
-  // fragments of slot 0 for chunk k + 1 -- has returned; the barrier covers the other waves' shares and tells that every
-  // wave is through with raw(k): its buffer takes raw(k + 2)).
+  // One chunk.  At its top raw(k + 1) has landed (this wave's share: everything but the six newest loads -- the A fragments
+  // of slot 1 for this chunk -- has returned; the barrier covers the other waves' shares) and every wave is through with
+  // raw(k - 1) -- its last reader was slot 1 of chunk k - 1, built in that chunk's first half --, whose buffer takes
+  // raw(k + 2): a whole chunk to land.  No barrier, DMA issue or exposed LDS latency sits between the two halves: the first
+  // reads of the set the second half builds are issued at the end of the first (a stamped run of the two-buffer version, which
+  // had all three there, measured the second half at 1500-1700 cycles against 790-1090 for the first).
   auto chunk = [&](auto z_, int k, bool has_next) __attribute__((always_inline)) {
-    half(I0{}, z_, k, true, has_next);
+    W4_FINE(0);
     if (has_next) {
       __builtin_amdgcn_s_waitcnt(w4_waitcnt(6, 15));
+      W4_FINE(1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      W4_FINE(2);
       issue_raw(k + 2);
+    }
+    half(I0{}, z_, k, true, has_next);
+    if (has_next) {
       load0(0);
       fence();
     }
+    W4_FINE(3);
     half(I1{}, z_, k, has_next, has_next);
     if (has_next) {
-      // the addresses of the next chunk's reads: slot 0's flip behind its last read of raw(k + 1), slot 1's now
-      aA0 += hdelta; aB0 += hdelta; hdelta = -hdelta;
-      aAp += ldelta; aBp += ldelta; ldelta = -ldelta;
+      rotate(aA0, aB0, hbuf);
+      rotate(aAp, aBp, lbuf);
       load1(0);
       fence();
     }
+    W4_FINE(4);
+    if (k < 30) W4_STAMP(3 + k);
   };
 
   // ---- prologue: two raw chunks and the first A fragments in flight; slot 0 of chunk 0 is built without MFMAs to hide under
+  W4_STAMP(0);
+#ifdef DVSR_CONV_TRACE
+  if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + 60] = __builtin_amdgcn_s_memrealtime();
+#endif
   issue_raw(0);
   issue_raw(1);   // (at least two chunks: conv2d_packed_prepare)
   gldA(I0{}, I0{}, 0); gldA(I0{}, I2{}, 0); gldA(I0{}, I1{}, 0);
@@ -344,19 +394,24 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
   __builtin_amdgcn_s_waitcnt(w4_waitcnt(NI + 12, 0));   // raw(0) (and the zero fill) of this wave
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  W4_STAMP(1);
   load0(0);
-  comb_split(I0{}, I0{}); load0(1);
-  comb_split(I0{}, I1{}); load0(2);
-  comb_split(I0{}, I2{}); load0(3);
-  comb_split(I0{}, I3{});
+  wait_lds(); comb_split(I0{}, I0{}); load0(1); fence();
+  wait_lds(); comb_split(I0{}, I1{}); load0(2); fence();
+  wait_lds(); comb_split(I0{}, I2{}); load0(3); fence();
+  wait_lds(); comb_split(I0{}, I3{});
   finalize_a(I0{}); finalize_b(I0{});
-  aA0 += hdelta; aB0 += hdelta; hdelta = -hdelta;   // slot 0 of chunk 1 reads raw buffer 1
+  rotate(aA0, aB0, hbuf);   // slot 0 of chunk 1 reads raw buffer 1
   load1(0);
   fence();
+  W4_STAMP(2);
 
+  // (a static s_setprio 1 for the second-dispatched half of the workgroup, which loses the VALU arbitration on its SIMD to the
+  // older wave and arrives last at every barrier, measured equal: 104.3 / 181.3 us against 103.2 / 185.8 without)
   chunk(T{}, 0, true);
   for (int k = 1; k + 1 < a.nchunks; ++k) chunk(F{}, k, true);
   chunk(F{}, a.nchunks - 1, false);
+  W4_STAMP(40);
 
   // ---- epilogue.  Y = A^T M A, A^T = [[1, 1, 1, 0], [0, 1, -1, -1]].  (the lane index passes through an opaque asm: nothing
   // of the epilogue's per-lane addressing can be hoisted above the K loop, where every register is spoken for)
@@ -395,7 +450,9 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+  W4_STAMP(50);
   lds_barrier();   // every wave is past its last raw read
+  W4_STAMP(51);
   auto write_round = [&](auto r_, w4f2 (&ex)[4][2]) __attribute__((always_inline)) {
     constexpr int R = decltype(r_)::value;
 #pragma unroll
@@ -510,14 +567,30 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
   f32x4 y0[2][2], y1[2][2];
   w4f2 ex0[4][2], ex1[4][2];
   write_round(R0{}, ex0);
+  W4_STAMP(52);
   lds_barrier();
+  W4_STAMP(53);
   read_round(y0);
+  W4_STAMP(54);
   lds_barrier();   // the reads of the first round are done
+  W4_STAMP(55);
   write_round(R1{}, ex1);
+  W4_STAMP(56);
   finish_round(R0{}, y0, ex0);
+  W4_STAMP(57);
   lds_barrier();
   read_round(y1);
+  W4_STAMP(58);
   finish_round(R1{}, y1, ex1);
+#ifdef DVSR_CONV_TRACE
+  W4_STAMP(41);
+  __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged
+  W4_STAMP(42);
+  if (a.trace && threadIdx.x == 0) {
+    a.trace[(size_t)blockIdx.x * 64 + 61] = __builtin_amdgcn_s_memrealtime();
+    a.trace[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_ID
+  }
+#endif
 }
 
 template <int TC>

@@ -85,7 +85,14 @@ key = ((hw >> 8) & 0xFF).astype(np.int64)
 print("start deciles (us, s_memrealtime):", np.percentile((t[:, 60] - t[:, 60].min()) / 100.0, [0, 10, 25, 50, 75, 90, 100]).round(1))
 print("end   deciles (us, s_memrealtime):", np.percentile((t[:, 61] - t[:, 60].min()) / 100.0, [0, 10, 25, 50, 75, 90, 100]).round(1))
 
-if t[:, 20].any():   # conv2d_wino3_kernel: stamps inside phase 6 (chunk 3, rows 0/1) of waves 0 and 4 (one SIMD)
+if t[:, 24].any() and not t[:, 27].any():   # conv2d_wino4_kernel: stamps inside chunk 3 of waves 0 and 4 (one SIMD)
+    names = ["vmcnt wait (raw k+1, A of slot 0)", "s_barrier", "DMA issue + half 0 (slot 0 MFMAs | slot 1 built)", "half 1 (slot 1 MFMAs | slot 0 of k+1 built)"]
+    for w, base in ((0, 20), (4, 30)):
+        for i, nm in enumerate(names):
+            stat("wave %d: %s" % (w, nm), t[:, base + i + 1] - t[:, base + i])
+        stat("wave %d: chunk total" % w, t[:, base + 4] - t[:, base])
+    stat("wave 4 start - wave 0 start", t[:, 30] - t[:, 20])
+elif t[:, 20].any():   # conv2d_wino3_kernel: stamps inside phase 6 (chunk 3, rows 0/1) of waves 0 and 4 (one SIMD)
     names = ["wait for operands", "M0 (6 MFMAs + loads of pair 1)", "V (transform + split + writes)", "vmcnt / lgkmcnt wait",
              "s_barrier", "M1 (6 MFMAs + loads of next pair 0)", "tail (raw reads, DMA issue)"]
     for w, base in ((0, 20), (4, 30)):
