@@ -112,13 +112,15 @@ def test_mfdn_x4_vs_oracle_shapes(b, t, h, w):
         assert relerr(a + b_, c) < 2e-5, k   # 1.3e-5 observed with the 2x2 data gradient on the bf16 3-way split
 
 
-def test_mfdn_split_2x2_form_matches_fp32_kernels(monkeypatch):
+@pytest.mark.parametrize("h,w", [(176, 320), (180, 320), (172, 312)])
+def test_mfdn_split_2x2_form_matches_fp32_kernels(h, w, monkeypatch):
     """The 2x2 space-to-depth form of the 4x4 stride-2 convolutions on the bf16 3-way operand split (engine.hip
     Builder::conv, DVSR_EST_SPLIT2; taken from a workgroup per CU upwards, hence 2 x 5 x 176 x 320) against the same tape
     with those launches on the fp32 MFMA kernel: output to fp32 round-off, every parameter gradient within the kink-flip
-    budget of two fp32 evaluations (see test_mfdn_x4_vs_oracle_shapes)."""
+    budget of two fp32 evaluations (see test_mfdn_x4_vs_oracle_shapes).  180 x 320 and 172 x 312 give ragged tiles on both
+    levels of the split kernels (90 x 160: rows % 4 = 2; 86 x 156 / 43 x 78: ragged rows and columns, an odd row count)."""
     sd = synth.mfdn_state_dict(5)
-    x = synth.clip(31, 2, 5, 176, 320, smooth=False).transpose(1, 2).contiguous().cuda()
+    x = synth.clip(31, 2, 5, h, w, smooth=False).transpose(1, 2).contiguous().cuda()
     go = None
     res = {}
     for mode in ("0", "1"):
@@ -132,6 +134,45 @@ def test_mfdn_split_2x2_form_matches_fp32_kernels(monkeypatch):
     assert relerr(res["1"][0], res["0"][0]) < 2e-6
     for k in res["0"][1]:
         assert relerr(res["1"][1][k], res["0"][1][k]) < 5e-3, k
+
+
+def test_mfdn_split_convs_per_channel_scales_and_non_finite(monkeypatch):
+    """The estimators' split convolutions (3x3 over padded inputs and the 2x2 space-to-depth form, both on the exact 3-way bf16
+    split: DVSR_EST_SPLIT / DVSR_EST_SPLIT2) with per-channel activation scales over six decades: the chain
+    conv_i -> LeakyReLU -> conv_{i+1} is re-parametrised channel by channel (output channel c of conv_i times s_c, input
+    channel c of conv_{i+1} divided by it: the same function, LeakyReLU being positively homogeneous), so the tensors the
+    split kernels read span 1e-3 .. 1e+3 per channel.  Split tape == fp32 tape on the same weights to the fp32 bar, and both
+    == the un-scaled network to re-association round-off.  A NaN (or inf) in frame 3 of a clip poisons its whole plane through
+    the image mean (LRimg_estimator.py:92-93) and from there frames 1..4 of that clip through the two temporal convolutions
+    (conv0, conv5: three frames each): both tapes return NaN exactly there, frame 0 and the other clip stay finite."""
+    sd = synth.mfdn_state_dict(5)
+    sd2 = OrderedDict((k, v.clone()) for k, v in sd.items())
+    for i, (a, b_) in enumerate((("conv1", "conv2"), ("conv2", "conv3"), ("conv3", "conv4"))):
+        c = sd2[a + ".weight"].shape[0]
+        sc = torch.logspace(-3, 3, c)[torch.randperm(c, generator=torch.Generator().manual_seed(40 + i))]
+        sd2[a + ".weight"] *= sc.view(c, 1, 1, 1)
+        sd2[a + ".bias"] *= sc
+        sd2[b_ + ".weight"] /= sc.view(1, c, 1, 1)
+    x = synth.clip(33, 2, 5, 176, 320, smooth=False).transpose(1, 2).contiguous().cuda()
+    out = {}
+    for name, state, split in (("plain32", sd, "0"), ("scaled32", sd2, "0"), ("scaled_split", sd2, "1")):
+        monkeypatch.setenv("DVSR_EST_SPLIT", split)
+        monkeypatch.setenv("DVSR_EST_SPLIT2", split)
+        with torch.no_grad():
+            out[name] = _mfdn(state, nf=64, in_nc=3, scale=4)(x).clone()
+    assert not torch.equal(out["scaled32"], out["scaled_split"])     # (the switch did change the kernels)
+    assert relerr(out["scaled_split"], out["scaled32"]) < 2e-6
+    assert relerr(out["scaled_split"], out["plain32"]) < 2e-5
+    for val in (float("nan"), float("inf")):
+        xb = x.clone()
+        xb[1, 2, 3, 50, 60] = val
+        for split in ("0", "1"):
+            monkeypatch.setenv("DVSR_EST_SPLIT", split)
+            monkeypatch.setenv("DVSR_EST_SPLIT2", split)
+            with torch.no_grad():
+                y = _mfdn(sd, nf=64, in_nc=3, scale=4)(xb)
+            assert bool(torch.isfinite(y[0]).all()) and bool(torch.isfinite(y[1][:, 0]).all()), (val, split)
+            assert bool(torch.isnan(y[1][:, 1:]).all()), (val, split)
 
 
 def test_estimator_rejects_input_grad_and_bad_shapes():

@@ -482,6 +482,128 @@ def _winograd_case(n, c0, c1, cout, h, w, act, res, ps, force, pipe, monkeypatch
     return list(geo)
 
 
+# ---- domain of exactness of the 3-way bf16 split: x = hi + mid + lo is exact while mid and lo, 2^-8 and 2^-16 of
+# x, stay NORMAL bf16 numbers (|x| >= 2^-110 or x == 0) and hi does not round to infinity (|x| < 2^127); the kernels below are
+# held to the fp32 bar inside it and to what was measured outside it (tools/split_edge_probe.py, profiles/r05_split_edges.txt).
+def _wino_split_conv(x, wt, b, monkeypatch, wino=True):
+    import ctypes
+    from dynavsr_amd import _lib as L
+    monkeypatch.setenv("DVSR_CONV_WINO", "2" if wino else "0")
+    monkeypatch.setenv("DVSR_CONV_WINO3", "1")
+    n, c, h, w = x.shape
+    cout = wt.shape[0]
+    dx, dw, db_ = dev(x), dev(wt), dev(b)
+    y = torch.empty(n, cout, h, w, device="cuda")
+    d = L.Conv2dDesc(L.ptr(dx), None, L.ptr(dw), L.ptr(db_), None, L.ptr(y), n, c, 0, h, w, cout, 3, 1, 1, 0, 0, 1, 0, 0)
+    geo = (ctypes.c_int * 4)()
+    L.check(L.lib().dvsr_conv2d_packed_geometry(d, ctypes.byref(geo)), "dvsr_conv2d_packed_geometry")
+    assert list(geo)[3] == (4 if wino else 1), list(geo)
+    ws = torch.empty(max(int(L.lib().dvsr_conv2d_packed_workspace_bytes(d)), 16), dtype=torch.uint8, device="cuda")
+    L.check(L.lib().dvsr_conv2d_forward_packed(d, ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_forward_packed")
+    return y.cpu()
+
+
+def _split_case():
+    n, c, cout, h, w = 4, 64, 64, 96, 128   # (large enough for the cost model's Winograd branch: the K-split kernel takes small grids)
+    return (rnd(n, c, h, w, seed=1), rnd(cout, c, 3, 3, seed=2, scale=1 / np.sqrt(c * 9)), rnd(cout, seed=3, scale=0.1))
+
+
+def test_split_winograd_per_channel_scales(monkeypatch):
+    """Per-channel scales over ten decades (1e-6 .. 1e+4) on the INPUT channels (the inverse on the weights, outputs O(1)) and
+    on the OUTPUT channels of the weights (error per channel): the split is per value, so no channel borrows precision from
+    another -- the fp32 bar holds on every channel."""
+    x, wt, b = _split_case()
+    c = x.shape[1]
+    s = torch.logspace(-6, 4, c, dtype=torch.float64)
+    xa, wa = x * s.view(1, c, 1, 1), wt / s.view(1, c, 1, 1)
+    assert relerr(_wino_split_conv(xa, wa, b, monkeypatch), F.conv2d(xa, wa, b, 1, 1)) < 2e-6
+    wb = wt * s.view(c, 1, 1, 1)
+    y, ref = _wino_split_conv(x, wb, torch.zeros(c, dtype=torch.float64), monkeypatch).double(), F.conv2d(x, wb, None, 1, 1)
+    per_channel = (y - ref).flatten(2).norm(dim=2).norm(dim=0) / ref.flatten(2).norm(dim=2).norm(dim=0)
+    assert float(per_channel.max()) < 2e-6, per_channel
+
+
+@pytest.mark.parametrize("e,bar", [(100, 2e-6), (-100, 2e-6), (-108, 2e-6), (-116, 1e-5), (-120, 1e-4), (-124, 2e-3)])
+def test_split_winograd_magnitude_range(e, bar, monkeypatch):
+    """Inputs scaled by 2^e.  Inside the domain of exactness (|V| >= 2^-110: e >= -108 with these O(1) data) the fp32 bar; below
+    it the mid / lo pieces turn into bf16 subnormals and the error grows gracefully -- measured 1.9e-6 at 2^-116, 3.0e-5 at
+    2^-120, 4.7e-4 at 2^-124, against 4.3e-7 for the fp32 kernels, which are exact down to fp32's own subnormals: the stated
+    difference of the split kernels (the absolute error stays below 2^-133 x the reduction length)."""
+    x, wt, b = _split_case()
+    xt = x * 2.0 ** e
+    ref = F.conv2d(xt, wt, None, 1, 1)
+    got = _wino_split_conv(xt, wt, torch.zeros(wt.shape[0], dtype=torch.float64), monkeypatch)
+    assert bool(torch.isfinite(got).all())
+    up = 2.0 ** -e   # (compare at O(1): conftest.relerr guards its denominator with 1e-30)
+    assert relerr(got.double() * up, ref * up) < bar, relerr(got.double() * up, ref * up)
+    if e <= -116:   # (the fp32 kernel on the same data: the reference behaviour the difference is measured against)
+        got32 = _wino_split_conv(xt, wt, torch.zeros(wt.shape[0], dtype=torch.float64), monkeypatch, wino=False)
+        assert relerr(got32.double() * up, ref * up) < 2e-6
+
+
+@pytest.mark.parametrize("val", [float("inf"), float("nan")])
+def test_split_winograd_non_finite_input(val, monkeypatch):
+    """One inf / one NaN input element.  The outputs are non-finite EXACTLY where the fp64 convolution's are (the 3 x 3 support
+    of the element in every output channel: the Winograd transforms of a tile only mix values an output depends on) and
+    untouched elsewhere.  The VALUE differs for inf: the split's residual inf - inf makes it NaN where the fp32 kernels return
+    +-inf (arch_util.py:48-52 has no non-finite handling to preserve; stated in DESIGN 3.3)."""
+    x, wt, b = _split_case()
+    x = x.clone()
+    x[1, 7, 21, 34] = val
+    ref = F.conv2d(x, wt, b, 1, 1)
+    got = _wino_split_conv(x, wt, b, monkeypatch)
+    bad_ref, bad = ~torch.isfinite(ref), ~torch.isfinite(got)
+    assert int(bad_ref.sum()) == 9 * wt.shape[0] and torch.equal(bad, bad_ref)
+    assert bool(torch.isnan(got[bad]).all())
+    assert relerr(torch.where(bad, torch.zeros_like(got), got), torch.where(bad, torch.zeros_like(ref), ref)) < 2e-6
+    ref32 = _wino_split_conv(x, wt, b, monkeypatch, wino=False)
+    assert torch.equal(~torch.isfinite(ref32), bad_ref)
+    assert bool((torch.isnan(ref32[bad_ref]) if val != val else torch.isinf(ref32[bad_ref])).all())
+
+
+def _wgrad_split3(x, gy):
+    from dynavsr_amd import _lib as L
+    n, c, h, w = x.shape
+    cout = gy.shape[1]
+    xg, gg = dev(x), dev(gy)
+    gw, gb = torch.empty(cout, c, 3, 3, device="cuda"), torch.empty(cout, device="cuda")
+    d = L.Conv2dDesc(L.ptr(xg), None, None, None, None, None, n, c, 0, h, w, cout, 3, 1, 1, 0, 0, 1, 0, 0)
+    ws = torch.empty(max(int(L.lib().dvsr_conv2d_backward_workspace_bytes(d)), 16), dtype=torch.uint8, device="cuda")
+    L.check(L.lib().dvsr_conv2d_wgrad_split3(d, L.ptr(gg), L.ptr(gw), L.ptr(gb), ws.data_ptr(), ws.numel(), L.stream()),
+            "dvsr_conv2d_wgrad_split3")
+    return gw.cpu()
+
+
+def _wgrad_ref(x, gy):
+    wz = torch.zeros(gy.shape[1], x.shape[1], 3, 3, dtype=torch.float64, requires_grad=True)
+    (g,) = torch.autograd.grad(F.conv2d(x, wz, padding=1), wz, gy)
+    return g
+
+
+def test_split_wgrad_scales_range_and_non_finite():
+    """conv2d_wgrad_split3_kernel on the same edge cases: per-input-channel scales over ten decades (error per channel), tiny
+    inputs (2^-100, 2^-112: fp32 bar; 2^-120: 3.5e-5 measured, bf16-subnormal pieces), one inf / NaN input element (non-finite on
+    exactly the 9 x Cout gradient entries of its channel, as NaN)."""
+    x, gy = rnd(2, 64, 48, 64, seed=1), rnd(2, 64, 48, 64, seed=5)
+    c = x.shape[1]
+    s = torch.logspace(-6, 4, c, dtype=torch.float64)
+    xa = x * s.view(1, c, 1, 1)
+    got, ref = _wgrad_split3(xa, gy).double(), _wgrad_ref(xa, gy)
+    per_channel = (got - ref).flatten(2).norm(dim=2).norm(dim=0) / ref.flatten(2).norm(dim=2).norm(dim=0)
+    assert float(per_channel.max()) < 2e-6, per_channel
+    for e, bar in ((-100, 2e-6), (-112, 2e-6), (-120, 2e-4)):
+        up = 2.0 ** -e   # (compare at O(1): conftest.relerr guards its denominator with 1e-30)
+        assert relerr(_wgrad_split3(x * 2.0 ** e, gy).double() * up, _wgrad_ref(x * 2.0 ** e, gy) * up) < bar, e
+    for val in (float("inf"), float("nan")):
+        xi = x.clone()
+        xi[1, 7, 20, 33] = val
+        got, ref = _wgrad_split3(xi, gy), _wgrad_ref(xi, gy)
+        bad_ref, bad = ~torch.isfinite(ref), ~torch.isfinite(got)
+        assert int(bad_ref.sum()) == 9 * gy.shape[1] and torch.equal(bad, bad_ref)
+        assert bool(torch.isnan(got[bad]).all())
+        assert relerr(torch.where(bad, torch.zeros_like(got), got), torch.where(bad, torch.zeros_like(ref), ref)) < 2e-6
+
+
 @pytest.mark.parametrize("blk", ["0", "1", "2", "3"])
 def test_conv3x3_winograd_bf16x3_other_forms(blk):
     """The A/B forms of conv2d_wino3_kernel (DVSR_CONV_WINO3_BLK: 0 four xn per wave, 1 one xn per wave with U through the
