@@ -81,7 +81,7 @@ int conv2_pch(int ks, int stride) {  // packed floats per (64-cout block, chunk)
 // wt = 1 (data gradient): this conv's (cin, cout, tap) = original (cout, cin slice, mirrored tap).
 __global__ void pack_weights_kernel(PackTable t) {
   const PackEntry& e = t.e[blockIdx.y];
-  if (e.bf || e.perm >= 3) return;  // packed by pack_weights_bf16_kernel / pack_weights_wino(3)_kernel
+  if (e.bf || e.perm >= 3) return;  // packed by pack_weights_bf16_kernel / pack_weights_wino(3)_kernel / pack_weights_dcn3_kernel
   const int kq4 = e.CC / 8;
   const size_t per_chunk = (size_t)e.pch;
   const size_t total = (size_t)e.ncb * e.nchunks * per_chunk;
@@ -147,8 +147,13 @@ __global__ void pack_weights_bf16_kernel(PackTable t) {
 
 int pack_weights_run(const PackTable& t, hipStream_t st) {
   if (t.n <= 0) return DVSR_OK;
-  bool any_f32 = false, any_bf = false, any_wino = false, any_wino3 = false;
-  for (int i = 0; i < t.n; ++i) (t.e[i].bf ? any_bf : (t.e[i].perm == 3 ? any_wino : (t.e[i].perm == 4 ? any_wino3 : any_f32))) = true;
+  bool any_f32 = false, any_bf = false, any_wino = false, any_wino3 = false, any_dcn3 = false;
+  for (int i = 0; i < t.n; ++i)
+    (t.e[i].bf ? any_bf : (t.e[i].perm == 3 ? any_wino : (t.e[i].perm == 4 ? any_wino3 : (t.e[i].perm == 6 ? any_dcn3 : any_f32)))) = true;
+  if (any_dcn3) {
+    int rc = pack_weights_dcn3_run(t, st);
+    if (rc) return rc;
+  }
   if (any_wino) {
     int rc = pack_weights_wino_run(t, st);
     if (rc) return rc;

@@ -219,7 +219,7 @@ struct Builder {
     o.N = N; o.c0 = C; o.H = H; o.W = W; o.Cout = C; o.dg = dg; o.act = act;
     o.y = alloc(name, (size_t)N * C * H * W);
     if (C % (dg * 8) == 0) {  // LDS-sampler kernel: weights packed like a conv with 8-channel chunks
-      o.wp_floats = (size_t)ceil_div(C, 64) * (C / 8) * conv2_pch(3, 1);
+      o.wp_floats = (size_t)ceil_div(C, 64) * (C / 8) * mdcn_pack_floats();
       o.wp_off = alloc("", o.wp_floats * p.wsets).off;
     }
     p.ops.push_back(o);
@@ -840,7 +840,8 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
         e = PackEntry{};   // (slots are reused after a flush: no field may keep the previous occupant's value -- perm!)
         e.w = P[o.pw] + (size_t)ws * o.Cout * o.c0 * 9; e.P = fwd_base + o.wp_off + (size_t)ws * o.wp_floats;
         e.Cout = o.Cout; e.Ctot = o.c0; e.KK = 9; e.CC = 8; e.wt = 0;
-        e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64); e.nchunks = o.c0 / 8; e.pch = conv2_pch(3, 1); e.bf = 0;
+        e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64); e.nchunks = o.c0 / 8; e.bf = 0; e.perm = mdcn_pack_perm(o.W);
+        e.pch = e.perm == 6 ? mdcn_pack_floats() : conv2_pch(3, 1);   // (the chunk pitch of the layout; the slot fits either)
         if (t.n == 48) { int rc = flush(); if (rc) return rc; }
       }
     }
@@ -910,7 +911,7 @@ static int run_forward_op(const dvsr_edvr_plan& p, const Op& o, const float* con
         return mdcn_forward_packed_run(bs.at(o.x0), om, bstride, om + (size_t)o.dg * 18 * o.H * o.W, bstride, 1,
                                        bs.arena + o.wp_off, P[o.pb], bs.at(o.y), o.N, o.c0, o.H, o.W, o.Cout,
                                        o.dg, o.act, st, p.wsets > 1 ? o.N / p.wsets : 1,
-                                       p.wsets > 1 ? (long long)o.wp_floats : 0, p.wsets > 1 ? o.Cout : 0);
+                                       p.wsets > 1 ? (long long)o.wp_floats : 0, p.wsets > 1 ? o.Cout : 0, mdcn_pack_perm(o.W));
       return mdcn_forward_run(bs.at(o.x0), om, bstride, om + (size_t)o.dg * 18 * o.H * o.W, bstride, 1,
                               P[o.pw], P[o.pb], bs.at(o.y), o.N, o.c0, o.H, o.W, o.Cout, 3, 3, 1, 1,
                               1, 1, o.dg, o.act, st);

@@ -84,10 +84,29 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
                       size_t ws_bytes, hipStream_t st, int groups = 1, long long gw_gs = 0, long long gb_gs = 0,
                       long long w_gs = 0);  // w_gs != 0: group g of the batch convolves with w + g * w_gs (per-sample weights)
 
+// pack_perm: the layout `wp` is in -- 0 the fp32 conv pack (pack_weights_kernel, 8-channel chunks), 6 the three bf16 pieces of
+// mdcn_split.hip; whoever makes the pack asks mdcn_pack_perm(W) and hands the answer back here.
 int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, const float* msk,
                             long long msk_bs, int mask_logit, const float* wp, const float* b, float* out,
                             int N, int C, int H, int W, int Cout, int dg, int act, hipStream_t st, int wdiv = 1,
-                            long long w_gs = 0, int b_gs = 0);
+                            long long w_gs = 0, int b_gs = 0, int pack_perm = 0);
+int mdcn_fwd_variant();      // DVSR_DCN_FWD, read once: 3 split (default), 0 dma, 2 reg, 1 lds
+int mdcn_pack_floats();      // fp32-sized slots per (64-cout block, 8-channel chunk) of a DCN weight pack (either layout fits)
+int mdcn_pack_perm(int W);   // PackEntry::perm of a DCN weight pack for images of width W
+int pack_weights_dcn3_run(const PackTable& t, hipStream_t st);   // mdcn_split.hip: entries with perm == 6
+
+struct DcnK2 {
+  const float* x; const float* off; const float* msk; const float* wp; const float* bias; float* out;
+  long long off_bstride, msk_bstride;
+  int mask_logit;
+  int N, C, H, W, Cout, dg, act;
+  int tiles_x, tiles_y, ntiles, ncb, nchunks;
+  int wdiv = 1; long long w_gs = 0; int b_gs = 0;   // per-sample weight sets (common.h: wset_ptr)
+#ifdef DVSR_CONV_TRACE
+  long long* trace;  // debug build only (tools/dcn_trace.py): 64 cycle stamps per workgroup
+#endif
+};
+int mdcn_fwd_split_launch(const DcnK2& k, int grid, int mask_logit, hipStream_t st);   // mdcn_split.hip
 
 // misc.hip
 int upsample_bilinear_fwd(const float* x, float* y, size_t planes, int H, int W, int S, float mul,

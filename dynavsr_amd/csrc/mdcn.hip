@@ -201,17 +201,7 @@ extern "C" int dvsr_mdcn_pack_forward(const float* x, const float* om, const flo
 // =================================================================================================
 namespace dvsr {
 
-struct DcnK2 {
-  const float* x; const float* off; const float* msk; const float* wp; const float* bias; float* out;
-  long long off_bstride, msk_bstride;
-  int mask_logit;
-  int N, C, H, W, Cout, dg, act;
-  int tiles_x, tiles_y, ntiles, ncb, nchunks;
-  int wdiv = 1; long long w_gs = 0; int b_gs = 0;   // per-sample weight sets (common.h: wset_ptr)
-#ifdef DVSR_CONV_TRACE
-  long long* trace;  // debug build only (tools/dcn_trace.py): 64 cycle stamps per workgroup
-#endif
-};
+// (DcnK2: kernels.h -- shared with mdcn_split.hip)
 #ifdef DVSR_CONV_TRACE
 #define DCN_STAMP(i)                                                                               \
   do {                                                                                             \
@@ -1001,7 +991,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_dma_kernel(DcnK2 a) {
 int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, const float* msk,
                             long long msk_bs, int mask_logit, const float* wp, const float* b, float* out,
                             int N, int C, int H, int W, int Cout, int dg, int act, hipStream_t st, int wdiv,
-                            long long w_gs, int b_gs) {
+                            long long w_gs, int b_gs, int pack_perm) {
   DVSR_REQUIRE(x && off && msk && wp && out, DVSR_ERR_INVALID, "mdcn_forward_packed: null pointer");
   DVSR_REQUIRE(dg > 0 && C % (dg * 8) == 0, DVSR_ERR_UNSUPPORTED,
                "mdcn_forward_packed: needs C/dg to be a multiple of 8 (got %d/%d)", C, dg);
@@ -1017,16 +1007,22 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
   if (g_dcn_countdown >= 0) --g_dcn_countdown;
 #endif
   const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
-  static int variant = -1;  // DVSR_DCN_FWD=lds selects the LDS-column-tile kernel (A/B aid)
-  if (variant < 0) { const char* v = getenv("DVSR_DCN_FWD"); variant = (v && v[0] == 'l') ? 1 : ((v && v[0] == 'r') ? 2 : 0); }
-  if (variant == 1 && C == dg * 8) {
+  // DVSR_DCN_FWD: (default) the contraction on the bf16 pipe under the exact 3-way split (mdcn_split.hip; the pack is in its
+  // own layout, mdcn_pack_perm()); dma = the fp32-MFMA DMA-staged kernel below, reg = its register-staged form, lds = the
+  // LDS-column-tile kernel (A/B aids).  Read once per process: the packs and the kernels must agree.
+  const int variant = mdcn_fwd_variant();
+  if (variant == 1 && C == dg * 8 && pack_perm == 0) {
     hipLaunchKernelGGL(mdcn_fwd_lds_kernel<4>, dim3(grid), dim3(256), 0, st, k);
     return check_launch("mdcn_fwd_lds_kernel");
   }
   // DMA-staged kernel when the 16-byte groups line up (DVSR_DCN_FWD=reg keeps the register-staged one, A/B aid)
   const bool aligned = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)off | (uintptr_t)msk) & 15) == 0 && off_bs % 4 == 0 &&
                        msk_bs % 4 == 0;
-  if (variant == 0 && aligned) {
+  if (pack_perm == 6) {   // the pack is in the split kernel's layout (mdcn_pack_perm: chosen where the pack was made)
+    DVSR_REQUIRE(aligned, DVSR_ERR_UNSUPPORTED, "mdcn_forward_packed: the split kernel needs W %% 4 == 0 and 16-byte aligned tensors (W=%d)", W);
+    return mdcn_fwd_split_launch(k, grid, mask_logit, st);
+  }
+  if ((variant == 0 || variant == 3) && aligned) {
     static PerDeviceOnce attr_once_t, attr_once_f;
     set_dyn_lds_once(attr_once_t, (const void*)mdcn_fwd_dma_kernel<true>, DcnDmaShape::LDS_BYTES);
     set_dyn_lds_once(attr_once_f, (const void*)mdcn_fwd_dma_kernel<false>, DcnDmaShape::LDS_BYTES);
@@ -1047,7 +1043,7 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
 // Same contract as dvsr_mdcn_forward restricted to stride = pad = dil = 1, C/dg = 8.
 extern "C" size_t dvsr_mdcn_forward_fast_workspace_bytes(int C, int Cout, int dg) {
   (void)dg;
-  return (size_t)dvsr::ceil_div(Cout, 64) * dvsr::ceil_div(C, 8) * dvsr::conv2_pch(3, 1) * sizeof(float);
+  return (size_t)dvsr::ceil_div(Cout, 64) * dvsr::ceil_div(C, 8) * dvsr::mdcn_pack_floats() * sizeof(float);
 }
 
 extern "C" int dvsr_mdcn_forward_fast(const float* x, const float* offset, const float* mask, const float* w,
@@ -1062,10 +1058,13 @@ extern "C" int dvsr_mdcn_forward_fast(const float* x, const float* offset, const
   t.n = 1;
   PackEntry& e = t.e[0];
   e.w = w; e.P = (float*)workspace; e.Cout = Cout; e.Ctot = C; e.KK = 9; e.CC = 8; e.wt = 0; e.w_ctot = 0;
-  e.w_coff = 0; e.ncb = ceil_div(Cout, 64); e.nchunks = C / 8; e.pch = conv2_pch(3, 1); e.bf = 0;
+  const bool aligned = (((uintptr_t)x | (uintptr_t)offset | (uintptr_t)mask) & 15) == 0 && ((size_t)H * W) % 4 == 0;
+  e.w_coff = 0; e.ncb = ceil_div(Cout, 64); e.nchunks = C / 8; e.bf = 0;
+  e.perm = aligned ? mdcn_pack_perm(W) : 0;   // (unaligned tensors: the register-staged fp32 kernel and its pack)
+  e.pch = e.perm == 6 ? mdcn_pack_floats() : conv2_pch(3, 1);   // the chunk pitch of the layout (the workspace fits either)
   int rc = pack_weights_run(t, (hipStream_t)stream);
   if (rc) return rc;
   const long long P = (long long)H * W;
   return mdcn_forward_packed_run(x, offset, (long long)dg * 18 * P, mask, (long long)dg * 9 * P, 0,
-                                 (const float*)workspace, b, out, N, C, H, W, Cout, dg, act, (hipStream_t)stream);
+                                 (const float*)workspace, b, out, N, C, H, W, Cout, dg, act, (hipStream_t)stream, 1, 0, 0, e.perm);
 }
