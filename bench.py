@@ -717,9 +717,12 @@ def _dry_run(rank, world, args):
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
             "config": {"workload": "none (dry run)", "clips_per_step": world},
+            "protocol": None, "value_one_clip_in_flight": None, "runtime": None,
             "one_clip_in_flight": None, "roofline": None, "kernel_breakdown_ms_per_step": None, "end_to_end_tflops": None,
             "inner_step": _merge_rank_leg([b_[0] for b_ in both]),
             "per_frame_pipeline": _merge_rank_leg([b_[1] for b_ in both]),
+            "inner_step_clips_per_s": _merge_rank_leg([b_[0] for b_ in both]).get("value"),
+            "per_frame_pipeline_frames_per_s": _merge_rank_leg([b_[1] for b_ in both]).get("value"),
             "meta_step": {"ranks": world, "allreduce": {"backend": "gloo", "bytes": nbytes, "executed": grouped,
                                                          "averaged_correctly": ok}},
             "validation": {"frames": frames, "sharding": "range(rank, frames, world)",
@@ -727,6 +730,17 @@ def _dry_run(rank, world, args):
     if world == 1:   # legs of the one-GPU line only
         line.update({"experimental_bf16_split": None, "edvr_l_bf16": None, "other_backbones": None, "cpu_baseline": None})
     return line
+
+
+def _rt_report(dev):
+    """hw queue setting + the side-stream overlap probe on the current stream and on a FRESH stream (the cached answer for the
+    current stream predates whatever created streams since; a new stream shows what a plan on a new launch stream would get)."""
+    from dynavsr_amd import _lib as L
+    r = L.runtime_report(dev)
+    fresh = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(fresh):
+        r["side_stream_overlaps_fresh_stream"] = int(L.lib().dvsr_side_stream_overlaps(L.stream()))
+    return r
 
 
 def main():
@@ -845,6 +859,10 @@ def main():
             "value": world * S * args.steps / elapsed, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # (`value` counts S clips in flight per GPU since round 4; rounds 1-3 measured one at a time: compare like with like)
+            "protocol": "%d clip(s) in flight per GPU, one HIP stream each; value_one_clip_in_flight = the one-at-a-time "
+                        "protocol of rounds 1-3" % S,
+            "value_one_clip_in_flight": 1e3 / ms_one,
             "config": {"workload": "EDVR-M x4 forward (PCD deformable alignment + TSA fusion + "
                                    "reconstruction), clips of 1x5x3x%dx%d -> 3x%dx%d (BASELINE.json configs[1]); one step = "
                                    "%d clip(s) per GPU, one per HIP stream (adapt.super_resolve_video)"
@@ -969,6 +987,13 @@ def main():
         if rank == 0:
             line["inner_step"] = _merge_rank_leg([b_[0] for b_ in both])
             line["per_frame_pipeline"] = _merge_rank_leg([b_[1] for b_ in both])
+            # (top-level scalars of the two legs BASELINE's metric is named after)
+            line["inner_step_clips_per_s"] = line["inner_step"].get("value")
+            line["per_frame_pipeline_frames_per_s"] = line["per_frame_pipeline"].get("value")
+    if rank == 0:
+        # what the process got from the runtime: the hardware-queue setting and the MEASURED overlap of the weight-gradient
+        # side stream with the launch stream (dvsr_side_stream_overlaps), before any RCCL communicator exists
+        line["runtime"] = dict(_rt_report(dev), probed="before the RCCL group")
     # The RCCL communicator is created only now: once it exists, its helper threads slow host-bound launch sequences down
     # (EDVR-L bf16 forward+backward, ~700 launches in 10.5 ms, measured 14.1 ms when the meta leg ran first; the inner-step
     # per-frame loop 8.2 -> 10.0 ms; the GPU-bound legs do not move).
@@ -984,6 +1009,8 @@ def main():
             if world > 1:
                 raise
             dist_err = "%s: %s" % (type(e).__name__, e)
+    if rank == 0 and line is not None and rccl is not None:
+        line["runtime"]["side_stream_overlaps_with_rccl_group"] = _rt_report(dev)["side_stream_overlaps_fresh_stream"]
     meta = None
     if not args.no_meta:   # every rank takes part (the collective)
         try:

@@ -33,6 +33,18 @@ def configure_runtime(hw_queues=6):
     return {"hw_queues": _runtime["hw_queues"], "effective": _runtime["effective"]}
 
 
+def runtime_report(device=None):
+    """What the process actually got: the hardware-queue setting, whether it came in time, and the MEASURED answer to the
+    question it exists for -- does the plans' weight-gradient side stream run beside the current stream of `device`
+    (dvsr_side_stream_overlaps: 1 / 0 / -1 unknown)?  bench.py records it in its line."""
+    r = configure_runtime()
+    overlaps = None
+    if torch.cuda.is_available():
+        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+            overlaps = int(lib().dvsr_side_stream_overlaps(stream()))
+    return {"hw_queues": r["hw_queues"], "effective": r["effective"], "side_stream_overlaps": overlaps}
+
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libdynavsr_hip.so")
 _lib = None
@@ -145,6 +157,7 @@ def _declare(lib):
         "dvsr_debug_mfma_shadow": (I, [P, P, I, I, I, I, I, P]),
         "dvsr_edvr_tensor_info": (I, [P, c_char_p, POINTER(LL), POINTER(LL)]),
         "dvsr_edvr_plan_work": (I, [P, POINTER(ctypes.c_double * 9)]),
+        "dvsr_side_stream_overlaps": (I, [P]),
         "dvsr_edvr_op_output": (I, [P, I, I, POINTER(c_int), POINTER(LL), POINTER(LL)]),
         "dvsr_estimator_plan_work": (I, [P, POINTER(ctypes.c_double * 9)]),
     }

@@ -811,19 +811,104 @@ struct Bases {
   }
 };
 
-// The weight-gradient side stream, one per device for the whole process (never destroyed).  Plans on different launch
-// streams share it: their weight gradients then queue behind each other, ordered by the plans' own fork / join events.
-static hipStream_t shared_side_stream() {
+// The weight-gradient side streams: a small pool per device for the whole process (never destroyed).  Plans on different
+// launch streams share it: their weight gradients then queue behind each other, ordered by the plans' own fork / join events.
+// Candidate 0 is THE side stream whenever it runs beside the launch stream; the others exist only for launch streams it
+// shares a hardware queue with (side_stream_for).
+constexpr int SIDE_POOL = 4;
+static hipStream_t pool_side_stream(int i) {
   static std::mutex mu;
-  static hipStream_t streams[64] = {};
+  static hipStream_t streams[64][SIDE_POOL] = {};
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || i < 0 || i >= SIDE_POOL) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lock(mu);
-  if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
+  if (!streams[dev][i] && hipStreamCreateWithFlags(&streams[dev][i], hipStreamNonBlocking) != hipSuccess) {
     (void)hipGetLastError();
-    streams[dev] = nullptr;
+    streams[dev][i] = nullptr;
   }
-  return streams[dev];
+  return streams[dev][i];
+}
+static hipStream_t shared_side_stream() { return pool_side_stream(0); }
+
+// ---- does work on the side stream run BESIDE work on a launch stream?
+// ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and two streams that land on one queue run
+// behind each other: a plan whose weight gradients sit on such a side stream pays the fork / join events and gets no
+// overlap (the inner step measured 10.0 instead of 8.2 ms with an RCCL communicator's streams in the process, r02-r04).
+// Which queue a stream gets depends on every stream the process created before -- nothing a plan can know -- so it is
+// MEASURED, once per (device, launch stream): a kernel that spins for 150 us on the launch stream, a marker kernel on the
+// side stream behind it; the marker's start time tells whether it waited for the spinner.  dvsr_edvr_backward falls back to
+// single-stream weight gradients for a launch stream that fails the probe.  DVSR_BWD_PROBE=0 skips it (assume overlap).
+__global__ void probe_spin_kernel(long long* out, long long ticks) {
+  const long long t0 = __builtin_amdgcn_s_memrealtime();
+  long long t = t0;
+  while (t - t0 < ticks) { __builtin_amdgcn_s_sleep(8); t = __builtin_amdgcn_s_memrealtime(); }
+  out[0] = t0;
+  out[1] = t;
+}
+__global__ void probe_mark_kernel(long long* out) { out[2] = __builtin_amdgcn_s_memrealtime(); }
+
+// 1: overlaps, 0: serialised, -1: could not tell (capturing, allocation failure, probe disabled by the caller)
+static int probe_side_overlap(hipStream_t st, hipStream_t side) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return -1; }
+  long long* d = nullptr;
+  if (hipMalloc(&d, 4 * sizeof(long long)) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  int res = -1;
+  long long h[4] = {0, 0, 0, 0};
+  // (the streams are drained first: what is still queued on either would be measured instead)
+  if (hipStreamSynchronize(st) == hipSuccess && hipStreamSynchronize(side) == hipSuccess &&
+      hipMemsetAsync(d, 0, sizeof(h), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+    hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, st, d, 15000LL);   // 150 us of the 100 MHz counter
+    hipLaunchKernelGGL(probe_mark_kernel, dim3(1), dim3(64), 0, side, d);
+    if (hipStreamSynchronize(side) == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+        hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[1] > h[0] && h[2] > 0)
+      res = h[2] < h[1] - 5000 ? 1 : 0;   // the marker started at least 50 us before the spinner ended
+  }
+  (void)hipGetLastError();
+  (void)hipFree(d);
+  return res;
+}
+
+// The side stream to use beside launch stream `st`: the first of the pool that the probe finds running concurrently with
+// it (a new stream lands on another hardware queue than its predecessor, so one of four consecutive candidates is off the
+// launch stream's queue unless everything is on one), cached per (device, launch stream).  nullptr: none overlaps -- the
+// caller keeps its weight gradients on `st`.  *known = false: the probe could not run (stream capture): candidate 0, unprobed.
+static hipStream_t side_stream_for(hipStream_t st, bool* known = nullptr) {
+  static const bool probe_on = [] { const char* v = getenv("DVSR_BWD_PROBE"); return !(v && v[0] == '0'); }();
+  if (known) *known = probe_on;
+  if (!probe_on) return shared_side_stream();
+  struct Entry { int dev; hipStream_t st, side; };
+  static std::mutex mu;
+  static std::vector<Entry> cache;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& e : cache)
+    if (e.dev == dev && e.st == st) return e.side;
+  for (int i = 0; i < SIDE_POOL; ++i) {
+    hipStream_t cand = pool_side_stream(i);
+    if (!cand) break;
+    const int r = probe_side_overlap(st, cand);
+    if (r < 0) {   // (capturing: no measurement possible, nothing cached)
+      if (known) *known = false;
+      return shared_side_stream();
+    }
+    if (r == 1) {
+      cache.push_back({dev, st, cand});
+      return cand;
+    }
+  }
+  cache.push_back({dev, st, nullptr});
+  return nullptr;
+}
+
+// 1: a side stream of the pool runs beside `stream` on this device (the plans fork their weight gradients onto it), 0: none
+// does (they stay on `stream`), -1: unknown (see probe_side_overlap)
+extern "C" int dvsr_side_stream_overlaps(dvsr_stream_t stream) {
+  bool known = true;
+  hipStream_t side = side_stream_for((hipStream_t)stream, &known);
+  if (!known) return -1;
+  return side ? 1 : 0;
 }
 
 // Packs the weights of every conv of the tape (forward: wt=0; backward: the two transposed views).
@@ -988,10 +1073,10 @@ extern "C" int dvsr_edvr_plan_create_ex(const dvsr_edvr_config* cfg, int B, int 
 
 extern "C" void dvsr_edvr_plan_destroy(dvsr_edvr_plan* p) {
   if (!p) return;
-  if (p->side) {
-    (void)hipStreamSynchronize(p->side);
+  if (p->side) (void)hipStreamSynchronize(p->side);   // (the side streams are process-wide, per device: not destroyed)
+  if (p->ev_fork) {
     (void)hipEventDestroy(p->ev_fork);
-    (void)hipEventDestroy(p->ev_join);   // (the side stream is the process-wide one of its device: not destroyed)
+    (void)hipEventDestroy(p->ev_join);
   }
   delete p;
 }
@@ -1034,22 +1119,27 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
     DVSR_REQUIRE(hipMemsetAsync(grad_x, 0, n * sizeof(float), st) == hipSuccess, DVSR_ERR_HIP,
                  "edvr_backward: memset of grad_x failed");
   }
-  // fork/join state of the side stream (created on first use, owned by the plan)
+  // fork/join state of the side stream (events created on first use, owned by the plan)
   bool use_side = p->side_streams != 0;
-  if (use_side && !p->side) {
-    // ONE side stream per device for all plans (shared_side_stream): ROCm maps streams onto a few hardware queues
+  if (use_side && !p->ev_fork) {
+    // Side streams are per DEVICE, shared by all plans (pool_side_stream): ROCm maps streams onto a few hardware queues
     // (GPU_MAX_HW_QUEUES, 4 by default; more than ~6 in use and the command processor time-slices them: EDVR-L
     // forward+backward 20 -> 31 ms), and streams that share a queue run behind each other.  With a stream per plan the
     // mapping, and with it the overlap, depended on how many plans and other streams (an RCCL communicator holds some)
     // the process had created before: the inner step measured 8.2 or 10.0 ms, EDVR-L fp32 forward+backward 20.1 or
     // 23.5 ms.  dynavsr_amd/_lib.py asks for 6 queues: launch stream, RCCL's, this one, adapt_video's.
-    if ((p->side = shared_side_stream()) == nullptr ||
-        hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
-      p->side = nullptr;
+      p->ev_fork = nullptr;
       use_side = false;
     }
+  }
+  // ... and WHICH of them runs beside this launch stream is measured (side_stream_for: once per launch stream); none: the
+  // fork / join events would only cost, the weight gradients stay on the launch stream
+  if (use_side) {
+    p->side = side_stream_for(st);
+    if (!p->side) use_side = false;
   }
   void* wscratch = (char*)scratch + p->scratch_bytes;
   // the weight-gradient slot regions: zeroed once here, every reduce re-zeroes what it read
@@ -1466,8 +1556,8 @@ extern "C" int dvsr_estimator_plan_create_ex(const dvsr_estimator_config* cfg, i
 extern "C" void dvsr_estimator_plan_destroy(dvsr_estimator_plan* ep) {
   if (!ep) return;
   dvsr_edvr_plan& p = ep->core;
-  if (p.side) {
-    (void)hipStreamSynchronize(p.side);
+  if (p.side) (void)hipStreamSynchronize(p.side);
+  if (p.ev_fork) {
     (void)hipEventDestroy(p.ev_fork);
     (void)hipEventDestroy(p.ev_join);
   }

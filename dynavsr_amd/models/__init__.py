@@ -27,7 +27,18 @@ def _make(kind, opt):
 
 def create_model(opt):
     from .. import configure_runtime
-    configure_runtime()     # before the wrappers touch the device (dynavsr_amd/_lib.py:configure_runtime)
+    rt = configure_runtime()     # before the wrappers touch the device (dynavsr_amd/_lib.py:configure_runtime)
+    if not rt["effective"]:
+        # (HIP was initialised before the first create_model -- a driver that sets the device or creates a process group first,
+        # train_dynavsr.py:23-30: the request for more hardware queues came too late.  Not fatal: the plans measure whether
+        # their side stream overlaps and fall back to one stream where it does not; but say so, loudly, once.)
+        import warnings
+        msg = ("dynavsr_amd: GPU_MAX_HW_QUEUES could not be raised (HIP was already initialised; it is %s). The weight-gradient "
+               "side stream may share a hardware queue with other streams of this process; plans whose probe finds that fall "
+               "back to single-stream weight gradients. Export GPU_MAX_HW_QUEUES=6 or call dynavsr_amd.configure_runtime() "
+               "before the first CUDA/HIP call." % (rt["hw_queues"] or "unset (4)"))
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
+        logger.warning(msg)
     kinds = opt['model']
     if '+' in kinds:
         return [_make(k, opt) for k in kinds.split('+')]

@@ -217,6 +217,13 @@ int dvsr_edvr_op_info(const dvsr_edvr_plan* plan, int index, char* kind, int kin
  * F(2x2,3x3) kernels do 16/36 of theirs; launches on the exact 3-way bf16 operand split issue six bf16 products per fp32
  * product.  bench.py's roofline fractions price the issued figures against the peak of the pipe they were issued to. */
 int dvsr_edvr_plan_work(const dvsr_edvr_plan* plan, double* out9);
+/* Does the plans' weight-gradient side stream run BESIDE `stream` on the current device?  ROCm maps HIP streams onto
+ * GPU_MAX_HW_QUEUES hardware queues and two streams on one queue serialise -- which queue a stream gets depends on every
+ * stream the process created before (an initialised RCCL communicator holds some; train_dynavsr.py:23-30 creates it first).
+ * Measured once per (device, stream) with a 150 us two-kernel probe and cached: 1 overlaps, 0 serialised (dvsr_edvr_backward /
+ * dvsr_estimator_backward then launch their weight gradients on `stream` itself instead of forking), -1 unknown (the stream is
+ * being captured, or DVSR_BWD_PROBE=0).  Synchronises `stream`. */
+int dvsr_side_stream_overlaps(dvsr_stream_t stream);
 /* Test aid: where launch `index` of the forward tape leaves its result (which = 0; 1 = the second output of the pool /
  * TSA-gate launches).  *in_arena = 1: offset_floats counts from the start of the workspace (every activation of a
  * need_grad forward stays there); 0: the launch writes the output tensor. */

@@ -334,6 +334,28 @@ def test_hw_queue_default_is_explicit_and_respects_the_user(monkeypatch):
     assert os.environ["GPU_MAX_HW_QUEUES"] == "6"
 
 
+def test_create_model_warns_when_the_queue_request_comes_too_late(monkeypatch):
+    """create_model in a process whose HIP runtime is already up (the reference's trainer initialises its process group first,
+    train_dynavsr.py:23-30): GPU_MAX_HW_QUEUES cannot be raised any more -- configure_runtime() reports effective = False and
+    create_model says so loudly (a RuntimeWarning naming the remedy), once per call, instead of silently running on."""
+    import importlib
+    import warnings
+    import torch
+    from dynavsr_amd import _lib as L
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    importlib.reload(L)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    from dynavsr_amd.models import create_model
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        create_model(cpu_opt())
+    msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+    assert any("GPU_MAX_HW_QUEUES" in m and "configure_runtime" in m for m in msgs), msgs
+    assert L.configure_runtime() == {"hw_queues": None, "effective": False} and "GPU_MAX_HW_QUEUES" not in os.environ
+    monkeypatch.undo()
+    importlib.reload(L)
+
+
 @pytest.mark.parametrize("launcher", ["self", "torchrun"])
 def test_bench_two_ranks_dry_run(launcher):
     """`python bench.py --gpus 2` must start its own ranks (no launcher: README.md:92-96 starts the reference's trainer
@@ -367,9 +389,9 @@ def test_bench_two_ranks_dry_run(launcher):
     for leg in ("inner_step", "per_frame_pipeline"):
         assert line[leg]["ranks"] == 2 and line[leg]["per_rank_value"] == [1.0, 2.0] and line[leg]["value"] == 3.0
         assert line[leg]["min_rank_value"] == 1.0 and line[leg]["max_rank_value"] == 2.0
-    # ... and the line has the key set of a GPU line (recorded on one MI355X: profiles/r04_bench_line.json) minus the legs
+    # ... and the line has the key set of a GPU line (recorded on one MI355X: profiles/r05_bench_line.json) minus the legs
     # that only the one-GPU line carries
-    rec_path = os.path.join(root, "profiles", "r04_bench_line.json")
+    rec_path = os.path.join(root, "profiles", "r05_bench_line.json")
     if os.path.exists(rec_path):
         with open(rec_path) as f:
             rec = json.loads(f.read().strip().splitlines()[-1])
