@@ -536,7 +536,7 @@ def super_resolve_video(opt, net, clips, in_flight=2):
     over a batch of 8 clips: 180.4).  Every clip runs the launches it would run alone (its own plan and workspace, keyed
     by the stream), so the outputs are bit-identical to `net(clip)`.  A yielded frame stays valid until the generator is
     advanced `in_flight` times; clips and results are ordered against the caller's current stream."""
-    main = torch.cuda.current_stream()
+    main = None
     streams = None
     pending = []
     was_training = net.training
@@ -547,6 +547,8 @@ def super_resolve_video(opt, net, clips, in_flight=2):
             if not lq.is_cuda:
                 lq = lq.cuda()
             if streams is None:
+                # (the caller's stream ON THE CLIPS' DEVICE -- not the current device's, which may be another one)
+                main = torch.cuda.current_stream(lq.device)
                 streams = _clip_streams(lq.device, max(1, int(in_flight)))
             if len(pending) == len(streams):         # the oldest clip ran on the stream this one is about to take
                 sr, ev = pending.pop(0)
@@ -563,11 +565,17 @@ def super_resolve_video(opt, net, clips, in_flight=2):
             if s != main:
                 lq.record_stream(s)
             pending.append((sr, ev))
-        for sr, ev in pending:
+        while pending:
+            sr, ev = pending.pop(0)
             main.wait_event(ev)
             sr.record_stream(main)
             yield sr
     finally:
+        # a generator closed early leaves forwards running on the side streams: whatever the caller does next on its stream
+        # (an inner step updates the weights they read) must come behind them
+        for sr, ev in pending:
+            main.wait_event(ev)
+            sr.record_stream(main)
         net.train(was_training)
 
 

@@ -13,10 +13,16 @@ import torch
 from . import _lib as L
 
 _plans = {}
-# Environment switches that the native plan builder reads when it chooses kernels (conv2_choose, build_backward): they are
-# part of the plan-cache key, so a plan built under one setting is never handed out under another.
-_GEOMETRY_ENV = ("DVSR_CONV_WINO", "DVSR_CONV_WINO3", "DVSR_CONV_WINO_T16", "DVSR_CONV_V1", "DVSR_CONV_DMA", "DVSR_CONV_TILE",
-                 "DVSR_CONV_KSPLIT_BELOW", "DVSR_DCN_BWD", "DVSR_EST_FUSE_PAD", "DVSR_EST_SPLIT", "DVSR_EST_SPLIT2", "DVSR_FUSE_ACT_BWD", "DVSR_BWD_STREAMS")
+# Environment switches the native plan builder reads EVERY TIME it builds a plan (conv2_choose, Builder::conv, build_backward,
+# dvsr_*_plan_create): they are part of the plan-cache key, so a plan built under one setting is never handed out under another.
+_GEOMETRY_ENV = ("DVSR_CONV_WINO", "DVSR_CONV_WINO3", "DVSR_CONV_V1", "DVSR_EST_SPLIT", "DVSR_EST_SPLIT2", "DVSR_FUSE_ACT_BWD",
+                 "DVSR_BWD_STREAMS")
+# ... and the ones the native side reads ONCE PER PROCESS (function-local statics): changing them after the first plan has no
+# effect, so they are deliberately NOT in the key -- set them before the first call (the A/B tools run one process per value).
+_PROCESS_ENV = ("DVSR_CONV_WINO_T16", "DVSR_CONV_WINO3_BLK", "DVSR_CONV_DMA", "DVSR_CONV_DMAROW", "DVSR_CONV_TILE",
+                "DVSR_CONV_KSPLIT_BELOW", "DVSR_CONV_KSPLIT_NT", "DVSR_CONV_CC16_BELOW", "DVSR_SPLIT_TH8_FROM", "DVSR_WGRAD_SPLIT3",
+                "DVSR_WGRAD_SPLITS", "DVSR_DCN_FWD", "DVSR_DCN_BWD", "DVSR_EST_FUSE_PAD", "DVSR_FUSE_RES_BWD", "DVSR_BWD_FORK_EVERY",
+                "DVSR_BWD_PROBE")
 
 
 # dvsr_edvr_plan_work's nine doubles (include/dynavsr_hip.h): *_executed = fp32 products as the kernels shape them,
@@ -71,8 +77,10 @@ class Plan:
         return list(ms)
 
     def work(self):
-        """Contraction FLOPs of the two tapes: {'fwd_algorithmic', 'fwd_executed', 'bwd_algorithmic', 'bwd_executed'}
-        (launches on the Winograd kernel issue 16/36 of their algorithmic multiplies)."""
+        """dvsr_edvr_plan_work's nine figures by name (_WORK_KEYS): fwd / bwd _algorithmic (2 x MACs of the direct sums) and
+        _executed (fp32 products as the kernels shape them: launches on the Winograd kernels issue 16/36 of their algorithmic
+        multiplies), fwd_bytes (algorithmic bytes of the forward tape), and fwd / bwd _f32_pipe / _bf16_pipe (FLOPs issued to
+        either matrix pipe: a launch on the exact 3-way bf16 split issues six bf16 products per fp32 product)."""
         out = (ctypes.c_double * 9)()
         L.check(L.lib().dvsr_edvr_plan_work(self._h, ctypes.byref(out)), "dvsr_edvr_plan_work")
         return dict(zip(_WORK_KEYS, out))
