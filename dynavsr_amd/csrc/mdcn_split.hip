@@ -10,11 +10,12 @@
 // (profiles/r04_mfma_overlap.txt), and a tap's six products are twelve v_mfma_f32_32x32x16_bf16 = 384 cycles.
 //
 // What changes against the fp32 kernel:
-//   * B operand: a lane still samples exactly the (pixel, channel) values it owned before -- pixel (row 2 wave + nt, column
-//     lane & 31), channels 2 kk + (lane >> 5) --; the four blended values of a pixel row are split into three bf16 pieces as
-//     two channel pairs (11 vector instructions per pair) and v_permlane32_swap turns (hi, mid) / (hi copy, lo) of the two
-//     lane halves into the fragments B1 = (hi | mid), B2 = (hi | lo) of all EIGHT channels of the pixel: K = 16 = 8 channels x
-//     2 pieces, lanes 32-63 carry K 8..15; channel order inside a lane half (0, 2, 4, 6, 1, 3, 5, 7), the weight pack's;
+//   * B operand: the lane halves are PIXEL ROWS now -- lane (lo, hi) samples all EIGHT channels of pixel (row 2 wave + hi,
+//     column lo), so the geometry of a pixel (mask sigmoid, floor, window address, four corner weights) is computed once
+//     instead of once per lane half (~55 of a tap's vector instructions) --; the eight blended values are split into three
+//     bf16 pieces as four channel pairs (11 vector instructions per pair) and v_permlane32_swap turns (hi, mid) / (hi copy,
+//     lo) of the two rows into the fragments B1[row] = (hi | mid), B2[row] = (hi | lo): K = 16 = 8 channels x 2 pieces, lanes
+//     32-63 carry K 8..15 (conv2d_wino4.hip's exchange);
 //   * A operand: pack_weights_dcn3_kernel lays the weights out as [tap][piece][cout 64][8 channels] bf16 (16-byte records:
 //     the fragment layout), read straight from global memory one tap ahead (A1 = (hi | hi), A2 = (mid | hi), A3 = (lo | mid)
 //     by lane half) -- no weight image in the LDS (54 KB per workgroup instead of 72), no weight DMA;
@@ -44,7 +45,7 @@ typedef __bf16 dsbf2 __attribute__((ext_vector_type(2)));
 typedef __bf16 dsbf8 __attribute__((ext_vector_type(8)));
 typedef unsigned dsu4 __attribute__((ext_vector_type(4)));
 
-// P16[cb][k][tap][piece][cout 64][slot 8] = piece of W(cout = cb*64 + col, cin = k*8 + ch(slot), tap), ch = (0,2,4,6,1,3,5,7)
+// P16[cb][k][tap][piece][cout 64][slot 8] = piece of W(cout = cb*64 + col, cin = k*8 + slot, tap)
 __global__ void pack_weights_dcn3_kernel(PackTable t) {
   const PackEntry& e = t.e[blockIdx.y];
   if (e.perm != 6) return;
@@ -56,7 +57,7 @@ __global__ void pack_weights_dcn3_kernel(PackTable t) {
     const int tap = (int)(r % 9);
     const size_t ck = r / 9;
     const int k = (int)(ck % e.nchunks), cb = (int)(ck / e.nchunks);
-    const int co = cb * 64 + col, ci = k * 8 + (s < 4 ? 2 * s : 2 * (s - 4) + 1);
+    const int co = cb * 64 + col, ci = k * 8 + s;
     float v = 0.f;
     if (co < e.Cout && ci < e.Ctot) v = e.w[((size_t)co * e.Ctot + ci) * 9 + tap];
     const __bf16 h = (__bf16)v;
@@ -131,14 +132,9 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
   const float* offn = a.off + (size_t)n * a.off_bstride;
   const float* mskn = a.msk + (size_t)n * a.msk_bstride;
   const int px = ox0 + lo;
-  int py[2], prow[2];
-  bool pv[2];
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    py[nt] = oy0 + 2 * wave + nt;
-    pv[nt] = py[nt] < a.H && px < a.W;
-    prow[nt] = (2 * wave + nt) * TW + lo;
-  }
+  const int py = oy0 + 2 * wave + hi;          // this lane's pixel row (lane halves = the wave's two rows)
+  const bool pv = py < a.H && px < a.W;
+  const int prow = (2 * wave + hi) * TW + lo;
 
   // window groups of this lane: L = 64 (wave + 4 jj) + lane = (channel, row, column group)
   unsigned xo[Sh::NXI];
@@ -174,10 +170,8 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
 
   // LDS byte addresses of this lane's operands (inline-asm reads of the tap loop)
   auto lds_addr = [](const float* p) { return (unsigned)(size_t)((__attribute__((address_space(3))) const float*)p); };
-  const unsigned a_x = lds_addr(s_x) + (unsigned)(hi * XCH) * 4u;    // channel 2 kk + hi: + 2 kk XCH floats
-  unsigned a_om[2];
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) a_om[nt] = lds_addr(s_om) + (unsigned)prow[nt] * 4u;
+  const unsigned a_x = lds_addr(s_x);          // channel c: + c XCH floats
+  const unsigned a_om = lds_addr(s_om) + (unsigned)prow * 4u;
 
   // A fragments: [tap][piece][cout][8 ch] bf16; lane halves read the pieces A1: hi|hi, A2: mid|hi, A3: lo|mid
   const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + (size_t)cb * a.nchunks * (Sh::PACK_BYTES / 4);
@@ -231,54 +225,62 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
     // that sit between the twelve MFMAs of tap t; LDS reads are inline asm, their results pass through one s_waitcnt asm
     // before the blends; operands ping-pong between two register sets by tap parity.
     struct Geo { float w1, w2, w3, w4, h_im, w_im, m, lh, lw; int ry, rx; unsigned addr; bool inwin; };
-    auto om_issue = [&](auto TAP, float (&o)[2][3]) {
+    auto om_issue = [&](auto TAP, float (&o)[3]) {
       constexpr int tap = decltype(TAP)::value;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const unsigned ad = a_om[nt];  // (a local: asm operands of a generic lambda do not capture)
-        f32x2 hw2;  // (dh, dw): planes 2 tap and 2 tap + 1, 1 KiB = 4 x 64 dwords apart
-        asm volatile("ds_read2st64_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read_b32 %1, %2 offset:%5"
-                     : "=&v"(hw2), "=&v"(o[nt][2])
-                     : "v"(ad), "i"(2 * tap * 4), "i"((2 * tap + 1) * 4), "i"((18 + tap) * 1024));
-        o[nt][0] = hw2[0]; o[nt][1] = hw2[1];
-      }
+      const unsigned ad = a_om;  // (a local: asm operands of a generic lambda do not capture)
+      f32x2 hw2;  // (dh, dw): planes 2 tap and 2 tap + 1, 1 KiB = 4 x 64 dwords apart
+      asm volatile("ds_read2st64_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read_b32 %1, %2 offset:%5"
+                   : "=&v"(hw2), "=&v"(o[2])
+                   : "v"(ad), "i"(2 * tap * 4), "i"((2 * tap + 1) * 4), "i"((18 + tap) * 1024));
+      o[0] = hw2[0]; o[1] = hw2[1];
     };
-    // c[4 kk + {0,1,2,3}] = (y,x) (y,x+1) (y+1,x) (y+1,x+1) of channel 2 kk + hi; half 0 = kk 0,1, half 1 = kk 2,3
-    auto corners_issue = [&](unsigned addr, float (&c)[16], int half) {
-      if (half == 0)
+    // c[4 ch + {0,1,2,3}] = (y,x) (y,x+1) (y+1,x) (y+1,x+1) of channel ch; quarter q = channels 2 q, 2 q + 1
+    auto corners_issue = [&](unsigned addr, float (&c)[32], int q) {
+      if (q == 0)
         asm volatile(
             "ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:4\n\tds_read_b32 %2, %8 offset:192\n\tds_read_b32 %3, %8 offset:196\n\t"
-            "ds_read_b32 %4, %8 offset:6912\n\tds_read_b32 %5, %8 offset:6916\n\tds_read_b32 %6, %8 offset:7104\n\tds_read_b32 %7, %8 offset:7108"
+            "ds_read_b32 %4, %8 offset:3456\n\tds_read_b32 %5, %8 offset:3460\n\tds_read_b32 %6, %8 offset:3648\n\tds_read_b32 %7, %8 offset:3652"
             : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+            : "v"(addr));
+      else if (q == 1)
+        asm volatile(
+            "ds_read_b32 %0, %8 offset:6912\n\tds_read_b32 %1, %8 offset:6916\n\tds_read_b32 %2, %8 offset:7104\n\tds_read_b32 %3, %8 offset:7108\n\t"
+            "ds_read_b32 %4, %8 offset:10368\n\tds_read_b32 %5, %8 offset:10372\n\tds_read_b32 %6, %8 offset:10560\n\tds_read_b32 %7, %8 offset:10564"
+            : "=&v"(c[8]), "=&v"(c[9]), "=&v"(c[10]), "=&v"(c[11]), "=&v"(c[12]), "=&v"(c[13]), "=&v"(c[14]), "=&v"(c[15])
+            : "v"(addr));
+      else if (q == 2)
+        asm volatile(
+            "ds_read_b32 %0, %8 offset:13824\n\tds_read_b32 %1, %8 offset:13828\n\tds_read_b32 %2, %8 offset:14016\n\tds_read_b32 %3, %8 offset:14020\n\t"
+            "ds_read_b32 %4, %8 offset:17280\n\tds_read_b32 %5, %8 offset:17284\n\tds_read_b32 %6, %8 offset:17472\n\tds_read_b32 %7, %8 offset:17476"
+            : "=&v"(c[16]), "=&v"(c[17]), "=&v"(c[18]), "=&v"(c[19]), "=&v"(c[20]), "=&v"(c[21]), "=&v"(c[22]), "=&v"(c[23])
             : "v"(addr));
       else
         asm volatile(
-            "ds_read_b32 %0, %8 offset:13824\n\tds_read_b32 %1, %8 offset:13828\n\tds_read_b32 %2, %8 offset:14016\n\tds_read_b32 %3, %8 offset:14020\n\t"
-            "ds_read_b32 %4, %8 offset:20736\n\tds_read_b32 %5, %8 offset:20740\n\tds_read_b32 %6, %8 offset:20928\n\tds_read_b32 %7, %8 offset:20932"
-            : "=&v"(c[8]), "=&v"(c[9]), "=&v"(c[10]), "=&v"(c[11]), "=&v"(c[12]), "=&v"(c[13]), "=&v"(c[14]), "=&v"(c[15])
+            "ds_read_b32 %0, %8 offset:20736\n\tds_read_b32 %1, %8 offset:20740\n\tds_read_b32 %2, %8 offset:20928\n\tds_read_b32 %3, %8 offset:20932\n\t"
+            "ds_read_b32 %4, %8 offset:24192\n\tds_read_b32 %5, %8 offset:24196\n\tds_read_b32 %6, %8 offset:24384\n\tds_read_b32 %7, %8 offset:24388"
+            : "=&v"(c[24]), "=&v"(c[25]), "=&v"(c[26]), "=&v"(c[27]), "=&v"(c[28]), "=&v"(c[29]), "=&v"(c[30]), "=&v"(c[31])
             : "v"(addr));
     };
-    static_assert(XW * 4 == 192 && 2 * XCH * 4 == 6912, "corners_issue hard-codes the window pitch");
+    static_assert(XW * 4 == 192 && XCH * 4 == 3456, "corners_issue hard-codes the window pitch");
 #define DCS_PIN8(c, o) asm volatile("" : "+v"(c[o]), "+v"(c[o + 1]), "+v"(c[o + 2]), "+v"(c[o + 3]), "+v"(c[o + 4]), "+v"(c[o + 5]), "+v"(c[o + 6]), "+v"(c[o + 7]))
-    // row 0's corners: everything but the 15 newest LDS reads has returned (row 1's 16 and the offsets / masks follow it)
-    auto landed0 = [&](float (&c0)[16]) {
-      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c0[4]), "+v"(c0[5]), "+v"(c0[6]), "+v"(c0[7]));
-      DCS_PIN8(c0, 8);
+    // the first two quarters: everything but the 15 newest LDS reads has returned (the other 16 corners and the offsets /
+    // masks follow them)
+    auto landed_a = [&](float (&c)[32]) {
+      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+      DCS_PIN8(c, 8);
     };
-    auto landed1 = [&](float (&c1)[16]) {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]), "+v"(c1[4]), "+v"(c1[5]), "+v"(c1[6]), "+v"(c1[7]));
-      DCS_PIN8(c1, 8);
+    auto landed_b = [&](float (&c)[32]) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[16]), "+v"(c[17]), "+v"(c[18]), "+v"(c[19]), "+v"(c[20]), "+v"(c[21]), "+v"(c[22]), "+v"(c[23]));
+      DCS_PIN8(c, 24);
     };
-    auto landed_om = [&](float (&o)[2][3]) {
-      asm volatile("" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[0][2]), "+v"(o[1][0]), "+v"(o[1][1]), "+v"(o[1][2]));
-    };
-    auto geom_a = [&](auto TAP, int nt, const float (&o)[3], Geo& q) {
+    auto landed_om = [&](float (&o)[3]) { asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2])); };
+    auto geom_a = [&](auto TAP, const float (&o)[3], Geo& q) {
       constexpr int tap = decltype(TAP)::value;
       constexpr int ki = tap / 3, kj = tap - ki * 3;
       float m = o[2];
       if (MASK_LOGIT) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
       q.m = m;
-      q.h_im = (float)(py[nt] - 1 + ki) + o[0];
+      q.h_im = (float)(py - 1 + ki) + o[0];
       q.w_im = (float)(px - 1 + kj) + o[1];
       asm volatile("" : "+v"(q.m), "+v"(q.h_im), "+v"(q.w_im));
     };
@@ -290,85 +292,90 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
       q.addr = a_x + (unsigned)(ryc * XW + rxc) * 4u;
       asm volatile("" : "+v"(q.lh), "+v"(q.lw), "+v"(q.ry), "+v"(q.rx), "+v"(q.addr));
     };
-    auto geom_b2 = [&](int nt, Geo& q, int& fix) {
+    auto geom_b2 = [&](Geo& q, int& fix) {
       // (bitwise on purpose: a short-circuit splits the tap into basic blocks)
       const int inwin = ((unsigned)q.ry <= (unsigned)(XH - 2)) & ((unsigned)q.rx <= (unsigned)(XW - 2));
       q.inwin = inwin;
       const float hh = 1.f - q.lh, hw = 1.f - q.lw;
-      const float ms = ((int)pv[nt] & inwin) ? q.m : 0.f;
+      const float ms = ((int)pv & inwin) ? q.m : 0.f;
       q.w1 = hh * hw * ms; q.w2 = hh * q.lw * ms; q.w3 = q.lh * hw * ms; q.w4 = q.lh * q.lw * ms;
-      fix |= (int)pv[nt] & (inwin ^ 1);  // outside the window: the exact path decides (it applies the image gate itself)
+      fix |= (int)pv & (inwin ^ 1);  // outside the window: the exact path decides (it applies the image gate itself)
       asm volatile("" : "+v"(q.w1), "+v"(q.w2), "+v"(q.w3), "+v"(q.w4), "+v"(fix));
     };
-    auto blend2 = [&](const Geo& q, const float (&c)[16], int k0, f32x4& B) {
-      const float b0 = q.w1 * c[4 * k0] + q.w2 * c[4 * k0 + 1] + q.w3 * c[4 * k0 + 2] + q.w4 * c[4 * k0 + 3];
-      const float b1 = q.w1 * c[4 * k0 + 4] + q.w2 * c[4 * k0 + 5] + q.w3 * c[4 * k0 + 6] + q.w4 * c[4 * k0 + 7];
-      B[k0] = b0; B[k0 + 1] = b1;
+    auto blend2 = [&](const Geo& q, const float (&c)[32], int k0, float (&B)[8]) {   // channels k0, k0 + 1
+      B[k0] = q.w1 * c[4 * k0] + q.w2 * c[4 * k0 + 1] + q.w3 * c[4 * k0 + 2] + q.w4 * c[4 * k0 + 3];
+      B[k0 + 1] = q.w1 * c[4 * k0 + 4] + q.w2 * c[4 * k0 + 5] + q.w3 * c[4 * k0 + 6] + q.w4 * c[4 * k0 + 7];
     };
-    auto fixup = [&](const Geo (&q)[2], f32x4 (&B)[2]) {
+    auto fixup = [&](const Geo& q, float (&B)[8]) {
+      if (!pv || q.inwin) return;
+      DcnTap tp;  // sample leaves the staged window: exact clamped global gathers
+      const bool in = make_tap(q.h_im, q.w_im, a.H, a.W, tp);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        if (!pv[nt] || q[nt].inwin) continue;
-        DcnTap tp;  // sample leaves the staged window: exact clamped global gathers
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (make_tap(q[nt].h_im, q[nt].w_im, a.H, a.W, tp)) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float* pl = xg + (size_t)(2 * c + hi) * HW;
-            const float v1 = tp.v1 ? pl[tp.o1] : 0.f, v2 = tp.v2 ? pl[tp.o2] : 0.f;
-            const float v3 = tp.v3 ? pl[tp.o3] : 0.f, v4 = tp.v4 ? pl[tp.o4] : 0.f;
-            b[c] = (tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4) * q[nt].m;
-          }
+      for (int c = 0; c < 8; ++c) {
+        float b = 0.f;
+        if (in) {
+          const float* pl = xg + (size_t)c * HW;
+          const float v1 = tp.v1 ? pl[tp.o1] : 0.f, v2 = tp.v2 ? pl[tp.o2] : 0.f;
+          const float v3 = tp.v3 ? pl[tp.o3] : 0.f, v4 = tp.v4 ? pl[tp.o4] : 0.f;
+          b = (tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4) * q.m;
         }
-        B[nt] = b;
+        B[c] = b;
       }
     };
-    // the four blended values of a pixel row (channels 2 kk + hi) -> three exact bf16 pieces per channel pair
-    unsigned Hq[2][2], Mq[2][2], Lq[2][2];   // [pixel row][pair: kk 0,1 | kk 2,3]
-    auto split_row = [&](int nt, const f32x4& bf) {
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const float v0 = bf[2 * p], v1 = bf[2 * p + 1];
-        const unsigned h = dcs_cvt_pk(v0, v1);
-        const float r0 = v0 - __builtin_bit_cast(float, h << 16), r1 = v1 - __builtin_bit_cast(float, h & 0xffff0000u);
-        const unsigned m = dcs_cvt_pk(r0, r1);
-        const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
-        Hq[nt][p] = h; Mq[nt][p] = m; Lq[nt][p] = dcs_cvt_pk(q0, q1);
-      }
+    // the eight blended values of the lane's pixel -> three exact bf16 pieces per channel pair
+    unsigned Hq[4], Mq[4], Lq[4];
+    auto split_pair = [&](int p, const float (&bf)[8]) {
+      const float v0 = bf[2 * p], v1 = bf[2 * p + 1];
+      const unsigned h = dcs_cvt_pk(v0, v1);
+      const float r0 = v0 - __builtin_bit_cast(float, h << 16), r1 = v1 - __builtin_bit_cast(float, h & 0xffff0000u);
+      const unsigned m = dcs_cvt_pk(r0, r1);
+      const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+      Hq[p] = h; Mq[p] = m; Lq[p] = dcs_cvt_pk(q0, q1);
     };
-    // ... and the fragments of all eight channels: one half exchange per register.  Bq[..][0] = B1 = (hi | mid), [1] = B2 = (hi | lo)
+    // ... and the fragments of both pixel rows: one half exchange per register (lower lanes hold row 0, upper lanes row 1).
+    // Bq[..][row][0] = B1 = (hi | mid), [1] = B2 = (hi | lo)
     dsu4 Bq[2][2][2];   // [tap parity][pixel row][B1 | B2]
-    auto frag_row = [&](int par, int nt) {
-      const unsigned hc0 = Hq[nt][0], hc1 = Hq[nt][1];
-      const auto s0 = __builtin_amdgcn_permlane32_swap(Hq[nt][0], Mq[nt][0], false, false);
-      const auto s1 = __builtin_amdgcn_permlane32_swap(Hq[nt][1], Mq[nt][1], false, false);
-      Bq[par][nt][0] = dsu4{s0[0], s1[0], s0[1], s1[1]};
-      const auto t0 = __builtin_amdgcn_permlane32_swap(hc0, Lq[nt][0], false, false);
-      const auto t1 = __builtin_amdgcn_permlane32_swap(hc1, Lq[nt][1], false, false);
-      Bq[par][nt][1] = dsu4{t0[0], t1[0], t0[1], t1[1]};
+    auto frags = [&](int par) {
+      unsigned hc[4], h1[4], m1[4], c1[4], l1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hc[i] = Hq[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(Hq[i], Mq[i], false, false);
+        h1[i] = s0[0]; m1[i] = s0[1];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const auto t0 = __builtin_amdgcn_permlane32_swap(hc[i], Lq[i], false, false);
+        c1[i] = t0[0]; l1[i] = t0[1];
+      }
+      Bq[par][0][0] = dsu4{h1[0], h1[1], h1[2], h1[3]};
+      Bq[par][1][0] = dsu4{m1[0], m1[1], m1[2], m1[3]};
+      Bq[par][0][1] = dsu4{c1[0], c1[1], c1[2], c1[3]};
+      Bq[par][1][1] = dsu4{l1[0], l1[1], l1[2], l1[3]};
     };
 
-    float om[2][2][3];           // [tap parity][pixel row][dh, dw, mask]
-    f32x4 Bf[2];                 // the blended fp32 values of the tap being prepared
+    float om[2][3];              // [tap parity][dh, dw, mask]
+    float Bf[8];                 // the blended fp32 values of the tap being prepared
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     {  // tap 0 of the chunk: nothing to hide behind
-      Geo gq[2];
-      float c0[16], c1[16];
+      Geo gq;
+      float c[32];
       int fix = 0;
       om_issue(I0{}, om[0]);
       om_issue(I1{}, om[1]);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(om[0][0][0]), "+v"(om[0][0][1]), "+v"(om[0][0][2]), "+v"(om[0][1][0]), "+v"(om[0][1][1]), "+v"(om[0][1][2]));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(om[0][0]), "+v"(om[0][1]), "+v"(om[0][2]));
       landed_om(om[1]);
-      geom_a(I0{}, 0, om[0][0], gq[0]); geom_a(I0{}, 1, om[0][1], gq[1]);
-      geom_b1(gq[0]); geom_b2(0, gq[0], fix); corners_issue(gq[0].addr, c0, 0); corners_issue(gq[0].addr, c0, 1);
-      geom_b1(gq[1]); geom_b2(1, gq[1], fix); corners_issue(gq[1].addr, c1, 0); corners_issue(gq[1].addr, c1, 1);
-      landed1(c0); landed1(c1);
-      blend2(gq[0], c0, 0, Bf[0]); blend2(gq[0], c0, 2, Bf[0]);
-      blend2(gq[1], c1, 0, Bf[1]); blend2(gq[1], c1, 2, Bf[1]);
+      geom_a(I0{}, om[0], gq);
+      geom_b1(gq); geom_b2(gq, fix);
+      corners_issue(gq.addr, c, 0); corners_issue(gq.addr, c, 1); corners_issue(gq.addr, c, 2); corners_issue(gq.addr, c, 3);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+      DCS_PIN8(c, 8); DCS_PIN8(c, 16); DCS_PIN8(c, 24);
+      blend2(gq, c, 0, Bf); blend2(gq, c, 2, Bf); blend2(gq, c, 4, Bf); blend2(gq, c, 6, Bf);
       if (fix) fixup(gq, Bf);
-      split_row(0, Bf[0]); split_row(1, Bf[1]);
-      frag_row(0, 0); frag_row(0, 1);
+      split_pair(0, Bf); split_pair(1, Bf); split_pair(2, Bf); split_pair(3, Bf);
+      frags(0);
     }
     if (kc < 2) DCS_STAMP(4 + 30 * kc);
 #define DCS_SB __builtin_amdgcn_sched_barrier(0)
@@ -384,42 +391,42 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
       constexpr bool nx = tap + 1 < KK;
       using TN = std::integral_constant<int, (tap + 1 < KK ? tap + 1 : tap)>;
       using TNN = std::integral_constant<int, (tap + 2 < KK ? tap + 2 : tap)>;
-      Geo gq[2];
-      float c0[16], c1[16];
+      Geo gq;
+      float c[32];
       int fix = 0;
       DCS_SB;
       if (nx) a_load(nxt, kc, tap + 1);
-      if (nx) { geom_a(TN{}, 0, om[nxt][0], gq[0]); geom_a(TN{}, 1, om[nxt][1], gq[1]); }
+      if (nx) geom_a(TN{}, om[nxt], gq);
       DCS_MF(0, 0, 0);
-      if (nx) { geom_b1(gq[0]); geom_b2(0, gq[0], fix); }
+      if (nx) { geom_b1(gq); geom_b2(gq, fix); }
       DCS_MF(0, 0, 1);
-      if (nx) { corners_issue(gq[0].addr, c0, 0); corners_issue(gq[0].addr, c0, 1); }
+      if (nx) { corners_issue(gq.addr, c, 0); corners_issue(gq.addr, c, 1); }
       DCS_MF(0, 1, 0);
-      if (nx) { geom_b1(gq[1]); geom_b2(1, gq[1], fix); }
+      if (nx) { corners_issue(gq.addr, c, 2); corners_issue(gq.addr, c, 3); }
       DCS_MF(0, 1, 1);
-      if (nx) { corners_issue(gq[1].addr, c1, 0); corners_issue(gq[1].addr, c1, 1); }
-      DCS_MF(2, 0, 0);
       if (tap + 2 < KK) om_issue(TNN{}, om[cur]);  // (om[cur] held this tap's values: consumed one tap ago)
+      DCS_MF(2, 0, 0);
+      if (nx) { landed_a(c); blend2(gq, c, 0, Bf); blend2(gq, c, 2, Bf); }
       DCS_MF(2, 0, 1);
-      if (nx) { landed0(c0); blend2(gq[0], c0, 0, Bf[0]); blend2(gq[0], c0, 2, Bf[0]); }
-      DCS_MF(2, 1, 0);
       if (nx) {
-        landed1(c1);
+        landed_b(c);
         if (tap + 2 < KK) landed_om(om[cur]);
-        blend2(gq[1], c1, 0, Bf[1]); blend2(gq[1], c1, 2, Bf[1]);
+        blend2(gq, c, 4, Bf); blend2(gq, c, 6, Bf);
       }
-      DCS_MF(2, 1, 1);
+      DCS_MF(2, 1, 0);
       if (nx) {
         if (fix) fixup(gq, Bf);
       }
+      DCS_MF(2, 1, 1);
+      if (nx) split_pair(0, Bf);
       DCS_MF(1, 0, 0);
-      if (nx) split_row(0, Bf[0]);
+      if (nx) split_pair(1, Bf);
       DCS_MF(1, 0, 1);
-      if (nx) split_row(1, Bf[1]);
+      if (nx) split_pair(2, Bf);
       DCS_MF(1, 1, 0);
-      if (nx) frag_row(nxt, 0);
+      if (nx) split_pair(3, Bf);
       DCS_MF(1, 1, 1);
-      if (nx) frag_row(nxt, 1);
+      if (nx) frags(nxt);
       if (kc < 2) DCS_STAMP(5 + 30 * kc + tap);
     };
     tap_body(std::integral_constant<int, 0>{}); tap_body(std::integral_constant<int, 1>{});
