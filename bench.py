@@ -123,7 +123,7 @@ def _opt():
 def _sources_digest():
     """Identity of the conv kernel sources the committed PMC traffic figure was collected on."""
     h = hashlib.sha256()
-    for f in ("conv2d_v2.hip", "conv2d_wino.hip", "conv2d_wino3.hip", "small_grid.h", "common.h"):
+    for f in ("conv2d_v2.hip", "conv2d_wino.hip", "conv2d_wino3.hip", "conv2d_wino4.hip", "small_grid.h", "common.h"):
         with open(os.path.join(ROOT, "dynavsr_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -936,7 +936,8 @@ def main():
             wn, wfl, wt, w3n, w3fl, w3t = wino[dom]
             executed = fl - (wfl + w3fl) * (1.0 - 16.0 / 36.0)
             roof["algorithm"] = ("%d of %d launches per step on the Winograd F(2x2,3x3) kernel with the 16 GEMMs on the bf16 "
-                                 "pipe under the exact 3-way operand split (conv2d_wino3.hip: fp32 results, 4/9 of the "
+                                 "pipe under the exact 3-way operand split (conv2d_wino4.hip, round 5: the B operand built in "
+                                 "registers; conv2d_wino3.hip under DVSR_CONV_WINO3_BLK=0..3: fp32 results, 4/9 of the "
                                  "multiplies x 6 bf16 products + transforms), %d on the fp32 Winograd kernel "
                                  "(conv2d_wino.hip), the rest on the direct implicit-GEMM kernels"
                                  % (w3n // reps, cnt // reps, wn // reps))
@@ -947,7 +948,8 @@ def main():
                              "fp32_products_tflops": executed / (t_ms * 1e-3) / 1e12,
                              "fp32_products_over_fp32_pipe_peak": executed / (t_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
             if w3t >= wt:
-                k_fl, k_t, k_n, k_name = w3fl * (16.0 / 36.0), w3t, w3n, "conv2d_wino3_kernel"
+                blk = os.environ.get("DVSR_CONV_WINO3_BLK", "4")
+                k_fl, k_t, k_n, k_name = w3fl * (16.0 / 36.0), w3t, w3n, ("conv2d_wino4_kernel" if blk == "4" else "conv2d_wino3_kernel")
                 roof.update(pipe_mix(0.0, 6.0 * k_fl / reps, k_t / reps * 1e-3))
             else:
                 k_fl, k_t, k_n, k_name = wfl * (16.0 / 36.0), wt, wn, "conv2d_wino_kernel"

@@ -91,9 +91,9 @@ rm -rf $out/dbt_FETCH_SIZE $out/dbt_WRITE_SIZE
 #     its cycle-stamp timeline (debug build), and the forward with the kernel switched off
 echo "== Winograd on the bf16 pipe, exact 3-way split (conv2d_wino3.hip, the default)" > $out/${tag}_wino_vs_direct.txt
 DVSR_CONV_WINO=2 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
-# r04: the forms of the bf16x3 kernel: 3 (default) one xn per wave + U fragments from global + one barrier per chunk,
+# r04 / r05: the forms of the bf16x3 kernel: 4 (default since r05, conv2d_wino4.hip) the B operand built in registers; 3 one xn per wave + U fragments from global + one barrier per chunk,
 #      2 the same with a barrier per phase, 1 one xn per wave with U through the LDS, 0 four xn per wave (one block each)
-for b in 3 2 1 0; do
+for b in 4 3 2 1 0; do
   echo "== DVSR_CONV_WINO3_BLK=$b" >> $out/${tag}_wino3_variants.txt
   DVSR_CONV_WINO=2 DVSR_CONV_WINO3_BLK=$b python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_variants.txt
 done
@@ -106,8 +106,8 @@ if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
   python tools/wino_trace.py 5 64 64 64 180 320 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
   echo "== the fp32 MFMA kernel (DVSR_CONV_WINO3=0)" >> $out/${tag}_wino_trace.txt
   DVSR_CONV_WINO3=0 python tools/wino_trace.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
-  echo "== the four-xn-per-wave form (DVSR_CONV_WINO3_BLK=0), with the stamps inside a phase" >> $out/${tag}_wino_trace.txt
-  DVSR_CONV_WINO3_BLK=0 python tools/wino_trace.py 5 64 64 64 180 320 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
+  echo "== the round-4 default (DVSR_CONV_WINO3_BLK=3: V through the LDS)" >> $out/${tag}_wino_trace.txt
+  DVSR_CONV_WINO3_BLK=3 python tools/wino_trace.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
   # run-time ablations of the bf16x3 kernel's four-xn-per-wave form (debug build; results are wrong when a bit is set):
   # 2 no input transform, 4 no DMA, 8 operands read once, 16 no barriers
   for ab in 0 2 4 8 16 6 30; do
@@ -117,14 +117,14 @@ if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
   # ... and of the default form: 2 no input transform, 4 no global loads (U fragments, raw halo), 8 no V operand reads,
   # 16 no barrier, 32 no MFMAs
   for ab in 0 2 4 8 16 32 30 62; do
-    echo "== default form, DVSR_CONV_ABLATE=$ab" >> $out/${tag}_wino3_ablation.txt
-    DVSR_CONV_WINO=2 DVSR_CONV_ABLATE=$ab DVSR_HIP_LIB=$PWD/dynavsr_amd/libdynavsr_hip_trace.so python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_ablation.txt
+    echo "== form 3 (the round-4 default), DVSR_CONV_ABLATE=$ab" >> $out/${tag}_wino3_ablation.txt
+    DVSR_CONV_WINO=2 DVSR_CONV_WINO3_BLK=3 DVSR_CONV_ABLATE=$ab DVSR_HIP_LIB=$PWD/dynavsr_amd/libdynavsr_hip_trace.so python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_ablation.txt
   done
 fi
 # r04: PMC picture of the bf16x3 Winograd kernel (LDS activity, wave wait / issue-stall split, instruction mix)
 for set in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   DVSR_CONV_WINO=2 rocprofv3 --pmc $set --kernel-trace -d $out/dbw -o p -- python tools/wino_bench.py --quick > /dev/null 2>&1
-  python tools/pmc_dump.py $out/dbw/p_results.db conv2d_wino3 >> $out/${tag}_wino3_pmc.txt; rm -rf $out/dbw
+  python tools/pmc_dump.py $out/dbw/p_results.db conv2d_wino4 >> $out/${tag}_wino3_pmc.txt; rm -rf $out/dbw
 done
 # r04: what the two waves of a SIMD share (micro-benchmarks behind DESIGN 3.1f)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/mfma_overlap.hip -o /tmp/mfma_overlap 2>/dev/null && /tmp/mfma_overlap > $out/${tag}_mfma_overlap.txt
@@ -139,4 +139,11 @@ for cfg in "2 1" "3 1" "1 8" "2 4"; do
   python tools/fwd_concurrent.py 180 320 20 $cfg 2>&1 | grep -E "stream|diff" >> $out/${tag}_fwd_clips_in_flight.txt
 done
 python tools/inner_two_streams.py 16 2 2>&1 | grep "inner step" >> $out/${tag}_fwd_clips_in_flight.txt
+# r05: the split's edge semantics, the bring-up orders against the stream -> hardware-queue assignment, the DCN forward on
+# the bf16 pipe against the fp32-MFMA kernel (per-launch tables)
+python tools/split_edge_probe.py 2>&1 | grep -v amdgpu > $out/${tag}_split_edges.txt
+python tools/queue_probe_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_queue_probe.txt
+DVSR_DCN_FWD=dma python tools/op_profile.py 180 320 5 2>&1 | grep -E "mdcn|total" > $out/${tag}_dcn_fwd_split_vs_dma.txt
+echo "== split (default)" >> $out/${tag}_dcn_fwd_split_vs_dma.txt
+grep -E "mdcn|total" $out/${tag}_per_launch_fwd180x320.txt >> $out/${tag}_dcn_fwd_split_vs_dma.txt
 du -sh gpurun_out
