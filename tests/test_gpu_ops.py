@@ -614,7 +614,22 @@ def test_conv3x3_winograd_bf16x3_other_forms(blk):
     import subprocess
     import sys
     env = dict(os.environ, DVSR_CONV_WINO3_BLK=blk)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_conv3x3_winograd and bf16x3 and not other_forms"],
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_conv3x3_winograd and bf16x3 and not other_forms and not wide_form"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
+def test_conv3x3_winograd_bf16x3_wide_form():
+    """conv2d_wino4w_kernel (DVSR_CONV_WINO_WIDE=1: 128 couts x 32 tiles per workgroup for Cout >= 128 -- built in round 5,
+    measured slower than the 64 x 64 form and therefore not the default) holds the same bars: the switch is read once per
+    process, so the bf16x3 cases (Cout = 256 + PixelShuffle, 216, the 16x16-tile shapes, upconv2 at 360x640) run in a child."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DVSR_CONV_WINO_WIDE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "test_conv3x3_winograd and bf16x3 and not other_forms and not wide_form"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
     assert " passed" in r.stdout
