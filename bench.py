@@ -488,13 +488,19 @@ def edvr_l_rates(dev, steps=10):
     x = synth.clip(9, 1, 7, 64, 64, smooth=False).to(dev)
     tgt = synth.clip(109, 1, 1, 256, 256, smooth=False)[:, 0].to(dev)
     # north_star's accuracy gate (PSNR vs ground truth within 0.02 dB of the reference arithmetic) on the synthetic
-    # substitute of tests/test_gpu_edvr.py::test_edvr_l_bf16_psnr_gate_in_north_star_terms
+    # substitute of tests/test_gpu_edvr.py::test_edvr_l_bf16_psnr_gate_in_north_star_terms: since round 5 a super-resolution
+    # PAIR at a trained network's operating point (synth.sr_pair: bilinear alone scores 30 dB; the network's residual branch
+    # damped, synth.damp_residual_branch) -- the round-3 substitute (unrelated noise images, 8 dB) is kept as `stress_*`
+    xs_lr, xs_gt = synth.sr_pair(91, 7, 64, 64)
+    xs_lr = xs_lr.to(dev)
+    hr_pair = util.tensor2img(xs_gt, mode="rgb")
     xs = synth.clip(91, 1, 7, 64, 64).to(dev)
     hr = util.tensor2img(synth.clip(92, 1, 1, 256, 256)[0, 0], mode="rgb")
-    out, y0, p0 = {}, None, None
+    out, y0, p0, s0 = {}, None, None, None
     for mode, name in ((0, "fp32_mfma"), (1, "bf16_operands"), (2, "bf16_split3")):
         net = EDVR(bf16_mfma=mode, **cfg)
-        net.load_state_dict(synth.edvr_state_dict(8, **cfg), strict=True)
+        sd_full = synth.edvr_state_dict(8, **cfg)
+        net.load_state_dict(sd_full, strict=True)
         net = net.to(dev)
 
         def fwd():
@@ -517,12 +523,16 @@ def edvr_l_rates(dev, steps=10):
             if key == "forward":
                 yf = y
         with torch.no_grad():
-            res["psnr_vs_synthetic_gt_db"] = util.calculate_psnr(util.tensor2img(net(xs)[0], mode="rgb"), hr)
+            res["stress_psnr_vs_unrelated_target_db"] = util.calculate_psnr(util.tensor2img(net(xs)[0], mode="rgb"), hr)
+            net.load_state_dict(synth.damp_residual_branch(sd_full), strict=True)
+            res["psnr_vs_synthetic_gt_db"] = util.calculate_psnr(util.tensor2img(net(xs_lr)[0], mode="rgb"), hr_pair)
+            net.load_state_dict(sd_full, strict=True)
         if mode == 0:
-            y0, p0 = yf, res["psnr_vs_synthetic_gt_db"]
+            y0, p0, s0 = yf, res["psnr_vs_synthetic_gt_db"], res["stress_psnr_vs_unrelated_target_db"]
         else:
             res["delta_psnr_vs_fp32_db"] = res["psnr_vs_synthetic_gt_db"] - p0
             res["passes_0p02_db_gate"] = abs(res["delta_psnr_vs_fp32_db"]) <= 0.02
+            res["stress_delta_psnr_vs_fp32_db"] = res["stress_psnr_vs_unrelated_target_db"] - s0
             d = (yf - y0).double()
             res["rel_l2_vs_fp32_mfma"] = float(d.norm() / y0.double().norm())
             res["psnr_db_vs_fp32_mfma"] = float(10 * torch.log10(1.0 / (d ** 2).mean()))

@@ -906,28 +906,47 @@ def test_edvr_l_config4_forward_backward(mode):
 def test_edvr_l_bf16_psnr_gate_in_north_star_terms():
     """BASELINE configs[4] / north_star: reduced precision is gated by PSNR-vs-ground-truth within 0.02 dB of the
     reference arithmetic.  No checkpoints or REDS tiles exist on the box, so -- as SURVEY 8d prescribes for configs[2] --
-    the substitute is a seeded smooth synthetic clip and its synthetic HR ground truth: EDVR-L x4 (nf 128, 7 frames, 40
-    blocks) 1x7x3x64x64 -> 3x256x256 through the exact-fp32 path (mode 0, itself held to the reference's golden), the
-    three-way bf16 split (mode 2) and the plain bf16-operand path (mode 1), PSNR of each against the same GT with the
-    reference's uint8 definition (utils/util.py:262-269 on tensor2img).
-    Finding (r03): mode 2 passes the gate (|delta| ~ 3e-6 dB); mode 1 does NOT on this substitute (0.030 dB with
-    random-init weights, which amplify the 2^-9 operand rounding through 95 convolutions) -- so the bf16-MFMA path of
-    configs[4] that is held to the reference's accuracy is mode 2; mode 1 stays an opt-in whose deviation is bounded
-    here at 0.1 dB and reported by bench.py."""
+    the substitute is synthetic, and since round 5 it sits at a MEANINGFUL operating point (the r04 review: at 8.28 dB a
+    0.03 dB difference says little): synth.sr_pair -- a smooth HR clip, its area-downscaled LR clip, the HR centre frame as
+    ground truth; bilinear up-sampling alone scores 30 dB -- and EDVR-L x4 (nf 128, 7 frames, 40 blocks) with its residual
+    branch damped to the size of a trained network's correction (synth.damp_residual_branch).  PSNR of the exact-fp32 path
+    (mode 0, itself held to the reference's golden), the plain bf16-operand path (mode 1) and the three-way bf16 split
+    (mode 2) against the same GT with the reference's uint8 definition (utils/util.py:262-269 on tensor2img).
+    Both reduced modes must hold the gate here; the round-3 substitute (unrelated noise images, 8 dB) stays as the stress
+    case below, where mode 1's deviation is only bounded (0.030 dB measured)."""
     from dynavsr_amd.utils import util
-    x = synth.clip(91, 1, 7, 64, 64).cuda()
-    gt = synth.clip(92, 1, 1, 256, 256)[0, 0]
+    lr, gt = synth.sr_pair(91, 7, 64, 64)
     hr = util.tensor2img(gt, mode="rgb")
     psnr = {}
     for mode in (0, 1, 2):
-        net = make_net(8, bf16_mfma=mode, **EDVR_L)
+        net = EDVR_l_net(mode, damped=True)
         with torch.no_grad():
-            sr = net(x)
+            sr = net(lr.cuda())
         psnr[mode] = util.calculate_psnr(util.tensor2img(sr[0], mode="rgb"), hr)
         del net
-    print("EDVR-L PSNR vs synthetic GT: fp32 %.4f dB, bf16 operands %.4f dB, bf16 split-3 %.4f dB" % (psnr[0], psnr[1], psnr[2]))
-    assert abs(psnr[2] - psnr[0]) <= 0.02, psnr          # the gate, on the path that claims it
-    assert abs(psnr[1] - psnr[0]) <= 0.1, psnr           # stated bound of the opt-in path (measured 0.030 dB)
+    print("EDVR-L PSNR vs synthetic GT (sr_pair, damped residual): fp32 %.4f dB, bf16 operands %.4f dB, bf16 split-3 %.4f dB"
+          % (psnr[0], psnr[1], psnr[2]))
+    assert psnr[0] >= 25.0, psnr                          # the operating point means something
+    assert abs(psnr[2] - psnr[0]) <= 0.02, psnr          # the gate
+    assert abs(psnr[1] - psnr[0]) <= 0.02, psnr          # ... also for the plain bf16-operand path at this operating point
+    # stress case of rounds 3-4: random-init residual branch against an unrelated target (8 dB)
+    x = synth.clip(91, 1, 7, 64, 64).cuda()
+    hr = util.tensor2img(synth.clip(92, 1, 1, 256, 256)[0, 0], mode="rgb")
+    for mode in (0, 1, 2):
+        net = EDVR_l_net(mode, damped=False)
+        with torch.no_grad():
+            psnr[mode] = util.calculate_psnr(util.tensor2img(net(x)[0], mode="rgb"), hr)
+        del net
+    assert abs(psnr[2] - psnr[0]) <= 0.02, psnr
+    assert abs(psnr[1] - psnr[0]) <= 0.1, psnr           # stated bound of the opt-in path there (measured 0.030 dB)
+
+
+def EDVR_l_net(mode, damped):
+    from dynavsr_amd.models.archs.EDVR_arch import EDVR
+    net = EDVR(bf16_mfma=mode, **EDVR_L)
+    sd = synth.edvr_state_dict(8, **EDVR_L)
+    net.load_state_dict(synth.damp_residual_branch(sd) if damped else sd, strict=True)
+    return net.cuda()
 
 
 # ---- per-clip parameter gradients: K clips through one tape (dvsr_edvr_plan_create_grouped) -----------------------------
