@@ -23,6 +23,12 @@
 
 namespace dvsr {
 
+#ifdef DVSR_CONV_TRACE
+static long long* g_wgrad_trace = nullptr;
+// every weight-gradient launch from now on stamps its timeline into buf (tools/wgrad_trace.py)
+extern "C" int dvsr_debug_wgrad_trace(void* buf) { g_wgrad_trace = (long long*)buf; return 0; }
+#endif
+
 template <int KS, int S>
 struct WgShape {
   static constexpr int TH = 2, TW = 32, NPX = TH * TW, KK = KS * KS;
@@ -309,6 +315,7 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
   out->ks = ks; out->stride = stride;
 #ifdef DVSR_CONV_TRACE
   { static const int nf = getenv("DVSR_WGRAD_NOFLUSH") ? atoi(getenv("DVSR_WGRAD_NOFLUSH")) : 0; k.noflush = nf; }
+  k.trace = g_wgrad_trace;
 #endif
   // small pixel grids: one kernel row per workgroup (conv2d_wgrad_pipe_kernel<3, true>); the pixel split is then
   // sized for ~two workgroups per CU over the three rows.  DVSR_WGRAD_KYS_BELOW=<tiles x cout blocks x cin blocks>
@@ -359,6 +366,30 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
     if (wide && gy_ok && stride == 1 && ks <= 3 && out->bf != 1) {   // (bf == 2: the split kernel has the same two vector forms)
       if (W % 4 == 0 && k.x_bs % 4 == 0 && ((uintptr_t)x & 15) == 0) k.vx = 4;
       else if (W % 2 == 0 && k.x_bs % 2 == 0 && ((uintptr_t)x & 7) == 0) k.vx = 2;
+    }
+  }
+  if (out->bf == 2 && k.vx != 0) {
+    // the split kernel's vector-staging form can run one kernel ROW per workgroup, two workgroups per CU (conv2d_wgrad_bf16.hip:
+    // conv2d_wgrad_split3v_kernel<.., KYS>).  It stages gy three times and x one and a half times, so it pays where a
+    // workgroup has few tiles and the fixed costs (first loads, flush, the tail of the last round) weigh most -- measured
+    // (tools/wgrad_bench.py, us with / without): 40 x 44x80 93 / 102, 8 x 44x80 40 / 51, 40 x 22x40 47 / 61, 1 x 176x320 52 / 63,
+    // but 40 x 176x320 1046 / 941, 64 -> 216 at 40 x 44x80 290 / 264.  DVSR_WGRAD_S3_KYS_BELOW=<tiles x cout blocks x cin
+    // blocks> moves the threshold (0 = never); DVSR_WGRAD_S3V=0 keeps the round-4 kernel.  Switches are read once per process.
+    static const int s3_below = [] {
+      const char* w = getenv("DVSR_WGRAD_S3V");
+      if (w && w[0] == '0') return 0;
+      const char* v = getenv("DVSR_WGRAD_S3_KYS_BELOW");
+      return v ? atoi(v) : 4000;
+    }();
+    const bool fits = (unsigned long long)Cin * H * W < (1ull << 30) && (unsigned long long)Cout * k.Ho * k.Wo < (1ull << 30);
+    const long long work = (long long)k.ntiles * k.nob * k.ncb;
+    if (work < s3_below && fits) {
+      // two workgroups per CU from ~1000 tiles, one below; rounded DOWN (one workgroup more than the CUs hold at once is a
+      // second round with one workgroup in it)
+      static const int s3_wgs = [] { const char* v = getenv("DVSR_WGRAD_S3_WGS"); return v ? atoi(v) : 0; }();
+      const int wgs = s3_wgs > 0 ? s3_wgs : (work >= 1000 ? 512 : 256);
+      out->kys = 1;
+      k.nsplit = per_group(wgs / (ks * k.nob * k.ncb));
     }
   }
   if (k.nslot > k.nsplit) k.nslot = k.nsplit;   // (the slot region was sized for the un-split launch: never larger)

@@ -564,11 +564,328 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad_split3_kernel(WgradK a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the vector-staging forms (VX = 4 / 2) of the kernel above, re-scheduled.  The arithmetic, the LDS images and the
+// flush are the same; what changed is WHEN things are issued -- one wave per SIMD has nobody to hide its stalls behind:
+//   * the compiler had sunk every operand read of the MFMA loop down to its first use (ds_read_b128 x2, s_waitcnt, v_alignbit
+//     ... in the middle of the MFMA stream: ~36 exposed LDS round trips per tile).  The reads of step i + 1 now sit above a
+//     scheduling fence at the TOP of step i and are waited for by an lgkmcnt(0) closed by a fence at the top of step i + 1
+//     (conv2d_wino4.hip's wait_lds): a whole step of MFMAs (576 cycles) covers them;
+//   * the next tile's global loads are issued from INSIDE the loop (behind the first step's MFMAs) instead of between the LDS
+//     stores and the barrier, with 32-bit lane offsets off a scalar sample base: validity is two compares and a select per
+//     vector (before: 64-bit multiply-adds under exec masks, ~500 instructions with the matrix pipe idle);
+//   * a workgroup's last tile loads / converts its own tile again instead of branching around the staging code (the loop body
+//     is one straight line);
+//   * v_cvt_pk_bf16_f32 as a vector conversion, not inline asm (no s_nop padding behind it).
+__device__ __forceinline__ void split3_pair_v(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  typedef float sf2 __attribute__((ext_vector_type(2)));
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(sf2{a, b}, wbf16x2));
+  const float r0 = a - __builtin_bit_cast(float, h << 16), r1 = b - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(sf2{r0, r1}, wbf16x2));
+  const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(sf2{q0, q1}, wbf16x2));
+}
+
+#ifdef DVSR_CONV_TRACE
+#define S3_STAMP(i)                                                                                                          \
+  do {                                                                                                                       \
+    if (a.trace && threadIdx.x == 0)                                                                                         \
+      a.trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define S3_STAMP(i) \
+  do {              \
+  } while (0)
+#endif
+
+// KYS: one kernel ROW per workgroup (block index = split * KS + ky): KS accumulator tiles and two x rows instead of KS * KS
+// and KS + 1 -- under 256 registers and 62 KB of LDS, so that TWO workgroups share a CU.  One wave per SIMD issues its MFMAs
+// and everything else one after the other (tools/wgrad_trace.py: 47 cycles per MFMA with the shuffles between them against
+// 37.5 alone; LDS stores, barriers and the first operand reads of a tile with the pipe idle); a second wave on the SIMD fills
+// those gaps (tools/mfma_overlap.hip: MFMAs of one wave and vector / LDS instructions of the other run at full rate).  The
+// price is staging: gy three times, x one and a half times.
+template <int KS, int VX, int SHIFT, bool KYS>
+__global__ __launch_bounds__(256, KYS ? 2 : 1) void conv2d_wgrad_split3v_kernel(WgradK a) {
+  static_assert(VX == 2 || VX == 4, "vector staging only");
+  constexpr int KR = KYS ? 1 : KS, NT = KR * KS, XR = 1 + KR, XC = 31 + KS;   // kernel rows / taps / x rows of a workgroup
+  constexpr int XCH0 = XR * S3_XROW + 8, XCH = (XCH0 / 8) % 2 ? XCH0 : XCH0 + 8, XP = 64 * XCH;                        // bf16 per channel / per piece of the x tile
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  __bf16* const s_g = smem16;
+  __bf16* const s_x = smem16 + 3 * S3_GP;
+  static_assert((XCH * 2 / 16) % 2 == 1, "channel stride: an odd number of 16-byte units");
+  constexpr int WWIN = ((XC + 2 * (VX - 1)) / VX) * VX;
+  constexpr int RV = WWIN / VX, XV = XR * RV;
+  constexpr int XM = (16 * XV + 63) / 64;
+  typedef float xvec __attribute__((ext_vector_type(VX)));
+
+  const int split = KYS ? blockIdx.x / KS : blockIdx.x, ky = KYS ? blockIdx.x % KS : 0, ob = blockIdx.y, cbk = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int ot = wave >> 1, ct = wave & 1;
+  const unsigned HW = (unsigned)a.H * a.W, HWo = (unsigned)a.Ho * a.Wo;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // ---- lane-fixed part of the staging map: byte offsets inside a sample, (row, column) inside the tile / window
+  unsigned g_rel[4], x_rel[XM];
+  int g_row[4], g_col[4], x_row[XM], x_col[XM], g_lds[4], x_lds[XM];
+  bool g_cok[4], x_cok[XM];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int idx = lane + 64 * m;
+    const int ch = idx >> 4;
+    g_row[m] = (idx >> 3) & 1; g_col[m] = (idx & 7) * 4;
+    const int co = ob * 64 + wave * 16 + ch;
+    g_cok[m] = co < a.Cout;
+    g_rel[m] = ((unsigned)(g_cok[m] ? co : 0) * HWo + (unsigned)g_row[m] * a.Wo + g_col[m]) * 4u;
+    g_lds[m] = (wave * 16 + ch) * S3_GROW + g_row[m] * 32 + g_col[m];
+  }
+#pragma unroll
+  for (int m = 0; m < XM; ++m) {
+    const int idx = lane + 64 * m;
+    const int c = idx / XV, r = idx - c * XV;
+    x_row[m] = r / RV; x_col[m] = (r - x_row[m] * RV) * VX;
+    const int ci = cbk * 64 + wave * 16 + c;
+    x_cok[m] = c < 16 && ci < a.Cin;
+    x_rel[m] = ((unsigned)(x_cok[m] ? ci : 0) * HW + (unsigned)x_row[m] * a.W + x_col[m]) * 4u;
+    x_lds[m] = c < 16 ? (wave * 16 + c) * XCH + x_row[m] * S3_XROW + x_col[m] : -1;
+  }
+
+  f32x4 vg[4];
+  xvec vx[XM];
+  bool vg_ok[4], vx_ok[XM];
+  auto issue_loads = [&](int tile) __attribute__((always_inline)) {
+    const int tx_ = tile % a.tiles_x;
+    const int t2 = tile / a.tiles_x;
+    const int ty_ = t2 % a.tiles_y;
+    const int n = t2 / a.tiles_y;
+    const int oy0 = ty_ * 2, ox0 = tx_ * 32;
+    const char* gn = reinterpret_cast<const char*>(a.gy + (size_t)n * a.Cout * HWo);
+    const unsigned g_tile = ((unsigned)oy0 * a.Wo + ox0) * 4u;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      vg_ok[m] = g_cok[m] && oy0 + g_row[m] < a.Ho && ox0 + g_col[m] < a.Wo;
+      vg[m] = *reinterpret_cast<const f32x4*>(gn + (vg_ok[m] ? g_rel[m] + g_tile : 0u));
+    }
+    const int iy0 = oy0 - a.pad + ky, ix0 = ox0 - a.pad - SHIFT;
+    const char* xn = reinterpret_cast<const char*>(a.x + (size_t)(n / a.x_bdiv) * a.x_bs);
+    const unsigned x_tile = (unsigned)(iy0 * a.W + ix0) * 4u;   // (may wrap: the sum with a valid lane's offset does not)
+#pragma unroll
+    for (int m = 0; m < XM; ++m) {
+      vx_ok[m] = x_cok[m] && (unsigned)(iy0 + x_row[m]) < (unsigned)a.H && (unsigned)(ix0 + x_col[m]) < (unsigned)a.W;
+      vx[m] = *reinterpret_cast<const xvec*>(xn + (vx_ok[m] ? x_rel[m] + x_tile : 0u));
+    }
+  };
+
+  unsigned wg0[4][3], wg1[4][3], wx0[XM][3], wx1[XM][3];
+  float dbl[4] = {0.f, 0.f, 0.f, 0.f};
+  float db_on = 1.f;   // 0 while a workgroup's last tile is staged a second time (see above)
+  auto convert_g = [&](int m) __attribute__((always_inline)) {
+    const f32x4 v = vg_ok[m] ? vg[m] : f32x4{0.f, 0.f, 0.f, 0.f};
+    dbl[m] = __builtin_fmaf(db_on, (v[0] + v[1]) + (v[2] + v[3]), dbl[m]);
+    split3_pair_v(v[0], v[1], wg0[m][0], wg0[m][1], wg0[m][2]);
+    split3_pair_v(v[2], v[3], wg1[m][0], wg1[m][1], wg1[m][2]);
+  };
+  auto convert_x = [&](int m) __attribute__((always_inline)) {
+    xvec v = vx[m];
+    if (!vx_ok[m]) {
+#pragma unroll
+      for (int e = 0; e < VX; ++e) v[e] = 0.f;
+    }
+    split3_pair_v(v[0], v[1], wx0[m][0], wx0[m][1], wx0[m][2]);
+    if (VX == 4) split3_pair_v(v[VX == 4 ? 2 : 0], v[VX == 4 ? 3 : 0], wx1[m][0], wx1[m][1], wx1[m][2]);
+  };
+  auto store_words = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        *reinterpret_cast<wbf16x4*>(s_g + q * S3_GP + g_lds[m]) = __builtin_bit_cast(wbf16x4, uint2{wg0[m][q], wg1[m][q]});
+#pragma unroll
+    for (int m = 0; m < XM; ++m) {
+      if (x_lds[m] < 0) continue;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (VX == 4) *reinterpret_cast<wbf16x4*>(s_x + q * XP + x_lds[m]) = __builtin_bit_cast(wbf16x4, uint2{wx0[m][q], wx1[m][q]});
+        else *reinterpret_cast<wbf16x2*>(s_x + q * XP + x_lds[m]) = __builtin_bit_cast(wbf16x2, wx0[m][q]);
+      }
+    }
+  };
+
+  wbf16x8 A[2][3], R0[2][3], R1[2][3];
+  const __bf16* const a_base = s_g + (ot * 32 + lo) * S3_GROW + 8 * hi;
+  const __bf16* const b_base = s_x + (ct * 32 + lo) * XCH + 8 * hi;
+  auto load_step = [&](auto st_, int rb) __attribute__((always_inline)) {
+    constexpr int st = decltype(st_)::value;
+    constexpr int kb = st / KR, ty = st - kb * KR;
+    constexpr int py = kb >> 1, px0 = (kb & 1) * 16;
+    // A of pixel block kb goes into A[kb & 1]: with KS steps per block its reads ride with the block's first step (two steps
+    // ahead, while block kb - 1 -- the other set -- is in use); with ONE step per block (KYS) two steps ahead would overwrite
+    // the set in use, so they are issued one step ahead instead (load_a below)
+    if (KR > 1 && ty == 0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) A[kb & 1][q] = *reinterpret_cast<const wbf16x8*>(a_base + q * S3_GP + 16 * kb);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const __bf16* bp = b_base + q * XP + (py + ty) * S3_XROW + px0;
+      R0[rb][q] = *reinterpret_cast<const wbf16x8*>(bp);
+      R1[rb][q] = *reinterpret_cast<const wbf16x8*>(bp + 8);
+    }
+  };
+
+  auto load_a = [&](auto kb_) __attribute__((always_inline)) {   // (KR == 1 only)
+    constexpr int kb = decltype(kb_)::value;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) A[kb & 1][q] = *reinterpret_cast<const wbf16x8*>(a_base + q * S3_GP + 16 * kb);
+  };
+
+  const WgSpan sp = wg_span(a, split);
+  int tile = sp.tile0;
+  S3_STAMP(0);
+  if (tile < sp.tile_end) {
+    issue_loads(tile);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) convert_g(m);
+#pragma unroll
+    for (int m = 0; m < XM; ++m) convert_x(m);
+  }
+  S3_STAMP(1);
+  [[maybe_unused]] int it = 0;
+  for (; tile < sp.tile_end; tile += a.nsplit) {
+    if (it == 2) S3_STAMP(4);
+    store_words();
+    const bool has_next = tile + a.nsplit < sp.tile_end;
+    const int tnext = has_next ? tile + a.nsplit : tile;
+    db_on = has_next ? 1.f : 0.f;
+    if (it == 2) S3_STAMP(5);
+    __syncthreads();
+    if (it == 2) S3_STAMP(6);
+    // two steps of operand reads in flight, the B fragments of step i + 1 shuffled together between the MFMAs of step i
+    wbf16x8 B[2][3][3];   // [step parity][piece][tx]
+    auto build_b = [&](int rb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const wbf16x8 r0 = R0[rb][q], r1 = R1[rb][q];
+        B[rb][q][0] = __builtin_shufflevector(r0, r1, SHIFT, SHIFT + 1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7);
+        B[rb][q][1] = __builtin_shufflevector(r0, r1, SHIFT + 1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7, SHIFT + 8);
+        B[rb][q][2] = __builtin_shufflevector(r0, r1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7, SHIFT + 8, SHIFT + 9);
+      }
+    };
+    if constexpr (KR == 1) load_a(std::integral_constant<int, 0>{});
+    load_step(std::integral_constant<int, 0>{}, 0);
+    load_step(std::integral_constant<int, 1>{}, 1);
+    build_b(0);
+    static_for<0, 4 * KR>([&](auto st_) __attribute__((always_inline)) {
+      constexpr int st = decltype(st_)::value;
+      constexpr int kb = st / KR, ty = st - kb * KR, rb = st & 1;
+      // the reads of step st + 2 go out HERE (R[rb] was consumed by build_b in the previous step): nothing of this step may be
+      // scheduled above them and they cannot sink to their first use; the compiler's own lgkmcnt(n) covers the older reads
+      if constexpr (st + 2 < 4 * KR) load_step(std::integral_constant<int, st + 2>{}, rb);
+      if constexpr (KR == 1 && st + 1 < 4) load_a(std::integral_constant<int, st + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (st == 0) issue_loads(tnext);
+      constexpr int QA[6] = {0, 0, 1, 0, 2, 1}, QB[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx)
+          acc[ty * KS + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[kb & 1][QA[pr]], B[rb][QB[pr]][tx], acc[ty * KS + tx], 0, 0, 0);
+      if constexpr (st + 1 < 4 * KR) build_b(rb ^ 1);
+      // the next tile's vectors landed steps ago: convert them (registers only) behind the last CS steps
+      constexpr int CS = 4 * KR >= 8 ? 8 : 4 * KR - 1;
+      if constexpr (st >= 4 * KR - CS) {
+        constexpr int j = st - (4 * KR - CS);
+        constexpr int perg = (4 + CS - 1) / CS, perx = (XM + CS - 1) / CS;
+#pragma unroll
+        for (int u = 0; u < perg; ++u)
+          if (j * perg + u < 4) convert_g(j * perg + u);
+#pragma unroll
+        for (int u = 0; u < perx; ++u)
+          if (j * perx + u < XM) convert_x(j * perx + u);
+      }
+      // one MFMA (32 cycles of the pipe), then up to four of the vector instructions above
+#ifndef S3_MG
+#define S3_MG 1
+#define S3_IL 4
+#endif
+#if S3_MG > 0
+#pragma unroll
+      for (int i = 0; i < 6 * KS / S3_MG; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, S3_MG, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, S3_IL, 0);
+      }
+#endif
+#ifdef DVSR_CONV_TRACE
+      __builtin_amdgcn_sched_barrier(0);
+      if (it == 2) S3_STAMP(10 + st);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    });
+    if (it == 2) S3_STAMP(7);
+    __syncthreads();
+    if (it == 2) S3_STAMP(8);
+    ++it;
+  }
+  S3_STAMP(2);
+
+  // ---- partial[slot][tap][o][c], as conv2d_wgrad_pipe_kernel
+  const int OP = a.nob * 64, CP = a.ncb * 64;
+  const int slot = sp.slot;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ob * 64 + ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int c = cbk * 64 + ct * 32 + lo;
+      unsafeAtomicAdd(a.partial + (((size_t)slot * (KS * KS) + ky * KS + t) * OP + o) * CP + c, acc[t][r]);
+    }
+  S3_STAMP(3);
+  if (cbk == 0 && ky == 0) {   // lanes 16 k .. 16 k + 15 staged channel (lane >> 4) + 4 m of this wave's 16
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float v = dbl[m];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+      const int co = ob * 64 + wave * 16 + (lane >> 4) + 4 * m;
+      if ((lane & 15) == 0 && co < OP) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + co, v);
+    }
+  }
+}
+
 template <int KS, int VX, int SHIFT>
 static int launch_split3(const WgradLaunch& l, hipStream_t st) {
+  if constexpr (VX != 0) {
+    // DVSR_WGRAD_S3V=0: the round-4 schedule of the same kernel (A/B switch, read once per process); samples whose byte
+    // offsets do not fit 32 bits keep it too.  l.kys (conv2d_wgrad_prepare): one kernel row per workgroup, two workgroups per CU
+    static const bool s3v = [] { const char* v = getenv("DVSR_WGRAD_S3V"); return !(v && v[0] == '0'); }();
+    const bool fits = (unsigned long long)l.k.Cin * l.k.H * l.k.W < (1ull << 30) && (unsigned long long)l.k.Cout * l.k.Ho * l.k.Wo < (1ull << 30);
+    if (l.kys) {
+      DVSR_REQUIRE(s3v && fits, DVSR_ERR_UNSUPPORTED, "conv2d_wgrad_split3: the row split needs the vector-staging kernel");
+      constexpr size_t lds = (size_t)(3 * S3_GP + 3 * 64 * (2 * S3_XROW + 8)) * 2;
+      auto kv = conv2d_wgrad_split3v_kernel<KS, VX, SHIFT, true>;
+      static PerDeviceOnce attr_once_k;
+      set_dyn_lds_once(attr_once_k, (const void*)kv, lds);
+      hipLaunchKernelGGL(kv, l.grid, dim3(256), lds, st, l.k);
+      return check_launch("conv2d_wgrad_split3v_kernel<kys>");
+    }
+    if (s3v && fits) {
+      auto kv = conv2d_wgrad_split3v_kernel<KS, VX, SHIFT, false>;
+      static PerDeviceOnce attr_once_v;
+      set_dyn_lds_once(attr_once_v, (const void*)kv, S3_LDS_BYTES);
+      hipLaunchKernelGGL(kv, l.grid, dim3(256), S3_LDS_BYTES, st, l.k);
+      return check_launch("conv2d_wgrad_split3v_kernel");
+    }
+  }
+  DVSR_REQUIRE(!l.kys, DVSR_ERR_UNSUPPORTED, "conv2d_wgrad_split3: the row split needs the vector-staging kernel");
   auto kern = conv2d_wgrad_split3_kernel<KS, VX, SHIFT>;
   static PerDeviceOnce attr_once;
-  set_dyn_lds_once(attr_once, (const void*)kern, S3_LDS_BYTES);hipLaunchKernelGGL(kern, l.grid, dim3(256), S3_LDS_BYTES, st, l.k);
+  set_dyn_lds_once(attr_once, (const void*)kern, S3_LDS_BYTES);
+  hipLaunchKernelGGL(kern, l.grid, dim3(256), S3_LDS_BYTES, st, l.k);
   return check_launch("conv2d_wgrad_split3_kernel");
 }
 

@@ -44,6 +44,7 @@ struct WgradK {
   int vx = 0;   // wide staging (conv2d_wgrad_wide_item): 4 / 2 = float4 / float2 x vectors (and float4 gy), 0 = scalar loads
 #ifdef DVSR_CONV_TRACE
   int noflush = 0;  // measurement aid of the debug build (DVSR_WGRAD_NOFLUSH=1): skip the atomic flush, results are wrong
+  long long* trace = nullptr;   // tools/wgrad_trace.py: 64 cycle stamps per workgroup (conv2d_wgrad_split3v_kernel)
 #endif
 };
 
