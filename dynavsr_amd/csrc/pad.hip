@@ -136,7 +136,7 @@ __global__ void pad_bwd_kernel(const float* __restrict__ gy, float* __restrict__
 // Four consecutive columns per thread (W % 4 == 0): the interior loads of the four elements are issued
 // together and the mask / output move as 16-byte accesses.  The one-element kernel above is latency-bound
 // (two dependent round trips per thread: 235 us for 217 MB at 5x64x176x320).
-template <int mode>
+template <int mode, bool ACC, bool MASK>
 __global__ void pad_bwd4_kernel(const float* __restrict__ gy, float* __restrict__ gx, int planes, int C,
                                 int H, int W, int T, int accumulate, const float* __restrict__ gmask,
                                 int gmask_act, int gmask_padded) {
@@ -170,56 +170,89 @@ __global__ void pad_bwd4_kernel(const float* __restrict__ gy, float* __restrict_
       return sp[k][r * Wp + q];
     };
     float* dst = gx + (size_t)plane * H * W;
-    const float* msk = gmask ? (gmask_padded ? gmask : gmask + (size_t)plane * H * W) : nullptr;
+    // four consecutive elements (row r, columns q0 .. q0 + 3, q0 odd) of a padded plane: 4-byte aligned vector loads (the
+    // padded pitch is W + 2: rows start at every alignment); in the space-to-depth layout the four are two pairs in the two
+    // column-parity planes of row parity r & 1
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    auto row4 = [&](const float* base, int r, int q0) -> f32x4 {
+      if (mode == PAD_REFLECT_S2D) {
+        const int Wh = Wp / 2, Hh = Hp / 2;
+        const float* pr = base + ((size_t)((r & 1) * 2) * Hh + (r >> 1)) * Wh;
+        const f2u odd = *reinterpret_cast<const f2u*>(pr + (size_t)Hh * Wh + (q0 >> 1));   // q0, q0 + 2
+        const f2u evn = *reinterpret_cast<const f2u*>(pr + ((q0 + 1) >> 1));               // q0 + 1, q0 + 3
+        return f32x4{odd[0], evn[0], odd[1], evn[1]};
+      }
+      const f4u v = *reinterpret_cast<const f4u*>(base + (size_t)r * Wp + q0);
+      return f32x4{v[0], v[1], v[2], v[3]};
+    };
+    const float* mbase = nullptr;   // the mask plane in the layout it has
+    if (gmask) {
+      if (!gmask_padded) mbase = gmask + (size_t)plane * H * W;
+      else if (mode == PAD_REFLECT_S2D) mbase = gmask + ((size_t)n * 4 * C + c * 4) * (size_t)(Hp / 2) * (Wp / 2);
+      else mbase = gmask + (size_t)plane * Hp * Wp;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < iq; i += gridDim.x * blockDim.x) {
       const int yy = i / Wq, x0 = (i - yy * Wq) * 4;
+      // every load of the element group goes out before anything is consumed (the border branch below used to sit between the
+      // gradient and the mask loads: two dependent round trips per thread)
+      f32x4 v[NPL];
+#pragma unroll
+      for (int k = 0; k < NPL; ++k)
+        if (k < np) v[k] = row4(sp[k], yy + 1, x0 + 1);
+      f32x4* d4 = reinterpret_cast<f32x4*>(dst + (size_t)yy * W + x0);
+      f32x4 m = {1.f, 1.f, 1.f, 1.f}, prev = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (MASK) {   // (one load at a selected address: no branch between the loads)
+        if (mode == PAD_REFLECT_S2D) {
+          m = gmask_padded ? row4(mbase, yy + 1, x0 + 1) : *reinterpret_cast<const f32x4*>(mbase + (size_t)yy * W + x0);
+        } else {
+          const float* ma = gmask_padded ? mbase + (size_t)(yy + 1) * Wp + x0 + 1 : mbase + (size_t)yy * W + x0;
+          const f4u mv = *reinterpret_cast<const f4u*>(ma);
+          m = f32x4{mv[0], mv[1], mv[2], mv[3]};
+        }
+      }
+      if constexpr (ACC) prev = *d4;
+      // The ring's adjoint is separable: output (yy, xx) sums g over rows {yy + 1} (+ ring row 0 / Hp - 1 when yy is the row
+      // the ring mirrors or replicates) x columns {xx + 1} (+ ring column 0 / Wp - 1 likewise).  Per row that is the four-element
+      // vector plus, for the thread at either end of the row, ONE ring element -- loaded by every lane at a clamped address and
+      // weighted 0 / 1 (no divergent load chains: nearly every wave holds a row end).
+      const int jl = lo_edge, jr = 3 - lo_edge;                  // which of the four elements the ring column folds into
+      const float wl = x0 == 0 ? 1.f : 0.f, wr = x0 == W - 4 ? 1.f : 0.f;
+      float el[NPL], er[NPL];
+#pragma unroll
+      for (int k = 0; k < NPL; ++k)
+        if (k < np) { el[k] = at(k, yy + 1, 0); er[k] = at(k, yy + 1, Wp - 1); }
       float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < NPL; ++k)
         if (k < np) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) s[j] += at(k, yy + 1, x0 + j + 1);
+          for (int j = 0; j < 4; ++j) s[j] += v[k][j];
+          s[jl] += wl * el[k];
+          s[jr] += wr * er[k];
         }
       const bool ry0 = yy == lo_edge, ry1 = yy == H - 1 - lo_edge;
-      const bool cx0 = x0 <= lo_edge, cx1 = x0 + 3 >= W - 1 - lo_edge;
-      if (ry0 || ry1 || cx0 || cx1) {  // next to the border: the padding ring reads these elements again
+      if (ry0 || ry1) {   // (two rows of a plane; both at once only when H - 1 = 2 lo_edge)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int xx = x0 + j;
-          int rows[3], cols[3], nr = 0, nc = 0;
-          rows[nr++] = yy + 1;
-          cols[nc++] = xx + 1;
-          if (ry0) rows[nr++] = 0;
-          if (ry1) rows[nr++] = Hp - 1;
-          if (xx == lo_edge) cols[nc++] = 0;
-          if (xx == W - 1 - lo_edge) cols[nc++] = Wp - 1;
+        for (int e = 0; e < 2; ++e) {
+          if (!(e ? ry1 : ry0)) continue;
+          const int rr = e ? Hp - 1 : 0;
 #pragma unroll
           for (int k = 0; k < NPL; ++k)
-            if (k < np)
+            if (k < np) {
+              const f32x4 u = row4(sp[k], rr, x0 + 1);
+              const float ul = at(k, rr, 0), ur = at(k, rr, Wp - 1);
 #pragma unroll
-              for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b)
-                  if (a < nr && b < nc && (a || b)) s[j] += at(k, rows[a], cols[b]);
+              for (int j2 = 0; j2 < 4; ++j2) s[j2] += u[j2];
+              s[jl] += wl * ul;
+              s[jr] += wr * ur;
+            }
         }
       }
       f32x4 o = {s[0], s[1], s[2], s[3]};
-      f32x4* d4 = reinterpret_cast<f32x4*>(dst + (size_t)yy * W + x0);
-      if (accumulate) o += *d4;
-      if (msk) {
+      if constexpr (ACC) o += prev;
+      if constexpr (MASK) {
         const float neg = gmask_act == ACT_LRELU ? 0.1f : (gmask_act == ACT_RELU ? 0.f : 1.f);
-        f32x4 m;
-        if (!gmask_padded) m = *reinterpret_cast<const f32x4*>(msk + (size_t)yy * W + x0);
-        else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = yy + 1, q = x0 + j + 1;
-            if (mode == PAD_REFLECT_S2D) {
-              const int Wh = Wp / 2, Hh = Hp / 2;
-              m[j] = msk[((size_t)n * 4 * C + c * 4 + (r & 1) * 2 + (q & 1)) * (size_t)Hh * Wh + (size_t)(r >> 1) * Wh + (q >> 1)];
-            } else m[j] = msk[(size_t)plane * Hp * Wp + (size_t)r * Wp + q];
-          }
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] *= m[j] > 0.f ? 1.f : neg;
       }
@@ -261,15 +294,17 @@ int pad_bwd(const float* gy, float* gx, int mode, int N, int C, int H, int W, in
   const int planes = N * C;
   if (W % 4 == 0 && (((uintptr_t)gx | (gmask_padded ? (uintptr_t)0 : (uintptr_t)gmask)) & 15) == 0) {
     const dim3 g4(ceil_div(H * (W / 4), 256), planes < 65535 ? planes : 65535);
-    if (mode == PAD_REFLECT)
-      hipLaunchKernelGGL(pad_bwd4_kernel<PAD_REFLECT>, g4, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate, gmask,
-                         gmask_act, gmask_padded);
-    else if (mode == PAD_REFLECT_S2D)
-      hipLaunchKernelGGL(pad_bwd4_kernel<PAD_REFLECT_S2D>, g4, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate,
-                         gmask, gmask_act, gmask_padded);
-    else
-      hipLaunchKernelGGL(pad_bwd4_kernel<PAD_REPL_T3>, g4, dim3(256), 0, st, gy, gx, planes, C, H, W, T, accumulate, gmask,
-                         gmask_act, gmask_padded);
+    auto go = [&](auto mode_, auto acc_, auto mask_) {
+      hipLaunchKernelGGL((pad_bwd4_kernel<decltype(mode_)::value, decltype(acc_)::value, decltype(mask_)::value>), g4, dim3(256), 0, st,
+                         gy, gx, planes, C, H, W, T, accumulate, gmask, gmask_act, gmask_padded);
+    };
+    auto pick = [&](auto mode_) {
+      if (accumulate) { if (gmask) go(mode_, std::true_type{}, std::true_type{}); else go(mode_, std::true_type{}, std::false_type{}); }
+      else { if (gmask) go(mode_, std::false_type{}, std::true_type{}); else go(mode_, std::false_type{}, std::false_type{}); }
+    };
+    if (mode == PAD_REFLECT) pick(std::integral_constant<int, PAD_REFLECT>{});
+    else if (mode == PAD_REFLECT_S2D) pick(std::integral_constant<int, PAD_REFLECT_S2D>{});
+    else pick(std::integral_constant<int, PAD_REPL_T3>{});
     return check_launch("pad_bwd4_kernel");
   }
   const dim3 grid(ceil_div(H * W, 256), planes < 65535 ? planes : 65535);
