@@ -136,14 +136,16 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
   const bool pv = py < a.H && px < a.W;
   const int prow = (2 * wave + hi) * TW + lo;
 
-  // window groups of this lane: L = 64 (wave + 4 jj) + lane = (channel, row, column group)
+  // window groups of this lane: L = 64 (wave + 4 jj) + lane = (row, channel, column group) -- the window is laid out
+  // [row][channel][column]: the two corners of a row are neighbours and the four channels x two corners of a row lie within
+  // 255 dwords of one base address, i.e. ONE ds_read2_b32 per (channel, row) instead of two ds_read_b32
   unsigned xo[Sh::NXI];
   bool xv[Sh::NXI];
 #pragma unroll
   for (int jj = 0; jj < Sh::NXI; ++jj) {
     const int L = 64 * (wave + 4 * jj) + lane;
-    const int c = L / (XH * XG), r = L - c * (XH * XG);
-    const int y = r / XG, g4 = r - y * XG;
+    const int y = L / (Sh::CPG * XG), r = L - y * (Sh::CPG * XG);
+    const int c = r / XG, g4 = r - c * XG;
     const int gy = wy0 + y, gx = wx0 + 4 * g4;
     const bool ok = L < Sh::NXG && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     xo[jj] = ok ? (unsigned)(((size_t)c * HW + (size_t)gy * a.W + gx) * 4) : 0u;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
     // ---- the nine taps, software-pipelined by hand as in mdcn_fwd_dma_kernel: the sampler of tap t + 1 is cut into pieces
     // that sit between the twelve MFMAs of tap t; LDS reads are inline asm, their results pass through one s_waitcnt asm
     // before the blends; operands ping-pong between two register sets by tap parity.
-    struct Geo { float w1, w2, w3, w4, h_im, w_im, m, lh, lw; int ry, rx; unsigned addr; bool inwin; };
+    struct Geo { ds2f w12, w34; float h_im, w_im, m, lh, lw; int ry, rx; unsigned addr; bool inwin; };
     auto om_issue = [&](auto TAP, float (&o)[3]) {
       constexpr int tap = decltype(TAP)::value;
       const unsigned ad = a_om;  // (a local: asm operands of a generic lambda do not capture)
@@ -234,44 +236,36 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
                    : "v"(ad), "i"(2 * tap * 4), "i"((2 * tap + 1) * 4), "i"((18 + tap) * 1024));
       o[0] = hw2[0]; o[1] = hw2[1];
     };
-    // c[4 ch + {0,1,2,3}] = (y,x) (y,x+1) (y+1,x) (y+1,x+1) of channel ch; quarter q = channels 2 q, 2 q + 1
-    auto corners_issue = [&](unsigned addr, float (&c)[32], int q) {
-      if (q == 0)
+    // cp[2 ch] = ((y,x), (y,x+1)), cp[2 ch + 1] = ((y+1,x), (y+1,x+1)) of channel ch; half h = channels 4 h .. 4 h + 3.
+    // Bases: addr (row y, channels 0-3), + 768 B (channels 4-7), + 1536 B (row y + 1), + 2304 B
+    auto corners_issue = [&](unsigned addr, ds2f (&cp)[16], int h) {
+      const unsigned b0 = addr + (h ? 768u : 0u), b1 = b0 + 1536u;
+      if (h == 0)
         asm volatile(
-            "ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:4\n\tds_read_b32 %2, %8 offset:192\n\tds_read_b32 %3, %8 offset:196\n\t"
-            "ds_read_b32 %4, %8 offset:3456\n\tds_read_b32 %5, %8 offset:3460\n\tds_read_b32 %6, %8 offset:3648\n\tds_read_b32 %7, %8 offset:3652"
-            : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
-            : "v"(addr));
-      else if (q == 1)
-        asm volatile(
-            "ds_read_b32 %0, %8 offset:6912\n\tds_read_b32 %1, %8 offset:6916\n\tds_read_b32 %2, %8 offset:7104\n\tds_read_b32 %3, %8 offset:7108\n\t"
-            "ds_read_b32 %4, %8 offset:10368\n\tds_read_b32 %5, %8 offset:10372\n\tds_read_b32 %6, %8 offset:10560\n\tds_read_b32 %7, %8 offset:10564"
-            : "=&v"(c[8]), "=&v"(c[9]), "=&v"(c[10]), "=&v"(c[11]), "=&v"(c[12]), "=&v"(c[13]), "=&v"(c[14]), "=&v"(c[15])
-            : "v"(addr));
-      else if (q == 2)
-        asm volatile(
-            "ds_read_b32 %0, %8 offset:13824\n\tds_read_b32 %1, %8 offset:13828\n\tds_read_b32 %2, %8 offset:14016\n\tds_read_b32 %3, %8 offset:14020\n\t"
-            "ds_read_b32 %4, %8 offset:17280\n\tds_read_b32 %5, %8 offset:17284\n\tds_read_b32 %6, %8 offset:17472\n\tds_read_b32 %7, %8 offset:17476"
-            : "=&v"(c[16]), "=&v"(c[17]), "=&v"(c[18]), "=&v"(c[19]), "=&v"(c[20]), "=&v"(c[21]), "=&v"(c[22]), "=&v"(c[23])
-            : "v"(addr));
+            "ds_read2_b32 %0, %8 offset1:1\n\tds_read2_b32 %1, %9 offset1:1\n\t"
+            "ds_read2_b32 %2, %8 offset0:48 offset1:49\n\tds_read2_b32 %3, %9 offset0:48 offset1:49\n\t"
+            "ds_read2_b32 %4, %8 offset0:96 offset1:97\n\tds_read2_b32 %5, %9 offset0:96 offset1:97\n\t"
+            "ds_read2_b32 %6, %8 offset0:144 offset1:145\n\tds_read2_b32 %7, %9 offset0:144 offset1:145"
+            : "=&v"(cp[0]), "=&v"(cp[1]), "=&v"(cp[2]), "=&v"(cp[3]), "=&v"(cp[4]), "=&v"(cp[5]), "=&v"(cp[6]), "=&v"(cp[7])
+            : "v"(b0), "v"(b1));
       else
         asm volatile(
-            "ds_read_b32 %0, %8 offset:20736\n\tds_read_b32 %1, %8 offset:20740\n\tds_read_b32 %2, %8 offset:20928\n\tds_read_b32 %3, %8 offset:20932\n\t"
-            "ds_read_b32 %4, %8 offset:24192\n\tds_read_b32 %5, %8 offset:24196\n\tds_read_b32 %6, %8 offset:24384\n\tds_read_b32 %7, %8 offset:24388"
-            : "=&v"(c[24]), "=&v"(c[25]), "=&v"(c[26]), "=&v"(c[27]), "=&v"(c[28]), "=&v"(c[29]), "=&v"(c[30]), "=&v"(c[31])
-            : "v"(addr));
+            "ds_read2_b32 %0, %8 offset1:1\n\tds_read2_b32 %1, %9 offset1:1\n\t"
+            "ds_read2_b32 %2, %8 offset0:48 offset1:49\n\tds_read2_b32 %3, %9 offset0:48 offset1:49\n\t"
+            "ds_read2_b32 %4, %8 offset0:96 offset1:97\n\tds_read2_b32 %5, %9 offset0:96 offset1:97\n\t"
+            "ds_read2_b32 %6, %8 offset0:144 offset1:145\n\tds_read2_b32 %7, %9 offset0:144 offset1:145"
+            : "=&v"(cp[8]), "=&v"(cp[9]), "=&v"(cp[10]), "=&v"(cp[11]), "=&v"(cp[12]), "=&v"(cp[13]), "=&v"(cp[14]), "=&v"(cp[15])
+            : "v"(b0), "v"(b1));
     };
-    static_assert(XW * 4 == 192 && XCH * 4 == 3456, "corners_issue hard-codes the window pitch");
+    static_assert(XW == 48 && Sh::CPG == 8, "corners_issue hard-codes the window pitch");
 #define DCS_PIN8(c, o) asm volatile("" : "+v"(c[o]), "+v"(c[o + 1]), "+v"(c[o + 2]), "+v"(c[o + 3]), "+v"(c[o + 4]), "+v"(c[o + 5]), "+v"(c[o + 6]), "+v"(c[o + 7]))
-    // the first two quarters: everything but the 15 newest LDS reads has returned (the other 16 corners and the offsets /
-    // masks follow them)
-    auto landed_a = [&](float (&c)[32]) {
-      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
-      DCS_PIN8(c, 8);
+    // the first half: everything but the 10 newest LDS reads has returned (the other 8 corner pairs and the offsets / masks
+    // follow them)
+    auto landed_a = [&](ds2f (&cp)[16]) {
+      asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(cp[0]), "+v"(cp[1]), "+v"(cp[2]), "+v"(cp[3]), "+v"(cp[4]), "+v"(cp[5]), "+v"(cp[6]), "+v"(cp[7]));
     };
-    auto landed_b = [&](float (&c)[32]) {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[16]), "+v"(c[17]), "+v"(c[18]), "+v"(c[19]), "+v"(c[20]), "+v"(c[21]), "+v"(c[22]), "+v"(c[23]));
-      DCS_PIN8(c, 24);
+    auto landed_b = [&](ds2f (&cp)[16]) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cp[8]), "+v"(cp[9]), "+v"(cp[10]), "+v"(cp[11]), "+v"(cp[12]), "+v"(cp[13]), "+v"(cp[14]), "+v"(cp[15]));
     };
     auto landed_om = [&](float (&o)[3]) { asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2])); };
     auto geom_a = [&](auto TAP, const float (&o)[3], Geo& q) {
@@ -289,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
       q.lh = q.h_im - hf; q.lw = q.w_im - wf;
       q.ry = (int)hf - wy0; q.rx = (int)wf - wx0;
       const int ryc = min(max(q.ry, 0), XH - 2), rxc = min(max(q.rx, 0), XW - 2);
-      q.addr = a_x + (unsigned)(ryc * XW + rxc) * 4u;
+      q.addr = a_x + (unsigned)(ryc * (Sh::CPG * XW) + rxc) * 4u;
       asm volatile("" : "+v"(q.lh), "+v"(q.lw), "+v"(q.ry), "+v"(q.rx), "+v"(q.addr));
     };
     auto geom_b2 = [&](Geo& q, int& fix) {
@@ -298,13 +292,17 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
       q.inwin = inwin;
       const float hh = 1.f - q.lh, hw = 1.f - q.lw;
       const float ms = ((int)pv & inwin) ? q.m : 0.f;
-      q.w1 = hh * hw * ms; q.w2 = hh * q.lw * ms; q.w3 = q.lh * hw * ms; q.w4 = q.lh * q.lw * ms;
+      q.w12 = ds2f{hh * hw * ms, hh * q.lw * ms}; q.w34 = ds2f{q.lh * hw * ms, q.lh * q.lw * ms};
       fix |= (int)pv & (inwin ^ 1);  // outside the window: the exact path decides (it applies the image gate itself)
-      asm volatile("" : "+v"(q.w1), "+v"(q.w2), "+v"(q.w3), "+v"(q.w4), "+v"(fix));
+      asm volatile("" : "+v"(q.w12), "+v"(q.w34), "+v"(fix));
     };
-    auto blend2 = [&](const Geo& q, const float (&c)[32], int k0, float (&B)[8]) {   // channels k0, k0 + 1
-      B[k0] = q.w1 * c[4 * k0] + q.w2 * c[4 * k0 + 1] + q.w3 * c[4 * k0 + 2] + q.w4 * c[4 * k0 + 3];
-      B[k0 + 1] = q.w1 * c[4 * k0 + 4] + q.w2 * c[4 * k0 + 5] + q.w3 * c[4 * k0 + 6] + q.w4 * c[4 * k0 + 7];
+    // channels k0, k0 + 1: the two corners of a row are one packed pair -- v_pk_mul_f32, v_pk_fma_f32 and one add per channel
+    auto blend2 = [&](const Geo& q, const ds2f (&cp)[16], int k0, float (&B)[8]) {
+#pragma unroll
+      for (int k = k0; k < k0 + 2; ++k) {
+        const ds2f t = __builtin_elementwise_fma(cp[2 * k + 1], q.w34, cp[2 * k] * q.w12);
+        B[k] = t[0] + t[1];
+      }
     };
     auto fixup = [&](const Geo& q, float (&B)[8]) {
       if (!pv || q.inwin) return;
@@ -361,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
     using I1 = std::integral_constant<int, 1>;
     {  // tap 0 of the chunk: nothing to hide behind
       Geo gq;
-      float c[32];
+      ds2f c[16];
       int fix = 0;
       om_issue(I0{}, om[0]);
       om_issue(I1{}, om[1]);
@@ -369,9 +367,9 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
       landed_om(om[1]);
       geom_a(I0{}, om[0], gq);
       geom_b1(gq); geom_b2(gq, fix);
-      corners_issue(gq.addr, c, 0); corners_issue(gq.addr, c, 1); corners_issue(gq.addr, c, 2); corners_issue(gq.addr, c, 3);
+      corners_issue(gq.addr, c, 0); corners_issue(gq.addr, c, 1);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
-      DCS_PIN8(c, 8); DCS_PIN8(c, 16); DCS_PIN8(c, 24);
+      DCS_PIN8(c, 8);
       blend2(gq, c, 0, Bf); blend2(gq, c, 2, Bf); blend2(gq, c, 4, Bf); blend2(gq, c, 6, Bf);
       if (fix) fixup(gq, Bf);
       split_pair(0, Bf); split_pair(1, Bf); split_pair(2, Bf); split_pair(3, Bf);
@@ -392,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
       using TN = std::integral_constant<int, (tap + 1 < KK ? tap + 1 : tap)>;
       using TNN = std::integral_constant<int, (tap + 2 < KK ? tap + 2 : tap)>;
       Geo gq;
-      float c[32];
+      ds2f c[16];
       int fix = 0;
       DCS_SB;
       if (nx) a_load(nxt, kc, tap + 1);
@@ -400,9 +398,9 @@ __global__ __launch_bounds__(256, 2) void mdcn_fwd_split_kernel(DcnK2 a) {
       DCS_MF(0, 0, 0);
       if (nx) { geom_b1(gq); geom_b2(gq, fix); }
       DCS_MF(0, 0, 1);
-      if (nx) { corners_issue(gq.addr, c, 0); corners_issue(gq.addr, c, 1); }
+      if (nx) corners_issue(gq.addr, c, 0);
       DCS_MF(0, 1, 0);
-      if (nx) { corners_issue(gq.addr, c, 2); corners_issue(gq.addr, c, 3); }
+      if (nx) corners_issue(gq.addr, c, 1);
       DCS_MF(0, 1, 1);
       if (tap + 2 < KK) om_issue(TNN{}, om[cur]);  // (om[cur] held this tap's values: consumed one tap ago)
       DCS_MF(2, 0, 0);
