@@ -56,6 +56,9 @@ struct Op {
   int pad_out = 0;
   struct T ypad;
   int fused_into = -1;
+  // OP_CONV: dual >= 0: this 1x1 conv and op `dual` (same input, 64 outputs each) run as ONE launch (conv1x1_dual.hip) when
+  // the tensors allow it; the partner carries fused_into = this op and launches nothing then.  The backward tape is unchanged.
+  int dual = -1;
   long long x0_bs = 0, x1_bs = 0;
   // streaming ops
   int S = 1;
@@ -336,6 +339,11 @@ static int build_plan(dvsr_edvr_plan& p) {
   }
   T fea = b.conv("tsa_fea", ffu, gated, Nf * C, none, 0, B, H, W, C, 1, 1, L);
   T att = b.conv("tsa_att1", s1, gated, Nf * C, none, 0, B, H, W, C, 1, 1, L);
+  {  // fea_fusion and sAtt_1 read the same 5 x 64-channel tensor (EDVR_arch.py:183-202): one pass over it
+    static const bool dual_on = [] { const char* v = getenv("DVSR_TSA_DUAL"); return !(v && v[0] == '0'); }();
+    const int ia = (int)p.ops.size() - 2, ib = ia + 1;
+    if (dual_on && C == 64 && !p.cfg.bf16_mfma) { p.ops[ia].dual = ib; p.ops[ib].fused_into = ia; }
+  }
   T pmx, pav;
   b.pool("tsa_pool1", att, (size_t)B * C, H, W, pmx, pav);
   att = b.conv("tsa_att2", s2, pmx, C, pav, C, B, H2, W2, C, 1, 1, L);
@@ -978,6 +986,17 @@ static int run_forward_op(const dvsr_edvr_plan& p, const Op& o, const float* con
       d.N = o.N; d.c0 = o.c0; d.c1 = o.c1; d.H = o.H; d.W = o.W; d.Cout = o.Cout; d.ks = o.ks;
       d.stride = o.stride; d.pad = conv_pad(o); d.act = o.act; d.pixel_shuffle = o.ps;
       if (o.pad_out) { d.y = bs.at(o.ypad); d.pixel_shuffle = o.pad_out; }
+      if (!bs.use_v1 && (o.dual >= 0 || o.fused_into >= 0)) {   // the pair of 1x1 convs over one input (see Op::dual)
+        const Op& oa = o.dual >= 0 ? o : p.ops[o.fused_into];
+        const Op& ob = p.ops[oa.dual];
+        const long long HW = (long long)oa.H * oa.W;
+        if (conv1x1_dual_ok(bs.at(oa.x0), P[oa.pw], P[ob.pw], bs.at(oa.y), bs.at(ob.y), oa.c0, HW)) {
+          if (o.fused_into >= 0) return DVSR_OK;   // the partner's launch wrote this op's output
+          return conv1x1_dual_run(bs.at(oa.x0), P[oa.pw], P[oa.pb], P[ob.pw], P[ob.pb], bs.at(oa.y), bs.at(ob.y), oa.N, oa.c0,
+                                  (int)HW, oa.act, st, p.wsets > 1 ? oa.N / p.wsets : 1,
+                                  p.wsets > 1 ? (long long)oa.Cout * oa.c0 : 0, p.wsets > 1 ? oa.Cout : 0);
+        }
+      }
       if (o.wmap) d.w = bs.arena + o.w2_off;
       d.x1_bdiv = o.x1_bdiv; d.x0_bstride = o.x0_bs; d.x1_bstride = o.x1_bs;
       if (bs.use_v1) return conv2d_run(d, ConvExtra(), st);

@@ -51,6 +51,10 @@ int pack_weights_wino3_run(const PackTable& t, hipStream_t st);  // conv2d_wino3
 int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo,
                       hipStream_t st);
 
+// conv1x1_dual.hip: two 1x1 convolutions (64 outputs each) over one input in one pass; x [N][Cin][HW], w [64][Cin]
+bool conv1x1_dual_ok(const float* x, const float* w0, const float* w1, const float* y0, const float* y1, int Cin, long long HW);
+int conv1x1_dual_run(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, float* y0, float* y1,
+                     int N, int Cin, int HW, int act, hipStream_t st, int wdiv = 1, long long w_gs = 0, int b_gs = 0);
 int conv3x3_small_cout_run(const float* x, const float* w, const float* bias, const float* res, float* y, int N,
                            int C, int H, int W, int Cout, int act, hipStream_t st, int wdiv = 1, long long w_gs = 0,
                            int b_gs = 0);

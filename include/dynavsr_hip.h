@@ -417,6 +417,14 @@ int dvsr_dynamic_filter_backward(const float* x_center, const float* filter_logi
                                  float* grad_logits, float* grad_residual, float* grad_x_center, int B, int H, int W,
                                  int scale, int adapt_official, dvsr_stream_t stream);
 
+/* ---- two 1x1 convolutions over one input (TSA fusion) ---------------------------------------------------
+ * EDVR_arch.py:183-202: fea = lrelu(fea_fusion(x)), att = lrelu(sAtt_1(x)) read the same [N][Cin][H][W] tensor (Cin = nframes *
+ * nf); one pass over it produces both [N][64][H][W] outputs.  w0 / w1: [64][Cin] (the modules' [64][Cin][1][1] weights), b0 /
+ * b1: [64] or NULL, act as in dvsr_conv2d_desc.  Needs Cin % 16 == 0, (H * W) % 4 == 0 and 16-byte aligned tensors; anything
+ * else returns DVSR_ERR_UNSUPPORTED (the plans fall back to two dvsr_conv2d launches). */
+int dvsr_conv1x1_dual(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, float* y0, float* y1,
+                      int N, int Cin, int H, int W, int act, dvsr_stream_t stream);
+
 /* ---- random patch crops of the inner step (train.maml.use_patch) -----------------------------------------
  * test_dynavsr.py:118-145 (and train_dynavsr.py:208-243) crop `num_patch` random patches out of the SLR clip and its
  * target with preprocessing.common_crop (data/meta_learner/preprocessing.py:57-85) and stack them into a batch.

@@ -231,3 +231,19 @@ def test_mfdn_stacked_tape_per_slice_weights(scale, k, t, h, w):
         assert relerr(y[i:i + 1], yi) < 1e-6
         bad = [(j, relerr(s_.grad[i], g_)) for j, (s_, g_) in enumerate(zip(stacked, gs)) if relerr(s_.grad[i], g_) > 1e-4]
         assert not bad, (i, bad)
+
+
+@pytest.mark.parametrize("below", ["0", "100000000"], ids=["never_row_split", "always_row_split"])
+def test_mfdn_gradients_under_both_weight_gradient_forms(below):
+    """The split weight gradient picks its form by launch size (conv2d_wgrad.hip: DVSR_WGRAD_S3_KYS_BELOW): small launches one
+    kernel row per workgroup, large ones all taps per workgroup.  The estimator's gradient tests (3x3 and the 2x2
+    space-to-depth form, float2 / float4 staging, ragged sizes, per-clip groups, 176x320) with either form forced on every
+    launch; the switch is read once per process, so they run in a child."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "vs_oracle_shapes or stacked_tape or golden"],
+                       env=dict(os.environ, DVSR_WGRAD_S3_KYS_BELOW=below), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout

@@ -329,6 +329,51 @@ def test_conv3x3_wgrad_split3(ops, n, cin, cout, h, w, pad):
     assert relerr(gb, gy.double().sum(dim=(0, 2, 3))) < 2e-6
 
 
+@pytest.mark.parametrize("env", [{"DVSR_WGRAD_S3_KYS_BELOW": "0"}, {"DVSR_WGRAD_S3V": "0"}, {"DVSR_WGRAD_S3_WGS": "96"}],
+                         ids=["one_workgroup_per_cu", "round4_schedule", "row_split_96_workgroups"])
+def test_conv3x3_wgrad_split3_other_schedules(env):
+    """test_conv3x3_wgrad_split3's shapes are small: by default they all run the row-split form of conv2d_wgrad_split3v_kernel
+    (one kernel row per workgroup, two workgroups per CU).  The same cases on the form with all nine taps per workgroup (what
+    the large layers run), on the round-4 kernel the A/B switch keeps, and on the row split with few workgroups (several tiles
+    per workgroup, the last one re-staged).  The switches are read once per process: each runs in a child."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "(test_conv3x3_wgrad_split3 and not other_schedules) or test_split_wgrad_scales_range_and_non_finite"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("n,cin,h,w,act", [(1, 320, 44, 80, 1), (2, 64, 9, 12, 0), (3, 16, 1, 4, 2), (1, 320, 180, 320, 1), (2, 112, 33, 20, 1)])
+def test_conv1x1_dual(ops, n, cin, h, w, act):
+    """conv1x1_dual_kernel (the TSA's fea_fusion + sAtt_1 over one input, EDVR_arch.py:183-202) against fp64: both outputs, the
+    three epilogues, pixel counts off the 128-pixel tiles (a partly filled last tile, a single 4-pixel group), one to twenty
+    16-channel chunks (the DMA ring with fewer chunks than stages), batches; and what it refuses."""
+    from dynavsr_amd import _lib as L
+    x = rnd(n, cin, h, w, seed=3)
+    w0, w1 = rnd(64, cin, seed=4) / cin ** 0.5, rnd(64, cin, seed=5) / cin ** 0.5
+    b0, b1 = rnd(64, seed=6), rnd(64, seed=7)
+    f = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.1), 2: F.relu}[act]
+    r0 = f(F.conv2d(x.double(), w0.double().view(64, cin, 1, 1), b0.double()))
+    r1 = f(F.conv2d(x.double(), w1.double().view(64, cin, 1, 1), b1.double()))
+    xg, g = dev(x), [dev(t) for t in (w0, b0, w1, b1)]
+    y0, y1 = torch.full((n, 64, h, w), float("nan"), device="cuda"), torch.full((n, 64, h, w), float("nan"), device="cuda")
+    L.check(L.lib().dvsr_conv1x1_dual(L.ptr(xg), L.ptr(g[0]), L.ptr(g[1]), L.ptr(g[2]), L.ptr(g[3]), L.ptr(y0), L.ptr(y1),
+                                      n, cin, h, w, act, L.stream()), "dvsr_conv1x1_dual")
+    assert relerr(y0, r0) < 2e-6 and relerr(y1, r1) < 2e-6, (relerr(y0, r0), relerr(y1, r1))
+    # no bias; and the shapes it leaves to the two-launch path
+    L.check(L.lib().dvsr_conv1x1_dual(L.ptr(xg), L.ptr(g[0]), None, L.ptr(g[2]), None, L.ptr(y0), L.ptr(y1),
+                                      n, cin, h, w, 0, L.stream()), "dvsr_conv1x1_dual")
+    assert relerr(y0, F.conv2d(x.double(), w0.double().view(64, cin, 1, 1))) < 2e-6
+    assert L.lib().dvsr_conv1x1_dual(L.ptr(xg), L.ptr(g[0]), None, L.ptr(g[2]), None, L.ptr(y0), L.ptr(y1),
+                                     n, cin - 8, h, w, 0, L.stream()) == -2          # Cin % 16
+    if (h * w) % 4 == 0 and w > 1:
+        assert L.lib().dvsr_conv1x1_dual(L.ptr(xg), L.ptr(g[0]), None, L.ptr(g[2]), None, L.ptr(y0), L.ptr(y1),
+                                         n, cin, h, w - 1, 0, L.stream()) in (-2, 0)  # (H * W) % 4 unless it happens to hold
+
+
 def test_inner_loss_tail(ops):
     """loss_pix + 10 * F.l1_loss(SLR, SLR_fixed) (test_dynavsr.py:264-274) as one native reduction: value, the
     pass-through gradient of the pixel loss, the sign gradient of the L1 term (sign(0) = 0 like torch), ragged
