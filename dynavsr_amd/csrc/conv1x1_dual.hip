@@ -7,14 +7,14 @@
 //   * a workgroup owns 128 CONSECUTIVE pixels of a sample (a 1x1 conv has no spatial structure: the plane is a flat array)
 //     and all 128 output channels: wave w computes the 32 channels (w & 1) * 32 .. of convolution w >> 1 for the 128 pixels
 //     (four 32x32 accumulator tiles); 450 workgroups at 1 x 180 x 320, two per CU;
-//   * x is read ONCE, by LDS-DMA into a three-stage ring of 16-channel chunks ([channel][pixel], 8 KB a stage): two chunks
+//   * x is read ONCE, by LDS-DMA into a three-stage ring of 16-channel chunks ([channel][pixel], 8 KB a stage, + 8 KB of weights): two chunks
 //     are in flight while one is consumed;
 //   * the MFMA's pixel index is permuted so that pixel block j holds the pixels {4 n + j}: lane n's B operands of the four
 //     blocks are ONE ds_read_b128 (x[c][4 n .. 4 n + 3]) and its sixteen results per output row are four consecutive pixels
 //     -- 16-byte stores;
-//   * the K index is permuted likewise: step i contracts channels (c0 + i, c0 + 8 + i), so lane half k reads the eight
-//     consecutive weights W[o][c0 + 8 k ..] as two 16-byte loads straight from the [Cout][Cin] parameter (no pack), one
-//     chunk ahead.
+//   * the K index is permuted likewise: step i contracts channels (c0 + i, c0 + 8 + i), so lane half k needs the eight
+//     consecutive weights W[o][c0 + 8 k ..]: the chunk's 128 x 16 weights ride in the same ring, DMAed straight from the
+//     [Cout][Cin] parameters (no pack) in a channel-group-major order that makes the operand reads conflict-free.
 // fp32 throughout (v_mfma_f32_32x32x2_f32: an fmaf chain per output, channel order 0, 8, 1, 9, ... within a chunk).
 #include "common.h"
 #include "kernels.h"
@@ -30,44 +30,46 @@ struct Dual1x1K {
 constexpr int D1_PX = 128, D1_CH = 16, D1_NST = 3;
 
 __global__ __launch_bounds__(256, 2) void conv1x1_dual_kernel(Dual1x1K a) {
-  __shared__ __attribute__((aligned(16))) float s_x[D1_NST][D1_CH * D1_PX];
+  // ring stage = [16 channels][128 pixels] of x, then the chunk's weights as [4 channel groups][128 couts][4 channels]
+  __shared__ __attribute__((aligned(16))) float s_r[D1_NST][2 * D1_CH * D1_PX];
   const int tile = blockIdx.x;
   const int n = tile / a.tiles_per_img, p0 = (tile - n * a.tiles_per_img) * D1_PX;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nn = lane & 31, k = lane >> 5;
   const int conv = wave >> 1, cw = (wave & 1) * 32;
-  const float* wsel = wset_ptr(conv ? a.w1 : a.w0, a.w_gs, n, a.wdiv);
   const float* bsel = wset_ptr(conv ? a.b1 : a.b0, a.b_gs, n, a.wdiv);
   const float* xn = a.x + (size_t)n * a.Cin * a.HW;
   const int nchunks = a.Cin / D1_CH;
 
-  // DMA map: group q = 64 (wave + 4 j) + lane = (channel q / 32 of the chunk, pixels 4 (q % 32) ..); pixels past the plane
-  // re-read its last group (they only feed outputs that are never stored)
-  unsigned doff[2];
+  // DMA maps (one instruction = 64 lanes x 16 bytes, written to the LDS in lane order).
+  // x: slot q = 64 (wave + 4 j) + lane = (channel q / 32 of the chunk, pixels 4 (q % 32) ..); pixels past the plane re-read its
+  //    last group (they only feed outputs that are never stored).
+  // w: slot q = (channel group q / 128, cout q % 128): four consecutive input channels of one output row, straight from the
+  //    [64][Cin] parameters (couts 64 .. 127 = the second convolution) -- group-major, so that the 32 lanes of an operand read
+  //    touch consecutive 16-byte slots.
+  const char* xsrc[2];
+  const char* wsrc[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int q = 64 * (wave + 4 * j) + lane;
     int px = p0 + 4 * (q & 31);
     px = px < a.HW ? px : a.HW - 4;
-    doff[j] = (unsigned)(((size_t)(q >> 5) * a.HW + px) * 4);
+    xsrc[j] = reinterpret_cast<const char*>(xn + (size_t)(q >> 5) * a.HW + px);
+    const int co = q & 127, g = q >> 7;
+    const float* wb = wset_ptr(co < 64 ? a.w0 : a.w1, a.w_gs, n, a.wdiv);
+    wsrc[j] = reinterpret_cast<const char*>(wb + (size_t)(co & 63) * a.Cin + 4 * g);
   }
   auto dma = [&](int kc, int stage) __attribute__((always_inline)) {
-    const char* src = reinterpret_cast<const char*>(xn + (size_t)kc * D1_CH * a.HW);
+    const size_t xo = (size_t)kc * D1_CH * a.HW * 4, wo = (size_t)kc * D1_CH * 4;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + doff[j]),
-                                       (__attribute__((address_space(3))) void*)(&s_x[stage][256 * (wave + 4 * j)]), 16, 0, 0);
-  };
-  // A operands of a chunk: W[cw + nn][16 kc + 8 k .. + 7]
-  const float* wrow = wsel + (size_t)(cw + nn) * a.Cin + 8 * k;
-  // the NEXT chunk's weights, in flight.  Inline-asm loads: with compiler-visible VMEM loads next to the LDS-DMAs the waitcnt
-  // pass falls back to vmcnt(0) (mixed event kinds on one counter); the explicit waits below carry An as an operand, so no
-  // use can move above them
-  f32x4 An[2];
-  auto load_a = [&](int kc) __attribute__((always_inline)) {
-    const float* pa = wrow + kc * D1_CH;
-    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(An[0]), "=&v"(An[1]) : "v"(pa) : "memory");
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[j] + xo),
+                                       (__attribute__((address_space(3))) void*)(&s_r[stage][256 * (wave + 4 * j)]), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + wo),
+                                       (__attribute__((address_space(3))) void*)(&s_r[stage][D1_CH * D1_PX + 256 * (wave + 4 * j)]), 16, 0, 0);
   };
 
   f32x16 acc[4];
@@ -76,45 +78,42 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dual_kernel(Dual1x1K a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // The loop body is branch-free: past the last chunk it re-fetches the last one (weights into An, the chunk into the stage
-  // chunk kc - 1 just left), so that every iteration issues the same four VMEM instructions and the queue position of each
-  // is static -- with conditional issues the compiler waits for vmcnt(0) behind the barrier.
+  // Every VMEM instruction of the loop is an LDS-DMA, four per chunk, and the body is branch-free (past the last chunk it
+  // re-fetches the last one into the stage chunk kc - 1 just left): the queue position of each is static and the waits are
+  // explicit.  (With compiler-tracked loads beside the DMAs the waitcnt pass put a vmcnt(0) behind the barrier, i.e. waited
+  // for the chunk that had just been put in flight; __syncthreads does the same.)  The LDS reads are inline asm for the same
+  // reason: the compiler cannot tell which stage a DMA in flight writes.
   const int last = nchunks - 1;
-  load_a(0);
   dma(0, 0);
   dma(last < 1 ? last : 1, 1);
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) const float*)&s_r[0][0]);
+  const unsigned xrd = (unsigned)(((8 * k) * D1_PX + 4 * nn) * 4);                                   // x[8 k + i][4 nn ..]
+  const unsigned wrd = (unsigned)((D1_CH * D1_PX + (2 * k) * 512 + (conv * 64 + cw + nn) * 4) * 4);   // w[cout][8 k .. 8 k + 7]
   for (int kc = 0; kc < nchunks; ++kc) {
-    // vmcnt counts in order; newest first the queue holds [DMA(kc + 1) x 2] [A(kc) x 2] [DMA(kc) x 2]: everything but the newest
-    // two instructions has landed.  (A raw s_barrier, not __syncthreads: that one waits for vmcnt(0), i.e. for the chunk
-    // that was just put in flight.)
-    asm volatile("s_waitcnt vmcnt(2)" : "+v"(An[0]), "+v"(An[1]) : : "memory");
-    __builtin_amdgcn_s_barrier();   // chunk kc is in the LDS for every wave; every wave is done with chunk kc - 1 (its stage is refilled below)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // newest first: [chunk kc + 1: 4 DMAs] [chunk kc: 4 DMAs] -- chunk kc has landed
+    __builtin_amdgcn_s_barrier();   // ... for every wave, and every wave is done with chunk kc - 1 (its stage is refilled below)
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 Ac[2] = {An[0], An[1]};
-    asm volatile("" : "+v"(Ac[0]), "+v"(Ac[1]));   // (a copy, so that the loads below can overwrite An)
-    load_a(kc + 1 < last ? kc + 1 : last);
     dma(kc + 2 < last ? kc + 2 : last, (kc + 2) % D1_NST);
-    __builtin_amdgcn_sched_barrier(0);   // (the loads go out before the MFMAs of this chunk)
-    // (inline-asm reads: behind visible LDS reads the compiler waits for vmcnt(0) -- it cannot tell which ring stage the DMAs in
-    // flight write -- which would serialise the ring)
-    const unsigned sb = (unsigned)(size_t)((__attribute__((address_space(3))) const float*)&s_x[kc % D1_NST][(8 * k) * D1_PX + 4 * nn]);
-    f32x4 b[8];
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned sb = lds0 + (unsigned)((kc % D1_NST) * (2 * D1_CH * D1_PX * 4));
+    f32x4 b[8], wv[2];
     asm volatile(
-        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:512\n\tds_read_b128 %2, %8 offset:1024\n\tds_read_b128 %3, %8 offset:1536\n\t"
-        "ds_read_b128 %4, %8 offset:2048\n\tds_read_b128 %5, %8 offset:2560\n\tds_read_b128 %6, %8 offset:3072\n\tds_read_b128 %7, %8 offset:3584\n\t"
+        "ds_read_b128 %8, %11\n\tds_read_b128 %9, %11 offset:2048\n\t"
+        "ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:512\n\tds_read_b128 %2, %10 offset:1024\n\tds_read_b128 %3, %10 offset:1536\n\t"
+        "ds_read_b128 %4, %10 offset:2048\n\tds_read_b128 %5, %10 offset:2560\n\tds_read_b128 %6, %10 offset:3072\n\tds_read_b128 %7, %10 offset:3584\n\t"
         "s_waitcnt lgkmcnt(0)"
-        : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
-        : "v"(sb));
-    static_assert(D1_PX * 4 == 512, "the read offsets hard-code the row pitch");
+        : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7]), "=&v"(wv[0]), "=&v"(wv[1])
+        : "v"(sb + xrd), "v"(sb + wrd));
+    static_assert(D1_PX * 4 == 512 && 128 * 16 == 2048, "the read offsets hard-code the pitches");
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float av = Ac[i >> 2][i & 3];
+      const float av = wv[i >> 2][i & 3];
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[i][j], acc[j], 0, 0, 0);
     }
-    // (the LDS reads of this chunk have returned -- the MFMAs consumed them -- before any wave passes the next barrier)
+    // (the LDS reads of this chunk have returned -- the asm waits for them -- before any wave passes the next barrier)
   }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(An[0]), "+v"(An[1]) : : "memory");   // no DMA may still be writing this workgroup's LDS when it ends
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be writing this workgroup's LDS when it ends
 
   const int px = p0 + 4 * nn;
   if (px >= a.HW) return;
