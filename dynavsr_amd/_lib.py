@@ -141,6 +141,7 @@ def _declare(lib):
         "dvsr_temporal_gather3_backward": (I, [P, P, I, I, I, LL, I, P]),
         "dvsr_dynamic_filter_forward": (I, [P, P, P, P, I, I, I, I, I, P]),
         "dvsr_dynamic_filter_backward": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+        "dvsr_conv3x3_small_cout": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
         "dvsr_conv1x1_dual": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
         "dvsr_patch_gather_forward": (I, [P, P, POINTER(c_int), POINTER(c_int), I, I, I, I, I, I, P]),
         "dvsr_patch_gather_backward": (I, [P, P, POINTER(c_int), POINTER(c_int), I, I, I, I, I, I, P]),

@@ -417,6 +417,14 @@ int dvsr_dynamic_filter_backward(const float* x_center, const float* filter_logi
                                  float* grad_logits, float* grad_residual, float* grad_x_center, int B, int H, int W,
                                  int scale, int adapt_official, dvsr_stream_t stream);
 
+/* ---- 3x3 convolution with very few outputs (EDVR's conv_last: 64 -> 3 at the HR size) -------------------------
+ * y = act(conv3x3(x, w) + bias) [+ res], stride 1, zero padding 1, Cout <= 4; x [N][C][H][W], w [Cout][C][3][3], res / y
+ * [N][Cout][H][W] (res may be NULL: EDVR_arch.py:311-312 adds the bilinear base frame here).  C = 64, Cout <= 3, W % 4 == 0
+ * and 16-byte aligned tensors run as a 9 Cout-row GEMM on the fp32 matrix pipe + a shift-add; everything else on the
+ * vector ALU. */
+int dvsr_conv3x3_small_cout(const float* x, const float* w, const float* bias, const float* res, float* y, int N, int C, int H,
+                            int W, int Cout, int act, dvsr_stream_t stream);
+
 /* ---- two 1x1 convolutions over one input (TSA fusion) ---------------------------------------------------
  * EDVR_arch.py:183-202: fea = lrelu(fea_fusion(x)), att = lrelu(sAtt_1(x)) read the same [N][Cin][H][W] tensor (Cin = nframes *
  * nf); one pass over it produces both [N][64][H][W] outputs.  w0 / w1: [64][Cin] (the modules' [64][Cin][1][1] weights), b0 /

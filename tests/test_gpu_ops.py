@@ -374,6 +374,48 @@ def test_conv1x1_dual(ops, n, cin, h, w, act):
                                          n, cin, h, w - 1, 0, L.stream()) in (-2, 0)  # (H * W) % 4 unless it happens to hold
 
 
+def _small_cout_case(n, c, cout, h, w, act, with_res):
+    from dynavsr_amd import _lib as L
+    x, wt, b = rnd(n, c, h, w, seed=3), rnd(cout, c, 3, 3, seed=4) / (3 * c ** 0.5), rnd(cout, seed=5)
+    res = rnd(n, cout, h, w, seed=6) if with_res else None
+    f = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.1), 2: F.relu}[act]
+    ref = f(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    if with_res:
+        ref = ref + res.double()
+    y = torch.full((n, cout, h, w), float("nan"), device="cuda")
+    xg, wg, bg = dev(x), dev(wt), dev(b)
+    rg = dev(res) if with_res else None
+    L.check(L.lib().dvsr_conv3x3_small_cout(L.ptr(xg), L.ptr(wg), L.ptr(bg), L.ptr(rg), L.ptr(y), n, c, h, w, cout, act,
+                                            L.stream()), "dvsr_conv3x3_small_cout")
+    assert relerr(y, ref) < 2e-6, relerr(y, ref)
+
+
+@pytest.mark.parametrize("n,c,cout,h,w,act,with_res", [(1, 64, 3, 176, 320, 0, True), (2, 64, 3, 13, 60, 1, False),
+                                                       (1, 64, 1, 6, 56, 0, True), (1, 64, 2, 7, 116, 2, True),
+                                                       (3, 64, 3, 5, 4, 0, False), (1, 64, 3, 720, 1280, 0, True),
+                                                       (1, 32, 3, 20, 36, 0, True), (1, 64, 4, 9, 20, 1, False),
+                                                       (2, 64, 3, 10, 30, 0, True)])
+def test_conv3x3_small_cout(ops, n, c, cout, h, w, act, with_res):
+    """EDVR's conv_last (64 -> 3 + the base frame, EDVR_arch.py:307-312) at op level against fp64: whole tiles, tiles cut by
+    either image edge, images smaller than a tile, 1 - 4 outputs, the three epilogues, batches, the 720 x 1280 layer, 32
+    channels, a width off the 16-byte groups."""
+    _small_cout_case(n, c, cout, h, w, act, with_res)
+
+
+def test_conv3x3_small_cout_matrix_pipe_form():
+    """The same cases with DVSR_CONV_LAST_MFMA=1: conv3x3_small_cout_mfma_kernel (a 27-row GEMM over the halo tile on the fp32
+    matrix pipe + a shift-add through the LDS; built in round 5, measured no faster than the vector-ALU kernel and therefore
+    off by default).  The switch is read once per process: a child."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "test_conv3x3_small_cout and not matrix_pipe_form"],
+                       env=dict(os.environ, DVSR_CONV_LAST_MFMA="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
 def test_inner_loss_tail(ops):
     """loss_pix + 10 * F.l1_loss(SLR, SLR_fixed) (test_dynavsr.py:264-274) as one native reduction: value, the
     pass-through gradient of the pixel loss, the sign gradient of the L1 term (sign(0) = 0 like torch), ragged
