@@ -857,6 +857,227 @@ __global__ __launch_bounds__(256, KYS ? 2 : 1) void conv2d_wgrad_split3v_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5 (late): the same tile on EIGHT waves -- two per SIMD WITHOUT staging anything twice (the row split above pays for
+// its second wave with gy three times and x one and a half times).  Wave (ot = wave & 1, ct = wave >> 1) owns 32 output
+// channels x 16 input channels on v_mfma_f32_16x16x32_bf16: K = 32 = one pixel row of the tile, two A blocks (16 couts each)
+// share a B block, 9 taps x 2 x 4 = 72 accumulator registers.  Six steps per tile (pixel row py, kernel row ty) of 36 MFMAs;
+// per step six 16-byte operand reads for B (+ six for A when py changes) and the same 36 shuffle instructions as the
+// four-wave form -- half the vector work per wave, and what is left runs beside the partner wave's MFMAs.  A wave stages 8
+// channels of either operand.  Same LDS images, same arithmetic, same flush.
+template <int KS, int VX, int SHIFT>
+__global__ __launch_bounds__(512, 2) void conv2d_wgrad_split3w_kernel(WgradK a) {
+  static_assert(VX == 2 || VX == 4, "vector staging only");
+  constexpr int NT = KS * KS, XR = 1 + KS, XC = 31 + KS;
+  constexpr int XCH0 = XR * S3_XROW + 8, XCH = (XCH0 / 8) % 2 ? XCH0 : XCH0 + 8, XP = 64 * XCH;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
+  __bf16* const s_g = smem16;
+  __bf16* const s_x = smem16 + 3 * S3_GP;
+  constexpr int WWIN = ((XC + 2 * (VX - 1)) / VX) * VX;
+  constexpr int RV = WWIN / VX, XV = XR * RV;
+  constexpr int XM = (8 * XV + 63) / 64;
+  typedef float xvec __attribute__((ext_vector_type(VX)));
+  typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+  const int split = blockIdx.x, ob = blockIdx.y, cbk = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, kg = lane >> 4;
+  const int ot = wave & 1, ct = wave >> 1;
+  const unsigned HW = (unsigned)a.H * a.W, HWo = (unsigned)a.Ho * a.Wo;
+
+  f32x4w acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[t][b] = f32x4w{0.f, 0.f, 0.f, 0.f};
+
+  // ---- lane-fixed staging map (8 channels of gy and of x per wave)
+  unsigned g_rel[2], x_rel[XM];
+  int g_row[2], g_col[2], x_row[XM], x_col[XM], g_lds[2], x_lds[XM];
+  bool g_cok[2], x_cok[XM];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int idx = lane + 64 * m;
+    const int ch = idx >> 4;
+    g_row[m] = (idx >> 3) & 1; g_col[m] = (idx & 7) * 4;
+    const int co = ob * 64 + wave * 8 + ch;
+    g_cok[m] = co < a.Cout;
+    g_rel[m] = ((unsigned)(g_cok[m] ? co : 0) * HWo + (unsigned)g_row[m] * a.Wo + g_col[m]) * 4u;
+    g_lds[m] = (wave * 8 + ch) * S3_GROW + g_row[m] * 32 + g_col[m];
+  }
+#pragma unroll
+  for (int m = 0; m < XM; ++m) {
+    const int idx = lane + 64 * m;
+    const int c = idx / XV, r = idx - c * XV;
+    x_row[m] = r / RV; x_col[m] = (r - x_row[m] * RV) * VX;
+    const int ci = cbk * 64 + wave * 8 + c;
+    x_cok[m] = c < 8 && ci < a.Cin;
+    x_rel[m] = ((unsigned)(x_cok[m] ? ci : 0) * HW + (unsigned)x_row[m] * a.W + x_col[m]) * 4u;
+    x_lds[m] = c < 8 ? (wave * 8 + c) * XCH + x_row[m] * S3_XROW + x_col[m] : -1;
+  }
+
+  f32x4 vg[2];
+  xvec vx[XM];
+  bool vg_ok[2], vx_ok[XM];
+  auto issue_loads = [&](int tile) __attribute__((always_inline)) {
+    const int tx_ = tile % a.tiles_x;
+    const int t2 = tile / a.tiles_x;
+    const int ty_ = t2 % a.tiles_y;
+    const int n = t2 / a.tiles_y;
+    const int oy0 = ty_ * 2, ox0 = tx_ * 32;
+    const char* gn = reinterpret_cast<const char*>(a.gy + (size_t)n * a.Cout * HWo);
+    const unsigned g_tile = ((unsigned)oy0 * a.Wo + ox0) * 4u;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      vg_ok[m] = g_cok[m] && oy0 + g_row[m] < a.Ho && ox0 + g_col[m] < a.Wo;
+      vg[m] = *reinterpret_cast<const f32x4*>(gn + (vg_ok[m] ? g_rel[m] + g_tile : 0u));
+    }
+    const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad - SHIFT;
+    const char* xn = reinterpret_cast<const char*>(a.x + (size_t)(n / a.x_bdiv) * a.x_bs);
+    const unsigned x_tile = (unsigned)(iy0 * a.W + ix0) * 4u;
+#pragma unroll
+    for (int m = 0; m < XM; ++m) {
+      vx_ok[m] = x_cok[m] && (unsigned)(iy0 + x_row[m]) < (unsigned)a.H && (unsigned)(ix0 + x_col[m]) < (unsigned)a.W;
+      vx[m] = *reinterpret_cast<const xvec*>(xn + (vx_ok[m] ? x_rel[m] + x_tile : 0u));
+    }
+  };
+
+  unsigned wg0[2][3], wg1[2][3], wx0[XM][3], wx1[XM][3];
+  float dbl[2] = {0.f, 0.f};
+  float db_on = 1.f;
+  auto convert_g = [&](int m) __attribute__((always_inline)) {
+    const f32x4 v = vg_ok[m] ? vg[m] : f32x4{0.f, 0.f, 0.f, 0.f};
+    dbl[m] = __builtin_fmaf(db_on, (v[0] + v[1]) + (v[2] + v[3]), dbl[m]);
+    split3_pair_v(v[0], v[1], wg0[m][0], wg0[m][1], wg0[m][2]);
+    split3_pair_v(v[2], v[3], wg1[m][0], wg1[m][1], wg1[m][2]);
+  };
+  auto convert_x = [&](int m) __attribute__((always_inline)) {
+    xvec v = vx[m];
+    if (!vx_ok[m]) {
+#pragma unroll
+      for (int e = 0; e < VX; ++e) v[e] = 0.f;
+    }
+    split3_pair_v(v[0], v[1], wx0[m][0], wx0[m][1], wx0[m][2]);
+    if (VX == 4) split3_pair_v(v[VX == 4 ? 2 : 0], v[VX == 4 ? 3 : 0], wx1[m][0], wx1[m][1], wx1[m][2]);
+  };
+  auto store_words = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        *reinterpret_cast<wbf16x4*>(s_g + q * S3_GP + g_lds[m]) = __builtin_bit_cast(wbf16x4, uint2{wg0[m][q], wg1[m][q]});
+#pragma unroll
+    for (int m = 0; m < XM; ++m) {
+      if (x_lds[m] < 0) continue;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (VX == 4) *reinterpret_cast<wbf16x4*>(s_x + q * XP + x_lds[m]) = __builtin_bit_cast(wbf16x4, uint2{wx0[m][q], wx1[m][q]});
+        else *reinterpret_cast<wbf16x2*>(s_x + q * XP + x_lds[m]) = __builtin_bit_cast(wbf16x2, wx0[m][q]);
+      }
+    }
+  };
+
+  // operands: A[block][piece] = gy[ot*32 + block*16 + l16][row py, pixels 8 kg ..]; R0 / R1 [piece] = x[ct*16 + l16][row py + ty,
+  // window columns 8 kg .. 8 kg + 15]
+  wbf16x8 A[2][3], R0[2][3], R1[2][3];
+  const __bf16* const a_base = s_g + (ot * 32 + l16) * S3_GROW + 8 * kg;
+  const __bf16* const b_base = s_x + (ct * 16 + l16) * XCH + 8 * kg;
+  auto load_a = [&](int py) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) A[b][q] = *reinterpret_cast<const wbf16x8*>(a_base + q * S3_GP + b * 16 * S3_GROW + py * 32);
+  };
+  auto load_r = [&](int row, int rb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const __bf16* bp = b_base + q * XP + row * S3_XROW;
+      R0[rb][q] = *reinterpret_cast<const wbf16x8*>(bp);
+      R1[rb][q] = *reinterpret_cast<const wbf16x8*>(bp + 8);
+    }
+  };
+
+  const WgSpan sp = wg_span(a, split);
+  int tile = sp.tile0;
+  if (tile < sp.tile_end) {
+    issue_loads(tile);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) convert_g(m);
+#pragma unroll
+    for (int m = 0; m < XM; ++m) convert_x(m);
+  }
+  for (; tile < sp.tile_end; tile += a.nsplit) {
+    store_words();
+    const bool has_next = tile + a.nsplit < sp.tile_end;
+    const int tnext = has_next ? tile + a.nsplit : tile;
+    db_on = has_next ? 1.f : 0.f;
+    __syncthreads();
+    load_a(0);
+    load_r(0, 0);
+    static_for<0, 2 * KS>([&](auto st_) __attribute__((always_inline)) {
+      constexpr int st = decltype(st_)::value;
+      constexpr int py = st / KS, ty = st - py * KS, rb = st & 1;
+      // this step's B fragments out of R[rb] (read one step ago); then the next step's reads go out, pinned above the MFMAs
+      wbf16x8 B[3][3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const wbf16x8 r0 = R0[rb][q], r1 = R1[rb][q];
+        B[q][0] = __builtin_shufflevector(r0, r1, SHIFT, SHIFT + 1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7);
+        B[q][1] = __builtin_shufflevector(r0, r1, SHIFT + 1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7, SHIFT + 8);
+        B[q][2] = __builtin_shufflevector(r0, r1, SHIFT + 2, SHIFT + 3, SHIFT + 4, SHIFT + 5, SHIFT + 6, SHIFT + 7, SHIFT + 8, SHIFT + 9);
+      }
+      if constexpr (st + 1 < 2 * KS) load_r((st + 1) / KS + (st + 1) % KS, rb ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (st == 0) issue_loads(tnext);
+      constexpr int QA[6] = {0, 0, 1, 0, 2, 1}, QB[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[ty * KS + tx][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][QA[pr]], B[QB[pr]][tx], acc[ty * KS + tx][b], 0, 0, 0);
+      // (A of the second pixel row: after the last MFMAs that read the first row's)
+      if constexpr (st == KS - 1) load_a(1);
+      // the next tile's vectors: converted behind the last steps (registers only)
+      constexpr int CS = 2 * KS - 2;
+      if constexpr (st >= 2 * KS - CS) {
+        constexpr int j = st - (2 * KS - CS);
+        constexpr int perx = (XM + CS - 1) / CS;
+        if (j < 2) convert_g(j);
+#pragma unroll
+        for (int u = 0; u < perx; ++u)
+          if (j * perx + u < XM) convert_x(j * perx + u);
+      }
+    });
+    __syncthreads();
+  }
+
+  // ---- partial[slot][tap][o][c]: D rows = 4 kg + r (couts), column = l16 (input channel)
+  const int OP = a.nob * 64, CP = a.ncb * 64;
+  const int slot = sp.slot;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = ob * 64 + ot * 32 + b * 16 + 4 * kg + r;
+        const int c = cbk * 64 + ct * 16 + l16;
+        unsafeAtomicAdd(a.partial + (((size_t)slot * NT + t) * OP + o) * CP + c, acc[t][b][r]);
+      }
+  if (cbk == 0) {   // lanes 16 k .. 16 k + 15 staged channel (lane >> 4) + 4 m of this wave's 8
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float v = dbl[m];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+      const int co = ob * 64 + wave * 8 + (lane >> 4) + 4 * m;
+      if ((lane & 15) == 0 && co < OP) unsafeAtomicAdd(a.dbp + (size_t)slot * OP + co, v);
+    }
+  }
+}
+
 template <int KS, int VX, int SHIFT>
 static int launch_split3(const WgradLaunch& l, hipStream_t st) {
   if constexpr (VX != 0) {
@@ -872,6 +1093,17 @@ static int launch_split3(const WgradLaunch& l, hipStream_t st) {
       set_dyn_lds_once(attr_once_k, (const void*)kv, lds);
       hipLaunchKernelGGL(kv, l.grid, dim3(256), lds, st, l.k);
       return check_launch("conv2d_wgrad_split3v_kernel<kys>");
+    }
+    // the eight-wave form (two waves per SIMD, 16x16x32 MFMAs) for the float4-staged launches that are not row-split: 7 - 14 %
+    // per launch over the four-wave form (profiles/r05_wgrad_s3w.txt); the float2 forms spill there and stay on four waves.
+    // DVSR_WGRAD_S3W=0: A/B switch, read once per process
+    static const bool s3w = [] { const char* v = getenv("DVSR_WGRAD_S3W"); return !(v && v[0] == '0'); }();
+    if (s3v && fits && s3w && VX == 4) {
+      auto kw = conv2d_wgrad_split3w_kernel<KS, VX, SHIFT>;
+      static PerDeviceOnce attr_once_w;
+      set_dyn_lds_once(attr_once_w, (const void*)kw, S3_LDS_BYTES);
+      hipLaunchKernelGGL(kw, l.grid, dim3(512), S3_LDS_BYTES, st, l.k);
+      return check_launch("conv2d_wgrad_split3w_kernel");
     }
     if (s3v && fits) {
       auto kv = conv2d_wgrad_split3v_kernel<KS, VX, SHIFT, false>;

@@ -21,7 +21,7 @@ _GEOMETRY_ENV = ("DVSR_CONV_WINO", "DVSR_CONV_WINO3", "DVSR_CONV_V1", "DVSR_EST_
 # effect, so they are deliberately NOT in the key -- set them before the first call (the A/B tools run one process per value).
 _PROCESS_ENV = ("DVSR_CONV_WINO_T16", "DVSR_CONV_WINO3_BLK", "DVSR_CONV_DMA", "DVSR_CONV_DMAROW", "DVSR_CONV_TILE",
                 "DVSR_CONV_KSPLIT_BELOW", "DVSR_CONV_KSPLIT_NT", "DVSR_CONV_CC16_BELOW", "DVSR_SPLIT_TH8_FROM", "DVSR_WGRAD_SPLIT3",
-                "DVSR_WGRAD_SPLITS", "DVSR_WGRAD_S3V", "DVSR_WGRAD_S3_KYS_BELOW", "DVSR_WGRAD_S3_WGS", "DVSR_DCN_FWD", "DVSR_DCN_BWD", "DVSR_EST_FUSE_PAD", "DVSR_FUSE_RES_BWD", "DVSR_BWD_FORK_EVERY",
+                "DVSR_WGRAD_SPLITS", "DVSR_WGRAD_S3V", "DVSR_WGRAD_S3_KYS_BELOW", "DVSR_WGRAD_S3_WGS", "DVSR_WGRAD_S3W", "DVSR_DCN_FWD", "DVSR_DCN_BWD", "DVSR_EST_FUSE_PAD", "DVSR_FUSE_RES_BWD", "DVSR_BWD_FORK_EVERY",
                 "DVSR_BWD_PROBE", "DVSR_TSA_DUAL")
 
 

@@ -329,13 +329,15 @@ def test_conv3x3_wgrad_split3(ops, n, cin, cout, h, w, pad):
     assert relerr(gb, gy.double().sum(dim=(0, 2, 3))) < 2e-6
 
 
-@pytest.mark.parametrize("env", [{"DVSR_WGRAD_S3_KYS_BELOW": "0"}, {"DVSR_WGRAD_S3V": "0"}, {"DVSR_WGRAD_S3_WGS": "96"}],
-                         ids=["one_workgroup_per_cu", "round4_schedule", "row_split_96_workgroups"])
+@pytest.mark.parametrize("env", [{"DVSR_WGRAD_S3_KYS_BELOW": "0"}, {"DVSR_WGRAD_S3_KYS_BELOW": "0", "DVSR_WGRAD_S3W": "0"},
+                                 {"DVSR_WGRAD_S3V": "0"}, {"DVSR_WGRAD_S3_WGS": "96"}],
+                         ids=["eight_waves", "four_waves", "round4_schedule", "row_split_96_workgroups"])
 def test_conv3x3_wgrad_split3_other_schedules(env):
     """test_conv3x3_wgrad_split3's shapes are small: by default they all run the row-split form of conv2d_wgrad_split3v_kernel
-    (one kernel row per workgroup, two workgroups per CU).  The same cases on the form with all nine taps per workgroup (what
-    the large layers run), on the round-4 kernel the A/B switch keeps, and on the row split with few workgroups (several tiles
-    per workgroup, the last one re-staged).  The switches are read once per process: each runs in a child."""
+    (one kernel row per workgroup, two workgroups per CU).  The same cases on the forms with all nine taps per workgroup (what
+    the large layers run: eight waves on 16x16x32 MFMAs for the float4-staged launches, four waves on 32x32x16 for the rest
+    and under DVSR_WGRAD_S3W=0), on the round-4 kernel the A/B switch keeps, and on the row split with few workgroups (several
+    tiles per workgroup, the last one re-staged).  The switches are read once per process: each runs in a child."""
     import os
     import subprocess
     import sys
