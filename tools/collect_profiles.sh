@@ -148,14 +148,15 @@ echo "== split (default)" >> $out/${tag}_dcn_fwd_split_vs_dma.txt
 grep -E "mdcn|total" $out/${tag}_per_launch_fwd180x320.txt >> $out/${tag}_dcn_fwd_split_vs_dma.txt
 # r05 (late): the split weight gradient -- round-4 schedule, re-scheduled, re-scheduled + row split -- per launch and in the
 # batched inner step; its timeline (debug build)
-for cfg in "DVSR_WGRAD_S3V=0" "DVSR_WGRAD_S3_KYS_BELOW=0" "DVSR_WGRAD_S3_KYS_BELOW=4000"; do
+for cfg in "DVSR_WGRAD_S3V=0" "DVSR_WGRAD_S3_KYS_BELOW=0 DVSR_WGRAD_S3W=0" "DVSR_WGRAD_S3_KYS_BELOW=0" "DVSR_WGRAD_S3_KYS_BELOW=4000"; do
   echo "== $cfg" >> $out/${tag}_wgrad_s3v_collect.txt
   env $cfg python tools/wgrad_bench.py 30 2>&1 | grep split >> $out/${tag}_wgrad_s3v_collect.txt
   env $cfg WGRAD_BENCH_BATCHED=1 python tools/wgrad_bench.py 30 2>&1 | grep split >> $out/${tag}_wgrad_s3v_collect.txt
   env $cfg python tools/inner_batch_bench.py 2>&1 | grep -E "batch of 8|per-frame loop" >> $out/${tag}_wgrad_s3v_collect.txt
 done
 if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
-  python tools/wgrad_trace.py 40 64 64 44 80 2>&1 | grep -v amdgpu > $out/${tag}_wgrad_trace_collect.txt
-  DVSR_WGRAD_S3_KYS_BELOW=0 python tools/wgrad_trace.py 40 64 64 44 80 2>&1 | grep -v amdgpu >> $out/${tag}_wgrad_trace_collect.txt
+  # (the stamps are in the four-wave forms: conv2d_wgrad_split3v_kernel, row-split and not)
+  DVSR_WGRAD_S3W=0 python tools/wgrad_trace.py 40 64 64 44 80 2>&1 | grep -v amdgpu > $out/${tag}_wgrad_trace_collect.txt
+  DVSR_WGRAD_S3W=0 DVSR_WGRAD_S3_KYS_BELOW=0 python tools/wgrad_trace.py 40 64 64 44 80 2>&1 | grep -v amdgpu >> $out/${tag}_wgrad_trace_collect.txt
 fi
 du -sh gpurun_out
