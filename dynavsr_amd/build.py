@@ -16,7 +16,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # per-file flags.  conv2d_wino4.hip: the SLP vectoriser turns the split's residual subtractions into v_pk_add_f32 on register
 # pairs it has to assemble with moves (36 v_mov per chunk) -- and packed fp32 is slower beside MFMAs anyway (MI355X guide).
-EXTRA = {"conv2d_wino4.hip": ["-fno-slp-vectorize"], "mdcn_split.hip": ["-fno-slp-vectorize"],
+EXTRA = {"conv2d_wino4.hip": ["-fno-slp-vectorize"], "conv2d_wino5.hip": ["-fno-slp-vectorize"], "mdcn_split.hip": ["-fno-slp-vectorize"],
          "conv2d_wgrad_bf16.hip": ["-fno-slp-vectorize"]}
 
 

@@ -147,9 +147,9 @@ __global__ void pack_weights_bf16_kernel(PackTable t) {
 
 int pack_weights_run(const PackTable& t, hipStream_t st) {
   if (t.n <= 0) return DVSR_OK;
-  bool any_f32 = false, any_bf = false, any_wino = false, any_wino3 = false, any_dcn3 = false;
+  bool any_f32 = false, any_bf = false, any_wino = false, any_wino3 = false, any_wino5 = false, any_dcn3 = false;
   for (int i = 0; i < t.n; ++i)
-    (t.e[i].bf ? any_bf : (t.e[i].perm == 3 ? any_wino : (t.e[i].perm == 4 ? any_wino3 : (t.e[i].perm == 6 ? any_dcn3 : any_f32)))) = true;
+    (t.e[i].bf ? any_bf : (t.e[i].perm == 3 ? any_wino : (t.e[i].perm == 4 ? any_wino3 : (t.e[i].perm == 5 ? any_wino5 : (t.e[i].perm == 6 ? any_dcn3 : any_f32))))) = true;
   if (any_dcn3) {
     int rc = pack_weights_dcn3_run(t, st);
     if (rc) return rc;
@@ -160,6 +160,10 @@ int pack_weights_run(const PackTable& t, hipStream_t st) {
   }
   if (any_wino3) {
     int rc = pack_weights_wino3_run(t, st);
+    if (rc) return rc;
+  }
+  if (any_wino5) {
+    int rc = pack_weights_wino5_run(t, st);
     if (rc) return rc;
   }
   if (any_f32) {
@@ -916,6 +920,9 @@ static int launch_ksplit(ConvK2 k, hipStream_t st) {
 // i.e. pure tile quantisation (e.g. Cout = 216 wastes 18 % of a 64-wide block but 4 % of 32-wide ones;
 // 575 tiles are 3 rounds of 64-wide but 5 half-size rounds of 32-wide blocks).  Ties go to MT=2 (half
 // the workgroups, half the weight traffic).
+// cycles of a conv2d_wino5_kernel workgroup (32 tiles of 4x4 outputs x 64 couts): per 8-channel chunk and fixed (prologue +
+// epilogue); first estimates, re-measured in profiles/r06_wino5_*.txt
+static constexpr double W5_CHUNK_CYC = 3600.0, W5_FIXED_CYC = 14000.0;
 static double conv2_pipe_cost(int TH, int MT, int KK, int CC, int N, int Ho, int Wo, int Cout) {
   const double wgs = (double)ceil_div(Wo, 32) * ceil_div(Ho, TH) * N * ceil_div(Cout, 32 * MT);
   return ceil(wgs / 256.0) * 64.0 * KK * (CC / 2) * (TH / 4) * MT;
@@ -1018,6 +1025,21 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
     const double w16 = (wino3_on && t16_on) ? wino_cost(16, 16) : 1e300;
     const double best = std::min(std::min(w4, w8), w16);
     // (both Winograd kernels hold a workgroup's whole working set in ~150 KB of LDS: gfx950's 160 KB, checked, not assumed)
+    // DVSR_CONV_WINO5 (read per call): Winograd F(4x4, 3x3) on the bf16 pipe (conv2d_wino5.hip: 32 tiles of 4x4 outputs x 64
+    // couts per workgroup, 768 threads, 156 KB of LDS).  Forward launches only (allow bit 3: plain / residual / PixelShuffle(2)
+    // stores of whole 4x4 tiles, no accumulate / gradient mask).  0: off, 1: where the model says it is faster (default),
+    // 2: wherever it is eligible (A/B aid), 3: eligible and 16x32-pixel workgroup tiles (A/B aid).
+    int wino5_on = 1;
+    if (const char* v = getenv("DVSR_CONV_WINO5")) wino5_on = atoi(v);
+    if (wino5_on && wino3_on && (allow_ksplit & 8) && Ho % 4 == 0 && Wo % 4 == 0 && device_lds_optin() >= (size_t)156 * 1024) {
+      auto w5_cost = [&](int oh, int ow) {
+        const double wgs = (double)ceil_div(Wo, ow) * ceil_div(Ho, oh) * N * ceil_div(Cout, 64);
+        return ceil(wgs / cus) * (nch * W5_CHUNK_CYC + W5_FIXED_CYC) / 2.07;
+      };
+      const double f8 = w5_cost(8, 64), f16 = w5_cost(16, 32);
+      const double best5 = std::min(f8, f16);
+      if (wino5_on >= 2 || (best5 < best && best5 < direct)) return ConvGeo{8, wino5_on == 3 ? 16 : (f16 < f8 ? 16 : 8), 2, 0, 5};
+    }
     if ((wino_on == 2 || best < direct) && device_lds_optin() >= (size_t)155 * 1024)
       return ConvGeo{8, (w16 < w4 && w16 < w8) ? 16 : (w8 < w4 ? 8 : 4), 2, 0, wino3_on ? 4 : 3};
   }
@@ -1039,6 +1061,7 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
 int conv2_pch_cc(int ks, int cc, int bf, int dma) {
   if (dma == 3) return 16 * 2 * 64 * 4;   // Winograd image: 16 transformed taps x 8 channels x 64 couts
   if (dma == 4) return 2 * 6144;          // the same as three bf16 pieces: 2 phases x 24 KB
+  if (dma == 5) return 36 * 2 * 2 * 256;  // F(4x4, 3x3): 36 points x 2 cout halves x (hi | mid), (hi | lo) fragments of 1 KB
   return (bf == 2 ? 3 : 1) * 2 * ks * ks * (bf ? cc / 16 : cc / 8) * 2 * 32 * 4;
 }
 
@@ -1099,9 +1122,11 @@ int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const Conv
                  "16-byte aligned inputs and W %% 4 == 0 (W=%d c0=%d c1=%d)", d.W, d.c0, d.c1);
   } else if (geo.dma) {
     DVSR_REQUIRE(geo.dma < 3 || d.c0 + d.c1 >= 16, DVSR_ERR_UNSUPPORTED, "conv2d_packed: the Winograd kernel needs two 8-channel chunks");
+    DVSR_REQUIRE(geo.dma != 5 || (!ex.accum && !ex.gmask && d.H % 4 == 0 && d.W % 4 == 0 && (geo.th == 8 || geo.th == 16)), DVSR_ERR_UNSUPPORTED,
+                 "conv2d_packed: the F(4x4, 3x3) kernel stores whole 4x4 tiles of forward launches (H=%d W=%d th=%d)", d.H, d.W, geo.th);
     DVSR_REQUIRE(geo.dma < 3 || d.pixel_shuffle == 0 || (d.pixel_shuffle == 2 && d.Cout % 4 == 0 && !d.res && !ex.accum && !ex.gmask),
                  DVSR_ERR_UNSUPPORTED, "conv2d_packed: the Winograd kernel stores plain or PixelShuffle(2) tiles (ps=%d)", d.pixel_shuffle);
-    DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && d.pad == 1 && !ex.in_ps && !ex.in_dil && geo.cc == 8 && (geo.th == 4 || geo.th == 8 || (geo.th == 16 && geo.dma == 4)) &&
+    DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && d.pad == 1 && !ex.in_ps && !ex.in_dil && geo.cc == 8 && (geo.th == 4 || geo.th == 8 || (geo.th == 16 && geo.dma >= 4)) &&
                      d.W % 4 == 0 && d.c0 % 8 == 0 && d.c1 % 8 == 0 && k.x0_bs % 4 == 0 && k.x1_bs % 4 == 0 &&
                      ((uintptr_t)d.x0 & 15) == 0 && ((uintptr_t)d.x1 & 15) == 0,
                  DVSR_ERR_UNSUPPORTED, "conv2d_packed: the DMA-halo kernel needs 3x3/s1/pad 1, plain 16-byte aligned inputs, "
@@ -1151,6 +1176,7 @@ int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtr
   }
   if (geo.dma == 3) return conv2d_wino_launch(k, geo.th, st);
   if (geo.dma == 4) return conv2d_wino3_launch(k, geo.th, st);
+  if (geo.dma == 5) return conv2d_wino5_launch(k, geo.th, st);
   if (geo.dma == 2) {
     if (d.ks == 7) return geo.mt == 2 ? launch_dmarow<7, 4, 2>(k, st) : launch_dmarow<7, 4, 1>(k, st);
     return geo.mt == 2 ? launch_dmarow<9, 4, 2>(k, st) : launch_dmarow<9, 4, 1>(k, st);
@@ -1209,7 +1235,7 @@ OpPack op_pack(int ks, int stride, int pad, int N, int Ho, int Wo, int Cout, int
   using namespace dvsr;
   OpPack o;
   const bool k3 = ks == 3 && stride == 1 && pad == 1, kbig = (ks == 7 || ks == 9) && stride == 1 && pad == ks / 2;
-  o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, Ctot, (k3 && plain ? 1 : 0) | ((k3 || kbig) && aligned ? 2 : 0) | (k3 && aligned ? 4 : 0));
+  o.geo = conv2_choose(ks, stride, N, Ho, Wo, Cout, Ctot, (k3 && plain ? 1 : 0) | ((k3 || kbig) && aligned ? 2 : 0) | (k3 && aligned ? 4 | 8 : 0));
   o.floats = (size_t)ceil_div(Cout, 64) * ceil_div(Ctot, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, 0, o.geo.dma);
   return o;
 }
@@ -1249,9 +1275,9 @@ extern "C" size_t dvsr_conv2d_packed_workspace_bytes(const dvsr_conv2d_desc* d) 
   const size_t a = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, d->Cout, ctot, true).floats;
   const size_t b = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, ctot, d->Cout, true).floats;
   const size_t c = op_pack(d->ks, 1, d->ks / 2, d->N, d->H, d->W, d->Cout, ctot, false).floats;
-  // (the Winograd image of a 3x3 layer: 16 transformed taps instead of 9)
+  // (the Winograd images of a 3x3 layer: 16 transformed taps instead of 9 -- F(4x4, 3x3): 36, as two fragments each)
   const size_t w = d->ks == 3 ? (size_t)std::max(dvsr::ceil_div(d->Cout, 64) * dvsr::ceil_div(ctot, 8), dvsr::ceil_div(ctot, 64) * dvsr::ceil_div(d->Cout, 8)) *
-                                    dvsr::conv2_pch_cc(3, 8, 0, 4) : 0;
+                                    std::max(dvsr::conv2_pch_cc(3, 8, 0, 4), dvsr::conv2_pch_cc(3, 8, 0, 5)) : 0;
   return std::max(std::max(a, b), std::max(c, w)) * sizeof(float);
 }
 

@@ -1,0 +1,489 @@
+// 3x3 / stride 1 / pad 1 convolution by Winograd F(4x4, 3x3) on the bf16 matrix pipe at fp32 accuracy (the exact 3-way operand
+// split of conv2d_wino3.hip / conv2d_wino4.hip; EDVR_arch.py:254-313 is what is being computed) -- round 6, "form 5".
+//
+// Why.  Three rounds of re-scheduling F(2x2, 3x3) (forms 0-4) ended issue-bound: ~295 instructions per wave and chunk for 24
+// MFMAs.  F(4x4, 3x3) changes the arithmetic: 36 transformed-domain points per 16 outputs instead of 16 per 4 -- MFMAs, packed
+// weight traffic, transformed values to build and epilogue exchange bytes per output all x 0.5625.  Points 0, +-1, +-2, inf
+// (Lavin & Gray's matrices): measured rel-L2 of a 64-channel layer against fp64 9e-7 (F(2x2): 1.4e-7, the direct fp32 sum
+// 4.3e-7; oracle/winograd.py restates the transforms, tests/test_gpu_ops.py holds the kernel to 4e-6).
+//
+// Shape.  A workgroup owns 32 tiles of 4x4 outputs (TC tiles per tile row: 8 x 64 or 16 x 32 pixels) x 64 couts x 36 points
+// = 1152 accumulator registers per lane -- the whole CU holds 2048, so one workgroup per CU, TWELVE waves (three per SIMD,
+// <= 168 registers each):
+//   * consumer role: wave (xi = wave % 6, mh = wave / 6) owns the six points (xi, nu = 0..5) of ONE 32-cout half: 6 x 16
+//     accumulator registers, 18 MFMAs per 8-channel chunk;
+//   * producer role: wave (pair = wave & 3, group = wave >> 2), lane (tile = lane & 31, parity = lane >> 5) transforms channel
+//     2 pair + parity of its tile for the row pair xi in {1,2} | {3,4} | {0,5} (one row pass shared by the two rows: e +- o),
+//     all six nu; v_permlane32_swap then hands lower lanes the (even, odd) channel values of the first xi and upper lanes those
+//     of the second, each lane splits six channel PAIRS into three exact bf16 pieces (v_cvt_pk_bf16_f32) and stores 18 words.
+// The transformed input V goes THROUGH THE LDS as pure pieces, V[point][piece][tile][channel pair] (1536 bytes per point,
+// 54 KB per chunk, two images): with 36 points on 12 waves the register-built operand of form 4 does not fit (a wave would
+// hold 96 accumulators + two generations of three fragment sets in 168 registers), and the image decouples who transforms
+// from who multiplies -- every lane of the workgroup has exactly one transform task per chunk.
+//
+// Products.  x = hi + mid + lo for both operands, six of nine partial products (those above 2^-24), two per MFMA (K = 16 =
+// 8 channels x 2 pieces, lanes 32-63 carry K 8..15):
+//     X = (Uh | Um) . (Vh | Vh)  ->  Uh Vh + Um Vh          X . (Vm | Vm)  ->  Uh Vm + Um Vm          W = (Uh | Ul) . (Vl | Vh)  ->  Uh Vl + Ul Vh
+// so a (point, cout half, chunk) needs TWO 1 KB weight fragments (X twice, W once) instead of three, and the three V fragments
+// are 16-byte LDS reads whose lane halves simply point at different pieces.  The packed weights
+// P16[cb][k][point 36][mh 2][X | W][lane half 2][cout 32][8 ch] come straight from global memory (L2), one point ahead.
+//
+// Pipeline.  Chunk k: consumers multiply V(k) (image k & 1) while producers build V(k + 1) from raw(k + 1) into the other
+// image and the LDS-DMA fetches raw(k + 2) into the raw buffer raw(k) has left; ONE barrier per chunk.  Raw halo: 16-byte
+// buffer-load LDS-DMA as in form 4 (unconditional; lanes outside the image carry an offset the resource rejects).
+//
+// Epilogue.  Y = A^T M A.  The six nu of a row are in one wave: the column transform (6 -> 4 values) is done in registers,
+// then per cout half one exchange round through the LDS ([xi][j][register quad][lane] x 16 B = 96 KB), eight reader waves
+// (tile, 2 couts) apply the row transform, bias, activation, residual and store 16-byte output rows (PixelShuffle(2): 32).
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+#include "small_grid.h"
+
+namespace dvsr {
+
+typedef float w5f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 w5bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 w5bf2 __attribute__((ext_vector_type(2)));
+typedef unsigned w5u4 __attribute__((ext_vector_type(4)));
+
+constexpr int W5_PCH = 36 * 2 * 2 * 256;   // fp32-sized slots of one packed (64-cout block, 8-channel chunk): 144 KB
+
+template <int TC>
+struct Wino5Shape {
+  static constexpr int CC = 8, NTILE = 32, TRW = NTILE / TC, NT = 768;
+  static constexpr int OH = 4 * TRW, OW = 4 * TC;        // output pixels of the workgroup tile
+  static constexpr int IH = OH + 2, RP = OW + 8, GR = RP / 4;
+  static constexpr int NG = CC * IH * GR;                // 16-byte groups of one chunk's raw halo image
+  static constexpr int NI = (NG + NT - 1) / NT;
+  static constexpr int RAWPAD = NI * NT * 4;             // floats of one raw buffer (every lane of every DMA has a slot)
+  static constexpr int VIMG = 36 * 3 * 32 * 4;           // 32-bit words of one V image
+  static constexpr int XCH = 6 * 16 * 64 * 4;            // floats of the epilogue's exchange image (96 KB)
+  static constexpr int LOOP = 2 * RAWPAD + 2 * VIMG;
+  static constexpr size_t LDS_BYTES = (size_t)(LOOP > XCH ? LOOP : XCH) * sizeof(float);
+};
+
+constexpr int w5_waitcnt(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
+
+__device__ __forceinline__ unsigned w5_cvt_pk(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(w5f2{a, b}, w5bf2));
+}
+__device__ __forceinline__ void w5_dma16(__amdgpu_buffer_rsrc_t rs, float* lds, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w5_rsrc(const float* base, int num_records) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, num_records, 0x00020000);
+}
+
+// P16[cb][k][p][mh][frag][half][cout 32][8 ch]: pieces of U = G g G^T, G of F(4x4, 3x3) (computed in fp64, rounded once to
+// fp32, split exactly); frag X = (hi | mid), frag W = (hi | lo).  One thread = one (cout, cin) pair.
+__global__ void pack_weights_wino5_kernel(PackTable t) {
+  const PackEntry& e = t.e[blockIdx.y];
+  if (e.perm != 5) return;
+  __bf16* const P16 = reinterpret_cast<__bf16*>(e.P);
+  const size_t total = (size_t)e.ncb * e.nchunks * 512;   // (cout, cin) pairs incl. padding
+  constexpr double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                              {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i & 7), col = (int)((i >> 3) & 63);
+    const size_t ck = i >> 9;
+    const int k = (int)(ck % e.nchunks), cb = (int)(ck / e.nchunks);
+    const int co = cb * 64 + col, ci = k * 8 + c8;
+    double g[3][3];
+    const bool ok = co < e.Cout && ci < e.Ctot;
+    const float* src = !e.wt ? e.w + ((size_t)co * e.Ctot + ci) * 9 : e.w + ((size_t)ci * e.w_ctot + e.w_coff + co) * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) g[tap / 3][tap % 3] = ok ? (double)src[e.wt ? 8 - tap : tap] : 0.0;
+    double c[6][3];
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) c[xi][b] = G[xi][0] * g[0][b] + G[xi][1] * g[1][b] + G[xi][2] * g[2][b];
+    const int mh = col >> 5, c32 = col & 31;
+    __bf16* dst = P16 + ck * (size_t)(2 * W5_PCH) + (size_t)mh * 1024 + (size_t)c32 * 8 + c8;
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+      for (int nu = 0; nu < 6; ++nu) {
+        const float u = (float)(c[xi][0] * G[nu][0] + c[xi][1] * G[nu][1] + c[xi][2] * G[nu][2]);
+        const __bf16 h = (__bf16)u;
+        const float r1 = u - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        __bf16* d = dst + (size_t)(xi * 6 + nu) * 2048;
+        d[0] = h; d[256] = m;       // X: lanes 0-31 hi, lanes 32-63 mid
+        d[512] = h; d[768] = l;     // W: hi | lo
+      }
+  }
+}
+
+int pack_weights_wino5_run(const PackTable& t, hipStream_t st) {
+  hipLaunchKernelGGL(pack_weights_wino5_kernel, dim3(64, t.n), dim3(256), 0, st, t);
+  return check_launch("pack_weights_wino5_kernel");
+}
+
+template <int TC>
+__global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
+  using Sh = Wino5Shape<TC>;
+  constexpr int IH = Sh::IH, RP = Sh::RP, GR = Sh::GR, NI = Sh::NI;
+  constexpr int CHF = IH * RP;              // floats between two channels of one quad of the raw image
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const raw0 = smem;                                         // two raw chunks
+  unsigned* const vimg0 = reinterpret_cast<unsigned*>(smem + 2 * Sh::RAWPAD);   // two V images
+
+  const int id = blockIdx.x;
+  const int q_ = id >> 3;  // XCD-aware order, as conv2d_pipe_item
+  const int cbi = q_ % a.ncb;
+  const int j_ = q_ / a.ncb;
+  const int tile = (id & 7) * a.tiles_per_xcd + j_;
+  if (j_ >= a.tiles_per_xcd || tile >= a.ntiles) return;
+  const int tx_ = tile % a.tiles_x;
+  const int t2 = tile / a.tiles_x;
+  const int ty_ = t2 % a.tiles_y;
+  const int n = t2 / a.tiles_y;
+  const int oy0 = ty_ * Sh::OH, ox0 = tx_ * Sh::OW;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const size_t HW = (size_t)a.H * a.W;
+  const float* x0n = a.x0 + (size_t)n * a.x0_bs;
+  const float* x1n = a.c1 ? a.x1 + (size_t)(n / a.x1_bdiv) * a.x1_bs : x0n;
+
+  // ---- raw halo groups this lane moves.  DMA instruction jj of a chunk moves channels 4 jj .. 4 jj + 3: lane tid < 720 =
+  // (channel quad member cq, row, column group); the second instruction differs from the first by a SCALAR offset of four
+  // channels, so one per-lane offset serves both.  LDS float index of (channel c, row iy, column x): (c >> 2) * 3072 +
+  // (c & 3) * CHF + iy * RP + x.
+  static_assert(IH * GR * 4 <= Sh::NT && NI == 2, "one DMA instruction moves four channels");
+  unsigned hoff;
+  {
+    const int cq = tid / (IH * GR), rr = tid - cq * (IH * GR);
+    const int iy = rr / GR, g = rr - iy * GR;
+    const int gy = oy0 - 1 + iy, gx = ox0 - 4 + 4 * g;
+    const bool live = tid < 4 * IH * GR;
+    const bool ok = live && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    hoff = ok ? (unsigned)(((size_t)cq * HW + (size_t)gy * a.W + gx) * 4) : 0x80000000u;
+    if (live && !ok) {
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) *reinterpret_cast<f32x4*>(raw0 + (bb * Sh::NT + tid) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const unsigned chunk_bytes = (unsigned)(Sh::CC * HW * 4), quad_bytes = (unsigned)(4 * HW * 4);
+  auto issue_raw = [&](int k) __attribute__((always_inline)) {   // raw chunk k -> buffer k & 1 (past the last chunk: nothing)
+    const bool live = k < a.nchunks;
+    const bool second = k * Sh::CC >= a.c0;  // only possible when c1 > 0; a chunk never straddles the two inputs
+    const unsigned soff = live ? (unsigned)(second ? k - a.c0 / Sh::CC : k) * chunk_bytes : 0u;
+    const __amdgpu_buffer_rsrc_t rs = w5_rsrc(second ? x1n : x0n, live ? 0x7fffffff : 0);
+    float* dst = raw0 + (k & 1) * Sh::RAWPAD + 256 * wave;
+    w5_dma16(rs, dst, hoff, soff);
+    w5_dma16(rs, dst + Sh::NT * 4, hoff, soff + quad_bytes);
+  };
+
+  // ---- consumer role: wave (xi, mh)
+  const int cxi = wave % 6, cmh = wave / 6;
+  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + (size_t)cbi * a.nchunks * W5_PCH;
+  const __amdgpu_buffer_rsrc_t wrsrc = w5_rsrc(wp_cb, -1);
+  const unsigned avoff = (unsigned)(lane * 16);
+  const int asb = (cxi * 6 * 2 + cmh) * 2048;      // byte offset of (point (xi, 0), mh) inside a chunk of the pack
+  // weight fragments: a ring of three (fragment g = 2 nu + (0: X, 1: W) of a chunk lives in slot g % 3; twelve per chunk, so the
+  // ring position is the same in every chunk): one in use, two in flight
+  f32x4 AF[3];
+  auto gldA = [&](auto g_, int k) __attribute__((always_inline)) {   // fragment G (0..11) of chunk k
+    constexpr int G = decltype(g_)::value;
+#ifdef W5_NOA   // (probe build, results wrong: only the first fragments are loaded -- what do the weight loads cost?)
+    if (k > 0 || G > 2) return;
+#endif
+    const int soff = k * (W5_PCH * 4) + asb + (G >> 1) * 4096 + (G & 1) * 1024;
+    AF[G % 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)avoff, soff, 0));
+  };
+  // V fragments: (point (xi, 0), piece 0, tile lo) of the image being read; the (Vl | Vh) fragment: lower lanes piece 2,
+  // upper lanes piece 0.  The pointers move to the other image at the end of every chunk (+- VIMG).
+  const unsigned* vrd = vimg0 + cxi * 6 * 384 + lo * 4;
+  const unsigned* vrd_lh = vrd + (hi ? 0 : 256);
+
+  // ---- producer role: wave (pair, group), lane (tile, parity)
+  const int ppair = wave & 3, pgrp = wave >> 2;
+  const int trow_t = lo / TC, tcol_t = lo - trow_t * TC;
+  const int pch = 2 * ppair + hi;
+  // the patch's first aligned group in the raw buffer the producer reads next (chunk 0: buffer 0; inside chunk k: buffer of
+  // chunk k + 1); the V words it writes next (prologue: image 0; inside chunk k: image of chunk k + 1)
+  const float* prd = raw0 + (pch >> 2) * (Sh::NT * 4) + (pch & 3) * CHF + 4 * trow_t * RP + 4 * tcol_t;
+  // first / second row of the group (0: xi 1, 2; 1: xi 3, 4; 2: xi 0, 5); lower lanes store the first, upper lanes the second
+  const int pxa = pgrp == 0 ? 1 : (pgrp == 1 ? 3 : 0), pxb = pgrp == 0 ? 2 : (pgrp == 1 ? 4 : 5);
+  unsigned* vwr = vimg0 + (hi ? pxb : pxa) * 6 * 384 + lo * 4 + ppair;
+  // rows 1..4 of B^T: e +- o, e = d4 + al d2, o = be d3 + ga d1
+  const float al = pgrp == 0 ? -4.f : -1.f, be = pgrp == 0 ? 1.f : 2.f, ga = pgrp == 0 ? -4.f : -2.f;
+
+  float pd[2][6];       // raw rows in flight
+  float pe[6], po[6];   // row pass
+  float pva[6], pvb[6]; // transformed values of the two rows
+  auto ld_row = [&](float (&d)[6], int row) __attribute__((always_inline)) {
+    const float* p = prd + row * RP;
+    const w5f2 l2 = *reinterpret_cast<const w5f2*>(p + 2);
+    const f32x4 m4 = *reinterpret_cast<const f32x4*>(p + 4);
+    const w5f2 h2 = *reinterpret_cast<const w5f2*>(p + 8);
+    d[0] = l2[1]; d[1] = m4[0]; d[2] = m4[1]; d[3] = m4[2]; d[4] = m4[3]; d[5] = h2[0];
+  };
+  // one row of B^T applied along a 6-vector: nu 0 and 5 single, (1, 2) and (3, 4) as e +- o
+  auto colpass = [&](const float (&r)[6], float (&v)[6]) __attribute__((always_inline)) {
+    v[0] = __builtin_fmaf(4.f, r[0], __builtin_fmaf(-5.f, r[2], r[4]));
+    v[5] = __builtin_fmaf(4.f, r[1], __builtin_fmaf(-5.f, r[3], r[5]));
+    const float e1 = __builtin_fmaf(-4.f, r[2], r[4]), o1 = __builtin_fmaf(-4.f, r[1], r[3]);
+    v[1] = e1 + o1; v[2] = e1 - o1;
+    const float e2 = r[4] - r[2], o2 = r[3] - r[1];
+    v[3] = __builtin_fmaf(2.f, o2, e2); v[4] = __builtin_fmaf(-2.f, o2, e2);
+  };
+  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+  // slice S of the producer's work for one chunk; the consumer's MFMAs go between the slices.  Never more than two raw rows
+  // in registers: groups 0, 1 read (2, 4), (1, 3); group 2 reads (2, 4), (0, 5), (3, 1).
+  auto prod = [&](auto s_) __attribute__((always_inline)) {
+    constexpr int S = decltype(s_)::value;
+    if constexpr (S == 0) {
+      ld_row(pd[0], 2); ld_row(pd[1], 4);
+    } else if constexpr (S == 1) {
+      if (pgrp == 2) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) pe[j] = __builtin_fmaf(-5.f, pd[0][j], pd[1][j]);
+        ld_row(pd[0], 0); ld_row(pd[1], 5);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) pe[j] = __builtin_fmaf(al, pd[0][j], pd[1][j]);
+        ld_row(pd[0], 1); ld_row(pd[1], 3);
+      }
+    } else if constexpr (S == 2) {
+      if (pgrp == 2) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { pe[j] = __builtin_fmaf(4.f, pd[0][j], pe[j]); po[j] = pd[1][j]; }
+        ld_row(pd[0], 3); ld_row(pd[1], 1);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float o = __builtin_fmaf(ga, pd[0][j], be * pd[1][j]);
+          po[j] = pe[j] - o;
+          pe[j] = pe[j] + o;
+        }
+      }
+    } else if constexpr (S == 3) {
+      if (pgrp == 2) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) po[j] = __builtin_fmaf(4.f, pd[1][j], __builtin_fmaf(-5.f, pd[0][j], po[j]));
+      }
+    } else if constexpr (S == 4) {
+      colpass(pe, pva);
+    } else if constexpr (S == 5) {
+      colpass(po, pvb);
+    } else if constexpr (S == 6) {
+      // lower lanes: (even, odd channel) of the first row; upper lanes: of the second row
+#pragma unroll
+      for (int v = 0; v < 6; ++v) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pva[v]), __builtin_bit_cast(unsigned, pvb[v]), false, false);
+        // (through unsigned temporaries: __builtin_bit_cast(float, s0[1]) on the vector element reads element 0 -- hipcc 7.2)
+        const unsigned u0 = s0[0], u1 = s0[1];
+        pva[v] = __builtin_bit_cast(float, u0); pvb[v] = __builtin_bit_cast(float, u1);
+      }
+    } else if constexpr (S >= 7 && S < 13) {
+      constexpr int V = S - 7;
+      const float v0 = pva[V], v1 = pvb[V];
+      const unsigned h = w5_cvt_pk(v0, v1);
+      const float r0 = v0 - __builtin_bit_cast(float, h << 16), r1 = v1 - __builtin_bit_cast(float, h & 0xffff0000u);
+      const unsigned m = w5_cvt_pk(r0, r1);
+      const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+      unsigned* d = vwr + V * 384;
+      d[0] = h; d[128] = m; d[256] = w5_cvt_pk(q0, q1);
+    }
+  };
+  constexpr int NSLICE = 13;
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int v = 0; v < 6; ++v)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+
+  // V fragments: two buffers, fragment f = 3 nu + (0: Vh | Vh, 1: Vm | Vm, 2: Vl | Vh) in buffer f & 1 -- one in use, one landing
+  w5u4 BF[2];
+  auto ldB = [&](auto f_) __attribute__((always_inline)) {
+    constexpr int F = decltype(f_)::value, NU = F / 3, W = F % 3;
+    if constexpr (W == 0) BF[F & 1] = *reinterpret_cast<const w5u4*>(vrd + NU * 384);
+    else if constexpr (W == 1) BF[F & 1] = *reinterpret_cast<const w5u4*>(vrd + NU * 384 + 128);
+    else BF[F & 1] = *reinterpret_cast<const w5u4*>(vrd_lh + NU * 384);
+  };
+  auto mma = [&](f32x16& c, const f32x4& av, const w5u4& bv) __attribute__((always_inline)) {
+#ifdef W5_NOMMA   // (probe build, results wrong: the operands are consumed by a cheap VALU op instead of the MFMA)
+    c[0] += av[0] * __builtin_bit_cast(float, bv[0]);
+    return;
+#endif
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w5bf8, av), __builtin_bit_cast(w5bf8, bv), c, 0, 0, 0);
+  };
+  auto lds_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  int vstep = Sh::VIMG, rstep = Sh::RAWPAD;   // the image / raw buffer the pointers move to at the end of a chunk
+
+  // One chunk: 18 MFMAs (fragment f = 3 nu + i: X Vhh, X Vmm, W Vlh of point nu); behind MFMA f the V fragment f + 2 goes
+  // into the buffer f has just read, the weight fragment two ahead into the ring slot that has become free, and slice f of
+  // the producer's work.
+  auto chunk = [&](auto produce_, int k) __attribute__((always_inline)) {
+    constexpr bool PRODUCE = decltype(produce_)::value;
+#ifndef W5_NODMA   // (probe build, results wrong: the chunk loop fetches no raw halo)
+    issue_raw(k + 2);
+#endif
+    ldB(std::integral_constant<int, 0>{}); ldB(std::integral_constant<int, 1>{});
+    const int knext = k + 1 < a.nchunks ? k + 1 : k;   // (past the last chunk: a harmless reload, the same loads on every path)
+    static_for<0, 18>([&](auto f_) __attribute__((always_inline)) {
+      constexpr int F = decltype(f_)::value, NU = F / 3, I = F % 3;
+      constexpr int G = 2 * NU + (I == 2 ? 1 : 0);   // the weight fragment this MFMA reads
+      mma(acc[NU], AF[G % 3], BF[F & 1]);
+      if constexpr (F + 2 < 18) ldB(std::integral_constant<int, (F + 2 < 18 ? F + 2 : 0)>{});
+      // the fragment MFMA F was the last reader of is G for I == 1 (X) and I == 2 (W): its slot takes fragment G + 3
+      if constexpr (I != 0) {
+        constexpr int GN = G + 3;
+        if constexpr (GN < 12) gldA(std::integral_constant<int, (GN < 12 ? GN : 0)>{}, k);
+        else gldA(std::integral_constant<int, (GN >= 12 ? GN - 12 : 0)>{}, knext);
+      }
+      if constexpr (PRODUCE) prod(std::integral_constant<int, F>{});
+      fence();
+    });
+    // raw(k + 2) of this wave has landed (everything but the three newest loads: the next chunk's first weight fragments), the
+    // V words are written; the barrier hands both over and frees the image and the raw buffer this chunk has read
+    __builtin_amdgcn_s_waitcnt(w5_waitcnt(3, 0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    vrd += vstep; vrd_lh += vstep; vwr -= vstep; prd -= rstep;
+    vstep = -vstep; rstep = -rstep;
+  };
+
+  // ---- prologue: two raw chunks in flight, V(0) built with nothing to hide under
+  issue_raw(0);
+  issue_raw(1);
+  gldA(std::integral_constant<int, 0>{}, 0); gldA(std::integral_constant<int, 1>{}, 0); gldA(std::integral_constant<int, 2>{}, 0);
+  __builtin_amdgcn_s_waitcnt(w5_waitcnt(NI + 3, 0));   // raw(0) (and the zero fill) of this wave
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  static_for<0, NSLICE>([&](auto s_) __attribute__((always_inline)) { prod(s_); fence(); });
+  __builtin_amdgcn_s_waitcnt(w5_waitcnt(3, 0));        // raw(1)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  vwr += Sh::VIMG; prd += Sh::RAWPAD;   // the producer moves on to raw(1) -> V(1)
+
+  for (int k = 0; k + 1 < a.nchunks; ++k) chunk(std::true_type{}, k);
+  chunk(std::false_type{}, a.nchunks - 1);
+
+  // ---- epilogue.  A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]].  Column transform in registers:
+  // Z_j = sum_nu M[nu] A^T[j][nu]
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));   // (nothing of the epilogue's addressing may be hoisted above the chunk loop)
+  f32x16 Z[4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float sa = acc[1][r] + acc[2][r], da = acc[1][r] - acc[2][r];
+    const float sb = acc[3][r] + acc[4][r], db = acc[3][r] - acc[4][r];
+    Z[0][r] = acc[0][r] + sa + sb;
+    Z[1][r] = __builtin_fmaf(2.f, db, da);
+    Z[2][r] = __builtin_fmaf(4.f, sb, sa);
+    Z[3][r] = __builtin_fmaf(8.f, db, da) + acc[5][r];
+  }
+  // exchange image: [xi 6][j 4][rq 4][lane 64] x 16 B; reader (waves 0-7): lane' = writer lane (tile, hi), rq' = wave & 3,
+  // cout pair cp = wave >> 2 of the register quad
+  float* const xw = smem + (cxi * 16 * 64 + lane_e) * 4;
+  const int rq_r = wave & 3, cp_r = wave >> 2;
+  const float* const xr = smem + (rq_r * 64 + lane_e) * 4 + cp_r * 2;
+  const int lo_e = lane_e & 31, hi_e = lane_e >> 5;
+  const int trow_e = lo_e / TC, tcol_e = lo_e - trow_e * TC;
+  const int oy = oy0 + 4 * trow_e, ox = ox0 + 4 * tcol_e;
+  const size_t HWo = (size_t)a.Ho * a.Wo;
+  const float slope = a.act == ACT_LRELU ? 0.1f : (a.act == ACT_RELU ? 0.f : 1.f);
+  const float* bias = wset_ptr(a.bias, a.b_gs, n, a.wdiv);
+  lds_barrier();   // every wave is past its last V read
+#pragma unroll 1
+  for (int m = 0; m < 2; ++m) {
+    if (cmh == m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          *reinterpret_cast<f32x4*>(xw + (j * 4 + rq) * 256) = f32x4{Z[j][4 * rq], Z[j][4 * rq + 1], Z[j][4 * rq + 2], Z[j][4 * rq + 3]};
+    }
+    lds_barrier();
+    if (wave < 8) {
+      const int co0 = cbi * 64 + m * 32 + 8 * rq_r + 4 * hi_e + 2 * cp_r;   // this thread's two couts: co0, co0 + 1
+      float y[2][4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w5f2 z[6];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) z[x] = *reinterpret_cast<const w5f2*>(xr + (x * 16 + j * 4) * 256);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float sa = z[1][c] + z[2][c], da = z[1][c] - z[2][c];
+          const float sb = z[3][c] + z[4][c], db = z[3][c] - z[4][c];
+          y[c][0][j] = z[0][c] + sa + sb;
+          y[c][1][j] = __builtin_fmaf(2.f, db, da);
+          y[c][2][j] = __builtin_fmaf(4.f, sb, sa);
+          y[c][3][j] = __builtin_fmaf(8.f, db, da) + z[5][c];
+        }
+      }
+      const bool px_ok = oy < a.Ho && ox < a.Wo;   // (whole tiles: Ho, Wo are multiples of 4)
+      if (px_ok && co0 < a.Cout) {
+        const bool two = co0 + 1 < a.Cout;
+        const float b0 = bias ? bias[co0] : 0.f, b1 = (bias && two) ? bias[co0 + 1] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v0 = y[0][i][j] + b0, v1 = y[1][i][j] + b1;
+            y[0][i][j] = fmaxf(v0, v0 * slope);
+            y[1][i][j] = fmaxf(v1, v1 * slope);
+          }
+        if (a.ps == 0) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            if (c == 1 && !two) break;
+            const size_t base = ((size_t)n * a.Cout + co0 + c) * HWo + (size_t)oy * a.Wo + ox;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              f32x4 v = {y[c][i][0], y[c][i][1], y[c][i][2], y[c][i][3]};
+              if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + base + (size_t)i * a.Wo);
+              *reinterpret_cast<f32x4*>(a.y + base + (size_t)i * a.Wo) = v;
+            }
+          }
+        } else {
+          // PixelShuffle(2): couts 4 q + 2 dy + dx; this thread holds dy = cp_r, dx = 0, 1 of channel q = co0 >> 2
+          const int cq = co0 >> 2, dy = (co0 >> 1) & 1;
+          float* dst = a.y + (((size_t)n * (a.Cout >> 2) + cq) * (2 * a.Ho) + (2 * oy + dy)) * (size_t)(2 * a.Wo) + 2 * ox;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float* d = dst + (size_t)(2 * i) * (2 * a.Wo);
+            *reinterpret_cast<f32x4*>(d) = f32x4{y[0][i][0], y[1][i][0], y[0][i][1], y[1][i][1]};
+            *reinterpret_cast<f32x4*>(d + 4) = f32x4{y[0][i][2], y[1][i][2], y[0][i][3], y[1][i][3]};
+          }
+        }
+      }
+    }
+    if (m == 0) lds_barrier();   // the reads of the first round are done
+  }
+}
+
+template <int TC>
+static int launch_wino5(ConvK2 k, hipStream_t st) {
+  using Sh = Wino5Shape<TC>;
+  auto kern = conv2d_wino5_kernel<TC>;
+  static PerDeviceOnce attr_once;
+  set_dyn_lds_once(attr_once, (const void*)kern, Sh::LDS_BYTES);
+  k.tiles_x = ceil_div(k.Wo, Sh::OW); k.tiles_y = ceil_div(k.Ho, Sh::OH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
+  k.ncb = ceil_div(k.Cout, 64);
+  k.tiles_per_xcd = ceil_div(k.ntiles, 8);
+  k.nitems = k.tiles_per_xcd * 8 * k.ncb;
+  hipLaunchKernelGGL(kern, dim3(k.nitems), dim3(768), Sh::LDS_BYTES, st, k);
+  return check_launch("conv2d_wino5_kernel");
+}
+
+// th = 8: 8 x 64-pixel workgroup tiles (2 x 16 tiles of 4 x 4), th = 16: 16 x 32 (4 x 8 tiles)
+int conv2d_wino5_launch(const ConvK2& k, int th, hipStream_t st) {
+  return th == 16 ? launch_wino5<8>(k, st) : launch_wino5<16>(k, st);
+}
+
+}  // namespace dvsr

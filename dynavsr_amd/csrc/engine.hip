@@ -198,7 +198,9 @@ struct Builder {
       // ... and the Winograd kernel where the DMA-halo kernel could run (bit 2; its epilogue stores plain or
       // PixelShuffle(2) tiles)
       const int ks_ok = (plain && (c1 == 0 || c0 % 32 == 0) ? 1 : 0) | (plain && c0 % 8 == 0 && c1 % 8 == 0 ? 2 | 4 : 0);
-      o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1, (ps == 0 || (ps == 2 && !res.valid())) ? ks_ok : (ks_ok & ~4)), Ho, Wo, Cout);
+      // bit 3: the FORWARD launch may take the F(4x4, 3x3) kernel (the data gradients below never do: accumulate / mask epilogues)
+      const int fwd_ok = (ps == 0 || (ps == 2 && !res.valid())) ? (ks_ok | ((ks_ok & 4) ? 8 : 0)) : (ks_ok & ~4);
+      o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1, fwd_ok), Ho, Wo, Cout);
       o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, o.geo.bf, o.geo.dma);
       o.wp_off = alloc("", o.wp_floats * p.wsets).off;   // one pack per weight set, consecutive
       for (int which = 0; which < 2; ++which) {

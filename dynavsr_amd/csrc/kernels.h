@@ -30,7 +30,7 @@ struct PackEntry {
   int Cout, Ctot, KK, CC, wt, w_ctot, w_coff, ncb, nchunks, pch;
   int bf = 0;  // 1: bf16 image for the bf16 MFMA kernel (pch still counts fp32-sized slots)
   int perm = 0;  // 1: channel order of the DMA-halo kernel (ConvGeo::dma); 3: Winograd-transformed image (conv2d_wino.hip);
-                 // 4: the same as three bf16 pieces (conv2d_wino3.hip)
+                 // 4: the same as three bf16 pieces (conv2d_wino3.hip); 5: the F(4x4, 3x3) image of conv2d_wino5.hip
 };
 struct PackTable {
   int n;
@@ -40,7 +40,8 @@ int conv2_pch(int ks, int stride);  // floats per packed (cout block, chunk)
 int conv2_cc(int ks, int stride);   // input channels per chunk
 int pack_weights_run(const PackTable& t, hipStream_t st);
 // channels per chunk, tile rows (x32 px), 32-cout halves per workgroup; dma: 1 DMA-halo kernel, 2 row-split 7x7 / 9x9,
-// 3 Winograd F(2x2, 3x3) kernel (th = 4: 4x64-pixel tiles, th = 8: 8x32), 4 the same on the bf16 pipe (exact 3-way split)
+// 3 Winograd F(2x2, 3x3) kernel (th = 4: 4x64-pixel tiles, th = 8: 8x32), 4 the same on the bf16 pipe (exact 3-way split),
+// 5 Winograd F(4x4, 3x3) on the bf16 pipe (conv2d_wino5.hip; th = 8: 8x64-pixel workgroup tiles, th = 16: 16x32)
 struct ConvGeo { int cc, th, mt; int bf = 0; int dma = 0; };
 // allow: bit 0 = the K-split small-grid kernel may be chosen, bit 1 = the DMA-halo kernel (plain pad-1 inputs, see conv2d_v2.hip),
 // bit 2 = the Winograd kernel (bit 1's conditions + an epilogue it implements: plain or PixelShuffle(2) stores)
@@ -48,6 +49,7 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
 int conv2_pch_cc(int ks, int cc, int bf = 0, int dma = 0);   // fp32-sized slots per packed (64-cout block, chunk of cc channels)
 int pack_weights_wino_run(const PackTable& t, hipStream_t st);   // conv2d_wino.hip: entries with perm == 3
 int pack_weights_wino3_run(const PackTable& t, hipStream_t st);  // conv2d_wino3.hip: entries with perm == 4
+int pack_weights_wino5_run(const PackTable& t, hipStream_t st);  // conv2d_wino5.hip: entries with perm == 5 (F(4x4, 3x3))
 int conv2d_packed_run(const dvsr_conv2d_desc& d, const float* wp, const ConvExtra& ex, const ConvGeo& geo,
                       hipStream_t st);
 

@@ -74,6 +74,7 @@ int conv2d_wgrad_launch(const WgradLaunch& l, hipStream_t st);
 int conv2d_wino_launch(const ConvK2& k, int th, hipStream_t st);   // conv2d_wino.hip (ConvGeo::dma == 3)
 int conv2d_wino3_launch(const ConvK2& k, int th, hipStream_t st);  // conv2d_wino3.hip (ConvGeo::dma == 4)
 int conv2d_wino4_launch(const ConvK2& k, int th, hipStream_t st);  // conv2d_wino4.hip (the same image, B operand in registers)
+int conv2d_wino5_launch(const ConvK2& k, int th, hipStream_t st);  // conv2d_wino5.hip (ConvGeo::dma == 5: F(4x4, 3x3), th = 8 | 16)
 int conv2d_wgrad_bf16_launch(const WgradLaunch& l, hipStream_t st);
 int conv2d_wgrad_split3_launch(const WgradLaunch& l, hipStream_t st);   // bf = 2: exact 3-way bf16 split (fp32 accuracy)
 
