@@ -43,6 +43,18 @@
 
 namespace dvsr {
 
+#ifdef DVSR_CONV_TRACE
+// cycle stamps of the debug build (tools/wino5_trace.py): thread 0 of every workgroup
+#define W5_STAMP(i)                                                                                       \
+  do {                                                                                                    \
+    if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define W5_STAMP(i) \
+  do {              \
+  } while (0)
+#endif
+
 typedef float w5f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 w5bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 w5bf2 __attribute__((ext_vector_type(2)));
@@ -236,13 +248,14 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
   };
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
   // slice S of the producer's work for one chunk; the consumer's MFMAs go between the slices.  Never more than two raw rows
-  // in registers: groups 0, 1 read (2, 4), (1, 3); group 2 reads (2, 4), (0, 5), (3, 1).
-  auto prod = [&](auto s_) __attribute__((always_inline)) {
+  // in registers: groups 0, 1 read (2, 4), (1, 3); group 2 (G2) reads (2, 4), (0, 5), (3, 1).
+  auto prod = [&](auto s_, auto g2_) __attribute__((always_inline)) {
     constexpr int S = decltype(s_)::value;
+    constexpr bool G2 = decltype(g2_)::value;   // the wave's group is 2 (rows xi 0 and 5)
     if constexpr (S == 0) {
       ld_row(pd[0], 2); ld_row(pd[1], 4);
     } else if constexpr (S == 1) {
-      if (pgrp == 2) {
+      if constexpr (G2) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) pe[j] = __builtin_fmaf(-5.f, pd[0][j], pd[1][j]);
         ld_row(pd[0], 0); ld_row(pd[1], 5);
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
         ld_row(pd[0], 1); ld_row(pd[1], 3);
       }
     } else if constexpr (S == 2) {
-      if (pgrp == 2) {
+      if constexpr (G2) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) { pe[j] = __builtin_fmaf(4.f, pd[0][j], pe[j]); po[j] = pd[1][j]; }
         ld_row(pd[0], 3); ld_row(pd[1], 1);
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
         }
       }
     } else if constexpr (S == 3) {
-      if (pgrp == 2) {
+      if constexpr (G2) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) po[j] = __builtin_fmaf(4.f, pd[1][j], __builtin_fmaf(-5.f, pd[0][j], po[j]));
       }
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
 #pragma unroll
       for (int v = 0; v < 6; ++v) {
         const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pva[v]), __builtin_bit_cast(unsigned, pvb[v]), false, false);
-        // (through unsigned temporaries: __builtin_bit_cast(float, s0[1]) on the vector element reads element 0 -- hipcc 7.2)
+        // (through unsigned temporaries: __builtin_bit_cast(float, s0[1]) on the vector ELEMENT reads element 0 -- hipcc 7.2)
         const unsigned u0 = s0[0], u1 = s0[1];
         pva[v] = __builtin_bit_cast(float, u0); pvb[v] = __builtin_bit_cast(float, u1);
       }
@@ -290,7 +303,11 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
       const unsigned m = w5_cvt_pk(r0, r1);
       const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
       unsigned* d = vwr + V * 384;
+#ifdef W5_NOVW   // (probe build, results wrong: one V word per point instead of three)
+      d[0] = h ^ m ^ w5_cvt_pk(q0, q1);
+#else
       d[0] = h; d[128] = m; d[256] = w5_cvt_pk(q0, q1);
+#endif
     }
   };
   constexpr int NSLICE = 13;
@@ -324,10 +341,14 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
   int vstep = Sh::VIMG, rstep = Sh::RAWPAD;   // the image / raw buffer the pointers move to at the end of a chunk
 
   // One chunk: 18 MFMAs (fragment f = 3 nu + i: X Vhh, X Vmm, W Vlh of point nu); behind MFMA f the V fragment f + 2 goes
-  // into the buffer f has just read, the weight fragment two ahead into the ring slot that has become free, and slice f of
+  // into the buffer f has just read, the weight fragment three ahead into the ring slot that has become free, and slice f of
   // the producer's work.
-  auto chunk = [&](auto produce_, int k) __attribute__((always_inline)) {
+  auto chunk = [&](auto produce_, auto g2_, int k) __attribute__((always_inline)) {
+#ifdef W5_NOPROD   // (probe build, results wrong: no transform work inside the chunk loop)
+    constexpr bool PRODUCE = false;
+#else
     constexpr bool PRODUCE = decltype(produce_)::value;
+#endif
 #ifndef W5_NODMA   // (probe build, results wrong: the chunk loop fetches no raw halo)
     issue_raw(k + 2);
 #endif
@@ -337,14 +358,19 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
       constexpr int F = decltype(f_)::value, NU = F / 3, I = F % 3;
       constexpr int G = 2 * NU + (I == 2 ? 1 : 0);   // the weight fragment this MFMA reads
       mma(acc[NU], AF[G % 3], BF[F & 1]);
-      if constexpr (F + 2 < 18) ldB(std::integral_constant<int, (F + 2 < 18 ? F + 2 : 0)>{});
+#ifdef W5_NOBR   // (probe build, results wrong: the two V fragments read at the chunk top serve all 18 MFMAs)
+      if constexpr (false)
+#else
+      if constexpr (F + 2 < 18)
+#endif
+        ldB(std::integral_constant<int, (F + 2 < 18 ? F + 2 : 0)>{});
       // the fragment MFMA F was the last reader of is G for I == 1 (X) and I == 2 (W): its slot takes fragment G + 3
       if constexpr (I != 0) {
         constexpr int GN = G + 3;
         if constexpr (GN < 12) gldA(std::integral_constant<int, (GN < 12 ? GN : 0)>{}, k);
         else gldA(std::integral_constant<int, (GN >= 12 ? GN - 12 : 0)>{}, knext);
       }
-      if constexpr (PRODUCE) prod(std::integral_constant<int, F>{});
+      if constexpr (PRODUCE) prod(std::integral_constant<int, F>{}, g2_);
       fence();
     });
     // raw(k + 2) of this wave has landed (everything but the three newest loads: the next chunk's first weight fragments), the
@@ -352,25 +378,39 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
     __builtin_amdgcn_s_waitcnt(w5_waitcnt(3, 0));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (k < 16) W5_STAMP(3 + k);
     vrd += vstep; vrd_lh += vstep; vwr -= vstep; prd -= rstep;
     vstep = -vstep; rstep = -rstep;
   };
 
   // ---- prologue: two raw chunks in flight, V(0) built with nothing to hide under
+  W5_STAMP(0);
+#ifdef DVSR_CONV_TRACE
+  if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + 60] = __builtin_amdgcn_s_memrealtime();
+#endif
   issue_raw(0);
   issue_raw(1);
-  gldA(std::integral_constant<int, 0>{}, 0); gldA(std::integral_constant<int, 1>{}, 0); gldA(std::integral_constant<int, 2>{}, 0);
+  static_for<0, 3>([&](auto g_) __attribute__((always_inline)) { gldA(g_, 0); });
   __builtin_amdgcn_s_waitcnt(w5_waitcnt(NI + 3, 0));   // raw(0) (and the zero fill) of this wave
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  static_for<0, NSLICE>([&](auto s_) __attribute__((always_inline)) { prod(s_); fence(); });
+  W5_STAMP(1);
+  if (pgrp == 2) static_for<0, NSLICE>([&](auto s_) __attribute__((always_inline)) { prod(s_, std::true_type{}); fence(); });
+  else static_for<0, NSLICE>([&](auto s_) __attribute__((always_inline)) { prod(s_, std::false_type{}); fence(); });
   __builtin_amdgcn_s_waitcnt(w5_waitcnt(3, 0));        // raw(1)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  W5_STAMP(2);
   vwr += Sh::VIMG; prd += Sh::RAWPAD;   // the producer moves on to raw(1) -> V(1)
 
-  for (int k = 0; k + 1 < a.nchunks; ++k) chunk(std::true_type{}, k);
-  chunk(std::false_type{}, a.nchunks - 1);
+  // (one loop per producer group shape: the two differ in the rows they read and in the row pass)
+  if (pgrp == 2) {
+    for (int k = 0; k + 1 < a.nchunks; ++k) chunk(std::true_type{}, std::true_type{}, k);
+  } else {
+    for (int k = 0; k + 1 < a.nchunks; ++k) chunk(std::true_type{}, std::false_type{}, k);
+  }
+  chunk(std::false_type{}, std::false_type{}, a.nchunks - 1);
+  W5_STAMP(40);
 
   // ---- epilogue.  A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]].  Column transform in registers:
   // Z_j = sum_nu M[nu] A^T[j][nu]
@@ -397,7 +437,9 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
   const size_t HWo = (size_t)a.Ho * a.Wo;
   const float slope = a.act == ACT_LRELU ? 0.1f : (a.act == ACT_RELU ? 0.f : 1.f);
   const float* bias = wset_ptr(a.bias, a.b_gs, n, a.wdiv);
+  W5_STAMP(50);
   lds_barrier();   // every wave is past its last V read
+  W5_STAMP(51);
 #pragma unroll 1
   for (int m = 0; m < 2; ++m) {
     if (cmh == m) {
@@ -407,7 +449,9 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
         for (int rq = 0; rq < 4; ++rq)
           *reinterpret_cast<f32x4*>(xw + (j * 4 + rq) * 256) = f32x4{Z[j][4 * rq], Z[j][4 * rq + 1], Z[j][4 * rq + 2], Z[j][4 * rq + 3]};
     }
+    W5_STAMP(52 + 4 * m);
     lds_barrier();
+    W5_STAMP(53 + 4 * m);
     if (wave < 8) {
       const int co0 = cbi * 64 + m * 32 + 8 * rq_r + 4 * hi_e + 2 * cp_r;   // this thread's two couts: co0, co0 + 1
       float y[2][4][4];
@@ -463,8 +507,19 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
         }
       }
     }
+    W5_STAMP(54 + 4 * m);
     if (m == 0) lds_barrier();   // the reads of the first round are done
+    W5_STAMP(55 + 4 * m);
   }
+#ifdef DVSR_CONV_TRACE
+  W5_STAMP(41);
+  __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged
+  W5_STAMP(42);
+  if (a.trace && threadIdx.x == 0) {
+    a.trace[(size_t)blockIdx.x * 64 + 61] = __builtin_amdgcn_s_memrealtime();
+    a.trace[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_ID
+  }
+#endif
 }
 
 template <int TC>
