@@ -1061,7 +1061,7 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
 int conv2_pch_cc(int ks, int cc, int bf, int dma) {
   if (dma == 3) return 16 * 2 * 64 * 4;   // Winograd image: 16 transformed taps x 8 channels x 64 couts
   if (dma == 4) return 2 * 6144;          // the same as three bf16 pieces: 2 phases x 24 KB
-  if (dma == 5) return 36 * 2 * 2 * 256;  // F(4x4, 3x3): 36 points x 2 cout halves x (hi | mid), (hi | lo) fragments of 1 KB
+  if (dma == 5) return 18 * 2 * 3 * 256;  // F(4x4, 3x3): 18 point pairs x 2 cout halves x 3 fragments of 1 KB (X, X', L)
   return (bf == 2 ? 3 : 1) * 2 * ks * ks * (bf ? cc / 16 : cc / 8) * 2 * 32 * 4;
 }
 

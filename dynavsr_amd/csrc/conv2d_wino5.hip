@@ -60,11 +60,11 @@ typedef __bf16 w5bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 w5bf2 __attribute__((ext_vector_type(2)));
 typedef unsigned w5u4 __attribute__((ext_vector_type(4)));
 
-constexpr int W5_PCH = 36 * 2 * 2 * 256;   // fp32-sized slots of one packed (64-cout block, 8-channel chunk): 144 KB
+constexpr int W5_PCH = 18 * 2 * 3 * 256;   // fp32-sized slots of one packed (64-cout block, 8-channel chunk): 18 point pairs x 2 cout halves x 3 KB
 
 template <int TC>
 struct Wino5Shape {
-  static constexpr int CC = 8, NTILE = 32, TRW = NTILE / TC, NT = 768;
+  static constexpr int CC = 8, NTILE = 32, TRW = NTILE / TC, NT = 768;   // NT: 16-byte slots per channel quad of a raw chunk
   static constexpr int OH = 4 * TRW, OW = 4 * TC;        // output pixels of the workgroup tile
   static constexpr int IH = OH + 2, RP = OW + 8, GR = RP / 4;
   static constexpr int NG = CC * IH * GR;                // 16-byte groups of one chunk's raw halo image
@@ -88,8 +88,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t w5_rsrc(const float* base, int
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, num_records, 0x00020000);
 }
 
-// P16[cb][k][p][mh][frag][half][cout 32][8 ch]: pieces of U = G g G^T, G of F(4x4, 3x3) (computed in fp64, rounded once to
-// fp32, split exactly); frag X = (hi | mid), frag W = (hi | lo).  One thread = one (cout, cin) pair.
+// P16[cb][k][xi][q][mh][frag 3][lane half 2][cout 32][8 ch]: pieces of U = G g G^T, G of F(4x4, 3x3) (computed in fp64, rounded
+// once to fp32, split exactly), for the point pair (xi, nu = 2 q) / (xi, 2 q + 1): frag 0 = X of the even point (hi | mid),
+// frag 1 = X' of the odd point (mid | hi), frag 2 = L (lo of the odd point | lo of the even point).  One thread = one
+// (cout, cin) pair.
 __global__ void pack_weights_wino5_kernel(PackTable t) {
   const PackEntry& e = t.e[blockIdx.y];
   if (e.perm != 5) return;
@@ -113,7 +115,7 @@ __global__ void pack_weights_wino5_kernel(PackTable t) {
 #pragma unroll
       for (int b = 0; b < 3; ++b) c[xi][b] = G[xi][0] * g[0][b] + G[xi][1] * g[1][b] + G[xi][2] * g[2][b];
     const int mh = col >> 5, c32 = col & 31;
-    __bf16* dst = P16 + ck * (size_t)(2 * W5_PCH) + (size_t)mh * 1024 + (size_t)c32 * 8 + c8;
+    __bf16* dst = P16 + ck * (size_t)(2 * W5_PCH) + (size_t)mh * 1536 + (size_t)c32 * 8 + c8;
 #pragma unroll
     for (int xi = 0; xi < 6; ++xi)
 #pragma unroll
@@ -123,9 +125,9 @@ __global__ void pack_weights_wino5_kernel(PackTable t) {
         const float r1 = u - (float)h;
         const __bf16 m = (__bf16)r1;
         const __bf16 l = (__bf16)(r1 - (float)m);
-        __bf16* d = dst + (size_t)(xi * 6 + nu) * 2048;
-        d[0] = h; d[256] = m;       // X: lanes 0-31 hi, lanes 32-63 mid
-        d[512] = h; d[768] = l;     // W: hi | lo
+        __bf16* d = dst + (size_t)(xi * 3 + (nu >> 1)) * 3072;
+        if (nu & 1) { d[512] = m; d[768] = h; d[1024] = l; }   // X' = (mid | hi); L lower lanes
+        else { d[0] = h; d[256] = m; d[1280] = l; }           // X = (hi | mid); L upper lanes
       }
   }
 }
@@ -136,10 +138,11 @@ int pack_weights_wino5_run(const PackTable& t, hipStream_t st) {
 }
 
 template <int TC>
-__global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
+__global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
   using Sh = Wino5Shape<TC>;
-  constexpr int IH = Sh::IH, RP = Sh::RP, GR = Sh::GR, NI = Sh::NI;
+  constexpr int IH = Sh::IH, RP = Sh::RP, GR = Sh::GR;
   constexpr int CHF = IH * RP;              // floats between two channels of one quad of the raw image
+  constexpr int QF = 768 * 4;               // floats between the two channel quads of a raw chunk
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const raw0 = smem;                                         // two raw chunks
   unsigned* const vimg0 = reinterpret_cast<unsigned*>(smem + 2 * Sh::RAWPAD);   // two V images
@@ -160,256 +163,263 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lo = lane & 31, hi = lane >> 5;
   const size_t HW = (size_t)a.H * a.W;
-  const float* x0n = a.x0 + (size_t)n * a.x0_bs;
-  const float* x1n = a.c1 ? a.x1 + (size_t)(n / a.x1_bdiv) * a.x1_bs : x0n;
-
-  // ---- raw halo groups this lane moves.  DMA instruction jj of a chunk moves channels 4 jj .. 4 jj + 3: lane tid < 720 =
-  // (channel quad member cq, row, column group); the second instruction differs from the first by a SCALAR offset of four
-  // channels, so one per-lane offset serves both.  LDS float index of (channel c, row iy, column x): (c >> 2) * 3072 +
-  // (c & 3) * CHF + iy * RP + x.
-  static_assert(IH * GR * 4 <= Sh::NT && NI == 2, "one DMA instruction moves four channels");
-  unsigned hoff;
-  {
-    const int cq = tid / (IH * GR), rr = tid - cq * (IH * GR);
-    const int iy = rr / GR, g = rr - iy * GR;
-    const int gy = oy0 - 1 + iy, gx = ox0 - 4 + 4 * g;
-    const bool live = tid < 4 * IH * GR;
-    const bool ok = live && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-    hoff = ok ? (unsigned)(((size_t)cq * HW + (size_t)gy * a.W + gx) * 4) : 0x80000000u;
-    if (live && !ok) {
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) *reinterpret_cast<f32x4*>(raw0 + (bb * Sh::NT + tid) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  const unsigned chunk_bytes = (unsigned)(Sh::CC * HW * 4), quad_bytes = (unsigned)(4 * HW * 4);
-  auto issue_raw = [&](int k) __attribute__((always_inline)) {   // raw chunk k -> buffer k & 1 (past the last chunk: nothing)
-    const bool live = k < a.nchunks;
-    const bool second = k * Sh::CC >= a.c0;  // only possible when c1 > 0; a chunk never straddles the two inputs
-    const unsigned soff = live ? (unsigned)(second ? k - a.c0 / Sh::CC : k) * chunk_bytes : 0u;
-    const __amdgpu_buffer_rsrc_t rs = w5_rsrc(second ? x1n : x0n, live ? 0x7fffffff : 0);
-    float* dst = raw0 + (k & 1) * Sh::RAWPAD + 256 * wave;
-    w5_dma16(rs, dst, hoff, soff);
-    w5_dma16(rs, dst + Sh::NT * 4, hoff, soff + quad_bytes);
-  };
-
-  // ---- consumer role: wave (xi, mh)
-  const int cxi = wave % 6, cmh = wave / 6;
-  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + (size_t)cbi * a.nchunks * W5_PCH;
-  const __amdgpu_buffer_rsrc_t wrsrc = w5_rsrc(wp_cb, -1);
-  const unsigned avoff = (unsigned)(lane * 16);
-  const int asb = (cxi * 6 * 2 + cmh) * 2048;      // byte offset of (point (xi, 0), mh) inside a chunk of the pack
-  // weight fragments: a ring of three (fragment g = 2 nu + (0: X, 1: W) of a chunk lives in slot g % 3; twelve per chunk, so the
-  // ring position is the same in every chunk): one in use, two in flight
-  f32x4 AF[3];
-  auto gldA = [&](auto g_, int k) __attribute__((always_inline)) {   // fragment G (0..11) of chunk k
-    constexpr int G = decltype(g_)::value;
-#ifdef W5_NOA   // (probe build, results wrong: only the first fragments are loaded -- what do the weight loads cost?)
-    if (k > 0 || G > 2) return;
-#endif
-    const int soff = k * (W5_PCH * 4) + asb + (G >> 1) * 4096 + (G & 1) * 1024;
-    AF[G % 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)avoff, soff, 0));
-  };
-  // V fragments: (point (xi, 0), piece 0, tile lo) of the image being read; the (Vl | Vh) fragment: lower lanes piece 2,
-  // upper lanes piece 0.  The pointers move to the other image at the end of every chunk (+- VIMG).
-  const unsigned* vrd = vimg0 + cxi * 6 * 384 + lo * 4;
-  const unsigned* vrd_lh = vrd + (hi ? 0 : 256);
-
-  // ---- producer role: wave (pair, group), lane (tile, parity)
-  const int ppair = wave & 3, pgrp = wave >> 2;
-  const int trow_t = lo / TC, tcol_t = lo - trow_t * TC;
-  const int pch = 2 * ppair + hi;
-  // the patch's first aligned group in the raw buffer the producer reads next (chunk 0: buffer 0; inside chunk k: buffer of
-  // chunk k + 1); the V words it writes next (prologue: image 0; inside chunk k: image of chunk k + 1)
-  const float* prd = raw0 + (pch >> 2) * (Sh::NT * 4) + (pch & 3) * CHF + 4 * trow_t * RP + 4 * tcol_t;
-  // first / second row of the group (0: xi 1, 2; 1: xi 3, 4; 2: xi 0, 5); lower lanes store the first, upper lanes the second
-  const int pxa = pgrp == 0 ? 1 : (pgrp == 1 ? 3 : 0), pxb = pgrp == 0 ? 2 : (pgrp == 1 ? 4 : 5);
-  unsigned* vwr = vimg0 + (hi ? pxb : pxa) * 6 * 384 + lo * 4 + ppair;
-  // rows 1..4 of B^T: e +- o, e = d4 + al d2, o = be d3 + ga d1
-  const float al = pgrp == 0 ? -4.f : -1.f, be = pgrp == 0 ? 1.f : 2.f, ga = pgrp == 0 ? -4.f : -2.f;
-
-  float pd[2][6];       // raw rows in flight
-  float pe[6], po[6];   // row pass
-  float pva[6], pvb[6]; // transformed values of the two rows
-  auto ld_row = [&](float (&d)[6], int row) __attribute__((always_inline)) {
-    const float* p = prd + row * RP;
-    const w5f2 l2 = *reinterpret_cast<const w5f2*>(p + 2);
-    const f32x4 m4 = *reinterpret_cast<const f32x4*>(p + 4);
-    const w5f2 h2 = *reinterpret_cast<const w5f2*>(p + 8);
-    d[0] = l2[1]; d[1] = m4[0]; d[2] = m4[1]; d[3] = m4[2]; d[4] = m4[3]; d[5] = h2[0];
-  };
-  // one row of B^T applied along a 6-vector: nu 0 and 5 single, (1, 2) and (3, 4) as e +- o
-  auto colpass = [&](const float (&r)[6], float (&v)[6]) __attribute__((always_inline)) {
-    v[0] = __builtin_fmaf(4.f, r[0], __builtin_fmaf(-5.f, r[2], r[4]));
-    v[5] = __builtin_fmaf(4.f, r[1], __builtin_fmaf(-5.f, r[3], r[5]));
-    const float e1 = __builtin_fmaf(-4.f, r[2], r[4]), o1 = __builtin_fmaf(-4.f, r[1], r[3]);
-    v[1] = e1 + o1; v[2] = e1 - o1;
-    const float e2 = r[4] - r[2], o2 = r[3] - r[1];
-    v[3] = __builtin_fmaf(2.f, o2, e2); v[4] = __builtin_fmaf(-2.f, o2, e2);
-  };
   auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
-  // slice S of the producer's work for one chunk; the consumer's MFMAs go between the slices.  Never more than two raw rows
-  // in registers: groups 0, 1 read (2, 4), (1, 3); group 2 (G2) reads (2, 4), (0, 5), (3, 1).
-  auto prod = [&](auto s_, auto g2_) __attribute__((always_inline)) {
-    constexpr int S = decltype(s_)::value;
-    constexpr bool G2 = decltype(g2_)::value;   // the wave's group is 2 (rows xi 0 and 5)
-    if constexpr (S == 0) {
-      ld_row(pd[0], 2); ld_row(pd[1], 4);
-    } else if constexpr (S == 1) {
-      if constexpr (G2) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) pe[j] = __builtin_fmaf(-5.f, pd[0][j], pd[1][j]);
-        ld_row(pd[0], 0); ld_row(pd[1], 5);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) pe[j] = __builtin_fmaf(al, pd[0][j], pd[1][j]);
-        ld_row(pd[0], 1); ld_row(pd[1], 3);
-      }
-    } else if constexpr (S == 2) {
-      if constexpr (G2) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) { pe[j] = __builtin_fmaf(4.f, pd[0][j], pe[j]); po[j] = pd[1][j]; }
-        ld_row(pd[0], 3); ld_row(pd[1], 1);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const float o = __builtin_fmaf(ga, pd[0][j], be * pd[1][j]);
-          po[j] = pe[j] - o;
-          pe[j] = pe[j] + o;
-        }
-      }
-    } else if constexpr (S == 3) {
-      if constexpr (G2) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) po[j] = __builtin_fmaf(4.f, pd[1][j], __builtin_fmaf(-5.f, pd[0][j], po[j]));
-      }
-    } else if constexpr (S == 4) {
-      colpass(pe, pva);
-    } else if constexpr (S == 5) {
-      colpass(po, pvb);
-    } else if constexpr (S == 6) {
-      // lower lanes: (even, odd channel) of the first row; upper lanes: of the second row
-#pragma unroll
-      for (int v = 0; v < 6; ++v) {
-        const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pva[v]), __builtin_bit_cast(unsigned, pvb[v]), false, false);
-        // (through unsigned temporaries: __builtin_bit_cast(float, s0[1]) on the vector ELEMENT reads element 0 -- hipcc 7.2)
-        const unsigned u0 = s0[0], u1 = s0[1];
-        pva[v] = __builtin_bit_cast(float, u0); pvb[v] = __builtin_bit_cast(float, u1);
-      }
-    } else if constexpr (S >= 7 && S < 13) {
-      constexpr int V = S - 7;
-      const float v0 = pva[V], v1 = pvb[V];
-      const unsigned h = w5_cvt_pk(v0, v1);
-      const float r0 = v0 - __builtin_bit_cast(float, h << 16), r1 = v1 - __builtin_bit_cast(float, h & 0xffff0000u);
-      const unsigned m = w5_cvt_pk(r0, r1);
-      const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
-      unsigned* d = vwr + V * 384;
-#ifdef W5_NOVW   // (probe build, results wrong: one V word per point instead of three)
-      d[0] = h ^ m ^ w5_cvt_pk(q0, q1);
-#else
-      d[0] = h; d[128] = m; d[256] = w5_cvt_pk(q0, q1);
-#endif
-    }
-  };
-  constexpr int NSLICE = 13;
-
-  f32x16 acc[6];
-#pragma unroll
-  for (int v = 0; v < 6; ++v)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
-
-  // V fragments: two buffers, fragment f = 3 nu + (0: Vh | Vh, 1: Vm | Vm, 2: Vl | Vh) in buffer f & 1 -- one in use, one landing
-  w5u4 BF[2];
-  auto ldB = [&](auto f_) __attribute__((always_inline)) {
-    constexpr int F = decltype(f_)::value, NU = F / 3, W = F % 3;
-    if constexpr (W == 0) BF[F & 1] = *reinterpret_cast<const w5u4*>(vrd + NU * 384);
-    else if constexpr (W == 1) BF[F & 1] = *reinterpret_cast<const w5u4*>(vrd + NU * 384 + 128);
-    else BF[F & 1] = *reinterpret_cast<const w5u4*>(vrd_lh + NU * 384);
-  };
-  auto mma = [&](f32x16& c, const f32x4& av, const w5u4& bv) __attribute__((always_inline)) {
-#ifdef W5_NOMMA   // (probe build, results wrong: the operands are consumed by a cheap VALU op instead of the MFMA)
-    c[0] += av[0] * __builtin_bit_cast(float, bv[0]);
-    return;
-#endif
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w5bf8, av), __builtin_bit_cast(w5bf8, bv), c, 0, 0, 0);
-  };
   auto lds_barrier = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  int vstep = Sh::VIMG, rstep = Sh::RAWPAD;   // the image / raw buffer the pointers move to at the end of a chunk
-
-  // One chunk: 18 MFMAs (fragment f = 3 nu + i: X Vhh, X Vmm, W Vlh of point nu); behind MFMA f the V fragment f + 2 goes
-  // into the buffer f has just read, the weight fragment three ahead into the ring slot that has become free, and slice f of
-  // the producer's work.
-  auto chunk = [&](auto produce_, auto g2_, int k) __attribute__((always_inline)) {
-#ifdef W5_NOPROD   // (probe build, results wrong: no transform work inside the chunk loop)
-    constexpr bool PRODUCE = false;
-#else
-    constexpr bool PRODUCE = decltype(produce_)::value;
-#endif
-#ifndef W5_NODMA   // (probe build, results wrong: the chunk loop fetches no raw halo)
-    issue_raw(k + 2);
-#endif
-    ldB(std::integral_constant<int, 0>{}); ldB(std::integral_constant<int, 1>{});
-    const int knext = k + 1 < a.nchunks ? k + 1 : k;   // (past the last chunk: a harmless reload, the same loads on every path)
-    static_for<0, 18>([&](auto f_) __attribute__((always_inline)) {
-      constexpr int F = decltype(f_)::value, NU = F / 3, I = F % 3;
-      constexpr int G = 2 * NU + (I == 2 ? 1 : 0);   // the weight fragment this MFMA reads
-      mma(acc[NU], AF[G % 3], BF[F & 1]);
-#ifdef W5_NOBR   // (probe build, results wrong: the two V fragments read at the chunk top serve all 18 MFMAs)
-      if constexpr (false)
-#else
-      if constexpr (F + 2 < 18)
-#endif
-        ldB(std::integral_constant<int, (F + 2 < 18 ? F + 2 : 0)>{});
-      // the fragment MFMA F was the last reader of is G for I == 1 (X) and I == 2 (W): its slot takes fragment G + 3
-      if constexpr (I != 0) {
-        constexpr int GN = G + 3;
-        if constexpr (GN < 12) gldA(std::integral_constant<int, (GN < 12 ? GN : 0)>{}, k);
-        else gldA(std::integral_constant<int, (GN >= 12 ? GN - 12 : 0)>{}, knext);
-      }
-      if constexpr (PRODUCE) prod(std::integral_constant<int, F>{}, g2_);
-      fence();
-    });
-    // raw(k + 2) of this wave has landed (everything but the three newest loads: the next chunk's first weight fragments), the
-    // V words are written; the barrier hands both over and frees the image and the raw buffer this chunk has read
-    __builtin_amdgcn_s_waitcnt(w5_waitcnt(3, 0));
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (k < 16) W5_STAMP(3 + k);
-    vrd += vstep; vrd_lh += vstep; vwr -= vstep; prd -= rstep;
-    vstep = -vstep; rstep = -rstep;
-  };
-
-  // ---- prologue: two raw chunks in flight, V(0) built with nothing to hide under
   W5_STAMP(0);
 #ifdef DVSR_CONV_TRACE
   if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + 60] = __builtin_amdgcn_s_memrealtime();
 #endif
-  issue_raw(0);
-  issue_raw(1);
-  static_for<0, 3>([&](auto g_) __attribute__((always_inline)) { gldA(g_, 0); });
-  __builtin_amdgcn_s_waitcnt(w5_waitcnt(NI + 3, 0));   // raw(0) (and the zero fill) of this wave
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  W5_STAMP(1);
-  if (pgrp == 2) static_for<0, NSLICE>([&](auto s_) __attribute__((always_inline)) { prod(s_, std::true_type{}); fence(); });
-  else static_for<0, NSLICE>([&](auto s_) __attribute__((always_inline)) { prod(s_, std::false_type{}); fence(); });
-  __builtin_amdgcn_s_waitcnt(w5_waitcnt(3, 0));        // raw(1)
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  W5_STAMP(2);
-  vwr += Sh::VIMG; prd += Sh::RAWPAD;   // the producer moves on to raw(1) -> V(1)
 
-  // (one loop per producer group shape: the two differ in the rows they read and in the row pass)
-  if (pgrp == 2) {
-    for (int k = 0; k + 1 < a.nchunks; ++k) chunk(std::true_type{}, std::true_type{}, k);
-  } else {
-    for (int k = 0; k + 1 < a.nchunks; ++k) chunk(std::true_type{}, std::false_type{}, k);
+  if (wave >= 12) {
+    // =================================================================================================================
+    // PRODUCER waves 12..15: wave pw moves the raw halo (its quarter of the DMA) and transforms channel pair pw -- lane (tile,
+    // parity) = channel 2 pw + parity of one tile, ALL six rows xi: the six raw rows are read once, the row pass shares
+    // e +- o between (1, 2) and (3, 4), then per row pair (1, 2), (3, 4), (0, 5): column pass, the lane-half exchange that
+    // pairs the even and the odd channel, the exact 3-way split and 18 stores.  ~430 instructions per chunk, none of them
+    // between a consumer and its MFMAs.
+    const int pw = wave - 12, ptid = tid - 768;   // 0..255
+    const float* x0n = a.x0 + (size_t)n * a.x0_bs;
+    const float* x1n = a.c1 ? a.x1 + (size_t)(n / a.x1_bdiv) * a.x1_bs : x0n;
+    // raw halo groups this lane moves: a chunk = 2 channel quads x 720 groups (channel 4, row, column group) = 3 DMA
+    // instructions of the 256 producer lanes per quad; the second quad differs from the first by a SCALAR offset.  LDS float
+    // index of (channel c, row iy, column x): (c >> 2) * QF + (c & 3) * CHF + iy * RP + x.
+    static_assert(IH * GR * 4 == 720, "a channel quad is 720 groups");
+    unsigned hoff[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      const int L = jj * 256 + ptid;
+      const int cq = L / (IH * GR), rr = L - cq * (IH * GR);
+      const int iy = rr / GR, g = rr - iy * GR;
+      const int gy = oy0 - 1 + iy, gx = ox0 - 4 + 4 * g;
+      const bool live = L < 4 * IH * GR;
+      const bool ok = live && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      hoff[jj] = ok ? (unsigned)(((size_t)cq * HW + (size_t)gy * a.W + gx) * 4) : 0x80000000u;
+      if (live && !ok) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) *reinterpret_cast<f32x4*>(raw0 + (bb >> 1) * Sh::RAWPAD + (bb & 1) * QF + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const unsigned chunk_bytes = (unsigned)(Sh::CC * HW * 4), quad_bytes = (unsigned)(4 * HW * 4);
+    auto issue_raw = [&](int k) __attribute__((always_inline)) {   // raw chunk k -> buffer k & 1 (past the last chunk: nothing)
+      const bool live = k < a.nchunks;
+      const bool second = k * Sh::CC >= a.c0;  // only possible when c1 > 0; a chunk never straddles the two inputs
+      const unsigned soff = live ? (unsigned)(second ? k - a.c0 / Sh::CC : k) * chunk_bytes : 0u;
+      const __amdgpu_buffer_rsrc_t rs = w5_rsrc(second ? x1n : x0n, live ? 0x7fffffff : 0);
+      float* dst = raw0 + (k & 1) * Sh::RAWPAD + 256 * pw;
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        w5_dma16(rs, dst + jj * 1024, hoff[jj], soff);
+        w5_dma16(rs, dst + QF + jj * 1024, hoff[jj], soff + quad_bytes);
+      }
+    };
+    const int trow_t = lo / TC, tcol_t = lo - trow_t * TC;
+    const int pch = 2 * pw + hi;
+    // the patch's first aligned group in the raw buffer read next; the V words written next (lower lanes: the first row of a
+    // row pair, upper lanes: the second), image of the chunk being built
+    const float* prd = raw0 + (pch >> 2) * QF + (pch & 3) * CHF + 4 * trow_t * RP + 4 * tcol_t;
+    unsigned* vw12 = vimg0 + (hi ? 2 : 1) * 6 * 384 + lo * 4 + pw;
+    unsigned* vw34 = vimg0 + (hi ? 4 : 3) * 6 * 384 + lo * 4 + pw;
+    unsigned* vw05 = vimg0 + (hi ? 5 : 0) * 6 * 384 + lo * 4 + pw;
+    auto ld_row = [&](float (&d)[6], int row) __attribute__((always_inline)) {
+      const float* p = prd + row * RP;
+      const w5f2 l2 = *reinterpret_cast<const w5f2*>(p + 2);
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(p + 4);
+      const w5f2 h2 = *reinterpret_cast<const w5f2*>(p + 8);
+      d[0] = l2[1]; d[1] = m4[0]; d[2] = m4[1]; d[3] = m4[2]; d[4] = m4[3]; d[5] = h2[0];
+    };
+    // one row of B^T applied along a 6-vector: nu 0 and 5 single, (1, 2) and (3, 4) as e +- o
+    auto colpass = [&](const float (&r)[6], float (&v)[6]) __attribute__((always_inline)) {
+      v[0] = __builtin_fmaf(4.f, r[0], __builtin_fmaf(-5.f, r[2], r[4]));
+      v[5] = __builtin_fmaf(4.f, r[1], __builtin_fmaf(-5.f, r[3], r[5]));
+      const float e1 = __builtin_fmaf(-4.f, r[2], r[4]), o1 = __builtin_fmaf(-4.f, r[1], r[3]);
+      v[1] = e1 + o1; v[2] = e1 - o1;
+      const float e2 = r[4] - r[2], o2 = r[3] - r[1];
+      v[3] = __builtin_fmaf(2.f, o2, e2); v[4] = __builtin_fmaf(-2.f, o2, e2);
+    };
+    // rows ra (lower lanes' row) and rb (upper lanes' row) of B^T d for this lane's channel -> column pass, pairing, split, stores
+    auto finish_pair = [&](const float (&ra)[6], const float (&rb)[6], unsigned* vw) __attribute__((always_inline)) {
+      float va[6], vb[6];
+      colpass(ra, va);
+      colpass(rb, vb);
+#pragma unroll
+      for (int v = 0; v < 6; ++v) {
+        // lower lanes: (even, odd channel) of the first row; upper lanes: of the second row
+        const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, va[v]), __builtin_bit_cast(unsigned, vb[v]), false, false);
+        // (through unsigned temporaries: __builtin_bit_cast(float, s0[1]) on the vector ELEMENT reads element 0 -- hipcc 7.2)
+        const unsigned u0 = s0[0], u1 = s0[1];
+        const float v0 = __builtin_bit_cast(float, u0), v1 = __builtin_bit_cast(float, u1);
+        const unsigned h = w5_cvt_pk(v0, v1);
+        const float r0 = v0 - __builtin_bit_cast(float, h << 16), r1 = v1 - __builtin_bit_cast(float, h & 0xffff0000u);
+        const unsigned m = w5_cvt_pk(r0, r1);
+        const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+        unsigned* d = vw + v * 384;
+#ifdef W5_NOVW   // (probe build, results wrong: one V word per point instead of three)
+        d[0] = h ^ m ^ w5_cvt_pk(q0, q1);
+#else
+        d[0] = h; d[128] = m; d[256] = w5_cvt_pk(q0, q1);
+#endif
+      }
+    };
+    auto produce = [&]() __attribute__((always_inline)) {
+      float d0[6], d1[6], d2[6], d3[6], d4[6], d5[6];
+      ld_row(d1, 1); ld_row(d2, 2); ld_row(d3, 3); ld_row(d4, 4);
+      ld_row(d0, 0); ld_row(d5, 5);
+      float ra[6], rb[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float e = __builtin_fmaf(-4.f, d2[j], d4[j]), o = __builtin_fmaf(-4.f, d1[j], d3[j]);
+        ra[j] = e + o; rb[j] = e - o;
+      }
+      finish_pair(ra, rb, vw12);
+      fence();
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float e = d4[j] - d2[j], o = d3[j] - d1[j];
+        ra[j] = __builtin_fmaf(2.f, o, e); rb[j] = __builtin_fmaf(-2.f, o, e);
+      }
+      finish_pair(ra, rb, vw34);
+      fence();
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        ra[j] = __builtin_fmaf(4.f, d0[j], __builtin_fmaf(-5.f, d2[j], d4[j]));
+        rb[j] = __builtin_fmaf(4.f, d1[j], __builtin_fmaf(-5.f, d3[j], d5[j]));
+      }
+      finish_pair(ra, rb, vw05);
+    };
+    // ---- prologue: two raw chunks in flight, V(0) built
+    issue_raw(0);
+    issue_raw(1);
+    __builtin_amdgcn_s_waitcnt(w5_waitcnt(6, 0));   // raw(0) (and the zero fill) of this wave
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    produce();
+    __builtin_amdgcn_s_waitcnt(w5_waitcnt(0, 0));   // raw(1)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int vstep = Sh::VIMG, rstep = Sh::RAWPAD;
+    vw12 += vstep; vw34 += vstep; vw05 += vstep; prd += rstep;   // on to raw(1) -> V(1)
+    // ---- chunk k: raw(k + 2) into the buffer raw(k) has left, V(k + 1) from raw(k + 1)
+    for (int k = 0; k < a.nchunks; ++k) {
+#ifdef W5_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+#ifndef W5_NODMA   // (probe build, results wrong: the chunk loop fetches no raw halo)
+      issue_raw(k + 2);
+#endif
+#ifndef W5_NOPROD  // (probe build, results wrong: no transform work inside the chunk loop)
+      if (k + 1 < a.nchunks) produce();
+#endif
+      __builtin_amdgcn_s_waitcnt(w5_waitcnt(0, 0));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      vw12 -= vstep; vw34 -= vstep; vw05 -= vstep; prd -= rstep;
+      vstep = -vstep; rstep = -rstep;
+    }
+    // (the epilogue's four barriers; the producers hold no results)
+    lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier();
+    return;
   }
-  chunk(std::false_type{}, std::false_type{}, a.nchunks - 1);
+  {
+    // =================================================================================================================
+    // CONSUMER waves 0..11: wave (xi, mh) multiplies the six points (xi, nu) of one 32-cout half: 18 MFMAs per chunk, their
+    // weight fragments straight from global memory (a ring of three: one in use, two in flight), their V fragments from the
+    // LDS image (two buffers).  Nothing else: ~100 instructions per chunk, so a late fragment stalls nothing but its MFMA.
+    const int cxi = wave % 6, cmh = wave / 6;
+    f32x16 acc[6];
+#pragma unroll
+    for (int v = 0; v < 6; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+    const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + (size_t)cbi * a.nchunks * W5_PCH;
+    const __amdgpu_buffer_rsrc_t wrsrc = w5_rsrc(wp_cb, -1);
+    const unsigned avoff = (unsigned)(lane * 16);
+    const int asb = (cxi * 3 * 2 + cmh) * 3072;      // byte offset of (point pair (xi, 0), mh) inside a chunk of the pack
+    // Three weight fragments per point PAIR (2 q, 2 q + 1): X = (Uh | Um) of the even point, X' = (Um | Uh) of the odd one and
+    // L = (Ul odd | Ul even).  After the two MFMAs that read X its upper lanes take L's (W = (Uh | Ul)); after the two that
+    // read X' its lower lanes do (W' = (Ul | Uh), multiplied with the MIRRORED fragment (Vh | Vl)): 3 KB instead of 4 KB per
+    // pair and cout half cross the vector memory path, which is what bounds the chunk loop (profiles/r06_wino5_*.txt).
+    // Fragment g = 3 q + (0: X, 1: X', 2: L) of a chunk lives in slot g % 3: nine per chunk, one in use, two in flight.
+    f32x4 AF[3];
+    auto gldA = [&](auto g_, int k) __attribute__((always_inline)) {   // fragment G (0..8) of chunk k
+      constexpr int G = decltype(g_)::value;
+#ifdef W5_NOA   // (probe build, results wrong: only the first fragments are loaded -- what do the weight loads cost?)
+      if (k > 0 || G > 2) return;
+#endif
+      const int soff = k * (W5_PCH * 4) + asb + (G / 3) * 6144 + (G % 3) * 1024;
+      AF[G % 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)avoff, soff, 0));
+    };
+    // x <- (x in the lanes where keep, l elsewhere)
+    auto blend = [&](f32x4& x, const f32x4& l, bool keep) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = keep ? x[r] : l[r];
+    };
+    // V fragments: (point (xi, 0), piece 0, tile lo) of the image being read; the (Vl | Vh) fragment: lower lanes piece 2,
+    // upper lanes piece 0.  The pointers move to the other image at the end of every chunk (+- VIMG).
+    const unsigned* vrd = vimg0 + cxi * 6 * 384 + lo * 4;
+    const unsigned* vrd_lh = vrd + (hi ? 0 : 256);   // even points: (Vl | Vh)
+    const unsigned* vrd_hl = vrd + (hi ? 256 : 0);   // odd points:  (Vh | Vl)
+    // two buffers, fragment f = 3 nu + (0: Vh | Vh, 1: Vm | Vm, 2: Vl | Vh) in buffer f & 1 -- one in use, one landing
+    w5u4 BF[2];
+    auto ldB = [&](auto f_) __attribute__((always_inline)) {
+      constexpr int F = decltype(f_)::value, NU = F / 3, W = F % 3;
+      if constexpr (W == 0) BF[F & 1] = *reinterpret_cast<const w5u4*>(vrd + NU * 384);
+      else if constexpr (W == 1) BF[F & 1] = *reinterpret_cast<const w5u4*>(vrd + NU * 384 + 128);
+      else if constexpr (NU & 1) BF[F & 1] = *reinterpret_cast<const w5u4*>(vrd_hl + NU * 384);
+      else BF[F & 1] = *reinterpret_cast<const w5u4*>(vrd_lh + NU * 384);
+    };
+    auto mma = [&](f32x16& c, const f32x4& av, const w5u4& bv) __attribute__((always_inline)) {
+#ifdef W5_NOMMA   // (probe build, results wrong: the operands are consumed by a cheap VALU op instead of the MFMA)
+      c[0] += av[0] * __builtin_bit_cast(float, bv[0]);
+      return;
+#endif
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w5bf8, av), __builtin_bit_cast(w5bf8, bv), c, 0, 0, 0);
+    };
+    static_for<0, 3>([&](auto g_) __attribute__((always_inline)) { gldA(g_, 0); });
+    __builtin_amdgcn_s_barrier();   // raw(0) landed (the producers' business)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // V(0) built
+    asm volatile("" ::: "memory");
+    int vstep = Sh::VIMG;
+#ifdef W5_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    for (int k = 0; k < a.nchunks; ++k) {
+      ldB(std::integral_constant<int, 0>{}); ldB(std::integral_constant<int, 1>{});
+      const int knext = k + 1 < a.nchunks ? k + 1 : k;   // (past the last chunk: a harmless reload, the same loads on every path)
+      static_for<0, 18>([&](auto f_) __attribute__((always_inline)) {
+        constexpr int F = decltype(f_)::value, NU = F / 3, I = F % 3;
+        constexpr int XS = NU & 1;   // the slot of this point's X / X' (fragments 3 q and 3 q + 1; L in slot 2)
+        mma(acc[NU], AF[XS], BF[F & 1]);
+#ifdef W5_NOBR   // (probe build, results wrong: the two V fragments read at the chunk top serve all 18 MFMAs)
+        if constexpr (false)
+#else
+        if constexpr (F + 2 < 18)
+#endif
+          ldB(std::integral_constant<int, (F + 2 < 18 ? F + 2 : 0)>{});
+        if constexpr (I == 1) {
+          // X has been read twice: the lane half that held the mid pieces takes the lo pieces (even point: the upper half)
+          blend(AF[XS], AF[2], (NU & 1) ? hi != 0 : hi == 0);
+          // an odd point was L's last reader: its slot takes the next pair's L
+          if constexpr ((NU & 1) && NU < 5) gldA(std::integral_constant<int, 3 * ((NU < 5 ? NU : 1) / 2) + 5>{}, k);
+          if constexpr (NU == 5) gldA(std::integral_constant<int, 2>{}, knext);
+        }
+        if constexpr (I == 2) {
+          // the X slot takes the X of the next pair (same parity)
+          if constexpr (NU < 4) gldA(std::integral_constant<int, 3 * ((NU < 4 ? NU : 0) / 2) + 3 + (NU & 1)>{}, k);
+          else gldA(std::integral_constant<int, (NU & 1)>{}, knext);
+        }
+        fence();
+      });
+      // every V fragment of the image has been read; the barrier frees it for V(k + 2) and hands V(k + 1) over
+      lds_barrier();
+      if (k < 16) W5_STAMP(3 + k);
+      vrd += vstep; vrd_lh += vstep; vrd_hl += vstep;
+      vstep = -vstep;
+    }
   W5_STAMP(40);
 
   // ---- epilogue.  A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]].  Column transform in registers:
@@ -520,6 +530,7 @@ __global__ __launch_bounds__(768) void conv2d_wino5_kernel(ConvK2 a) {
     a.trace[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_ID
   }
 #endif
+  }
 }
 
 template <int TC>
@@ -532,7 +543,7 @@ static int launch_wino5(ConvK2 k, hipStream_t st) {
   k.ncb = ceil_div(k.Cout, 64);
   k.tiles_per_xcd = ceil_div(k.ntiles, 8);
   k.nitems = k.tiles_per_xcd * 8 * k.ncb;
-  hipLaunchKernelGGL(kern, dim3(k.nitems), dim3(768), Sh::LDS_BYTES, st, k);
+  hipLaunchKernelGGL(kern, dim3(k.nitems), dim3(1024), Sh::LDS_BYTES, st, k);
   return check_launch("conv2d_wino5_kernel");
 }
 
