@@ -176,8 +176,8 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
 
   if (wave >= 12) {
     // =================================================================================================================
-    // PRODUCER waves 12..15: wave pw moves the raw halo (its quarter of the DMA) and transforms channel pair pw -- lane (tile,
-    // parity) = channel 2 pw + parity of one tile, ALL six rows xi: the six raw rows are read once, the row pass shares
+    // PRODUCER waves 12..15: wave pw moves the raw halo (its quarter of the DMA) and transforms all 8 channels of the tiles
+    // 8 pw .. 8 pw + 7 -- lane (tile, channel pair, parity) = one channel of one tile, ALL six rows xi: the six raw rows are read once, the row pass shares
     // e +- o between (1, 2) and (3, 4), then per row pair (1, 2), (3, 4), (0, 5): column pass, the lane-half exchange that
     // pairs the even and the odd channel, the exact 3-way split and 18 stores.  ~430 instructions per chunk, none of them
     // between a consumer and its MFMAs.
@@ -216,14 +216,17 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
         w5_dma16(rs, dst + QF + jj * 1024, hoff[jj], soff + quad_bytes);
       }
     };
-    const int trow_t = lo / TC, tcol_t = lo - trow_t * TC;
-    const int pch = 2 * pw + hi;
+    // lane = (tile 8 pw + (lane & 7), channel pair (lane >> 3) & 3, parity lane >> 5): the 32 lanes of a store group write 32
+    // consecutive words of the V image (tile x pair) -- no bank conflict; a wave transforms all 8 channels of 8 tiles
+    const int ptile = 8 * pw + (lane & 7), ppair = (lane >> 3) & 3;
+    const int trow_t = ptile / TC, tcol_t = ptile - trow_t * TC;
+    const int pch = 2 * ppair + hi;
     // the patch's first aligned group in the raw buffer read next; the V words written next (lower lanes: the first row of a
     // row pair, upper lanes: the second), image of the chunk being built
     const float* prd = raw0 + (pch >> 2) * QF + (pch & 3) * CHF + 4 * trow_t * RP + 4 * tcol_t;
-    unsigned* vw12 = vimg0 + (hi ? 2 : 1) * 6 * 384 + lo * 4 + pw;
-    unsigned* vw34 = vimg0 + (hi ? 4 : 3) * 6 * 384 + lo * 4 + pw;
-    unsigned* vw05 = vimg0 + (hi ? 5 : 0) * 6 * 384 + lo * 4 + pw;
+    unsigned* vw12 = vimg0 + (hi ? 2 : 1) * 6 * 384 + ptile * 4 + ppair;
+    unsigned* vw34 = vimg0 + (hi ? 4 : 3) * 6 * 384 + ptile * 4 + ppair;
+    unsigned* vw05 = vimg0 + (hi ? 5 : 0) * 6 * 384 + ptile * 4 + ppair;
     auto ld_row = [&](float (&d)[6], int row) __attribute__((always_inline)) {
       const float* p = prd + row * RP;
       const w5f2 l2 = *reinterpret_cast<const w5f2*>(p + 2);
@@ -302,11 +305,12 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
     asm volatile("" ::: "memory");
     int vstep = Sh::VIMG, rstep = Sh::RAWPAD;
     vw12 += vstep; vw34 += vstep; vw05 += vstep; prd += rstep;   // on to raw(1) -> V(1)
+    // (the four producer waves are the last dispatched of the workgroup and lose every issue arbitration to the twelve consumers,
+    // which have slack: above them, 90.7 -> 86.5 us on the 8-chunk layer)
+    __builtin_amdgcn_s_setprio(3);
     // ---- chunk k: raw(k + 2) into the buffer raw(k) has left, V(k + 1) from raw(k + 1)
     for (int k = 0; k < a.nchunks; ++k) {
-#ifdef W5_PRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
+
 #ifndef W5_NODMA   // (probe build, results wrong: the chunk loop fetches no raw halo)
       issue_raw(k + 2);
 #endif
@@ -384,9 +388,6 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
     __builtin_amdgcn_s_barrier();   // V(0) built
     asm volatile("" ::: "memory");
     int vstep = Sh::VIMG;
-#ifdef W5_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
     for (int k = 0; k < a.nchunks; ++k) {
       ldB(std::integral_constant<int, 0>{}); ldB(std::integral_constant<int, 1>{});
       const int knext = k + 1 < a.nchunks ? k + 1 : k;   // (past the last chunk: a harmless reload, the same loads on every path)
