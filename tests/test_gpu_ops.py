@@ -571,6 +571,158 @@ def _winograd_case(n, c0, c1, cout, h, w, act, res, ps, force, pipe, monkeypatch
     return list(geo)
 
 
+# ---- Winograd F(4x4, 3x3) on the bf16 pipe (conv2d_wino5_kernel, geometry code 5): the no-grad forwards of the large layers ----
+def _f4_conv(x0, x1, wt, b, r, act, ps, monkeypatch, mode="2", dgrad_of=None):
+    """One launch through dvsr_conv2d_forward_packed (or _dgrad_packed) with DVSR_CONV_WINO5=mode; returns (y, geometry)."""
+    import ctypes
+    from dynavsr_amd import _lib as L
+    monkeypatch.setenv("DVSR_CONV_WINO", "2")
+    monkeypatch.setenv("DVSR_CONV_WINO3", "1")
+    monkeypatch.setenv("DVSR_CONV_WINO5", mode)
+    n, c0, h, w = x0.shape
+    c1 = x1.shape[1] if x1 is not None else 0
+    cout = wt.shape[0]
+    d0, d1, dw = dev(x0), (dev(x1) if c1 else None), dev(wt)
+    db_, dr = (dev(b) if b is not None else None), (dev(r) if r is not None else None)
+    y = torch.empty((n, cout // 4, 2 * h, 2 * w) if ps else (n, cout, h, w), device="cuda")
+    d = L.Conv2dDesc(L.ptr(d0), L.ptr(d1), L.ptr(dw), L.ptr(db_), L.ptr(dr), L.ptr(y), n, c0, c1, h, w, cout, 3, 1, 1, act, ps, 1, 0, 0)
+    geo = (ctypes.c_int * 4)()
+    L.check(L.lib().dvsr_conv2d_packed_geometry(d, ctypes.byref(geo)), "dvsr_conv2d_packed_geometry")
+    ws = torch.empty(max(int(L.lib().dvsr_conv2d_packed_workspace_bytes(d)), 16), dtype=torch.uint8, device="cuda")
+    if dgrad_of is not None:
+        gx = torch.empty(n, c0, h, w, device="cuda")
+        dgy = dev(dgrad_of)
+        L.check(L.lib().dvsr_conv2d_dgrad_packed(d, L.ptr(dgy), L.ptr(gx), ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_dgrad_packed")
+        return gx.cpu(), list(geo)
+    L.check(L.lib().dvsr_conv2d_forward_packed(d, ws.data_ptr(), ws.numel(), L.stream()), "dvsr_conv2d_forward_packed")
+    return y.cpu(), list(geo)
+
+
+@pytest.mark.parametrize("n,c0,c1,cout,h,w,act,res,ps", [
+    (5, 64, 0, 64, 180, 320, 2, False, 0),   # fe_rb of the headline clip: 23 x 5 workgroup tiles of 8 x 64 pixels, the last tile row half full
+    (4, 64, 64, 64, 96, 128, 1, True, 0),    # two inputs (16 chunks), residual
+    (1, 64, 0, 256, 92, 160, 1, False, 2),   # PixelShuffle(2) store, four cout blocks, ragged tile rows and columns
+    (3, 72, 0, 40, 88, 200, 0, False, 0),    # Cout % 32 != 0 (the second cout half idle), nine chunks, 200 = 3.125 workgroup tiles wide
+    (2, 8, 8, 64, 44, 80, 1, True, 0),       # two chunks: prologue + last chunk only
+    (2, 64, 0, 216, 96, 128, 0, False, 0),   # the offset / mask conv: the last 64-cout block holds 24
+    (1, 16, 0, 64, 4, 4, 0, False, 0),       # ONE 4 x 4 tile: 31 of the workgroup's 32 tiles outside the image
+])
+@pytest.mark.parametrize("mode", ["2", "3"])
+def test_conv3x3_winograd_f4x4(n, c0, c1, cout, h, w, act, res, ps, mode, monkeypatch):
+    """conv2d_wino5_kernel -- F(4x4, 3x3), 36 transformed points per 4x4 outputs, the exact 3-way bf16 split of both operands,
+    six of nine partial products -- against fp64 torch, both workgroup tile shapes (DVSR_CONV_WINO5=2: 8 x 64 pixels, =3:
+    16 x 32).  The bar is 4e-6 rel-L2 (1.5e-6 .. 2.0e-6 observed; F(2x2): 2.4e-7, the direct fp32 sum 4.3e-7): the transform's
+    constants (4, -5, 8, 1/24 ...) cost a factor of six, the price of 0.56 x the multiplies; max-abs <= 5e-5 on
+    O(1) outputs."""
+    cin = c0 + c1
+    x0 = rnd(n, c0, h, w, seed=1)
+    x1 = rnd(n, c1, h, w, seed=6) if c1 else None
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1 / np.sqrt(cin * 9))
+    b = rnd(cout, seed=3, scale=0.1)
+    r = rnd(n, cout, h, w, seed=4) if res else None
+    y, geo = _f4_conv(x0, x1, wt, b, r, act, ps, monkeypatch, mode)
+    assert geo[3] == 5 and geo[1] == (8 if mode == "2" else 16), geo
+    x = torch.cat([x0, x1], 1) if c1 else x0
+    ref = ACT[act](F.conv2d(x.double(), wt.double(), b.double(), 1, 1))
+    if res:
+        ref = ref + r.double()
+    if ps:
+        ref = F.pixel_shuffle(ref, 2)
+    assert relerr(y, ref) < 4e-6, relerr(y, ref)
+    assert float((y.double() - ref).abs().max()) < 5e-5
+    if c1 == 0 and not ps and not res:   # data gradient at op level: the same kernel over the transposed, tap-mirrored weights
+        gy = rnd(n, cout, h, w, seed=5)
+        gx, geo = _f4_conv(x0, None, wt, None, None, 0, 0, monkeypatch, mode, dgrad_of=gy)
+        ref_g = torch.nn.grad.conv2d_input((n, c0, h, w), wt.double(), gy.double(), 1, 1)
+        assert relerr(gx, ref_g) < 4e-6
+
+
+def test_conv3x3_winograd_f4x4_cost_model_and_eligibility(monkeypatch):
+    """DVSR_CONV_WINO5 unset: the cost model takes the F(4x4) kernel for the layers it was built for (the 5-frame layers at
+    180x320, the 360x640 / 720x1280 tail) and leaves the one-round grids (the N = 1 trunk) and the shapes it cannot store
+    whole 4x4 tiles for (H or W not a multiple of 4) to form 4; =0 switches it off."""
+    import ctypes
+    from dynavsr_amd import _lib as L
+    monkeypatch.setenv("DVSR_CONV_WINO3", "1")
+    monkeypatch.delenv("DVSR_CONV_WINO", raising=False)
+
+    def geo_of(n, c0, cout, h, w, ps=0):
+        x = torch.empty(n, c0, h, w, device="cuda")
+        d = L.Conv2dDesc(L.ptr(x), None, None, None, None, None, n, c0, 0, h, w, cout, 3, 1, 1, 0, ps, 1, 0, 0)
+        geo = (ctypes.c_int * 4)()
+        L.check(L.lib().dvsr_conv2d_packed_geometry(d, ctypes.byref(geo)), "dvsr_conv2d_packed_geometry")
+        return list(geo)
+
+    monkeypatch.delenv("DVSR_CONV_WINO5", raising=False)
+    assert geo_of(5, 64, 64, 180, 320)[3] == 5
+    assert geo_of(5, 64, 216, 180, 320)[3] == 5
+    assert geo_of(1, 64, 256, 360, 640, 2)[3] == 5
+    assert geo_of(1, 64, 64, 720, 1280)[3] == 5
+    assert geo_of(1, 64, 64, 180, 320)[3] == 4      # one round of workgroups either way: form 4 measures faster
+    assert geo_of(5, 64, 64, 90, 160)[3] == 4       # H % 4 != 0
+    monkeypatch.setenv("DVSR_CONV_WINO5", "0")
+    assert geo_of(5, 64, 64, 180, 320)[3] == 4
+
+
+@pytest.mark.parametrize("name,cout,h,w,ps", [("upconv2", 256, 360, 640, 2), ("HRconv", 64, 720, 1280, 0)])
+def test_conv3x3_winograd_f4x4_largest_geometries(name, cout, h, w, ps, monkeypatch):
+    """The two largest launches of the headline forward on the F(4x4) kernel: the whole output against form 4 (F(2x2), the
+    same split: <= 4e-6), three bands of rows against fp64 torch on the corresponding crops."""
+    n, c0 = 1, 64
+    x = rnd(n, c0, h, w, seed=11)
+    wt = rnd(cout, c0, 3, 3, seed=12, scale=1 / np.sqrt(c0 * 9))
+    b = rnd(cout, seed=13, scale=0.1)
+    y5, geo5 = _f4_conv(x, None, wt, b, None, 1, ps, monkeypatch, "2")
+    y4, geo4 = _f4_conv(x, None, wt, b, None, 1, ps, monkeypatch, "0")
+    assert geo5[3] == 5 and geo4[3] == 4
+    assert relerr(y5, y4) < 4e-6
+    s = 2 if ps else 1
+    for r0, r1 in ((0, 12), (h // 2 - 6, h // 2 + 6), (h - 12, h)):
+        a0, a1 = max(r0 - 1, 0), min(r1 + 1, h)
+        ref = F.leaky_relu(F.conv2d(x[:, :, a0:a1].double(), wt.double(), b.double(), 1, 1), 0.1)[:, :, r0 - a0:r0 - a0 + (r1 - r0)]
+        if ps:
+            ref = F.pixel_shuffle(ref, 2)
+        assert relerr(y5[:, :, s * r0:s * r1], ref) < 4e-6
+
+
+def test_conv3x3_winograd_f4x4_split_domain(monkeypatch):
+    """The split's domain on the F(4x4) kernel: per-channel scales over ten decades on the input channels (the inverse on the
+    weights) and on the output channels (error per channel), inputs scaled by 2^+-100 (V = B^T d B is up to 100 |d|: still far
+    from the exponent range's ends), and one inf / NaN input element: the outputs are non-finite on the 4x4 output tiles whose
+    6x6 patches hold the element (a SUPERSET of its 3x3 support -- the transforms mix a whole tile; arch_util.py:48-52 has no
+    non-finite handling to preserve) and match elsewhere."""
+    x, wt, b = _split_case()
+    c = x.shape[1]
+    s = torch.logspace(-6, 4, c, dtype=torch.float64)
+    xa, wa = x * s.view(1, c, 1, 1), wt / s.view(1, c, 1, 1)
+    y, geo = _f4_conv(xa, None, wa, b, None, 0, 0, monkeypatch)
+    assert geo[3] == 5 and relerr(y, F.conv2d(xa, wa, b, 1, 1)) < 4e-6
+    wb = wt * s.view(c, 1, 1, 1)
+    y, _ = _f4_conv(x, None, wb, None, None, 0, 0, monkeypatch)
+    ref = F.conv2d(x, wb, None, 1, 1)
+    per_channel = (y.double() - ref).flatten(2).norm(dim=2).norm(dim=0) / ref.flatten(2).norm(dim=2).norm(dim=0)
+    assert float(per_channel.max()) < 4e-6, per_channel
+    for e in (100, -100):
+        xt = x * 2.0 ** e
+        y, _ = _f4_conv(xt, None, wt, None, None, 0, 0, monkeypatch)
+        assert bool(torch.isfinite(y).all())
+        assert relerr(y.double() * 2.0 ** -e, F.conv2d(xt, wt, None, 1, 1) * 2.0 ** -e) < 4e-6
+    for val in (float("inf"), float("nan")):
+        xi = x.clone()
+        xi[1, 7, 21, 34] = val
+        ref = F.conv2d(xi, wt, b, 1, 1)
+        y, _ = _f4_conv(xi, None, wt, b, None, 0, 0, monkeypatch)
+        bad_ref, bad = ~torch.isfinite(ref), ~torch.isfinite(y)
+        assert bool((bad | ~bad_ref).all())                       # every output that depends on the element is non-finite
+        tiles = torch.zeros_like(bad)
+        tiles[1, :, 20:24, 32:36] = True                          # (21, 34) lies in the interior of ONE 4x4 tile's patch only ...
+        tiles[1, :, 20:24, 28:32] = True; tiles[1, :, 20:24, 36:40] = True   # ... column 34 = 32 + 2: not on a tile edge; row 21
+        tiles[1, :, 16:20, 28:40] = True; tiles[1, :, 24:28, 28:40] = True   # = 20 + 1: the halo rings of the neighbours reach it
+        assert bool((~bad | tiles).all())                         # ... and nothing outside the tiles whose patches hold it
+        ok = ~tiles
+        assert relerr(torch.where(ok, y, torch.zeros_like(y)), torch.where(ok, ref, torch.zeros_like(ref))) < 4e-6
+
+
 # ---- domain of exactness of the 3-way bf16 split (DESIGN 3.3): x = hi + mid + lo is exact while mid and lo, 2^-8 and 2^-16 of
 # x, stay NORMAL bf16 numbers (|x| >= 2^-110 or x == 0) and hi does not round to infinity (|x| < 2^127); the kernels below are
 # held to the fp32 bar inside it and to what was measured outside it (tools/split_edge_probe.py, profiles/r05_split_edges.txt).

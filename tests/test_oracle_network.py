@@ -152,3 +152,30 @@ def test_winograd_f2x2_3x3_restatement_equals_correlation():
     U = winograd.weight_transform(w)
     assert np.allclose(U[0, 0], w[:, :, 0, 0]) and np.allclose(U[3, 3], w[:, :, 2, 2])
     assert np.allclose(U[1, 1], w.sum((2, 3)) / 4)
+
+
+def test_winograd_f4x4_3x3_restatement_equals_correlation():
+    """oracle/winograd.py's F(4x4, 3x3) (the transforms conv2d_wino5.hip uses) against a plain 3x3 / stride-1 / pad-1
+    correlation: in fp64 the identity up to round-off; in the kernel's arithmetic (V in fp32, three bf16 pieces per operand,
+    six of nine partial products, fp32 sums) the bar tests/test_gpu_ops.py holds the kernel to (4e-6; 1e-6 .. 2e-6 observed on
+    64-channel layers: six times F(2x2), the price of the transform's larger constants)."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle import winograd
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((2, 16, 8, 12))
+    w = rs.standard_normal((7, 16, 3, 3)) / 12.0
+    b = rs.standard_normal(7)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1, 1).numpy()
+    got = winograd.conv3x3_winograd_f4(x, w, b)
+    assert np.abs(got - ref).max() < 1e-11
+    x32, w32 = x.astype(np.float32), w.astype(np.float32)
+    ref32 = F.conv2d(torch.from_numpy(x32).double(), torch.from_numpy(w32).double(), torch.from_numpy(b), 1, 1).numpy()
+    got3 = winograd.conv3x3_winograd_f4(x32, w32, b, split=True)
+    assert np.linalg.norm(got3 - ref32) / np.linalg.norm(ref32) < 4e-6
+    # the split is exact: hi + mid + lo == x for every fp32 value in the domain (|x| >= 2^-110)
+    v = (rs.standard_normal(4096) * 10.0 ** rs.uniform(-20, 20, 4096)).astype(np.float32)
+    h, m, lo = winograd.split3_bf16(v)
+    assert np.array_equal((h.astype(np.float64) + m + lo).astype(np.float32), v)
+    assert np.array_equal(h.view(np.uint32) & 0xFFFF, np.zeros(4096, np.uint32))
