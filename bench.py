@@ -88,7 +88,7 @@ def mfma_roof(t_ms, alg_flops, tapes, what, extra=None):
               "fp32_products_tflops": exe / (t_ms * 1e-3) / 1e12,
               "note": "%s: frac = time the two matrix pipes need at their dense peaks for the FLOPs ISSUED to them / time "
                       "(issued = SURVEY 8d's algorithmic FLOPs x the issued share of the leg's launch tapes: Winograd "
-                      "F(2x2,3x3) launches do 4/9 of their multiplies, launches on the exact 3-way bf16 split issue six "
+                      "F(2x2,3x3) launches do 4/9 of their multiplies, F(4x4,3x3) launches (no-grad forwards) 1/4, launches on the exact 3-way bf16 split issue six "
                       "bf16 products per fp32 product); achieved = issued FLOPs / time, peak = achieved / frac; "
                       "executed_flops / fp32_products_tflops = the fp32 products behind them (r03's `achieved`); "
                       "algorithmic_tflops = the same time priced with the direct sums" % what})
@@ -123,7 +123,7 @@ def _opt():
 def _sources_digest():
     """Identity of the conv kernel sources the committed PMC traffic figure was collected on."""
     h = hashlib.sha256()
-    for f in ("conv2d_v2.hip", "conv2d_wino.hip", "conv2d_wino3.hip", "conv2d_wino4.hip", "small_grid.h", "common.h"):
+    for f in ("conv2d_v2.hip", "conv2d_wino.hip", "conv2d_wino3.hip", "conv2d_wino4.hip", "conv2d_wino5.hip", "small_grid.h", "common.h"):
         with open(os.path.join(ROOT, "dynavsr_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -354,7 +354,7 @@ def per_frame_pipeline_rate(dev, clips=32, h=176, w=320, frames_per_batch=16):
     from dynavsr_amd import engine
     kb = frames_per_batch if out["batched"] <= out["overlapped"] else 1
     ecfg = (engine.MFDN, est.netE.nf, est.netE.in_nc, est.netE.scale, 5)
-    tapes = [(engine.get_plan(model.netG._cfg(), kb, h, w).work(), 2, 0),            # baseline + adapted forwards
+    tapes = [(engine.get_plan(model.netG._cfg(), kb, h, w).work(nograd=True), 2, 0),   # baseline + adapted forwards (no-grad)
              (engine.get_plan(model.netG._cfg(), kb, h // 4, w // 4, grad_groups=kb).work(), 1, 1),
              (engine.get_estimator_plan(ecfg, kb, h, w, grad_groups=kb).work(), 2, 1)]
     roof = mfma_roof(ms, fl, tapes, "whole per-frame pipeline (not one kernel)")
@@ -897,9 +897,10 @@ def main():
                 a = acc.setdefault(kind, [0.0, 0.0, 0.0, 0])
                 a[0] += t_ms; a[1] += fl; a[2] += by; a[3] += 1
                 tag = name[name.rfind("/"):]
-                if tag.endswith("w]") or tag.endswith("w3]"):   # launch geometry tag of dvsr_edvr_op_info: Winograd F(2x2, 3x3)
-                    wv = wino.setdefault(kind, [0, 0.0, 0.0, 0, 0.0, 0.0])   # (fp32 kernel | bf16x3 kernel): n, flops, ms
-                    o3 = 3 if tag.endswith("w3]") else 0
+                if tag.endswith("w]") or tag.endswith("w3]") or tag.endswith("w5]"):   # launch geometry tag of dvsr_edvr_op_info
+                    # (fp32 F(2x2) kernel | bf16x3 F(2x2) kernel | bf16x3 F(4x4) kernel): n, flops, ms
+                    wv = wino.setdefault(kind, [0, 0.0, 0.0, 0, 0.0, 0.0, 0, 0.0, 0.0])
+                    o3 = 6 if tag.endswith("w5]") else (3 if tag.endswith("w3]") else 0)
                     wv[o3] += 1; wv[o3 + 1] += fl; wv[o3 + 2] += t_ms
         dom = max(acc, key=lambda k: acc[k][0])
         t_ms, fl, by, cnt = acc[dom]
@@ -943,38 +944,48 @@ def main():
             # direct sum's 36; the bf16x3 kernel (conv2d_wino3.hip) issues each of them as six bf16 products.  The roofline
             # object is that of the kernel most of the class's time goes to; the contract's algorithmic rate (2 x MACs of the
             # direct 3x3 sum, SURVEY 8d, / time) is `algorithmic_tflops`.
-            wn, wfl, wt, w3n, w3fl, w3t = wino[dom]
-            executed = fl - (wfl + w3fl) * (1.0 - 16.0 / 36.0)
-            roof["algorithm"] = ("%d of %d launches per step on the Winograd F(2x2,3x3) kernel with the 16 GEMMs on the bf16 "
-                                 "pipe under the exact 3-way operand split (conv2d_wino4.hip, round 5: the B operand built in "
-                                 "registers; conv2d_wino3.hip under DVSR_CONV_WINO3_BLK=0..3: fp32 results, 4/9 of the "
-                                 "multiplies x 6 bf16 products + transforms), %d on the fp32 Winograd kernel "
-                                 "(conv2d_wino.hip), the rest on the direct implicit-GEMM kernels"
-                                 % (w3n // reps, cnt // reps, wn // reps))
+            wn, wfl, wt, w3n, w3fl, w3t, w5n, w5fl, w5t = wino[dom]
+            executed = fl - (wfl + w3fl) * (1.0 - 16.0 / 36.0) - w5fl * (1.0 - 36.0 / 144.0)
+            roof["algorithm"] = ("%d of %d launches per step on the Winograd F(4x4,3x3) kernel (conv2d_wino5.hip, round 6: 36 "
+                                 "transformed points per 4x4 outputs = 1/4 of the direct sum's multiplies, each issued as six bf16 "
+                                 "products under the exact 3-way operand split), %d on the F(2x2,3x3) kernel under the same split "
+                                 "(conv2d_wino4.hip: 4/9 of the multiplies x 6), %d on the fp32 Winograd kernel (conv2d_wino.hip), "
+                                 "the rest on the direct implicit-GEMM kernels"
+                                 % (w5n // reps, cnt // reps, w3n // reps, wn // reps))
             roof["executed_flops"] = executed / reps
             roof["mfma_flops_executed_frac"] = executed / fl
             roof["class"] = {"kind": dom, "launches_per_step": cnt // reps, "ms_per_step": t_ms / reps,
                              "share_of_step": t_ms / total_ms, "algorithmic_tflops": fl / (t_ms * 1e-3) / 1e12,
                              "fp32_products_tflops": executed / (t_ms * 1e-3) / 1e12,
                              "fp32_products_over_fp32_pipe_peak": executed / (t_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
-            if w3t >= wt:
+            roof["winograd_kernels"] = {
+                "conv2d_wino5_kernel": {"launches_per_step": w5n // reps, "ms_per_step": w5t / reps,
+                                        "algorithmic_tflops": (w5fl / (w5t * 1e-3) / 1e12) if w5t else None},
+                "conv2d_wino4_kernel": {"launches_per_step": w3n // reps, "ms_per_step": w3t / reps,
+                                        "algorithmic_tflops": (w3fl / (w3t * 1e-3) / 1e12) if w3t else None}}
+            if w5t >= w3t and w5t >= wt:
+                k_alg, k_fl, k_t, k_n, k_name = w5fl, w5fl * (36.0 / 144.0), w5t, w5n, "conv2d_wino5_kernel"
+                roof.update(pipe_mix(0.0, 6.0 * k_fl / reps, k_t / reps * 1e-3))
+            elif w3t >= wt:
                 blk = os.environ.get("DVSR_CONV_WINO3_BLK", "4")
-                k_fl, k_t, k_n, k_name = w3fl * (16.0 / 36.0), w3t, w3n, ("conv2d_wino4_kernel" if blk == "4" else "conv2d_wino3_kernel")
+                k_alg, k_fl, k_t, k_n, k_name = w3fl, w3fl * (16.0 / 36.0), w3t, w3n, ("conv2d_wino4_kernel" if blk == "4" else "conv2d_wino3_kernel")
                 roof.update(pipe_mix(0.0, 6.0 * k_fl / reps, k_t / reps * 1e-3))
             else:
-                k_fl, k_t, k_n, k_name = wfl * (16.0 / 36.0), wt, wn, "conv2d_wino_kernel"
+                k_alg, k_fl, k_t, k_n, k_name = wfl, wfl * (16.0 / 36.0), wt, wn, "conv2d_wino_kernel"
                 roof.update(pipe_mix(k_fl / reps, 0.0, k_t / reps * 1e-3))
             roof.update({"kernel": k_name, "launches_per_step": k_n // reps, "avg_launch_ms": k_t / k_n,
-                         "share_of_step": k_t / total_ms, "algorithmic_flops": (w3fl if w3t >= wt else wfl) / reps,
+                         "share_of_step": k_t / total_ms, "algorithmic_flops": k_alg / reps,
                          "executed_flops": k_fl / reps,
-                         "algorithmic_tflops": (w3fl if w3t >= wt else wfl) / (k_t * 1e-3) / 1e12,
+                         "algorithmic_tflops": k_alg / (k_t * 1e-3) / 1e12,
                          "fp32_products_tflops": k_fl / (k_t * 1e-3) / 1e12})
-            roof["winograd_launch_share_of_kernel_time"] = (wt + w3t) / t_ms
+            roof["winograd_launch_share_of_kernel_time"] = (wt + w3t + w5t) / t_ms
             roof["note"] = ("roofline of the kernel most of the step goes to (`kernel`; the whole conv3x3s1 class is under "
                             "`class`): achieved = FLOPs ISSUED to the matrix pipe it runs on / its time, frac = / that pipe's "
                             "dense peak -- the pipe's own utilisation (PMC SQ_VALU_MFMA_BUSY_CYCLES agrees: "
-                            "profiles/*_pmc_mfma_util.txt).  The bf16x3 kernel is bound by LDS bandwidth and issue, not by "
-                            "the pipe (DESIGN 3.1f): its fp32 products / time are `fp32_products_tflops` (r03's fp32 "
+                            "profiles/*_pmc_mfma_util.txt).  The bf16x3 kernels are bound by the weight fragments' way through "
+                            "the vector memory path and by the input transform, not by the pipe (DESIGN 3.1f-i): the F(4x4) "
+                            "kernel ISSUES 0.56 x the products of F(2x2) for the same outputs, so a lower `frac` at a shorter "
+                            "time is the point of it; fp32 products / time are `fp32_products_tflops` (r03's fp32 "
                             "Winograd kernel: 0.47 of the fp32 pipe for the same products at 5 %% more time); "
                             "algorithmic_tflops = SURVEY 8d's direct-sum FLOPs / the same time; with DVSR_CONV_WINO=0 the "
                             "direct kernels measure frac 0.70 of the fp32 pipe (profiles/*_wino_vs_direct.txt)")

@@ -159,6 +159,7 @@ def _declare(lib):
         "dvsr_debug_mfma_shadow": (I, [P, P, I, I, I, I, I, P]),
         "dvsr_edvr_tensor_info": (I, [P, c_char_p, POINTER(LL), POINTER(LL)]),
         "dvsr_edvr_plan_work": (I, [P, POINTER(ctypes.c_double * 9)]),
+        "dvsr_edvr_plan_work_nograd": (I, [P, POINTER(ctypes.c_double * 9)]),
         "dvsr_side_stream_overlaps": (I, [P]),
         "dvsr_edvr_op_output": (I, [P, I, I, POINTER(c_int), POINTER(LL), POINTER(LL)]),
         "dvsr_estimator_plan_work": (I, [P, POINTER(ctypes.c_double * 9)]),

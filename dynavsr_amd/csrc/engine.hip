@@ -71,6 +71,12 @@ struct Op {
   size_t wp_off = 0, dpk_off[2] = {0, 0};
   size_t wp_floats = 0, dpk_floats[2] = {0, 0};
   ConvGeo geo = {8, 8, 2}, dgeo[2] = {{8, 8, 2}, {8, 8, 2}};  // launch geometry chosen at plan time
+  // NO-GRAD forwards (a workspace without the gradient region: test(), the baseline / adapted forwards of the per-frame
+  // pipeline -- Video_base_model.py:197-201) may take another kernel for the same layer: the F(4x4, 3x3) Winograd kernel
+  // (conv2d_wino5.hip).  Training tapes keep `geo`, so that everything the backward re-reads, the batched == per-frame
+  // identities and the goldens of the inner step are what they were.  ng_off == wp_off: same geometry, same pack.
+  ConvGeo geo_ng = {8, 8, 2};
+  size_t wp_ng_off = 0, wp_ng_floats = 0;
 };
 
 // ---- backward tape -------------------------------------------------------------------------
@@ -198,11 +204,20 @@ struct Builder {
       // ... and the Winograd kernel where the DMA-halo kernel could run (bit 2; its epilogue stores plain or
       // PixelShuffle(2) tiles)
       const int ks_ok = (plain && (c1 == 0 || c0 % 32 == 0) ? 1 : 0) | (plain && c0 % 8 == 0 && c1 % 8 == 0 ? 2 | 4 : 0);
-      // bit 3: the FORWARD launch may take the F(4x4, 3x3) kernel (the data gradients below never do: accumulate / mask epilogues)
-      const int fwd_ok = (ps == 0 || (ps == 2 && !res.valid())) ? (ks_ok | ((ks_ok & 4) ? 8 : 0)) : (ks_ok & ~4);
+      const int fwd_ok = (ps == 0 || (ps == 2 && !res.valid())) ? ks_ok : (ks_ok & ~4);
       o.geo = as_bf(conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1, fwd_ok), Ho, Wo, Cout);
       o.wp_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, o.geo.cc) * conv2_pch_cc(ks, o.geo.cc, o.geo.bf, o.geo.dma);
       o.wp_off = alloc("", o.wp_floats * p.wsets).off;   // one pack per weight set, consecutive
+      // bit 3: the NO-GRAD forward may take the F(4x4, 3x3) kernel (never the data gradients: accumulate / mask epilogues)
+      o.geo_ng = o.geo; o.wp_ng_off = o.wp_off; o.wp_ng_floats = o.wp_floats;
+      if ((fwd_ok & 4) && !o.geo.bf) {
+        const ConvGeo g5 = conv2_choose(ks, stride, N, Ho, Wo, Cout, c0 + c1, fwd_ok | 8);
+        if (g5.dma == 5) {
+          o.geo_ng = g5;
+          o.wp_ng_floats = (size_t)ceil_div(Cout, 64) * ceil_div(c0 + c1, g5.cc) * conv2_pch_cc(ks, g5.cc, 0, 5);
+          o.wp_ng_off = alloc("", o.wp_ng_floats * p.wsets).off;
+        }
+      }
       for (int which = 0; which < 2; ++which) {
         const int ci = which ? c1 : c0;
         if (!ci) continue;
@@ -813,6 +828,7 @@ static int run_backward_op(const dvsr_edvr_plan& p, const BOp& b, const float* c
 
 struct Bases {
   float* arena; const float* x; float* out; bool use_v1;
+  bool nograd = false;   // the workspace has no gradient region: the forward may run the no-grad geometries (Op::geo_ng)
   float* at(const T& t) const {
     if (t.space == SP_ARENA) return arena + t.off;
     if (t.space == SP_INPUT) return const_cast<float*>(x) + t.off;
@@ -923,7 +939,7 @@ extern "C" int dvsr_side_stream_overlaps(dvsr_stream_t stream) {
 
 // Packs the weights of every conv of the tape (forward: wt=0; backward: the two transposed views).
 static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena_base, float* fwd_base,
-                    float* bwd_base, hipStream_t st) {
+                    float* bwd_base, hipStream_t st, bool nograd = false) {
   PackTable t;
   t.n = 0;
   auto flush = [&]() { int rc = pack_weights_run(t, st); t.n = 0; return rc; };
@@ -955,9 +971,11 @@ static int pack_all(const dvsr_edvr_plan& p, const float* const* P, float* arena
       if (fwd_base) {
         PackEntry& e = t.e[t.n++];
         e = PackEntry{};
-        e.w = wsrc + ws * wnum; e.P = fwd_base + o.wp_off + (size_t)ws * o.wp_floats; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
-        e.CC = o.geo.cc; e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
-        e.nchunks = ceil_div(ctot, e.CC); e.bf = o.geo.bf; e.perm = o.geo.dma; e.pch = conv2_pch_cc(o.ks, e.CC, e.bf, o.geo.dma);
+        const ConvGeo& fg = nograd ? o.geo_ng : o.geo;
+        e.w = wsrc + ws * wnum; e.Cout = o.Cout; e.Ctot = ctot; e.KK = KK;
+        e.P = nograd ? fwd_base + o.wp_ng_off + (size_t)ws * o.wp_ng_floats : fwd_base + o.wp_off + (size_t)ws * o.wp_floats;
+        e.CC = fg.cc; e.wt = 0; e.w_ctot = 0; e.w_coff = 0; e.ncb = ceil_div(o.Cout, 64);
+        e.nchunks = ceil_div(ctot, e.CC); e.bf = fg.bf; e.perm = fg.dma; e.pch = conv2_pch_cc(o.ks, e.CC, e.bf, fg.dma);
         if (t.n == 48) { int rc = flush(); if (rc) return rc; }
       }
       if (bwd_base) {
@@ -1007,6 +1025,10 @@ static int run_forward_op(const dvsr_edvr_plan& p, const Op& o, const float* con
                                       p.wsets > 1 ? o.N / p.wsets : 1, p.wsets > 1 ? (long long)o.Cout * o.c0 * 9 : 0,
                                       p.wsets > 1 ? o.Cout : 0);
       ConvExtra ex;
+      if (bs.nograd) {
+        set_wsets(p, o.N, o.wp_ng_floats, o.Cout, &ex);
+        return conv2d_packed_run(d, bs.arena + o.wp_ng_off, ex, o.geo_ng, st);
+      }
       set_wsets(p, o.N, o.wp_floats, o.Cout, &ex);
       return conv2d_packed_run(d, bs.arena + o.wp_off, ex, o.geo, st);
     }
@@ -1246,8 +1268,11 @@ extern "C" int dvsr_edvr_forward(const dvsr_edvr_plan* p, const float* const* pa
   DVSR_REQUIRE(ws_bytes >= p->arena_floats * sizeof(float), DVSR_ERR_WORKSPACE,
                "edvr_forward: workspace %zu < %zu bytes", ws_bytes, p->arena_floats * sizeof(float));
   Bases bs{(float*)ws, x, out, p->use_v1};
+  // a workspace too small for dvsr_edvr_backward is a no-grad forward (the header's contract: "allocate with need_grad = 1
+  // BEFORE the forward"): only then may a layer run on a kernel the backward's tape was not built around
+  bs.nograd = ws_bytes < dvsr_edvr_workspace_bytes(p, 1);
   if (!p->use_v1) {
-    int rc = pack_all(*p, params, bs.arena, bs.arena, nullptr, (hipStream_t)stream);
+    int rc = pack_all(*p, params, bs.arena, bs.arena, nullptr, (hipStream_t)stream, bs.nograd);
     if (rc != DVSR_OK) return rc;
   }
   for (const Op& o : p->ops) {
@@ -1298,8 +1323,13 @@ extern "C" int dvsr_edvr_op_info(const dvsr_edvr_plan* p, int index, char* kind,
   op_work(p->ops[index], &k, flops, bytes);
   snprintf(kind, kind_cap, "%s", k);
   if (p->ops[index].type == OP_CONV)
-    snprintf(name, name_cap, "%s[%d/%d/%d%s]", p->ops[index].name, p->ops[index].geo.cc, p->ops[index].geo.th,
-             p->ops[index].geo.mt, p->ops[index].geo.dma == 4 ? "w3" : (p->ops[index].geo.dma == 3 ? "w" : (p->ops[index].geo.dma ? "d" : "")));
+  {
+    // (the geometry of the NO-GRAD forward -- what dvsr_edvr_forward_timed's workspace runs; a training tape's forward runs
+    // Op::geo, which differs only where the tag ends in "w5": those layers are "w3" there)
+    const ConvGeo& g = p->ops[index].geo_ng;
+    snprintf(name, name_cap, "%s[%d/%d/%d%s]", p->ops[index].name, g.cc, g.th, g.mt,
+             g.dma == 5 ? "w5" : (g.dma == 4 ? "w3" : (g.dma == 3 ? "w" : (g.dma ? "d" : ""))));
+  }
   else
     snprintf(name, name_cap, "%s", p->ops[index].name);
   return DVSR_OK;
@@ -1307,13 +1337,14 @@ extern "C" int dvsr_edvr_op_info(const dvsr_edvr_plan* p, int index, char* kind,
 
 // Contraction work of a whole plan, forward and backward tapes (out: NINE doubles): out[0] / out[2] = algorithmic FLOPs (2 x MACs of the direct
 // sums: convolutions and the DCN contraction; weight + data gradients for the backward), out[1] / out[3] = the same work as
-// the kernels shape it, in fp32 products -- launches on the Winograd F(2x2, 3x3) kernels (geo.dma >= 3) do 16/36 of theirs;
+// the kernels shape it, in fp32 products -- launches on the Winograd F(2x2, 3x3) kernels (geo.dma 3, 4) do 16/36 of theirs, on
+// the F(4x4, 3x3) kernel (geo.dma 5) 36/144;
 // out[4] = algorithmic bytes of the forward tape.  out[5] / out[7] = FLOPs ISSUED to the fp32 matrix pipe
 // (v_mfma_f32_32x32x2_f32), out[6] / out[8] = FLOPs ISSUED to the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) by the forward /
 // backward tape: a launch on the exact 3-way operand split issues SIX bf16 products per fp32 product (geo.bf == 2, the
-// Winograd bf16x3 kernel geo.dma == 4, the split3 weight gradient), a plain bf16 launch (geo.bf == 1) one.  bench.py prices
+// Winograd bf16x3 kernels geo.dma == 4 / 5, the split3 weight gradient), a plain bf16 launch (geo.bf == 1) one.  bench.py prices
 // every roofline fraction with the issued figures against the peak of the pipe they were issued to.
-extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out9) {
+static int plan_work(const dvsr_edvr_plan* p, double* out9, bool nograd) {
   DVSR_REQUIRE(p && out9, DVSR_ERR_INVALID, "edvr_plan_work: null argument");
   double fa = 0, fe = 0, ba = 0, be = 0, fby = 0, f32p[2] = {0, 0}, bfp[2] = {0, 0};
   auto conv_part = [](const Op& o, int ci) {
@@ -1321,9 +1352,10 @@ extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out9) {
   };
   // one conv-shaped launch: f algorithmic FLOPs on geometry g -> (fp32 products done, pipe they go to)
   auto issue = [&](const ConvGeo& g, double f, double* ex, int pass) {
-    const double shaped = g.dma >= 3 ? f * (16.0 / 36.0) : f;
+    // (F(2x2, 3x3): 16 multiplies per 2x2 outputs instead of 36; F(4x4, 3x3), geo.dma == 5: 36 per 4x4 outputs instead of 144)
+    const double shaped = g.dma == 5 ? f * 0.25 : (g.dma >= 3 ? f * (16.0 / 36.0) : f);
     *ex += shaped;
-    if (g.dma == 4 || g.bf == 2) bfp[pass] += 6.0 * shaped;
+    if (g.dma == 4 || g.dma == 5 || g.bf == 2) bfp[pass] += 6.0 * shaped;
     else if (g.bf == 1) bfp[pass] += shaped;
     else f32p[pass] += shaped;
   };
@@ -1335,7 +1367,7 @@ extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out9) {
     }
     if (o.type == OP_CONV) {
       const double f = conv_part(o, o.c0 + o.c1);
-      fa += f; issue(o.geo, f, &fe, 0);
+      fa += f; issue(nograd ? o.geo_ng : o.geo, f, &fe, 0);
     } else if (o.type == OP_DCN) {
       const double f = 2.0 * (double)o.N * o.H * o.W * o.Cout * o.c0 * 9;
       fa += f; fe += f; f32p[0] += f;
@@ -1364,6 +1396,9 @@ extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out9) {
   out9[5] = f32p[0]; out9[6] = bfp[0]; out9[7] = f32p[1]; out9[8] = bfp[1];
   return DVSR_OK;
 }
+extern "C" int dvsr_edvr_plan_work(const dvsr_edvr_plan* p, double* out9) { return plan_work(p, out9, false); }
+// ... with the forward tape priced as a NO-GRAD forward runs it (Op::geo_ng: the F(4x4, 3x3) kernel where the plan takes it)
+extern "C" int dvsr_edvr_plan_work_nograd(const dvsr_edvr_plan* p, double* out9) { return plan_work(p, out9, true); }
 
 // Same launches as dvsr_edvr_forward with a hipEvent recorded on `stream` around every launch;
 // synchronises the stream and returns per-launch milliseconds (measurement aid for bench.py).
@@ -1378,7 +1413,8 @@ extern "C" int dvsr_edvr_forward_timed(const dvsr_edvr_plan* p, const float* con
   std::vector<hipEvent_t> ev(n + 1);
   for (auto& e : ev) DVSR_REQUIRE(hipEventCreate(&e) == hipSuccess, DVSR_ERR_HIP, "hipEventCreate failed");
   Bases bs{(float*)ws, x, out, p->use_v1};
-  int rc = p->use_v1 ? DVSR_OK : pack_all(*p, params, bs.arena, bs.arena, nullptr, st);
+  bs.nograd = ws_bytes < dvsr_edvr_workspace_bytes(p, 1);
+  int rc = p->use_v1 ? DVSR_OK : pack_all(*p, params, bs.arena, bs.arena, nullptr, st, bs.nograd);
   hipEventRecord(ev[0], st);
   for (size_t i = 0; i < n && rc == DVSR_OK; ++i) {
     rc = run_forward_op(*p, p->ops[i], params, bs, st);

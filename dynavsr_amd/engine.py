@@ -15,7 +15,7 @@ from . import _lib as L
 _plans = {}
 # Environment switches the native plan builder reads EVERY TIME it builds a plan (conv2_choose, Builder::conv, build_backward,
 # dvsr_*_plan_create): they are part of the plan-cache key, so a plan built under one setting is never handed out under another.
-_GEOMETRY_ENV = ("DVSR_CONV_WINO", "DVSR_CONV_WINO3", "DVSR_CONV_V1", "DVSR_EST_SPLIT", "DVSR_EST_SPLIT2", "DVSR_FUSE_ACT_BWD",
+_GEOMETRY_ENV = ("DVSR_CONV_WINO", "DVSR_CONV_WINO3", "DVSR_CONV_WINO5", "DVSR_CONV_V1", "DVSR_EST_SPLIT", "DVSR_EST_SPLIT2", "DVSR_FUSE_ACT_BWD",
                  "DVSR_BWD_STREAMS")
 # ... and the ones the native side reads ONCE PER PROCESS (function-local statics): changing them after the first plan has no
 # effect, so they are deliberately NOT in the key -- set them before the first call (the A/B tools run one process per value).
@@ -76,13 +76,15 @@ class Plan:
                 "dvsr_edvr_forward_timed")
         return list(ms)
 
-    def work(self):
-        """dvsr_edvr_plan_work's nine figures by name (_WORK_KEYS): fwd / bwd _algorithmic (2 x MACs of the direct sums) and
+    def work(self, nograd=False):
+        """dvsr_edvr_plan_work's (nograd: dvsr_edvr_plan_work_nograd's -- the forward tape as a forward WITHOUT the gradient
+        workspace runs it) nine figures by name (_WORK_KEYS): fwd / bwd _algorithmic (2 x MACs of the direct sums) and
         _executed (fp32 products as the kernels shape them: launches on the Winograd kernels issue 16/36 of their algorithmic
         multiplies), fwd_bytes (algorithmic bytes of the forward tape), and fwd / bwd _f32_pipe / _bf16_pipe (FLOPs issued to
         either matrix pipe: a launch on the exact 3-way bf16 split issues six bf16 products per fp32 product)."""
         out = (ctypes.c_double * 9)()
-        L.check(L.lib().dvsr_edvr_plan_work(self._h, ctypes.byref(out)), "dvsr_edvr_plan_work")
+        fn = L.lib().dvsr_edvr_plan_work_nograd if nograd else L.lib().dvsr_edvr_plan_work
+        L.check(fn(self._h, ctypes.byref(out)), "dvsr_edvr_plan_work")
         return dict(zip(_WORK_KEYS, out))
 
     def op_output(self, ws, index, which=0):

@@ -217,6 +217,11 @@ int dvsr_edvr_op_info(const dvsr_edvr_plan* plan, int index, char* kind, int kin
  * F(2x2,3x3) kernels do 16/36 of theirs; launches on the exact 3-way bf16 operand split issue six bf16 products per fp32
  * product.  bench.py's roofline fractions price the issued figures against the peak of the pipe they were issued to. */
 int dvsr_edvr_plan_work(const dvsr_edvr_plan* plan, double* out9);
+/* The same nine figures with the FORWARD tape priced as dvsr_edvr_forward runs it on a workspace WITHOUT the gradient region
+ * (workspace_bytes < dvsr_edvr_workspace_bytes(plan, 1): test(), Video_base_model.py:197-201): such a forward may run the
+ * Winograd F(4x4,3x3) kernel (36/144 of the direct sum's multiplies, six bf16 products each) on layers whose training tape
+ * keeps F(2x2,3x3); dvsr_edvr_op_info's tags ("w5") and dvsr_edvr_forward_timed describe that forward. */
+int dvsr_edvr_plan_work_nograd(const dvsr_edvr_plan* plan, double* out9);
 /* Does the plans' weight-gradient side stream run BESIDE `stream` on the current device?  ROCm maps HIP streams onto
  * GPU_MAX_HW_QUEUES hardware queues and two streams on one queue serialise -- which queue a stream gets depends on every
  * stream the process created before (an initialised RCCL communicator holds some; train_dynavsr.py:23-30 creates it first).

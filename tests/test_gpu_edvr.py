@@ -815,7 +815,7 @@ def test_winograd_path_equals_direct_path_forward_and_backward(monkeypatch):
         net = make_net(0)
         plan = engine.get_plan(net._cfg(), 1, 96, 128)
         tags = [nm for (_k, nm, _f, _b) in plan.op_info()]
-        nw = sum(1 for t in tags if t.endswith("w]") or t.endswith("w3]"))
+        nw = sum(1 for t in tags if t.endswith("w]") or t.endswith("w3]") or t.endswith("w5]"))
         assert (nw > 20) if mode == "1" else (nw == 0), (mode, nw)
         xg = x.cuda().requires_grad_(True)
         y = net(xg)
@@ -1025,7 +1025,13 @@ def test_edvr_stacked_tape_per_slice_weights(k, h, w):
     # forward only (the adapted forwards of a chunk): no gradient workspace
     with torch.no_grad():
         y2 = engine.EdvrStackedFunction.apply(x.detach(), net._cfg(), True, *[s_.detach() for s_ in stacked])
-    assert torch.equal(y2, y.detach())
+    # (bit-identical unless the no-grad forward takes the F(4x4, 3x3) kernel on some layer -- tag "w5" -- where the training
+    # tape keeps F(2x2): then the same sums by another algorithm, fp32 round-off apart)
+    plan = engine.get_plan(net._cfg(), k, h, w, grad_groups=k, weight_sets=k)
+    if any(nm.endswith("w5]") for (_k, nm, _f, _b) in plan.op_info()):
+        assert relerr(y2, y.detach()) < 5e-6
+    else:
+        assert torch.equal(y2, y.detach())
 
 
 @pytest.mark.parametrize("optimizer,overlap", [("Adam", True), ("SGD", False)])

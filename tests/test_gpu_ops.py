@@ -538,6 +538,7 @@ def _winograd_case(n, c0, c1, cout, h, w, act, res, ps, force, pipe, monkeypatch
     if force:
         monkeypatch.setenv("DVSR_CONV_WINO", "2")
     monkeypatch.setenv("DVSR_CONV_WINO3", "1" if pipe == "bf16x3" else "0")
+    monkeypatch.setenv("DVSR_CONV_WINO5", "0")   # (these cases hold the F(2x2) kernels; F(4x4): test_conv3x3_winograd_f4x4)
     cin = c0 + c1
     x0 = rnd(n, c0, h, w, seed=1)
     x1 = rnd(n, c1, h, w, seed=6) if c1 else None
@@ -731,6 +732,7 @@ def _wino_split_conv(x, wt, b, monkeypatch, wino=True):
     from dynavsr_amd import _lib as L
     monkeypatch.setenv("DVSR_CONV_WINO", "2" if wino else "0")
     monkeypatch.setenv("DVSR_CONV_WINO3", "1")
+    monkeypatch.setenv("DVSR_CONV_WINO5", "0")
     n, c, h, w = x.shape
     cout = wt.shape[0]
     dx, dw, db_ = dev(x), dev(wt), dev(b)
@@ -891,6 +893,7 @@ def test_conv3x3_winograd_largest_geometries(name, cout, h, w, ps, pipe, monkeyp
     b = rnd(cout, seed=13, scale=0.1)
     dx, dw, db_ = dev(x), dev(wt), dev(b)
     outs = {}
+    monkeypatch.setenv("DVSR_CONV_WINO5", "0")
     for mode in ("wino", "direct"):
         monkeypatch.setenv("DVSR_CONV_WINO", "2" if mode == "wino" else "0")
         monkeypatch.setenv("DVSR_CONV_WINO3", "1" if pipe == "bf16x3" else "0")
