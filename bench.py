@@ -878,6 +878,7 @@ def main():
                                    "%d clip(s) per GPU, one per HIP stream (adapt.super_resolve_video)"
                                    % (h, w, 4 * h, 4 * w, S),
                        "clips_per_step": world * S, "clips_in_flight_per_gpu": S,
+                       "value_one_clip_in_flight": 1e3 / ms_one,
                        "sharding": "independent clips per rank, no collective"},
             "one_clip_in_flight": {"value": 1e3 / ms_one, "unit": "frames/s", "ms_per_clip": ms_one,
                                    "note": "the same clips one at a time on one stream (rank 0): the protocol of rounds 1-3 "
@@ -1013,6 +1014,11 @@ def main():
             # (top-level scalars of the two legs BASELINE's metric is named after)
             line["inner_step_clips_per_s"] = line["inner_step"].get("value")
             line["per_frame_pipeline_frames_per_s"] = line["per_frame_pipeline"].get("value")
+            # (the driver's record keeps `config` verbatim and only the NAMES of other extra keys: the figures the metric is
+            # named after travel inside it too)
+            line["config"]["inner_step_clips_per_s"] = line["inner_step_clips_per_s"]
+            line["config"]["per_frame_pipeline_frames_per_s"] = line["per_frame_pipeline_frames_per_s"]
+            line["config"]["three_inner_steps_ms_per_frame"] = (line["inner_step"].get("three_inner_steps") or {}).get("ms_per_frame")
     if rank == 0:
         # what the process got from the runtime: the hardware-queue setting and the MEASURED overlap of the weight-gradient
         # side stream with the launch stream (dvsr_side_stream_overlaps), before any RCCL communicator exists
