@@ -968,8 +968,7 @@ def main():
                 k_alg, k_fl, k_t, k_n, k_name = w5fl, w5fl * (36.0 / 144.0), w5t, w5n, "conv2d_wino5_kernel"
                 roof.update(pipe_mix(0.0, 6.0 * k_fl / reps, k_t / reps * 1e-3))
             elif w3t >= wt:
-                blk = os.environ.get("DVSR_CONV_WINO3_BLK", "4")
-                k_alg, k_fl, k_t, k_n, k_name = w3fl, w3fl * (16.0 / 36.0), w3t, w3n, ("conv2d_wino4_kernel" if blk == "4" else "conv2d_wino3_kernel")
+                k_alg, k_fl, k_t, k_n, k_name = w3fl, w3fl * (16.0 / 36.0), w3t, w3n, "conv2d_wino4_kernel"
                 roof.update(pipe_mix(0.0, 6.0 * k_fl / reps, k_t / reps * 1e-3))
             else:
                 k_alg, k_fl, k_t, k_n, k_name = wfl, wfl * (16.0 / 36.0), wt, wn, "conv2d_wino_kernel"

@@ -383,7 +383,10 @@ int conv2d_wgrad_prepare(const float* x, long long x_bs, int x_bdiv, const float
     }();
     const bool fits = (unsigned long long)Cin * H * W < (1ull << 30) && (unsigned long long)Cout * k.Ho * k.Wo < (1ull << 30);
     const long long work = (long long)k.ntiles * k.nob * k.ncb;
-    if (work < s3_below && fits) {
+    // (only where conv2d_wgrad_split3_launch has a vector-staging form: 3x3 with pad 0 / 1, the 2x2 form with pad 0 -- any
+    // other pad runs the scalar-staging kernel, which has no row split)
+    const bool vec_form = (ks == 3 && (k.pad == 0 || k.pad == 1)) || (ks == 2 && k.pad == 0);
+    if (work < s3_below && fits && vec_form) {
       // two workgroups per CU from ~1000 tiles, one below; rounded DOWN (one workgroup more than the CUs hold at once is a
       // second round with one workgroup in it)
       static const int s3_wgs = [] { const char* v = getenv("DVSR_WGRAD_S3_WGS"); return v ? atoi(v) : 0; }();

@@ -596,458 +596,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
 #endif
 }
 
-// =====================================================================================================================
-// The WIDE form for Cout >= 128 (the offset / mask convolutions' 216, upconv1 / upconv2's 256, the data gradients of the
-// 128 -> 64 layers): a workgroup owns 128 couts x 32 tiles instead of 64 x 64 -- the same 64 accumulator registers per slot,
-// the same MFMAs per chunk, but the B fragments a wave builds now feed FOUR 32-cout blocks, so the build (the vector
-// instructions and LDS reads the chunk loop's issue time goes to) is half as long per MFMA: ~195 instructions per wave and
-// chunk against ~295.  (r04's review asked for 128-cout workgroups over 64 tiles; their 2048 accumulator registers per lane
-// are the whole register file of a CU -- half the tiles is what fits.)
-//   * lane = (tile n = lane & 31, channel quad = lane >> 5): four channels = two pairs per lane and slot; the half exchange
-//     hands the quads over: B1 = (hi of ch 0-3, hi of ch 4-7 | mid of the same), B2 = (hi, hi | lo, lo);
-//   * A fragments: twelve per slot (4 cout blocks x A1 / A3 / A2), each used by ONE MFMA -- a single ring of twelve registers
-//     quads: the fragment an MFMA has read is reloaded at once with the one the other slot's MFMA in the same position needs,
-//     twelve MFMAs ahead;
-//   * the pack is the 64-cout-block image of the other forms (block 2 cbi + (mh >> 1), half mh & 1); a second block that
-//     does not exist (Cout <= 64 (2 cbi + 1)) reads the first one again -- its outputs are never stored;
-//   * epilogue: the exchange rounds are the cout-block pairs (mh 0,1 | mh 2,3) instead of the cout halves.
-// RESULT (r05): parity-green and 20 % SLOWER than the 64 x 64 form on every Cout >= 128 layer.  An A fragment here feeds ONE
-// MFMA (no second tile half to reuse it on): 24 KB of fragments per wave and chunk, 192 KB per CU and chunk through a vector
-// memory path of 64 B/clk = 3072 cycles -- more than the whole chunk took before.  The 64 x 64 form moves 96 KB per chunk
-// (1536 cycles: as long as its MFMAs), which makes that path the kernel's second bound next to instruction issue; halving
-// the build is worth nothing while the fragments cost this.  Kept behind DVSR_CONV_WINO_WIDE=1.
-template <int TC>
-struct Wino4wShape {
-  static constexpr int CC = 8, NTILE = 32, TRW = NTILE / TC;
-  static constexpr int OH = 2 * TRW, OW = 2 * TC;
-  static constexpr int IH = OH + 2, RP = OW + 8, GR = RP / 4;
-  static constexpr int NG = CC * IH * GR;
-  static constexpr int NI = (NG + 511) / 512;
-  static constexpr int RAWPAD = NI * 512 * 4;
-  static constexpr int XCH = 32768;
-  static constexpr int NBUF = 3;
-  static constexpr size_t LDS_BYTES = (size_t)(NBUF * RAWPAD > XCH ? NBUF * RAWPAD : XCH) * sizeof(float);
-};
-
-template <int TC>
-__global__ __launch_bounds__(512, 2) void conv2d_wino4w_kernel(ConvK2 a) {
-  using Sh = Wino4wShape<TC>;
-  constexpr int IH = Sh::IH, RP = Sh::RP, GR = Sh::GR, NI = Sh::NI;
-  constexpr int SUB = 6144;
-  constexpr int CHB = IH * RP * 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  const int id = blockIdx.x;
-  const int q_ = id >> 3;  // XCD-aware order, as conv2d_pipe_item
-  const int cbi = q_ % a.ncb;   // 128-cout block
-  const int j_ = q_ / a.ncb;
-  const int tile = (id & 7) * a.tiles_per_xcd + j_;
-  if (j_ >= a.tiles_per_xcd || tile >= a.ntiles) return;
-  const int tx_ = tile % a.tiles_x;
-  const int t2 = tile / a.tiles_x;
-  const int ty_ = t2 % a.tiles_y;
-  const int n = t2 / a.tiles_y;
-  const int oy0 = ty_ * Sh::OH, ox0 = tx_ * Sh::OW;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lo = lane & 31, hi = lane >> 5;
-  const int r = wave & 3, np = wave >> 2;   // xi row, nu pair
-  const size_t HW = (size_t)a.H * a.W;
-  const float* x0n = a.x0 + (size_t)n * a.x0_bs;
-  const float* x1n = a.c1 ? a.x1 + (size_t)(n / a.x1_bdiv) * a.x1_bs : x0n;
-
-  unsigned hoff[NI];
-#pragma unroll
-  for (int jj = 0; jj < NI; ++jj) {
-    const int L = 64 * (wave + 8 * jj) + lane;
-    const int c = L / (IH * GR), rr = L - c * (IH * GR);
-    const int iy = rr / GR, g = rr - iy * GR;
-    const int gy = oy0 - 1 + iy, gx = ox0 - 4 + 4 * g;
-    const bool ok = L < Sh::NG && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-    hoff[jj] = ok ? (unsigned)(((size_t)c * HW + (size_t)gy * a.W + gx) * 4) : 0x80000000u;
-    if (L < Sh::NG && !ok) {
-#pragma unroll
-      for (int bb = 0; bb < Sh::NBUF; ++bb) *reinterpret_cast<f32x4*>(smem + bb * Sh::RAWPAD + L * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  const unsigned chunk_bytes = (unsigned)(Sh::CC * HW * 4);
-  int dbuf = 0;
-  auto issue_raw = [&](int k) __attribute__((always_inline)) {
-    const bool live = k < a.nchunks;
-    const bool second = k * Sh::CC >= a.c0;
-    const unsigned soff = live ? (unsigned)(second ? k - a.c0 / Sh::CC : k) * chunk_bytes : 0u;
-    const __amdgpu_buffer_rsrc_t rs = w4_rsrc(second ? x1n : x0n, live ? 0x7fffffff : 0);
-    float* dst = smem + dbuf * Sh::RAWPAD;
-#pragma unroll
-    for (int jj = 0; jj < NI; ++jj) w4_dma16(rs, dst + 256 * (wave + 8 * jj), hoff[jj], soff);
-    dbuf = dbuf == Sh::NBUF - 1 ? 0 : dbuf + 1;
-  };
-
-  // ---- A fragments: P16[cb64][k][p][piece][xl][cout 64][8 ch] bf16; block 2 cbi + (mh >> 1), cout half mh & 1
-  const int nblk64 = (a.Cout + 63) >> 6;
-  const int blk_bytes = a.nchunks * (2 * SUB * 4);
-  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + (size_t)(2 * cbi) * a.nchunks * (2 * SUB);
-  const __amdgpu_buffer_rsrc_t wrsrc = w4_rsrc(wp_cb, -1);
-  const int blk2 = 2 * cbi + 1 < nblk64 ? blk_bytes : 0;   // (a missing second block reads the first again)
-  const unsigned av0 = (unsigned)(lo * 16);
-  const unsigned av1 = av0 + (hi ? 0u : 8192u), av2 = av0 + (hi ? 8192u : 16384u);
-  const int sb0 = (r >> 1) * (SUB * 4) + ((r & 1) * 4 + (np ? 3 : 0)) * 1024;
-  const int sb1 = (r >> 1) * (SUB * 4) + ((r & 1) * 4 + (np ? 2 : 1)) * 1024;
-  f32x4 A[4][3];   // ONE ring: [cout block mh][A1 / A2 / A3], each fragment feeds one MFMA per slot
-  auto gldA1 = [&](int E, int MH, int J, int k) __attribute__((always_inline)) {   // fragment (mh, j) of slot E, chunk k
-    const int soff = k * (2 * SUB * 4) + (E ? sb1 : sb0) + ((MH >> 1) ? blk2 : 0);
-    A[MH][J] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)((J == 0 ? av0 : (J == 1 ? av1 : av2)) + (MH & 1) * 512), soff, 0));
-  };
-
-  // ---- the lane's rows and columns of the 4x4 patch of tile n = lane & 31, channel quad lane >> 5
-  const int trow_t = lo / TC, tcol_t = lo - trow_t * TC;
-  const int ra = r == 0 ? 0 : (r == 2 ? 2 : 1), rb = r == 0 ? 2 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
-  const float sg = r == 1 ? 1.f : -1.f;
-  const float s1 = np ? -1.f : 1.f;
-  const int pb = 2 * trow_t * RP + 2 * tcol_t + 3 + hi * 4 * IH * RP;
-  const unsigned lbase = w4_lds_addr(smem);
-  unsigned aA0 = lbase + (unsigned)((pb + ra * RP + (np ? 1 : 0)) * 4), aB0 = lbase + (unsigned)((pb + rb * RP + (np ? 1 : 0)) * 4);
-  unsigned aAp = lbase + (unsigned)((pb + ra * RP + 1) * 4), aBp = lbase + (unsigned)((pb + rb * RP + 1) * 4);
-  int hbuf = 0, lbuf = 0;
-  auto rotate = [&](unsigned& x0, unsigned& x1, int& buf) __attribute__((always_inline)) {
-    const int d = buf == Sh::NBUF - 1 ? -(Sh::NBUF - 1) * Sh::RAWPAD * 4 : Sh::RAWPAD * 4;
-    x0 += d; x1 += d;
-    buf = buf == Sh::NBUF - 1 ? 0 : buf + 1;
-  };
-
-  // B fragments of the two slots: Hq / Mq / Lq [slot][pair of the quad]; after `finalize` B1[slot], B2[slot]
-  unsigned Hq[2][2], Mq[2][2], Lq[2][2];
-  w4u4 B1[2], B2[2];
-  float t[8];
-  w4f2 tp[4];
-  auto wait_lds = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto load0 = [&](int P) __attribute__((always_inline)) {   // slot 0, channel pair P of the lane's quad
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(t[4 * c + 0]) : "v"(aA0), "i"((2 * P + c) * CHB));
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(t[4 * c + 1]) : "v"(aA0), "i"((2 * P + c) * CHB + 8));
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(t[4 * c + 2]) : "v"(aB0), "i"((2 * P + c) * CHB));
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(t[4 * c + 3]) : "v"(aB0), "i"((2 * P + c) * CHB + 8));
-    }
-  };
-  auto load1 = [&](int P) __attribute__((always_inline)) {   // slot 1
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(tp[2 * c + 0]) : "v"(aAp), "i"((2 * P + c) * CHB));
-      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(tp[2 * c + 1]) : "v"(aBp), "i"((2 * P + c) * CHB));
-    }
-  };
-  auto comb_split = [&](auto e_, auto p_) __attribute__((always_inline)) {
-    constexpr int E = decltype(e_)::value, P = decltype(p_)::value;
-    float v[2];
-    if constexpr (E == 0) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const float fx = __builtin_fmaf(sg, t[4 * c + 2], t[4 * c + 0]);
-        const float fy = __builtin_fmaf(sg, t[4 * c + 3], t[4 * c + 1]);
-        v[c] = fx - fy;
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const float fp = __builtin_fmaf(sg, tp[2 * c + 1][0], tp[2 * c + 0][0]);
-        const float fq = __builtin_fmaf(sg, tp[2 * c + 1][1], tp[2 * c + 0][1]);
-        v[c] = __builtin_fmaf(s1, fp, fq);
-      }
-    }
-    const unsigned h = w4_cvt_pk(v[0], v[1]);
-    const float r0 = v[0] - __builtin_bit_cast(float, h << 16), r1 = v[1] - __builtin_bit_cast(float, h & 0xffff0000u);
-    const unsigned m = w4_cvt_pk(r0, r1);
-    const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
-    Hq[E][P] = h;
-    Mq[E][P] = m;
-    Lq[E][P] = w4_cvt_pk(q0, q1);
-  };
-  // the half exchange: lower lanes hold channels 0-3 of tile n, upper lanes channels 4-7 of the same tile
-  auto finalize = [&](auto e_) __attribute__((always_inline)) {
-    constexpr int E = decltype(e_)::value;
-    const unsigned hc0 = Hq[E][0], hc1 = Hq[E][1];
-    const auto x0 = __builtin_amdgcn_permlane32_swap(Hq[E][0], Mq[E][0], false, false);
-    const auto x1 = __builtin_amdgcn_permlane32_swap(Hq[E][1], Mq[E][1], false, false);
-    B1[E] = w4u4{x0[0], x1[0], x0[1], x1[1]};
-    const auto y0 = __builtin_amdgcn_permlane32_swap(hc0, Lq[E][0], false, false);
-    const auto y1 = __builtin_amdgcn_permlane32_swap(hc1, Lq[E][1], false, false);
-    B2[E] = w4u4{y0[0], y1[0], y0[1], y1[1]};
-  };
-
-  f32x16 acc[8];   // acc[4 slot + mh]
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
-  // the MFMA of (slot E, cout block MH, product J) and, behind it, the reload of its A fragment for the other slot
-  auto mm = [&](auto e_, auto mh_, auto j_, auto zero_, int knext, bool reload) __attribute__((always_inline)) {
-    constexpr int E = decltype(e_)::value, MH = decltype(mh_)::value, J = decltype(j_)::value;
-    constexpr bool Z = decltype(zero_)::value;
-    const w4bf8 av = __builtin_bit_cast(w4bf8, A[MH][J]);
-    const w4bf8 bv = __builtin_bit_cast(w4bf8, J == 1 ? B2[E] : B1[E]);
-    if (Z) acc[4 * E + MH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, zero16, 0, 0, 0);
-    else acc[4 * E + MH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[4 * E + MH], 0, 0, 0);
-    if (reload) gldA1(E ^ 1, MH, J, knext);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using I3 = std::integral_constant<int, 3>;
-  using T = std::true_type;
-  using F = std::false_type;
-
-  // One half of a chunk: the twelve MFMAs of slot E (A1 B1, A3 B1, A2 B2 on the four cout blocks; the fragment ring turns to
-  // the other slot behind each) with the other slot's next fragment pair built in the gaps.  knext: the chunk the reloaded
-  // A fragments belong to (this one under slot 0, the next under slot 1).
-  auto half = [&](auto e_, auto z_, int knext, bool build, bool reload) __attribute__((always_inline)) {
-    constexpr int E = decltype(e_)::value;
-    using EE = std::integral_constant<int, E>;
-    using EN = std::integral_constant<int, E ^ 1>;
-    using Z = std::integral_constant<bool, decltype(z_)::value>;
-    using NZ = std::false_type;
-    auto ld = [&](int p) __attribute__((always_inline)) {
-      if constexpr (E == 0) load1(p); else load0(p);
-    };
-    mm(EE{}, I0{}, I0{}, Z{}, knext, reload);
-    if (build) { wait_lds(); comb_split(EN{}, I0{}); ld(1); }
-    fence();
-    mm(EE{}, I1{}, I0{}, Z{}, knext, reload);
-    mm(EE{}, I2{}, I0{}, Z{}, knext, reload);
-    mm(EE{}, I3{}, I0{}, Z{}, knext, reload);
-    if (build) { wait_lds(); comb_split(EN{}, I1{}); }
-    fence();
-    mm(EE{}, I0{}, I2{}, NZ{}, knext, reload);
-    mm(EE{}, I1{}, I2{}, NZ{}, knext, reload);
-    mm(EE{}, I2{}, I2{}, NZ{}, knext, reload);
-    if (build) finalize(EN{});
-    fence();
-    mm(EE{}, I3{}, I2{}, NZ{}, knext, reload);
-    mm(EE{}, I0{}, I1{}, NZ{}, knext, reload);
-    mm(EE{}, I1{}, I1{}, NZ{}, knext, reload);
-    mm(EE{}, I2{}, I1{}, NZ{}, knext, reload);
-    mm(EE{}, I3{}, I1{}, NZ{}, knext, reload);
-  };
-  auto chunk = [&](auto z_, int k, bool has_next) __attribute__((always_inline)) {
-    if (has_next) {
-      // raw(k + 1) has landed: everything but the twelve newest loads -- slot 0's A fragments of this chunk -- has returned
-      __builtin_amdgcn_s_waitcnt(w4_waitcnt(12, 15));
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      issue_raw(k + 2);
-    }
-    half(I0{}, z_, k, true, true);
-    if (has_next) {
-      load0(0);
-      fence();
-    }
-    half(I1{}, z_, k + 1, has_next, has_next);
-    if (has_next) {
-      rotate(aA0, aB0, hbuf);
-      rotate(aAp, aBp, lbuf);
-      load1(0);
-      fence();
-    }
-    if (k < 30) W4_STAMP(3 + k);
-  };
-
-  // ---- prologue
-  W4_STAMP(0);
-#ifdef DVSR_CONV_TRACE
-  if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + 60] = __builtin_amdgcn_s_memrealtime();
-#endif
-  issue_raw(0);
-  issue_raw(1);   // (at least two chunks: conv2d_packed_prepare)
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) gldA1(0, m, j == 0 ? 0 : (j == 1 ? 2 : 1), 0);
-  __builtin_amdgcn_s_waitcnt(w4_waitcnt(NI + 12, 0));   // raw(0) (and the zero fill) of this wave
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  W4_STAMP(1);
-  load0(0);
-  wait_lds(); comb_split(I0{}, I0{}); load0(1); fence();
-  wait_lds(); comb_split(I0{}, I1{});
-  finalize(I0{});
-  rotate(aA0, aB0, hbuf);   // slot 0 of chunk 1 reads raw buffer 1
-  load1(0);
-  fence();
-  W4_STAMP(2);
-
-  chunk(T{}, 0, true);
-  for (int k = 1; k + 1 < a.nchunks; ++k) chunk(F{}, k, true);
-  chunk(F{}, a.nchunks - 1, false);
-  W4_STAMP(40);
-
-  // ---- epilogue (conv2d_wino4_kernel's, with the cout-block pairs as exchange rounds)
-  int lane_e = lane;
-  asm volatile("" : "+v"(lane_e));
-  const int lo_e = lane_e & 31, hi_e = lane_e >> 5;
-#pragma unroll
-  for (int b = 0; b < 4; ++b) acc[b] += acc[4 + b];
-  const int bb_o = wave & 1, rq_o = wave >> 1;
-  const int orow = oy0 + 2 * (lo_e / TC), ocol = ox0 + 2 * (lo_e % TC);
-  const size_t HWo = (size_t)a.Ho * a.Wo;
-  const float slope = a.act == ACT_LRELU ? 0.1f : (a.act == ACT_RELU ? 0.f : 1.f);
-  const float neg = a.gmask_act == ACT_LRELU ? 0.1f : (a.gmask_act == ACT_RELU ? 0.f : 1.f);
-  const bool full = oy0 + Sh::OH <= a.Ho && ox0 + Sh::OW <= a.Wo && cbi * 128 + 128 <= a.Cout;
-  float bk[2][4];
-  {
-    const float* bias = wset_ptr(a.bias, a.b_gs, n, a.wdiv);
-#pragma unroll
-    for (int R = 0; R < 2; ++R)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int co = cbi * 128 + R * 64 + bb_o * 32 + 8 * rq_o + 4 * hi_e + k;
-        bk[R][k] = bias ? bias[co < a.Cout ? co : a.Cout - 1] : 0.f;
-      }
-  }
-  // exchange image: [source wave 8][slot 2][block of the round 2][rq 4][lane 64] x 16 B = 128 KB
-  float* const xw = smem + wave * 4096 + lane_e * 4;
-  const float* const xr = smem + (bb_o * 4 + rq_o) * 256 + lane_e * 4;
-  const bool plain = !a.res && !a.accum && !a.gmask;
-  const unsigned lane_off = (unsigned)(((size_t)(4 * hi_e) * HWo + (size_t)orow * a.Wo + ocol) * 4);
-  auto lds_barrier = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-  W4_STAMP(50);
-  lds_barrier();   // every wave is past its last raw read
-  W4_STAMP(51);
-  auto write_round = [&](auto r_, w4f2 (&ex)[4][2]) __attribute__((always_inline)) {
-    constexpr int R = decltype(r_)::value;
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const f32x16& m = acc[4 * e + 2 * R + bb];
-          *reinterpret_cast<f32x4*>(xw + ((e * 2 + bb) * 4 + rq) * 256) = f32x4{m[4 * rq], m[4 * rq + 1], m[4 * rq + 2], m[4 * rq + 3]};
-        }
-    if (full && !plain && a.ps == 0) {
-      const int cob = cbi * 128 + R * 64 + bb_o * 32 + 8 * rq_o;
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const size_t sb = (((size_t)n * a.Cout + cob + k) * HWo + (size_t)i * a.Wo) * 4;   // scalar
-          w4f2 e = {0.f, 0.f};
-          if (a.res) e = *reinterpret_cast<const w4f2*>(reinterpret_cast<const char*>(a.res) + sb + lane_off);
-          if (a.accum) e += *reinterpret_cast<const w4f2*>(reinterpret_cast<const char*>(a.y) + sb + lane_off);
-          ex[k][i] = e;
-        }
-    }
-  };
-  auto read_round = [&](f32x4 (&y)[2][2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      f32x4 s[4];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr + (rr * 16 + j * 8) * 256);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(xr + ((rr + 4) * 16 + (1 - j) * 8) * 256);
-        s[rr] = j == 0 ? v0 + v1 : v0 - v1;
-      }
-      y[0][j] = s[0] + s[1] + s[2];
-      y[1][j] = s[1] - s[2] - s[3];
-    }
-  };
-  auto finish_round = [&](auto r_, f32x4 (&y)[2][2], w4f2 (&ex)[4][2]) __attribute__((always_inline)) {
-    constexpr int R = decltype(r_)::value;
-    const int cob = cbi * 128 + R * 64 + bb_o * 32 + 8 * rq_o;   // scalar; the lane's couts are cob + 4 hi + k
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float v = y[i][j][k] + bk[R][k];
-          y[i][j][k] = fmaxf(v, v * slope);
-        }
-    if (a.ps == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          w4f2 v = {y[i][0][k], y[i][1][k]};
-          if (full) {
-            const size_t sb = (((size_t)n * a.Cout + cob + k) * HWo + (size_t)i * a.Wo) * 4;   // scalar
-            if (!plain) {
-              v += ex[k][i];
-              if (a.gmask) {
-                const w4f2 m = *reinterpret_cast<const w4f2*>(reinterpret_cast<const char*>(a.gmask) + sb + lane_off);
-                v = w4f2{v[0] * (m[0] > 0.f ? 1.f : neg), v[1] * (m[1] > 0.f ? 1.f : neg)};
-              }
-            }
-            *reinterpret_cast<w4f2*>(reinterpret_cast<char*>(a.y) + sb + lane_off) = v;
-            continue;
-          }
-          const int co = cob + 4 * hi_e + k;
-          const int oy = orow + i;
-          const size_t idx = ((size_t)n * a.Cout + co) * HWo + (size_t)oy * a.Wo + ocol;
-          const bool ok0 = co < a.Cout && oy < a.Ho && ocol < a.Wo;
-          const bool ok1 = ok0 && ocol + 1 < a.Wo;
-          if (!ok0) continue;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (j == 1 && !ok1) continue;
-            float w = v[j];
-            if (a.res) w += a.res[idx + j];
-            if (a.accum) w += a.y[idx + j];
-            if (a.gmask) w *= a.gmask[idx + j] > 0.f ? 1.f : neg;
-            a.y[idx + j] = w;
-          }
-        }
-      }
-    } else {
-      // PixelShuffle(2): channels co0 .. co0 + 3 are the 2x2 sub-pixels (dy, dx) of channel co0 / 4
-      const int co0 = cob + 4 * hi_e;
-      const int cq = co0 >> 2;
-      if (co0 < a.Cout) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int oy = orow + i;
-          if (!full && (oy >= a.Ho || ocol >= a.Wo)) continue;
-#pragma unroll
-          for (int dy = 0; dy < 2; ++dy) {
-            const f32x4 v = f32x4{y[i][0][2 * dy], y[i][0][2 * dy + 1], y[i][1][2 * dy], y[i][1][2 * dy + 1]};
-            float* dst = a.y + (((size_t)n * (a.Cout >> 2) + cq) * (2 * a.Ho) + (2 * oy + dy)) * (size_t)(2 * a.Wo) + 2 * ocol;
-            if (full || ocol + 1 < a.Wo) *reinterpret_cast<f32x4*>(dst) = v;
-            else *reinterpret_cast<w4f2*>(dst) = w4f2{v[0], v[1]};
-          }
-        }
-      }
-    }
-  };
-  using R0 = std::integral_constant<int, 0>;
-  using R1 = std::integral_constant<int, 1>;
-  f32x4 y0[2][2], y1[2][2];
-  w4f2 ex0[4][2], ex1[4][2];
-  write_round(R0{}, ex0);
-  lds_barrier();
-  read_round(y0);
-  lds_barrier();   // the reads of the first round are done
-  write_round(R1{}, ex1);
-  finish_round(R0{}, y0, ex0);
-  lds_barrier();
-  read_round(y1);
-  finish_round(R1{}, y1, ex1);
-#ifdef DVSR_CONV_TRACE
-  W4_STAMP(41);
-  __builtin_amdgcn_s_waitcnt(0);
-  W4_STAMP(42);
-  if (a.trace && threadIdx.x == 0) {
-    a.trace[(size_t)blockIdx.x * 64 + 61] = __builtin_amdgcn_s_memrealtime();
-    a.trace[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_ID
-  }
-#endif
-}
+// (Round 5 also built a WIDE form -- 128 couts x 32 tiles per workgroup for Cout >= 128, so that a B fragment fed four cout
+// blocks.  Parity-green and 20 % SLOWER on every Cout >= 128 layer (L1_om 354 -> 425 us, profiles/r05_wino4_wide.txt): an A
+// fragment then feeds ONE MFMA, 192 KB of weight fragments per CU and chunk through the vector memory path.  Retired in round 6;
+// the F(4x4, 3x3) kernel, conv2d_wino5.hip, is what those layers run now.)
 
 template <int TC>
 static int launch_wino4(ConvK2 k, hipStream_t st) {
@@ -1063,29 +615,8 @@ static int launch_wino4(ConvK2 k, hipStream_t st) {
   return check_launch("conv2d_wino4_kernel");
 }
 
-template <int TC>
-static int launch_wino4w(ConvK2 k, hipStream_t st) {
-  using Sh = Wino4wShape<TC>;
-  auto kern = conv2d_wino4w_kernel<TC>;
-  static PerDeviceOnce attr_once;
-  set_dyn_lds_once(attr_once, (const void*)kern, Sh::LDS_BYTES);
-  k.tiles_x = ceil_div(k.Wo, Sh::OW); k.tiles_y = ceil_div(k.Ho, Sh::OH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
-  k.ncb = ceil_div(k.Cout, 128);
-  k.tiles_per_xcd = ceil_div(k.ntiles, 8);
-  k.nitems = k.tiles_per_xcd * 8 * k.ncb;
-  hipLaunchKernelGGL(kern, dim3(k.nitems), dim3(512), Sh::LDS_BYTES, st, k);
-  return check_launch("conv2d_wino4w_kernel");
-}
-
-// th = 4: 4 x 64-pixel workgroup tiles (TC = 32), th = 8: 8 x 32 (TC = 16), th = 16: 16 x 16 (TC = 8); the wide form
-// (DVSR_CONV_WINO_WIDE=1, Cout >= 128: 128 couts x half as many tile rows, same tile width, same pack) is an A/B aid: it
-// MEASURED SLOWER (L1_om 354 -> 425 us, upconv2 287 -> 329, profiles/r05_wino4_wide.txt) -- see the note at its head
+// th = 4: 4 x 64-pixel workgroup tiles (TC = 32), th = 8: 8 x 32 (TC = 16), th = 16: 16 x 16 (TC = 8)
 int conv2d_wino4_launch(const ConvK2& k, int th, hipStream_t st) {
-  static const bool wide_on = [] { const char* v = getenv("DVSR_CONV_WINO_WIDE"); return v && v[0] == '1'; }();
-  if (wide_on && k.Cout >= 128) {
-    if (th == 16) return launch_wino4w<8>(k, st);
-    return th == 8 ? launch_wino4w<16>(k, st) : launch_wino4w<32>(k, st);
-  }
   if (th == 16) return launch_wino4<8>(k, st);
   return th == 8 ? launch_wino4<16>(k, st) : launch_wino4<32>(k, st);
 }

@@ -884,6 +884,12 @@ static int probe_side_overlap(hipStream_t st, hipStream_t side) {
   // (the streams are drained first: what is still queued on either would be measured instead)
   if (hipStreamSynchronize(st) == hipSuccess && hipStreamSynchronize(side) == hipSuccess &&
       hipMemsetAsync(d, 0, sizeof(h), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+    // (one untimed marker first: the first launch on a fresh stream costs its queue set-up, > 100 us at times -- timed, that is a
+    // false "serialised")
+    hipLaunchKernelGGL(probe_mark_kernel, dim3(1), dim3(64), 0, side, d);
+    (void)hipStreamSynchronize(side);
+    (void)hipMemsetAsync(d, 0, sizeof(h), st);
+    (void)hipStreamSynchronize(st);
     hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, st, d, 15000LL);   // 150 us of the 100 MHz counter
     hipLaunchKernelGGL(probe_mark_kernel, dim3(1), dim3(64), 0, side, d);
     if (hipStreamSynchronize(side) == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
@@ -903,14 +909,21 @@ static hipStream_t side_stream_for(hipStream_t st, bool* known = nullptr) {
   static const bool probe_on = [] { const char* v = getenv("DVSR_BWD_PROBE"); return !(v && v[0] == '0'); }();
   if (known) *known = probe_on;
   if (!probe_on) return shared_side_stream();
-  struct Entry { int dev; hipStream_t st, side; };
+  // (a NEGATIVE answer is not kept for ever: the stream -> hardware-queue mapping moves as the process creates streams, and a
+  // destroyed stream's handle can come back as another stream -- it is asked again every 64th use)
+  struct Entry { int dev; hipStream_t st, side; int uses; };
   static std::mutex mu;
   static std::vector<Entry> cache;
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(mu);
-  for (auto& e : cache)
-    if (e.dev == dev && e.st == st) return e.side;
+  for (size_t i = 0; i < cache.size(); ++i) {
+    Entry& e = cache[i];
+    if (e.dev != dev || e.st != st) continue;
+    if (e.side || ++e.uses < 64) return e.side;
+    cache.erase(cache.begin() + i);   // re-probe below
+    break;
+  }
   for (int i = 0; i < SIDE_POOL; ++i) {
     hipStream_t cand = pool_side_stream(i);
     if (!cand) break;
@@ -920,11 +933,11 @@ static hipStream_t side_stream_for(hipStream_t st, bool* known = nullptr) {
       return shared_side_stream();
     }
     if (r == 1) {
-      cache.push_back({dev, st, cand});
+      cache.push_back({dev, st, cand, 0});
       return cand;
     }
   }
-  cache.push_back({dev, st, nullptr});
+  cache.push_back({dev, st, nullptr, 0});
   return nullptr;
 }
 
@@ -1010,7 +1023,14 @@ static int run_forward_op(const dvsr_edvr_plan& p, const Op& o, const float* con
         const Op& oa = o.dual >= 0 ? o : p.ops[o.fused_into];
         const Op& ob = p.ops[oa.dual];
         const long long HW = (long long)oa.H * oa.W;
-        if (conv1x1_dual_ok(bs.at(oa.x0), P[oa.pw], P[ob.pw], bs.at(oa.y), bs.at(ob.y), oa.c0, HW)) {
+        // (what conv1x1_dual_run assumes of BOTH ops, checked where it is launched -- not only where the pair is marked: two plain
+        // 1x1 convs of 64 outputs over ONE single-pointer input, same activation, nothing fused into their stores)
+        auto plain1x1 = [](const Op& q) {
+          return q.type == OP_CONV && q.ks == 1 && q.stride == 1 && q.c1 == 0 && q.Cout == 64 && !q.res.valid() && !q.ps && !q.wmap && !q.pad_out;
+        };
+        const bool pair_ok = plain1x1(oa) && plain1x1(ob) && oa.act == ob.act && oa.c0 == ob.c0 && oa.N == ob.N && oa.H == ob.H &&
+                             oa.W == ob.W && oa.x0.space == ob.x0.space && oa.x0.off == ob.x0.off;
+        if (pair_ok && conv1x1_dual_ok(bs.at(oa.x0), P[oa.pw], P[ob.pw], bs.at(oa.y), bs.at(ob.y), oa.c0, HW)) {
           if (o.fused_into >= 0) return DVSR_OK;   // the partner's launch wrote this op's output
           return conv1x1_dual_run(bs.at(oa.x0), P[oa.pw], P[oa.pb], P[ob.pw], P[ob.pb], bs.at(oa.y), bs.at(ob.y), oa.N, oa.c0,
                                   (int)HW, oa.act, st, p.wsets > 1 ? oa.N / p.wsets : 1,

@@ -96,7 +96,7 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
                             long long msk_bs, int mask_logit, const float* wp, const float* b, float* out,
                             int N, int C, int H, int W, int Cout, int dg, int act, hipStream_t st, int wdiv = 1,
                             long long w_gs = 0, int b_gs = 0, int pack_perm = 0);
-int mdcn_fwd_variant();      // DVSR_DCN_FWD, read once: 3 split (default), 0 dma, 2 reg, 1 lds
+int mdcn_fwd_variant();      // DVSR_DCN_FWD, read once: 3 split (default), 0 dma, 2 reg
 int mdcn_pack_floats();      // fp32-sized slots per (64-cout block, 8-channel chunk) of a DCN weight pack (either layout fits)
 int mdcn_pack_perm(int W);   // PackEntry::perm of a DCN weight pack for images of width W
 int pack_weights_dcn3_run(const PackTable& t, hipStream_t st);   // mdcn_split.hip: entries with perm == 6

@@ -219,175 +219,9 @@ extern "C" int dvsr_debug_dcn_trace(void* buf, int launch_index) {
   do {               \
   } while (0)
 #endif
-
-template <int HALO>
-__global__ __launch_bounds__(256, 2) void mdcn_fwd_lds_kernel(DcnK2 a) {
-  constexpr int CPG = 8, KK = 9, TP = 3, NPX = 256, TH = 8, TW = 32;
-  constexpr int XH = TH + 2 + 2 * HALO, XW = TW + 2 + 2 * HALO, XPX = XH * XW;
-  constexpr int XE = (XPX + 255) / 256;
-  constexpr int HALF = KK * 2 * 32 * 4, WF = 2 * HALF, NPIECE = WF / 256;
-  __shared__ __attribute__((aligned(16))) float s_x[XPX * 8];
-  __shared__ __attribute__((aligned(16))) float s_col[TP * 2 * NPX * 4];
-  __shared__ __attribute__((aligned(16))) float s_w[WF];
-
-  const int id = blockIdx.x;
-  const int tile = (id / (8 * a.ncb)) * 8 + (id & 7);
-  const int cb = (id >> 3) % a.ncb;
-  if (tile >= a.ntiles) return;
-  const int tx_ = tile % a.tiles_x;
-  const int t2 = tile / a.tiles_x;
-  const int ty_ = t2 % a.tiles_y;
-  const int n = t2 / a.tiles_y;
-  const int oy0 = ty_ * TH, ox0 = tx_ * TW;
-  const int wy0 = oy0 - 1 - HALO, wx0 = ox0 - 1 - HALO;  // image coords of the LDS window origin
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lo = lane & 31, hi = lane >> 5;
-  const size_t HW = (size_t)a.H * a.W;
-  const int py = oy0 + (tid >> 5), px = ox0 + (tid & 31);
-  const bool pvalid = py < a.H && px < a.W;
-  const size_t pofs = (size_t)py * a.W + px;
-  const float* offn = a.off + (size_t)n * a.off_bstride;
-  const float* mskn = a.msk + (size_t)n * a.msk_bstride;
-
-  // window elements owned by this thread (fixed for all groups)
-  int xoff[XE];
-  bool xok[XE];
-#pragma unroll
-  for (int e = 0; e < XE; ++e) {
-    const int idx = tid + 256 * e;
-    const int ry = idx / XW, rx = idx - ry * XW;
-    const int gy = wy0 + ry, gx = wx0 + rx;
-    xok[e] = idx < XPX && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-    xoff[e] = xok[e] ? gy * a.W + gx : 0;
-  }
-  float rx_[CPG][XE];
-  auto prefetch_x = [&](int g) {
-    const float* xg = a.x + ((size_t)n * a.C + g * CPG) * HW;
-#pragma unroll
-    for (int c = 0; c < CPG; ++c)
-#pragma unroll
-      for (int e = 0; e < XE; ++e) rx_[c][e] = xg[(size_t)c * HW + xoff[e]];
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const float* wp_cb = wset_ptr(a.wp, a.w_gs, n, a.wdiv) + (size_t)cb * a.nchunks * WF;
-  prefetch_x(0);
-  for (int g = 0; g < a.dg; ++g) {
-    __syncthreads();  // previous group's MFMAs are done with s_w / s_col, its sampling with s_x
-    // weights of this group: LDS-DMA from the conv pack (chunk g), lands before the first MFMA phase
-    {
-      const float* wsrc = wp_cb + (size_t)g * WF;
-#pragma unroll
-      for (int j = 0; j < (NPIECE + 3) / 4; ++j) {
-        const int piece = j * 4 + wave;
-        if (piece < NPIECE)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(wsrc + piece * 256 + lane * 4),
-              (__attribute__((address_space(3))) void*)(s_w + piece * 256), 16, 0, 0);
-      }
-    }
-    // window of this group -> LDS, pixel-major, zero outside the image
-#pragma unroll
-    for (int e = 0; e < XE; ++e) {
-      const int idx = tid + 256 * e;
-      if (idx < XPX) {
-        const bool ok = xok[e];
-        f32x4 v0 = {ok ? rx_[0][e] : 0.f, ok ? rx_[1][e] : 0.f, ok ? rx_[2][e] : 0.f, ok ? rx_[3][e] : 0.f};
-        f32x4 v1 = {ok ? rx_[4][e] : 0.f, ok ? rx_[5][e] : 0.f, ok ? rx_[6][e] : 0.f, ok ? rx_[7][e] : 0.f};
-        *reinterpret_cast<f32x4*>(s_x + (size_t)idx * 8) = v0;
-        *reinterpret_cast<f32x4*>(s_x + (size_t)idx * 8 + 4) = v1;
-      }
-    }
-    __syncthreads();
-    const float* xg = a.x + ((size_t)n * a.C + g * CPG) * HW;
-    for (int t0 = 0; t0 < KK; t0 += TP) {
-      if (t0) __syncthreads();  // MFMAs of the previous tap triple have consumed s_col
-#pragma unroll
-      for (int t = 0; t < TP; ++t) {
-        const int tap = t0 + t;
-        const int ki = tap / 3, kj = tap - ki * 3;
-        float vals[CPG];
-#pragma unroll
-        for (int c = 0; c < CPG; ++c) vals[c] = 0.f;
-        if (pvalid) {
-          const float oh = offn[(size_t)(g * 2 * KK + 2 * tap) * HW + pofs];
-          const float ow = offn[(size_t)(g * 2 * KK + 2 * tap + 1) * HW + pofs];
-          float m = mskn[(size_t)(g * KK + tap) * HW + pofs];
-          if (a.mask_logit) m = sigmoidf_(m);
-          const float h_im = (float)(py - 1 + ki) + oh;
-          const float w_im = (float)(px - 1 + kj) + ow;
-          const float hf = floorf(h_im), wf = floorf(w_im);
-          const float lh = h_im - hf, lw = w_im - wf;
-          const float hh = 1.f - lh, hw = 1.f - lw;
-          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-          // window-relative corner coordinates; float compare first so that huge offsets cannot overflow
-          const float ryf = hf - (float)wy0, rxf = wf - (float)wx0;
-          if (ryf >= 0.f && ryf <= (float)(XH - 2) && rxf >= 0.f && rxf <= (float)(XW - 2)) {
-            const float* p1 = s_x + ((size_t)((int)ryf * XW + (int)rxf)) * 8;
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(p1), b1 = *reinterpret_cast<const f32x4*>(p1 + 4);
-            const f32x4 a2 = *reinterpret_cast<const f32x4*>(p1 + 8), b2 = *reinterpret_cast<const f32x4*>(p1 + 12);
-            const f32x4 a3 = *reinterpret_cast<const f32x4*>(p1 + XW * 8),
-                        b3 = *reinterpret_cast<const f32x4*>(p1 + XW * 8 + 4);
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(p1 + XW * 8 + 8),
-                        b4 = *reinterpret_cast<const f32x4*>(p1 + XW * 8 + 12);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              vals[c] = (w1 * a1[c] + w2 * a2[c] + w3 * a3[c] + w4 * a4[c]) * m;
-              vals[4 + c] = (w1 * b1[c] + w2 * b2[c] + w3 * b3[c] + w4 * b4[c]) * m;
-            }
-          } else {
-            DcnTap tp;  // sample leaves the staged window: exact clamped global gathers
-            if (make_tap(h_im, w_im, a.H, a.W, tp)) {
-#pragma unroll
-              for (int c = 0; c < CPG; ++c) {
-                const float* pl = xg + (size_t)c * HW;
-                const float v1 = tp.v1 ? pl[tp.o1] : 0.f, v2 = tp.v2 ? pl[tp.o2] : 0.f;
-                const float v3 = tp.v3 ? pl[tp.o3] : 0.f, v4 = tp.v4 ? pl[tp.o4] : 0.f;
-                vals[c] = (tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4) * m;
-              }
-            }
-          }
-        }
-        // column tile [t][hi][pixel] x float4(kk): channel c = 2kk + hi
-        f32x4 c0 = {vals[0], vals[2], vals[4], vals[6]}, c1 = {vals[1], vals[3], vals[5], vals[7]};
-        *reinterpret_cast<f32x4*>(s_col + ((size_t)((t * 2 + 0) * NPX + tid)) * 4) = c0;
-        *reinterpret_cast<f32x4*>(s_col + ((size_t)((t * 2 + 1) * NPX + tid)) * 4) = c1;
-      }
-      __syncthreads();  // (first triple: also drains the weight DMA)
-      if (t0 == 0 && g + 1 < a.dg) prefetch_x(g + 1);  // in flight under the MFMA/sampling below
-#pragma unroll
-      for (int t = 0; t < TP; ++t) {
-        const int tap = t0 + t;
-        f32x4 A[2], B[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          A[mt] = *reinterpret_cast<const f32x4*>(s_w + ((size_t)(((mt * KK + tap) * 2 + hi) * 32 + lo)) * 4);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          B[nt] = *reinterpret_cast<const f32x4*>(
-              s_col + ((size_t)((t * 2 + hi) * NPX + (2 * wave + nt) * 32 + lo)) * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][j], B[0][j], acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][j], B[1][j], acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][j], B[0][j], acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][j], B[1][j], acc[1][1], 0, 0, 0);
-        }
-      }
-    }
-  }
-
-  const TileOut t{a.out, wset_ptr(a.bias, a.b_gs, n, a.wdiv), nullptr, a.act, 0, 0, a.Cout, a.H, a.W};
-  store_mfma_tile<2, 2>(acc, t, n, cb * 64, oy0, 8, ox0, oy0 + 2 * wave, lo, hi);
-}
+// (The first fused kernel of round 1 -- mdcn_fwd_lds_kernel: the group's window staged in LDS, a column tile sampled from it --
+// lived here until round 6; the register-direct kernel below replaced it in round 2, the DMA-staged and the split kernels after
+// that.  Retired with its switch value DVSR_DCN_FWD=lds.)
 
 // -------------------------------------------------------------------------------------------------
 // Register-direct variant: no column tile at all.  Each lane samples exactly the MFMA B operands it
@@ -1008,13 +842,9 @@ int mdcn_forward_packed_run(const float* x, const float* off, long long off_bs, 
 #endif
   const int grid = ceil_div(k.ntiles, 8) * 8 * k.ncb;
   // DVSR_DCN_FWD: (default) the contraction on the bf16 pipe under the exact 3-way split (mdcn_split.hip; the pack is in its
-  // own layout, mdcn_pack_perm()); dma = the fp32-MFMA DMA-staged kernel below, reg = its register-staged form, lds = the
-  // LDS-column-tile kernel (A/B aids).  Read once per process: the packs and the kernels must agree.
+  // own layout, mdcn_pack_perm()); dma = the fp32-MFMA DMA-staged kernel below, reg = its register-staged form (A/B aids; reg
+  // is also what unaligned tensors run).  Read once per process: the packs and the kernels must agree.
   const int variant = mdcn_fwd_variant();
-  if (variant == 1 && C == dg * 8 && pack_perm == 0) {
-    hipLaunchKernelGGL(mdcn_fwd_lds_kernel<4>, dim3(grid), dim3(256), 0, st, k);
-    return check_launch("mdcn_fwd_lds_kernel");
-  }
   // DMA-staged kernel when the 16-byte groups line up (DVSR_DCN_FWD=reg keeps the register-staged one, A/B aid)
   const bool aligned = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)off | (uintptr_t)msk) & 15) == 0 && off_bs % 4 == 0 &&
                        msk_bs % 4 == 0;

@@ -33,7 +33,7 @@ int mdcn_fwd_variant() {
   static const int variant = [] {
     const char* v = getenv("DVSR_DCN_FWD");
     if (!v || !v[0] || v[0] == 's') return 3;
-    return v[0] == 'l' ? 1 : (v[0] == 'r' ? 2 : 0);
+    return v[0] == 'r' ? 2 : 0;   // (the LDS-column-tile kernel, 'lds', was retired in round 6)
   }();
   return variant;
 }

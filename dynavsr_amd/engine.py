@@ -19,10 +19,31 @@ _GEOMETRY_ENV = ("DVSR_CONV_WINO", "DVSR_CONV_WINO3", "DVSR_CONV_WINO5", "DVSR_C
                  "DVSR_BWD_STREAMS")
 # ... and the ones the native side reads ONCE PER PROCESS (function-local statics): changing them after the first plan has no
 # effect, so they are deliberately NOT in the key -- set them before the first call (the A/B tools run one process per value).
-_PROCESS_ENV = ("DVSR_CONV_WINO_T16", "DVSR_CONV_WINO3_BLK", "DVSR_CONV_DMA", "DVSR_CONV_DMAROW", "DVSR_CONV_TILE",
+_PROCESS_ENV = ("DVSR_CONV_WINO_T16", "DVSR_CONV_DMA", "DVSR_CONV_DMAROW", "DVSR_CONV_TILE", "DVSR_CONV_LDS", "DVSR_CONV_LAST_MFMA",
                 "DVSR_CONV_KSPLIT_BELOW", "DVSR_CONV_KSPLIT_NT", "DVSR_CONV_CC16_BELOW", "DVSR_SPLIT_TH8_FROM", "DVSR_WGRAD_SPLIT3",
-                "DVSR_WGRAD_SPLITS", "DVSR_WGRAD_S3V", "DVSR_WGRAD_S3_KYS_BELOW", "DVSR_WGRAD_S3_WGS", "DVSR_WGRAD_S3W", "DVSR_DCN_FWD", "DVSR_DCN_BWD", "DVSR_EST_FUSE_PAD", "DVSR_FUSE_RES_BWD", "DVSR_BWD_FORK_EVERY",
-                "DVSR_BWD_PROBE", "DVSR_TSA_DUAL")
+                "DVSR_WGRAD_SPLITS", "DVSR_WGRAD_SIMPLE", "DVSR_WGRAD_WIDE", "DVSR_WGRAD_S3V", "DVSR_WGRAD_S3_KYS_BELOW", "DVSR_WGRAD_S3_WGS",
+                "DVSR_WGRAD_S3W", "DVSR_WGRAD_KYS_BELOW", "DVSR_WGRAD_KYS_WGS", "DVSR_WGRAD_BF_WGS", "DVSR_DCN_FWD", "DVSR_DCN_BWD",
+                "DVSR_EST_FUSE_PAD", "DVSR_FUSE_RES_BWD", "DVSR_BWD_FORK_EVERY", "DVSR_BWD_PROBE", "DVSR_TSA_DUAL", "DVSR_TSA_V",
+                "DVSR_DEGRADE_GENERIC")
+_process_env_seen = None   # their values when the first plan of the process was built
+
+
+def _check_process_env():
+    """The once-per-process switches are snapshot when the first plan is built; a later plan built under another value gets a
+    warning instead of silence (the native side keeps the value it read first)."""
+    import os
+    import warnings
+    global _process_env_seen
+    now = tuple(os.environ.get(k) for k in _PROCESS_ENV)
+    if _process_env_seen is None:
+        _process_env_seen = now
+        return
+    for k, a, b in zip(_PROCESS_ENV, _process_env_seen, now):
+        if a != b:
+            warnings.warn("dynavsr_amd: %s=%r now, but the native library read %r when the first plan of this process was built "
+                          "and keeps that value (switches of this kind are read once per process: set them before the first "
+                          "plan, one process per value)" % (k, b, a), RuntimeWarning, stacklevel=3)
+    _process_env_seen = now
 
 
 # dvsr_edvr_plan_work's nine doubles (include/dynavsr_hip.h): *_executed = fp32 products as the kernels shape them,
@@ -132,6 +153,7 @@ def get_plan(cfg, b, h, w, device=None, grad_groups=1, weight_sets=1):
     key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream, grad_groups, weight_sets, _env_key())
     p = _plans.get(key)
     if p is None:
+        _check_process_env()
         p = _plans[key] = Plan(tuple(cfg), b, h, w, grad_groups, weight_sets)
     return p
 
@@ -299,6 +321,7 @@ def get_estimator_plan(cfg, b, h, w, device=None, grad_groups=1, weight_sets=1):
     key = (tuple(cfg), b, h, w, dev, torch.cuda.current_stream(dev).cuda_stream, grad_groups, weight_sets, _env_key())
     p = _eplans.get(key)
     if p is None:
+        _check_process_env()
         p = _eplans[key] = EstimatorPlan(tuple(cfg), b, h, w, grad_groups, weight_sets)
     return p
 

@@ -6,6 +6,7 @@ from collections import OrderedDict
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import load_golden, relerr
 from dynavsr_amd import synth
@@ -941,12 +942,48 @@ def test_edvr_l_bf16_psnr_gate_in_north_star_terms():
     assert abs(psnr[1] - psnr[0]) <= 0.1, psnr           # stated bound of the opt-in path there (measured 0.030 dB)
 
 
-def EDVR_l_net(mode, damped):
+def EDVR_l_net(mode, damped, seed=8, gain=0.02):
     from dynavsr_amd.models.archs.EDVR_arch import EDVR
     net = EDVR(bf16_mfma=mode, **EDVR_L)
-    sd = synth.edvr_state_dict(8, **EDVR_L)
-    net.load_state_dict(synth.damp_residual_branch(sd) if damped else sd, strict=True)
+    sd = synth.edvr_state_dict(seed, **EDVR_L)
+    net.load_state_dict(synth.damp_residual_branch(sd, gain) if damped else sd, strict=True)
     return net.cuda()
+
+
+def test_edvr_l_bf16_gate_sweep_over_gain_and_seed():
+    """The gate of the test above at ONE gain of the damped residual branch (0.02), one seed and one clip says how the reduced
+    modes behave at that operating point -- not that they hold it everywhere (r05 review / ADVICE: every trunk perturbation
+    reaches the output through conv_last, so the PSNR delta scales with the gain by construction).  The sweep: gain in
+    {0.01, 0.02, 0.05, 0.1, 1.0} x weight seeds {8, 9, 10}.  What is asserted:
+      * mode 2 (exact 3-way split) holds 0.02 dB at EVERY point -- it is the fp32 arithmetic;
+      * mode 1 (plain bf16 operands, opt-in) is characterised, not blessed: its deviation normalised by the gain -- the
+        rel-L2 of the residual branch's output against mode 0's, which does not depend on the gain -- stays below 3e-2, and
+        the PSNR delta is reported per point together with the largest gain at which all three seeds pass 0.02 dB
+        (profiles/r06_edvr_l_gate_sweep.txt has the table; bench.py reports `gate_holds_up_to_gain`)."""
+    from dynavsr_amd.utils import util
+    lr, gt = synth.sr_pair(91, 7, 64, 64)
+    hr = util.tensor2img(gt, mode="rgb")
+    base = F.interpolate(lr[0, 3:4], scale_factor=4, mode="bilinear", align_corners=False)[0].cuda()
+    rows = []
+    for seed in (8, 9, 10):
+        for gain in (0.01, 0.02, 0.05, 0.1, 1.0):
+            out = {}
+            for mode in (0, 1, 2):
+                net = EDVR_l_net(mode, damped=True, seed=seed, gain=gain)
+                with torch.no_grad():
+                    out[mode] = net(lr.cuda())[0]
+                del net
+            ps = {m: util.calculate_psnr(util.tensor2img(out[m], mode="rgb"), hr) for m in out}
+            branch = {m: (out[m] - base) for m in out}              # the residual branch's contribution (gain x trunk output)
+            nrm = {m: float((branch[m] - branch[0]).norm() / branch[0].norm()) for m in (1, 2)}
+            rows.append((seed, gain, ps[0], ps[1] - ps[0], ps[2] - ps[0], nrm[1], nrm[2]))
+    print("seed gain  psnr_fp32  d_bf16  d_split3  rel_branch_bf16  rel_branch_split3")
+    for r in rows:
+        print("%4d %5.2f %9.4f %+8.4f %+8.5f %12.3e %12.3e" % r)
+    assert all(abs(r[4]) <= 0.02 for r in rows), rows                 # mode 2: the gate, everywhere
+    assert all(r[6] < 2e-5 for r in rows), rows
+    assert all(r[5] < 3e-2 for r in rows), rows                       # mode 1: bounded in gain-independent terms
+    assert all(abs(r[3]) <= 0.02 for r in rows if r[1] <= 0.02), rows  # ... and inside the gate at the gains <= the r05 point
 
 
 # ---- per-clip parameter gradients: K clips through one tape (dvsr_edvr_plan_create_grouped) -----------------------------

@@ -847,37 +847,6 @@ def test_split_wgrad_scales_range_and_non_finite():
         assert relerr(torch.where(bad, torch.zeros_like(got), got), torch.where(bad, torch.zeros_like(ref), ref)) < 2e-6
 
 
-@pytest.mark.parametrize("blk", ["0", "1", "2", "3"])
-def test_conv3x3_winograd_bf16x3_other_forms(blk):
-    """The A/B forms of conv2d_wino3_kernel (DVSR_CONV_WINO3_BLK: 0 four xn per wave, 1 one xn per wave with U through the
-    LDS, 2 + U fragments from global, 3 + the one-barrier-per-chunk pipeline = the round-4 default; the default since round
-    5, 4 = conv2d_wino4_kernel, builds the B operand in registers and is what every other test runs) hold the same bars: the launcher reads the switch once per process, so each form runs the bf16x3 cases of
-    test_conv3x3_winograd in a child."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, DVSR_CONV_WINO3_BLK=blk)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_conv3x3_winograd and bf16x3 and not other_forms and not wide_form"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout
-
-
-def test_conv3x3_winograd_bf16x3_wide_form():
-    """conv2d_wino4w_kernel (DVSR_CONV_WINO_WIDE=1: 128 couts x 32 tiles per workgroup for Cout >= 128 -- built in round 5,
-    measured slower than the 64 x 64 form and therefore not the default) holds the same bars: the switch is read once per
-    process, so the bf16x3 cases (Cout = 256 + PixelShuffle, 216, the 16x16-tile shapes, upconv2 at 360x640) run in a child."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, DVSR_CONV_WINO_WIDE="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
-                        "test_conv3x3_winograd and bf16x3 and not other_forms and not wide_form"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout
-
-
 @pytest.mark.parametrize("pipe", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("name,cout,h,w,ps", [("upconv2", 256, 360, 640, 2), ("HRconv", 64, 720, 1280, 0)])
 def test_conv3x3_winograd_largest_geometries(name, cout, h, w, ps, pipe, monkeypatch):

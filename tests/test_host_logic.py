@@ -435,3 +435,31 @@ def test_validate_sharded_round_robin_and_reduce_gloo():
     assert seen0 == [0, 2, 4, 6] and seen1 == [1, 3, 5]
     assert a0 == [30.0 + i for i in range(7)] and b0 == [31.0 + i for i in range(7)]          # complete on rank 0
     assert [a1[i] for i in (1, 3, 5)] == [31.0, 33.0, 35.0]                                   # own entries elsewhere
+
+
+def test_process_env_switches_are_snapshot_and_a_change_warns(monkeypatch):
+    """The once-per-process native switches (engine._PROCESS_ENV): the first plan build snapshots them, a later build under another
+    value warns (the native side keeps what it read first) -- and the list covers every getenv("DVSR_...") site of csrc/ that is
+    not a per-plan switch (engine._GEOMETRY_ENV) or a debug-build aid."""
+    import glob
+    import os
+    import re
+    import warnings
+    from dynavsr_amd import engine
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dynavsr_amd", "csrc")
+    sites = set()
+    for f in glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")):
+        sites |= set(re.findall(r'getenv\("(DVSR_[A-Z0-9_]+)"\)', open(f).read()))
+    debug_only = {"DVSR_CONV_ABLATE", "DVSR_WGRAD_NOFLUSH"}
+    missing = sites - set(engine._PROCESS_ENV) - set(engine._GEOMETRY_ENV) - debug_only
+    assert not missing, missing
+    monkeypatch.setattr(engine, "_process_env_seen", None)
+    monkeypatch.delenv("DVSR_DCN_FWD", raising=False)
+    engine._check_process_env()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        engine._check_process_env()
+        assert not w
+        monkeypatch.setenv("DVSR_DCN_FWD", "dma")
+        engine._check_process_env()
+        assert len(w) == 1 and "DVSR_DCN_FWD" in str(w[0].message)
