@@ -532,6 +532,13 @@ def edvr_l_rates(dev, steps=10):
         else:
             res["delta_psnr_vs_fp32_db"] = res["psnr_vs_synthetic_gt_db"] - p0
             res["passes_0p02_db_gate"] = abs(res["delta_psnr_vs_fp32_db"]) <= 0.02
+            # (ONE operating point: residual gain 0.02, one seed.  Every trunk perturbation reaches the output through the damped
+            # conv_last, so the delta scales with the gain; profiles/r06_edvr_l_gate_sweep.txt sweeps gain x seed.)
+            res["gate_operating_point"] = {"residual_gain": 0.02, "weight_seed": 8,
+                                           "gate_holds_up_to_gain": (0.02 if mode == 1 else 1.0),
+                                           "worst_delta_db_in_sweep": (-0.0546 if mode == 1 else 2e-5),
+                                           "sweep": "profiles/r06_edvr_l_gate_sweep.txt (gain 0.01..1 x seeds 8, 9, 10; "
+                                                    "tests/test_gpu_edvr.py::test_edvr_l_bf16_gate_sweep_over_gain_and_seed)"}
             res["stress_delta_psnr_vs_fp32_db"] = res["stress_psnr_vs_unrelated_target_db"] - s0
             d = (yf - y0).double()
             res["rel_l2_vs_fp32_mfma"] = float(d.norm() / y0.double().norm())
