@@ -87,53 +87,55 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 echo "batched inner step K=16 LR 176x320, per batch: $(python tools/pmc_total.py $out/dbt_FETCH_SIZE/p_results.db $out/dbt_WRITE_SIZE/p_results.db 9 --json $out/pmc_traffic.json inner_step_batched frames_per_batch=16 h=176 w=320 | head -1)" > $out/${tag}_pmc_hbm_traffic_inner_step.txt
 rm -rf $out/dbt_FETCH_SIZE $out/dbt_WRITE_SIZE
-# 10. r03: Winograd F(2x2, 3x3) kernel against the direct DMA-halo kernel per layer shape (accuracy vs fp64, time per launch),
-#     its cycle-stamp timeline (debug build), and the forward with the kernel switched off
-echo "== Winograd on the bf16 pipe, exact 3-way split (conv2d_wino3.hip, the default)" > $out/${tag}_wino_vs_direct.txt
-DVSR_CONV_WINO=2 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
-# r04 / r05: the forms of the bf16x3 kernel: 4 (default since r05, conv2d_wino4.hip) the B operand built in registers; 3 one xn per wave + U fragments from global + one barrier per chunk,
-#      2 the same with a barrier per phase, 1 one xn per wave with U through the LDS, 0 four xn per wave (one block each)
-for b in 4 3 2 1 0; do
-  echo "== DVSR_CONV_WINO3_BLK=$b" >> $out/${tag}_wino3_variants.txt
-  DVSR_CONV_WINO=2 DVSR_CONV_WINO3_BLK=$b python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_variants.txt
-done
-echo "== Winograd on the fp32 MFMA (conv2d_wino.hip, DVSR_CONV_WINO3=0)" >> $out/${tag}_wino_vs_direct.txt
+# 10. the Winograd kernels per layer shape (accuracy vs fp64, time per launch incl. the weight pack): F(4x4, 3x3) on the bf16
+#     pipe (round 6, conv2d_wino5.hip), F(2x2, 3x3) on the bf16 pipe (conv2d_wino4.hip), on the fp32 MFMA (conv2d_wino.hip), the
+#     direct kernels
+echo "== Winograd F(4x4, 3x3) on the bf16 pipe, exact 3-way split (conv2d_wino5.hip; DVSR_CONV_WINO5=2: wherever eligible)" > $out/${tag}_wino_vs_direct.txt
+DVSR_CONV_WINO=2 DVSR_CONV_WINO5=2 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
+echo "== ... its 16 x 32-pixel workgroup tiles (DVSR_CONV_WINO5=3)" >> $out/${tag}_wino_vs_direct.txt
+DVSR_CONV_WINO=2 DVSR_CONV_WINO5=3 python tools/wino_bench.py --quick 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
+echo "== Winograd F(2x2, 3x3) on the bf16 pipe, exact 3-way split (conv2d_wino4.hip; DVSR_CONV_WINO5=0)" >> $out/${tag}_wino_vs_direct.txt
+DVSR_CONV_WINO=2 DVSR_CONV_WINO5=0 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
+echo "== Winograd F(2x2, 3x3) on the fp32 MFMA (conv2d_wino.hip, DVSR_CONV_WINO3=0)" >> $out/${tag}_wino_vs_direct.txt
 DVSR_CONV_WINO=2 DVSR_CONV_WINO3=0 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
 echo "== direct kernels (DVSR_CONV_WINO=0)" >> $out/${tag}_wino_vs_direct.txt
 DVSR_CONV_WINO=0 python tools/wino_bench.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_vs_direct.txt
 if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
-  python tools/wino_trace.py 2>&1 | grep -v amdgpu > $out/${tag}_wino_trace.txt
-  python tools/wino_trace.py 5 64 64 64 180 320 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
-  echo "== the fp32 MFMA kernel (DVSR_CONV_WINO3=0)" >> $out/${tag}_wino_trace.txt
-  DVSR_CONV_WINO3=0 python tools/wino_trace.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
-  echo "== the round-4 default (DVSR_CONV_WINO3_BLK=3: V through the LDS)" >> $out/${tag}_wino_trace.txt
-  DVSR_CONV_WINO3_BLK=3 python tools/wino_trace.py 2>&1 | grep -v amdgpu >> $out/${tag}_wino_trace.txt
-  # run-time ablations of the bf16x3 kernel's four-xn-per-wave form (debug build; results are wrong when a bit is set):
-  # 2 no input transform, 4 no DMA, 8 operands read once, 16 no barriers
-  for ab in 0 2 4 8 16 6 30; do
-    echo "== DVSR_CONV_WINO3_BLK=0 DVSR_CONV_ABLATE=$ab" >> $out/${tag}_wino3_ablation.txt
-    DVSR_CONV_WINO=2 DVSR_CONV_WINO3_BLK=0 DVSR_CONV_ABLATE=$ab DVSR_HIP_LIB=$PWD/dynavsr_amd/libdynavsr_hip_trace.so python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_ablation.txt
-  done
-  # ... and of the default form: 2 no input transform, 4 no global loads (U fragments, raw halo), 8 no V operand reads,
-  # 16 no barrier, 32 no MFMAs
-  for ab in 0 2 4 8 16 32 30 62; do
-    echo "== form 3 (the round-4 default), DVSR_CONV_ABLATE=$ab" >> $out/${tag}_wino3_ablation.txt
-    DVSR_CONV_WINO=2 DVSR_CONV_WINO3_BLK=3 DVSR_CONV_ABLATE=$ab DVSR_HIP_LIB=$PWD/dynavsr_amd/libdynavsr_hip_trace.so python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino3_ablation.txt
-  done
+  # cycle-stamp timelines (debug build): the F(4x4) kernel on the 8- and the 16-chunk layer, form 4 beside it
+  python tools/wino5_trace.py 5 64 0 64 180 320 2>&1 | grep -v amdgpu > $out/${tag}_wino5_trace.txt
+  python tools/wino5_trace.py 5 64 64 64 180 320 2>&1 | grep -v amdgpu >> $out/${tag}_wino5_trace.txt
+  DVSR_CONV_WINO5=0 python tools/wino_trace.py 2>&1 | grep -v amdgpu > $out/${tag}_wino_trace.txt
 fi
-# r04: PMC picture of the bf16x3 Winograd kernel (LDS activity, wave wait / issue-stall split, instruction mix)
-for set in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
-  DVSR_CONV_WINO=2 rocprofv3 --pmc $set --kernel-trace -d $out/dbw -o p -- python tools/wino_bench.py --quick > /dev/null 2>&1
-  python tools/pmc_dump.py $out/dbw/p_results.db conv2d_wino4 >> $out/${tag}_wino3_pmc.txt; rm -rf $out/dbw
+# compile-time probe builds of the F(4x4) kernel (results WRONG: each bounds what one term of the chunk loop costs), same box
+if [ -x tools/wino5_variants.sh ]; then
+  tools/wino5_variants.sh NOA NOPROD NOMMA NODMA NOBR NOVW NOPROD+NOA > /dev/null 2>&1
+  cp dynavsr_amd/libdynavsr_hip.so /tmp/base.so
+  for v in base NOA NOPROD NOMMA NODMA NOBR NOVW NOPROD+NOA base; do
+    if [ $v = base ]; then cp /tmp/base.so dynavsr_amd/libdynavsr_hip.so; else cp dynavsr_amd/libdynavsr_hip_w5_$v.so dynavsr_amd/libdynavsr_hip.so; fi
+    echo "== $v" >> $out/${tag}_wino5_ablation.txt
+    DVSR_CONV_WINO=2 DVSR_CONV_WINO5=2 python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino5_ablation.txt
+  done
+  cp /tmp/base.so dynavsr_amd/libdynavsr_hip.so; rm -f dynavsr_amd/libdynavsr_hip_w5_*.so
+fi
+# PMC picture of the two bf16x3 Winograd kernels on the same three layers (LDS activity, wave wait / issue split, instruction mix,
+# vector-memory path)
+for mode in 2 0; do
+  echo "== DVSR_CONV_WINO5=$mode" >> $out/${tag}_wino5_pmc.txt
+  for set in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
+    DVSR_CONV_WINO=2 DVSR_CONV_WINO5=$mode rocprofv3 --pmc $set --kernel-trace -d $out/dbw -o p -- python tools/wino_bench.py --quick > /dev/null 2>&1
+    python tools/pmc_dump.py $out/dbw/p_results.db conv2d_wino >> $out/${tag}_wino5_pmc.txt; rm -rf $out/dbw
+  done
 done
 # r04: what the two waves of a SIMD share (micro-benchmarks behind DESIGN 3.1f)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/mfma_overlap.hip -o /tmp/mfma_overlap 2>/dev/null && /tmp/mfma_overlap > $out/${tag}_mfma_overlap.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/wave_phase.hip -o /tmp/wave_phase 2>/dev/null && /tmp/wave_phase > $out/${tag}_wave_phase.txt
 python tools/graph_fwd_bench.py 2>&1 | grep -v amdgpu > $out/${tag}_graph_vs_eager_fwd.txt
-echo "== forward 180x320 with DVSR_CONV_WINO=0 (direct kernels only)" >> $out/${tag}_wino_vs_direct.txt
-DVSR_CONV_WINO=0 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-inner-step --no-split --no-meta --no-validation 2>/dev/null | tail -1 | python -c "
+for sw in "DVSR_CONV_WINO5=0" "DVSR_CONV_WINO=0"; do
+echo "== forward 180x320 with $sw" >> $out/${tag}_wino_vs_direct.txt
+env $sw python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-inner-step --no-split --no-meta --no-validation 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'])" >> $out/${tag}_wino_vs_direct.txt
+d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('value','ms_per_step','value_one_clip_in_flight')}, d['roofline']['kernel'], d['roofline']['frac'])" >> $out/${tag}_wino_vs_direct.txt
+done
 # r04: clips in flight on HIP streams against one clip at a time and against one forward over a batch of clips
 for cfg in "2 1" "3 1" "1 8" "2 4"; do
   python tools/fwd_concurrent.py 180 320 20 $cfg 2>&1 | grep -E "stream|diff" >> $out/${tag}_fwd_clips_in_flight.txt

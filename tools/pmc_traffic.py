@@ -33,11 +33,11 @@ for n, d in sorted(res.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", (0, 0))[
     if "dvsr" not in n:
         continue
     f, w = d.get("FETCH_SIZE", (0, 0)), d.get("WRITE_SIZE", (0, 0))
-    wide = "conv2d_dma_kernel" in n or "mdcn_fwd_dma_kernel" in n or "conv2d_wino_kernel" in n or "conv2d_wino3_kernel" in n or "conv2d_wino4_kernel" in n or "mdcn_fwd_split_kernel" in n
+    wide = "conv2d_dma_kernel" in n or "mdcn_fwd_dma_kernel" in n or "conv2d_wino_kernel" in n or "conv2d_wino4_kernel" in n or "conv2d_wino5_kernel" in n or "mdcn_fwd_split_kernel" in n
     fc = f[0] * (2.0 if wide else 1.0)
     lines.append("  %-64s %6d %14.1f %14s %14.1f" % (n[:64], f[1], f[0], ("%.1f" % fc) if wide else "-", w[0]))
     # every kernel bench.py files under "conv3x3s1": DMA-halo, register-staged (conv_first) and K-split 3x3 stride-1 convs
-    if "conv2d_dma_kernel" in n or "conv2d_wino_kernel" in n or "conv2d_wino3_kernel" in n or "conv2d_wino4_kernel" in n or "conv2d_pipe_kernel<3, 1" in n or "conv2d_ksplit_kernel" in n:
+    if "conv2d_dma_kernel" in n or "conv2d_wino_kernel" in n or "conv2d_wino4_kernel" in n or "conv2d_wino5_kernel" in n or "conv2d_pipe_kernel<3, 1" in n or "conv2d_ksplit_kernel" in n:
         tot["f"] += fc * f[1]; tot["w"] += w[0] * f[1]; tot["n"] += f[1]
 per = (tot["f"] + tot["w"]) / max(tot["n"], 1) * 1024
 lines.append("# dominant kernel (3x3/s1 conv, all kernels and geometries, corrected fetch): %.1f MB HBM traffic per launch (fetch %.1f + write %.1f) "
@@ -46,7 +46,7 @@ lines.append("# dominant kernel (3x3/s1 conv, all kernels and geometries, correc
 open(out_txt, "w").write("\n".join(lines) + "\n")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dig = hashlib.sha256()
-for f in ("conv2d_v2.hip", "conv2d_wino.hip", "conv2d_wino3.hip", "conv2d_wino4.hip", "small_grid.h", "common.h"):   # bench.py refuses the figure when these have changed since
+for f in ("conv2d_v2.hip", "conv2d_wino.hip", "conv2d_wino3.hip", "conv2d_wino4.hip", "conv2d_wino5.hip", "small_grid.h", "common.h"):   # bench.py refuses the figure when these have changed since
     dig.update(open(os.path.join(ROOT, "dynavsr_amd", "csrc", f), "rb").read())
 json.dump({"sources_sha256_16": dig.hexdigest()[:16], "conv3x3s1": {"bytes_per_launch": per, "fetch_bytes": tot["f"] / max(tot["n"], 1) * 1024,
                          "write_bytes": tot["w"] / max(tot["n"], 1) * 1024,
