@@ -1026,12 +1026,12 @@ ConvGeo conv2_choose(int ks, int stride, int N, int Ho, int Wo, int Cout, int Ct
     const double best = std::min(std::min(w4, w8), w16);
     // (both Winograd kernels hold a workgroup's whole working set in ~150 KB of LDS: gfx950's 160 KB, checked, not assumed)
     // DVSR_CONV_WINO5 (read per call): Winograd F(4x4, 3x3) on the bf16 pipe (conv2d_wino5.hip: 32 tiles of 4x4 outputs x 64
-    // couts per workgroup, 768 threads, 156 KB of LDS).  Forward launches only (allow bit 3: plain / residual / PixelShuffle(2)
-    // stores of whole 4x4 tiles, no accumulate / gradient mask).  0: off, 1: where the model says it is faster (default),
+    // couts per workgroup, 1024 threads, 156 KB of LDS).  Forward launches only (allow bit 3: plain / residual / PixelShuffle(2)
+    // stores of 4-pixel tile rows -- Wo % 4 == 0 --, no accumulate / gradient mask).  0: off, 1: where the model says it is faster (default),
     // 2: wherever it is eligible (A/B aid), 3: eligible and 16x32-pixel workgroup tiles (A/B aid).
     int wino5_on = 1;
     if (const char* v = getenv("DVSR_CONV_WINO5")) wino5_on = atoi(v);
-    if (wino5_on && wino3_on && (allow_ksplit & 8) && Ho % 4 == 0 && Wo % 4 == 0 && device_lds_optin() >= (size_t)156 * 1024) {
+    if (wino5_on && wino3_on && (allow_ksplit & 8) && Wo % 4 == 0 && device_lds_optin() >= (size_t)156 * 1024) {
       auto w5_cost = [&](int oh, int ow) {
         const double wgs = (double)ceil_div(Wo, ow) * ceil_div(Ho, oh) * N * ceil_div(Cout, 64);
         return ceil(wgs / cus) * (nch * W5_CHUNK_CYC + W5_FIXED_CYC) / 2.07;
@@ -1124,8 +1124,8 @@ int conv2d_packed_prepare(const dvsr_conv2d_desc& d, const float* wp, const Conv
                  "16-byte aligned inputs and W %% 4 == 0 (W=%d c0=%d c1=%d)", d.W, d.c0, d.c1);
   } else if (geo.dma) {
     DVSR_REQUIRE(geo.dma < 3 || d.c0 + d.c1 >= 16, DVSR_ERR_UNSUPPORTED, "conv2d_packed: the Winograd kernel needs two 8-channel chunks");
-    DVSR_REQUIRE(geo.dma != 5 || (!ex.accum && !ex.gmask && d.H % 4 == 0 && d.W % 4 == 0 && (geo.th == 8 || geo.th == 16)), DVSR_ERR_UNSUPPORTED,
-                 "conv2d_packed: the F(4x4, 3x3) kernel stores whole 4x4 tiles of forward launches (H=%d W=%d th=%d)", d.H, d.W, geo.th);
+    DVSR_REQUIRE(geo.dma != 5 || (!ex.accum && !ex.gmask && d.W % 4 == 0 && (geo.th == 8 || geo.th == 16)), DVSR_ERR_UNSUPPORTED,
+                 "conv2d_packed: the F(4x4, 3x3) kernel stores whole tile columns of forward launches (W=%d th=%d)", d.W, geo.th);
     DVSR_REQUIRE(geo.dma < 3 || d.pixel_shuffle == 0 || (d.pixel_shuffle == 2 && d.Cout % 4 == 0 && !d.res && !ex.accum && !ex.gmask),
                  DVSR_ERR_UNSUPPORTED, "conv2d_packed: the Winograd kernel stores plain or PixelShuffle(2) tiles (ps=%d)", d.pixel_shuffle);
     DVSR_REQUIRE(d.ks == 3 && d.stride == 1 && d.pad == 1 && !ex.in_ps && !ex.in_dil && geo.cc == 8 && (geo.th == 4 || geo.th == 8 || (geo.th == 16 && geo.dma >= 4)) &&

@@ -481,7 +481,8 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
           y[c][3][j] = __builtin_fmaf(8.f, db, da) + z[5][c];
         }
       }
-      const bool px_ok = oy < a.Ho && ox < a.Wo;   // (whole tiles: Ho, Wo are multiples of 4)
+      const bool px_ok = oy < a.Ho && ox < a.Wo;   // (Wo is a multiple of 4: whole tile columns; the last tile row may be cut)
+      const int nrow = a.Ho - oy < 4 ? a.Ho - oy : 4;
       if (px_ok && co0 < a.Cout) {
         const bool two = co0 + 1 < a.Cout;
         const float b0 = bias ? bias[co0] : 0.f, b1 = (bias && two) ? bias[co0 + 1] : 0.f;
@@ -500,6 +501,7 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
             const size_t base = ((size_t)n * a.Cout + co0 + c) * HWo + (size_t)oy * a.Wo + ox;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+              if (i >= nrow) break;
               f32x4 v = {y[c][i][0], y[c][i][1], y[c][i][2], y[c][i][3]};
               if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + base + (size_t)i * a.Wo);
               *reinterpret_cast<f32x4*>(a.y + base + (size_t)i * a.Wo) = v;
@@ -511,6 +513,7 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
           float* dst = a.y + (((size_t)n * (a.Cout >> 2) + cq) * (2 * a.Ho) + (2 * oy + dy)) * (size_t)(2 * a.Wo) + 2 * ox;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
+            if (i >= nrow) break;
             float* d = dst + (size_t)(2 * i) * (2 * a.Wo);
             *reinterpret_cast<f32x4*>(d) = f32x4{y[0][i][0], y[1][i][0], y[0][i][1], y[1][i][1]};
             *reinterpret_cast<f32x4*>(d + 4) = f32x4{y[0][i][2], y[1][i][2], y[0][i][3], y[1][i][3]};

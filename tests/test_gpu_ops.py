@@ -607,6 +607,8 @@ def _f4_conv(x0, x1, wt, b, r, act, ps, monkeypatch, mode="2", dgrad_of=None):
     (2, 8, 8, 64, 44, 80, 1, True, 0),       # two chunks: prologue + last chunk only
     (2, 64, 0, 216, 96, 128, 0, False, 0),   # the offset / mask conv: the last 64-cout block holds 24
     (1, 16, 0, 64, 4, 4, 0, False, 0),       # ONE 4 x 4 tile: 31 of the workgroup's 32 tiles outside the image
+    (5, 64, 0, 64, 90, 160, 1, True, 0),     # the L2 level of the headline clip: H % 4 == 2, the last tile row is cut (residual read too)
+    (2, 64, 0, 128, 90, 160, 1, False, 2),   # ... with the PixelShuffle(2) store
 ])
 @pytest.mark.parametrize("mode", ["2", "3"])
 def test_conv3x3_winograd_f4x4(n, c0, c1, cout, h, w, act, res, ps, mode, monkeypatch):
@@ -660,7 +662,8 @@ def test_conv3x3_winograd_f4x4_cost_model_and_eligibility(monkeypatch):
     assert geo_of(1, 64, 256, 360, 640, 2)[3] == 5
     assert geo_of(1, 64, 64, 720, 1280)[3] == 5
     assert geo_of(1, 64, 64, 180, 320)[3] == 4      # one round of workgroups either way: form 4 measures faster
-    assert geo_of(5, 64, 64, 90, 160)[3] == 4       # H % 4 != 0
+    assert geo_of(5, 64, 64, 90, 160)[3] == 5       # the L2 level (H % 4 == 2: the last tile row is cut): one round instead of two
+    assert geo_of(5, 64, 64, 90, 162)[3] != 5       # W % 4 != 0: no 16-byte tile rows (nor any DMA-halo kernel)
     monkeypatch.setenv("DVSR_CONV_WINO5", "0")
     assert geo_of(5, 64, 64, 180, 320)[3] == 4
 
