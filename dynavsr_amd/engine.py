@@ -7,6 +7,7 @@ Parameters stay ordinary leaf nn.Parameters, so external torch.optim objects, de
 `param.grad += g` in the DynaVSR drivers keep working.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -183,7 +184,26 @@ def _prep(t):
     return t.contiguous()
 
 
-class EdvrFunction(torch.autograd.Function):
+_grad_mode = threading.local()
+
+
+class _TapeFunction(torch.autograd.Function):
+    """autograd.Function whose forward knows whether the CALLER records a graph.  Inside Function.forward grad mode is
+    always off and ctx.needs_input_grad reports requires_grad of the inputs even under torch.no_grad(), so a no-grad
+    forward of a network with trainable parameters would otherwise size the activation arena for a backward that
+    never comes (and miss the engine's no-grad launch geometries, which it selects from the workspace size)."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        _grad_mode.enabled = torch.is_grad_enabled()
+        return super().apply(*args, **kwargs)
+
+
+def _need_grad(ctx):
+    return bool(getattr(_grad_mode, "enabled", True)) and any(ctx.needs_input_grad)
+
+
+class EdvrFunction(_TapeFunction):
     @staticmethod
     def forward(ctx, x, cfg, keep_ws, *params):
         if not x.is_cuda:
@@ -198,7 +218,7 @@ class EdvrFunction(torch.autograd.Function):
             raise RuntimeError("EDVR engine expects %d parameter tensors, got %d"
                                % (plan.n_params, len(params)))
         params = [_prep(p.detach()) for p in params]
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = _need_grad(ctx)
         ws = torch.empty(plan.workspace_bytes(need_grad), dtype=torch.uint8, device=x.device)
         out = x.new_empty((b, 3, cfg[5] * h, cfg[5] * w))
         plan.forward(params, x, out, ws)
@@ -220,7 +240,7 @@ class EdvrFunction(torch.autograd.Function):
         return (gx, None, None) + tuple(gparams)
 
 
-class EdvrStackedFunction(torch.autograd.Function):
+class EdvrStackedFunction(_TapeFunction):
     """K clips through ONE tape with PER-CLIP parameter gradients (dvsr_edvr_plan_create_grouped).
 
     x: [K,N,3,H,W]; every parameter arrives STACKED, [K, *shape]: slice k is frame k's private copy of the weights
@@ -247,7 +267,7 @@ class EdvrStackedFunction(torch.autograd.Function):
             raise RuntimeError("EDVR engine expects %d parameter tensors, got %d" % (plan.n_params, len(stacked)))
         stacked = [_prep(p.detach()) for p in stacked]
         params = stacked if per_slice else [p[0] for p in stacked]
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = _need_grad(ctx)
         ws = torch.empty(plan.workspace_bytes(need_grad), dtype=torch.uint8, device=x.device)
         out = x.new_empty((k, 3, cfg[5] * h, cfg[5] * w))
         plan.forward(params, x, out, ws)
@@ -326,7 +346,7 @@ def get_estimator_plan(cfg, b, h, w, device=None, grad_groups=1, weight_sets=1):
     return p
 
 
-class EstimatorFunction(torch.autograd.Function):
+class EstimatorFunction(_TapeFunction):
     """x: [B,C,T,H,W] (MFDN) or [B,C,H,W] (SFDN) -> same rank, spatially / scale.  The clip is data:
     no gradient is produced for x (LRestimator_model.py feeds `LQs`, test_dynavsr.py:237-241)."""
 
@@ -351,7 +371,7 @@ class EstimatorFunction(torch.autograd.Function):
         if len(params) != plan.n_params:
             raise RuntimeError("estimator engine expects %d parameter tensors, got %d" % (plan.n_params, len(params)))
         params = [_prep(p.detach()) for p in params]
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = _need_grad(ctx)
         ws = torch.empty(plan.workspace_bytes(need_grad), dtype=torch.uint8, device=x.device)
         out = x.new_empty(oshape)
         plan.forward(params, x, out, ws)
@@ -370,7 +390,7 @@ class EstimatorFunction(torch.autograd.Function):
         return (None, None) + tuple(gparams)
 
 
-class EstimatorStackedFunction(torch.autograd.Function):
+class EstimatorStackedFunction(_TapeFunction):
     """The estimator on K clips with per-clip parameter gradients: x [K,C,T,H,W] (MFDN) / [K*T,C,H,W] (SFDN, the frames
     of a clip consecutive), every parameter stacked [K, *shape] with K equal slices (see EdvrStackedFunction)."""
 
@@ -398,7 +418,7 @@ class EstimatorStackedFunction(torch.autograd.Function):
         if len(stacked) != plan.n_params:
             raise RuntimeError("estimator engine expects %d parameter tensors, got %d" % (plan.n_params, len(stacked)))
         stacked = [_prep(p.detach()) for p in stacked]
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = _need_grad(ctx)
         ws = torch.empty(plan.workspace_bytes(need_grad), dtype=torch.uint8, device=x.device)
         out = x.new_empty(oshape)
         plan.forward(stacked if per_slice else [p[0] for p in stacked], x, out, ws)

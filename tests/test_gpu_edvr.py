@@ -1071,6 +1071,37 @@ def test_edvr_stacked_tape_per_slice_weights(k, h, w):
         assert torch.equal(y2, y.detach())
 
 
+def test_no_grad_forward_of_a_trainable_network_takes_the_no_grad_arena_and_geometries():
+    """`with torch.no_grad(): net(x)` -- Video_base_model.test(), the baseline / adapted forwards of test_dynavsr.py --
+    on a network whose parameters require grad: ctx.needs_input_grad still says True there, so the tape function reads the
+    caller's grad mode instead.  The forward then allocates the activation arena only (the engine reads "no-grad" off the
+    workspace size) and runs the no-grad launch geometries: at 180x320 that is the F(4x4, 3x3) kernel (tag "w5") on the
+    large layers, and the result is that of dvsr_edvr_forward_timed on a no-grad arena -- bit for bit -- and of the
+    recording forward (F(2x2) kernels) to fp32 round-off."""
+    from dynavsr_amd import engine
+    net = make_net(0)
+    assert all(p.requires_grad for p in net.parameters())
+    x = synth.clip(77, 1, 5, 180, 320).cuda()
+    net._debug_ws = []
+    with torch.no_grad():
+        y = net(x)
+    plan, ws = net._debug_ws[-1]
+    assert ws.numel() == plan.workspace_bytes(False) < plan.workspace_bytes(True)
+    assert not y.requires_grad
+    tags = [nm for (_k, nm, _f, _b) in plan.op_info()]
+    assert sum(t.endswith("w5]") for t in tags) >= 10, tags
+    out = torch.empty_like(y)
+    ws2 = torch.empty(plan.workspace_bytes(False), dtype=torch.uint8, device="cuda")
+    plan.forward_timed([p.detach() for p in net.ordered_parameters()], x, out, ws2)
+    assert torch.equal(out, y)
+    y_rec = net(x)                                     # grad mode on: the recording tape, full workspace
+    assert y_rec.requires_grad and net._debug_ws[-1][1].numel() == plan.workspace_bytes(True)
+    assert relerr(y_rec.detach(), y) < 5e-6
+    net.requires_grad_(False)                          # nothing to record either: frozen weights, data input
+    z = net(x)
+    assert net._debug_ws[-1][1].numel() == plan.workspace_bytes(False) and torch.equal(z, y)
+
+
 @pytest.mark.parametrize("optimizer,overlap", [("Adam", True), ("SGD", False)])
 def test_adapt_video_batched_frames_equal_the_per_frame_loop(optimizer, overlap):
     """adapt_video(frames_per_batch=K): the inner steps of K consecutive frames as ONE batch with per-frame parameter
@@ -1157,7 +1188,9 @@ def test_adapt_video_batched_at_the_north_star_size():
     got = list(adapt_video(opt, model, est, modelcp, estcp, est_fixed, clips, frames_per_batch=4))
     assert len(got) == 4
     for (base, r), w_ in zip(got, want):
-        assert relerr(base.cpu(), w_[0]) < 1e-6
+        # (the batch's baseline forwards are 4-clip launches: the cost model may put a layer on F(4x4) that the one-clip
+        # forward runs on F(2x2) -- the same sums by another algorithm, fp32 round-off apart)
+        assert relerr(base.cpu(), w_[0]) < 5e-6
         assert abs(float(r["losses"][0]) - w_[2]) <= 2e-6 * abs(w_[2])
         assert relerr(r["slr"].cpu(), w_[3]) < 1e-6
         assert relerr(r["sr"].cpu(), w_[1]) < 1e-4

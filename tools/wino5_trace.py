@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Cycle-stamp timeline of one conv2d_wino5_kernel launch (debug build: python -m dynavsr_amd.build --trace).
     python tools/wino5_trace.py [N C0 C1 COUT H W]
-Stamps (thread 0 of every workgroup): 0 start, 1 first chunk landed, 2 V(0) built, 3 + k end of chunk k, 40 loop done,
-50 column transform done, 51.. the exchange rounds, 41 stores issued, 42 stores acknowledged; fine stamps of waves 0 / 4 / 8
-inside chunk 3 at 20 / 26 / 32 + i (0 top, 1-3 after MFMA 6 / 12 / 18, 4 DMA waited, 5 barrier passed).
+Stamps (thread 0 of every workgroup, a consumer wave): 0 start, 3 + k end of chunk k (k < 16; chunk 0 carries the prologue:
+raw(0) landed, V(0) built by the producer waves), 40 loop done, 50 column transform done, 51.. the exchange rounds,
+41 stores issued, 42 stores acknowledged.
 """
 import ctypes
 import os
@@ -62,25 +62,14 @@ rt = (t[:, 61] - t[:, 60]).astype(np.float64)
 print("core clock (cycle counter / s_memrealtime): %.0f MHz; kernel wall span %.1f us" %
       (np.median((t[:, 42] - t[:, 0]) / np.maximum(rt, 1)) * 100.0, (t[:, 61].max() - t[:, 60].min()) / 100.0))
 stat("workgroup lifetime", t[:, 42] - t[:, 0])
-stat("prologue: first DMA landed", t[:, 1] - t[:, 0])
-stat("prologue: V(0) built + raw(1) landed", t[:, 2] - t[:, 1])
 nch = (c0 + c1) // 8
-prev = t[:, 2]
-for k in range(nch):
+prev = t[:, 0]
+for k in range(min(nch, 16)):
     cur = t[:, 3 + k]
-    stat("chunk %d" % k, cur - prev)
+    stat("chunk %d%s" % (k, " (+ prologue)" if k == 0 else ""), cur - prev)
     prev = cur
+stat("chunks %d.. + loop exit" % min(nch, 16) if nch > 16 else "loop exit", t[:, 40] - prev)
 for nm, i0, i1 in (("epilogue: column transform", 40, 50), ("first barrier", 50, 51), ("round 0: LDS writes", 51, 52), ("round 0: barrier", 52, 53),
                    ("round 0: reads + row transform + stores", 53, 54), ("barrier (reads done)", 54, 55), ("round 1: LDS writes", 55, 56),
                    ("round 1: barrier", 56, 57), ("round 1: reads + row transform + stores", 57, 58), ("stores acknowledged", 41, 42)):
     stat(nm, t[:, i1] - t[:, i0])
-if nch > 3:
-    f = t[:, 19:40]
-    ok = (f[:, 0] != 0) & (f[:, 20] != 0)
-    if ok.any():
-        f = f[ok]
-        print("chunk 3, wave %s: cycles per MFMA slot (median over workgroups)" % os.environ.get("DVSR_CONV_ABLATE", "0"))
-        print("   ", " ".join("%5.0f" % np.median(f[:, i + 1] - f[:, i]) for i in range(18)))
-        stat("   wait for the DMA", f[:, 19] - f[:, 18])
-        stat("   barrier", f[:, 20] - f[:, 19])
-        stat("   whole chunk", f[:, 20] - f[:, 0])
