@@ -96,6 +96,7 @@ def _declare(lib):
         "dvsr_edvr_num_launches": (I, [P]),
         "dvsr_edvr_workspace_bytes": (c_size_t, [P, I]),
         "dvsr_edvr_forward": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P]),
+        "dvsr_edvr_forward_packed": (I, [P, POINTER(c_void_p), P, P, P, c_size_t, P]),
         "dvsr_edvr_backward": (I, [P, POINTER(c_void_p), P, P, POINTER(c_void_p), P, P, c_size_t, P]),
         "dvsr_edvr_num_backward_launches": (I, [P]),
         "dvsr_estimator_plan_create": (I, [POINTER(EstimatorConfig), I, I, I, POINTER(c_void_p)]),

@@ -19,7 +19,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import hipops, optim
+from . import engine, hipops, optim
 
 
 def make_inner_optimizer(opt, netG, netE):
@@ -534,11 +534,16 @@ def super_resolve_video(opt, net, clips, in_flight=2):
     rounds of workgroups each, the last one 40 % full, and 5-6 us of idle GPU between two launches -- and a second queue
     fills both: 161.9 -> 187.9 frames/s with two clips in flight, 189.2 with three (tools/fwd_concurrent.py; one forward
     over a batch of 8 clips: 180.4).  Every clip runs the launches it would run alone (its own plan and workspace, keyed
-    by the stream), so the outputs are bit-identical to `net(clip)`.  A yielded frame stays valid until the generator is
+    by the stream) except the weight packing, which only the first clip on a stream does (the workspace and the packs in it
+    are kept for the video; an in-place update of the weights between clips re-packs), so the outputs are bit-identical to
+    `net(clip)`.  A yielded frame stays valid until the generator is
     advanced `in_flight` times; clips and results are ordered against the caller's current stream."""
     main = None
     streams = None
     pending = []
+    # one workspace per (plan, stream) for the whole video, and with it the packed weights: the network is the same for every
+    # clip, so only the first forward on a stream packs (engine.FrozenWeights; keyed on the parameters' version counters)
+    frozen = engine.FrozenWeights()
     was_training = net.training
     net.eval()
     try:
@@ -558,7 +563,7 @@ def super_resolve_video(opt, net, clips, in_flight=2):
             s = streams[i % len(streams)]
             if s != main:
                 s.wait_stream(main)                  # the clip (and the weights) were produced on the caller's stream
-            with torch.cuda.stream(s), torch.no_grad():
+            with torch.cuda.stream(s), torch.no_grad(), frozen:
                 sr = net(backbone_input(opt, lq))
                 ev = torch.cuda.Event()
                 ev.record(s)

@@ -1282,8 +1282,24 @@ extern "C" int dvsr_edvr_backward(const dvsr_edvr_plan* p, const float* const* p
 
 extern "C" int dvsr_edvr_num_backward_launches(const dvsr_edvr_plan* p) { return p ? (int)p->bops.size() : -1; }
 
+static int edvr_forward_impl(const dvsr_edvr_plan* p, const float* const* params, const float* x, float* out, void* ws,
+                             size_t ws_bytes, dvsr_stream_t stream, bool packs_valid);
+
 extern "C" int dvsr_edvr_forward(const dvsr_edvr_plan* p, const float* const* params, const float* x,
                                  float* out, void* ws, size_t ws_bytes, dvsr_stream_t stream) {
+  return edvr_forward_impl(p, params, x, out, ws, ws_bytes, stream, false);
+}
+
+// The forward WITHOUT its weight-packing launches: the workspace still holds the packs an earlier dvsr_edvr_forward of this
+// plan left there for the same parameter values (a video's clips through one frozen network: Video_base_model.test() in a
+// loop -- the packs are six launches, ~2 % of a 180x320 forward, and a pure function of the weights).
+extern "C" int dvsr_edvr_forward_packed(const dvsr_edvr_plan* p, const float* const* params, const float* x,
+                                        float* out, void* ws, size_t ws_bytes, dvsr_stream_t stream) {
+  return edvr_forward_impl(p, params, x, out, ws, ws_bytes, stream, true);
+}
+
+static int edvr_forward_impl(const dvsr_edvr_plan* p, const float* const* params, const float* x, float* out, void* ws,
+                             size_t ws_bytes, dvsr_stream_t stream, bool packs_valid) {
   DVSR_REQUIRE(p && params && x && out && ws, DVSR_ERR_INVALID, "edvr_forward: null argument");
   DVSR_REQUIRE(ws_bytes >= p->arena_floats * sizeof(float), DVSR_ERR_WORKSPACE,
                "edvr_forward: workspace %zu < %zu bytes", ws_bytes, p->arena_floats * sizeof(float));
@@ -1291,7 +1307,7 @@ extern "C" int dvsr_edvr_forward(const dvsr_edvr_plan* p, const float* const* pa
   // a workspace too small for dvsr_edvr_backward is a no-grad forward (the header's contract: "allocate with need_grad = 1
   // BEFORE the forward"): only then may a layer run on a kernel the backward's tape was not built around
   bs.nograd = ws_bytes < dvsr_edvr_workspace_bytes(p, 1);
-  if (!p->use_v1) {
+  if (!p->use_v1 && !packs_valid) {
     int rc = pack_all(*p, params, bs.arena, bs.arena, nullptr, (hipStream_t)stream, bs.nograd);
     if (rc != DVSR_OK) return rc;
   }

@@ -76,11 +76,13 @@ class Plan:
     def workspace_bytes(self, need_grad):
         return int(L.lib().dvsr_edvr_workspace_bytes(self._h, int(need_grad)))
 
-    def forward(self, params, x, out, ws):
+    def forward(self, params, x, out, ws, packed=False):
+        """packed: `ws` still holds the weight packs of an earlier forward of this plan with these parameter values
+        (dvsr_edvr_forward_packed: the packing launches are skipped; FrozenWeights keeps that contract)."""
         arr = (ctypes.c_void_p * len(params))(*[L.ptr(p) for p in params])
-        L.check(L.lib().dvsr_edvr_forward(self._h, arr, L.ptr(x), L.ptr(out), ws.data_ptr(),
-                                          ws.numel() * ws.element_size(), L.stream()),
-                "dvsr_edvr_forward")
+        fn = L.lib().dvsr_edvr_forward_packed if packed else L.lib().dvsr_edvr_forward
+        L.check(fn(self._h, arr, L.ptr(x), L.ptr(out), ws.data_ptr(), ws.numel() * ws.element_size(), L.stream()),
+                "dvsr_edvr_forward_packed" if packed else "dvsr_edvr_forward")
 
     def backward(self, params, x, gout, gparams, gx, ws):
         arr = (ctypes.c_void_p * len(params))(*[L.ptr(p) for p in params])
@@ -203,6 +205,39 @@ def _need_grad(ctx):
     return bool(getattr(_grad_mode, "enabled", True)) and any(ctx.needs_input_grad)
 
 
+class FrozenWeights:
+    """Scope for the no-grad forwards of ONE network over many clips (a video through `Video_base_model.test()`,
+    test_dynavsr.py:200-204): inside `with frozen:` a no-grad EDVR forward keeps its workspace -- one per (launch plan, HIP
+    stream) -- in this object, and with it the packed weights, so that the next forward of the same plan on the same stream
+    skips the packing launches (dvsr_edvr_forward_packed; six launches, ~2 % of a 180x320 forward).  The packs are keyed on
+    the parameters' storage and autograd version counters: an optimiser step, `load_state_dict` or any in-place update
+    re-packs on the next call.  (Writes through `.data`, which do not bump the counter, are not seen: do not mix them
+    with a live scope.)  Results are bit-identical to forwards outside the scope.  Dropping the object frees the workspaces."""
+
+    def __init__(self):
+        self._slots = {}
+
+    def __enter__(self):
+        self._outer = getattr(_grad_mode, "frozen", None)
+        _grad_mode.frozen = self
+        return self
+
+    def __exit__(self, *exc):
+        _grad_mode.frozen = self._outer
+        return False
+
+    def slot(self, plan, device, params):
+        """-> (workspace, packs_valid) for a no-grad forward of `plan` on the current stream."""
+        key = (plan.key, device.index, torch.cuda.current_stream(device).cuda_stream)
+        sig = tuple((p.data_ptr(), p._version) for p in params)
+        have = self._slots.get(key)
+        if have is not None and have[1] == sig:
+            return have[0], True
+        ws = have[0] if have is not None else torch.empty(plan.workspace_bytes(False), dtype=torch.uint8, device=device)
+        self._slots[key] = (ws, sig)
+        return ws, False
+
+
 class EdvrFunction(_TapeFunction):
     @staticmethod
     def forward(ctx, x, cfg, keep_ws, *params):
@@ -217,11 +252,16 @@ class EdvrFunction(_TapeFunction):
         if len(params) != plan.n_params:
             raise RuntimeError("EDVR engine expects %d parameter tensors, got %d"
                                % (plan.n_params, len(params)))
+        leaves = params                  # (version counters are read off the caller's tensors, not off converted copies)
         params = [_prep(p.detach()) for p in params]
         need_grad = _need_grad(ctx)
-        ws = torch.empty(plan.workspace_bytes(need_grad), dtype=torch.uint8, device=x.device)
+        frozen = None if (need_grad or keep_ws is not None) else getattr(_grad_mode, "frozen", None)
+        if frozen is not None:
+            ws, packed = frozen.slot(plan, x.device, leaves)
+        else:
+            ws, packed = torch.empty(plan.workspace_bytes(need_grad), dtype=torch.uint8, device=x.device), False
         out = x.new_empty((b, 3, cfg[5] * h, cfg[5] * w))
-        plan.forward(params, x, out, ws)
+        plan.forward(params, x, out, ws, packed=packed)
         if need_grad:
             _stash(ctx, plan, ws, x, params)
         if keep_ws is not None:

@@ -195,6 +195,14 @@ int dvsr_edvr_num_launches(const dvsr_edvr_plan* plan);
 size_t dvsr_edvr_workspace_bytes(const dvsr_edvr_plan* plan, int need_grad);
 int dvsr_edvr_forward(const dvsr_edvr_plan* plan, const float* const* params, const float* x,
                       float* out, void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
+/* dvsr_edvr_forward without its weight-packing launches, for a FROZEN network run over many clips (Video_base_model.py:197-201
+ * `test()` called per clip of a video, test_dynavsr.py:200-204): `workspace` must be the workspace of an earlier
+ * dvsr_edvr_forward of THIS plan with the SAME parameter values and the same need_grad sizing, not written by anyone since
+ * (the packed weights live in it and are a pure function of the parameters).  Same launches otherwise, bit-identical
+ * results.  After the parameters change, call dvsr_edvr_forward once again.  The caller owns that contract: stale packs are
+ * not detected here (dynavsr_amd.engine keys them on the parameters' storage and version counters). */
+int dvsr_edvr_forward_packed(const dvsr_edvr_plan* plan, const float* const* params, const float* x,
+                             float* out, void* workspace, size_t workspace_bytes, dvsr_stream_t stream);
 /* Backward of dvsr_edvr_forward (first-order; replaces autograd through EDVR incl. the 20 calls of
  * modulated_deform_conv_cuda_backward per clip, deform_conv_cuda.cpp:566-679).  Must follow a forward
  * on the SAME workspace, which must have been sized with need_grad=1.  grad_out [B,3,sH,sW];

@@ -1102,6 +1102,50 @@ def test_no_grad_forward_of_a_trainable_network_takes_the_no_grad_arena_and_geom
     assert net._debug_ws[-1][1].numel() == plan.workspace_bytes(False) and torch.equal(z, y)
 
 
+def test_frozen_weights_scope_packs_once_per_stream_and_repacks_after_an_update(monkeypatch):
+    """engine.FrozenWeights / dvsr_edvr_forward_packed (the clips of a video through one network, super_resolve_video): the
+    first no-grad forward of a plan on a stream packs the weights, the following ones skip the packing launches and give the
+    bits of a forward outside the scope; an in-place update of a weight (an optimiser step, load_state_dict) bumps the
+    version counter and the next forward packs again; a recording forward inside the scope is untouched by it."""
+    from dynavsr_amd import engine
+    from dynavsr_amd.adapt import super_resolve_video
+    net = make_net(3)
+    xs = [synth.clip(80 + i, 1, 5, 64, 96).cuda() for i in range(4)]
+    with torch.no_grad():
+        want = [net(x).clone() for x in xs]
+    calls = []
+    real = engine.Plan.forward
+
+    def spy(self, params, x, out, ws, packed=False):
+        calls.append(bool(packed))
+        return real(self, params, x, out, ws, packed=packed)
+
+    monkeypatch.setattr(engine.Plan, "forward", spy)
+    frozen = engine.FrozenWeights()
+    with torch.no_grad(), frozen:
+        got = [net(x).clone() for x in xs]
+    assert calls == [False, True, True, True]
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    with frozen:                                         # grad mode on: the recording forward takes its own workspace
+        y = net(xs[0])
+    assert calls[-1] is False and y.requires_grad and relerr(y.detach(), want[0]) < 5e-6   # (the tape's own geometries)
+    del calls[:]
+    with torch.no_grad():
+        net.conv_first.weight.mul_(1.25)                 # in place: the version counter moves
+        want2 = net(xs[1]).clone()
+        with frozen:
+            got2 = [net(xs[1]).clone(), net(xs[1]).clone()]
+    assert calls == [False, False, True]
+    assert torch.equal(got2[0], want2) and torch.equal(got2[1], want2) and not torch.equal(want2, want[1])
+    # the generator: two clips in flight = two streams, each packs once
+    del calls[:]
+    out = [y_.clone() for y_ in super_resolve_video({"network_G": {"which_model_G": "EDVR"}}, net, [xs[i % 4] for i in range(6)],
+                                                     in_flight=2)]
+    assert calls == [False, False, True, True, True, True]
+    with torch.no_grad():
+        assert all(torch.equal(out[i], net(xs[i % 4])) for i in range(6))
+
+
 @pytest.mark.parametrize("optimizer,overlap", [("Adam", True), ("SGD", False)])
 def test_adapt_video_batched_frames_equal_the_per_frame_loop(optimizer, overlap):
     """adapt_video(frames_per_batch=K): the inner steps of K consecutive frames as ONE batch with per-frame parameter
