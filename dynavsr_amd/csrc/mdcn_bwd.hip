@@ -154,6 +154,8 @@ struct DcnF {
   int mask_logit, N, C, H, W, Cout, dg, tiles_x, tiles_y;
   int sub;  // 8-channel chunks per deformable group (1: EDVR-M, 2: EDVR-L); blockIdx.y walks the C/8 chunks
   int wdiv = 1; long long w_gs = 0;  // per-sample weight sets: frame n convolves with w + (n / wdiv) * w_gs
+  const float* wtp = nullptr;        // [weight set][C / 8][3][Cout / 2][64]: the A operands of phase 1 in LDS order (mdcn_bwd_wt_kernel)
+  int vec = 0;                       // W % 4 == 0 and x / gout 16-byte aligned: the window and the gout tiles are staged with 16-byte loads
 #ifdef DVSR_CONV_TRACE
   long long* trace;  // debug build only (tools/dcn_bwd_trace.py): 16 cycle stamps per workgroup
 #endif
@@ -180,11 +182,16 @@ extern "C" int dvsr_debug_dcn_bwd_trace(void* buf, int launch_index) {
 template <int HALO>
 __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   constexpr int TH = 8, TW = 32, XH = TH + 2 + 2 * HALO, XW = TW + 2 + 2 * HALO, XPX = XH * XW;
+  // The INPUT window's rows start at the 16-byte boundary left of the window (column ox0 - 8: XA0 columns before its first
+  // one) and are XWA floats long, so that a row is twelve aligned 16-byte groups, each wholly inside or outside the image
+  // when W % 4 == 0; the GRADIENT window keeps the tight pitch XW (two workgroups per CU: 27.6 + 48.4 KB each).
+  constexpr int XWA = 48, XA0 = 8 - 1 - HALO, XPXA = XH * XWA;
+  static_assert(XA0 >= 0 && XA0 + XW <= XWA, "the aligned window rows must cover the sampling window");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* const s_x = smem;             // [8][XPX] input window
-  float* const s_wt = smem + 8 * XPX;  // [3][Cout/2][64]: A operands, lane-major (MFMA phase only) ...
-  unsigned long long* const s_gq = reinterpret_cast<unsigned long long*>(smem + 8 * XPX);  // ... then [8][XPX] gradient window
-  __shared__ float s_max[4];
+  float* const s_x = smem;              // [8][XH][XWA] input window
+  float* const s_wt = smem + 8 * XPXA;  // [3][Cout/2][64]: A operands, lane-major (MFMA phase only) ...
+  unsigned long long* const s_gq = reinterpret_cast<unsigned long long*>(smem + 8 * XPXA);  // ... then [8][XPX] gradient window
+  __shared__ float s_max[8];
   const int KST = a.Cout >> 1;
 
   // blockIdx.y = 8-channel chunk kc of the input; its deformable group g supplies offsets / masks.  With more
@@ -201,45 +208,10 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   const float* xg = a.x + ((size_t)n * a.C + kc * 8) * HW;
   DCNB_STAMP(0);
 
-  // ---- stage the input window (zero outside the image), clear the gradient window, stage W^T.
-  // All global loads of a stage are issued before the first LDS write (a load per loop iteration would
-  // pay one memory latency per iteration).
-  constexpr int XE = (8 * XPX + 255) / 256;
-  {
-    float rx_[XE];
-#pragma unroll
-    for (int e = 0; e < XE; ++e) {
-      const int idx = tid + 256 * e;
-      const int c = idx / XPX, r = idx - c * XPX;
-      const int ry = r / XW, rx = r - ry * XW;
-      const int gy_ = wy0 + ry, gx_ = wx0 + rx;
-      const bool ok = idx < 8 * XPX && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W;
-      rx_[e] = ok ? xg[(size_t)c * HW + (size_t)gy_ * a.W + gx_] : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < XE; ++e) {
-      const int idx = tid + 256 * e;
-      if (idx < 8 * XPX) s_x[idx] = rx_[e];
-    }
-  }
-  const float* wn = wset_ptr(a.w, a.w_gs, n, a.wdiv);
-  for (int base = 0; base < 3 * KST * 64; base += 256 * 8) {
-    float rw[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int idx = base + tid + 256 * e;
-      const int l = idx & 63, kk = (idx >> 6) % KST, mt = idx / (64 * KST);
-      const int m = mt * 32 + (l & 31), o = 2 * kk + (l >> 5);
-      rw[e] = (idx < 3 * KST * 64 && m < 72) ? wn[((size_t)o * a.C + kc * 8 + (m & 7)) * 9 + (m >> 3)] : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int idx = base + tid + 256 * e;
-      if (idx < 3 * KST * 64) s_wt[idx] = rw[e];
-    }
-  }
-
-  // ---- pixels of this lane; their offsets / masks for all 9 taps are fetched now and used after the MFMAs
+  // ---- stage the input window (zero outside the image) and W^T.
+  // Round 6: both sets of loads are issued before the first LDS write (they used to be dependent round trips, and the W^T
+  // image 24 stride-9 gathers per lane: the stamps had 44 k cycles here); the lane's 54 offset / mask values are fetched
+  // after phase 1.
   const int px = ox0 + lo;
   int py[2];
   bool pv[2];
@@ -252,15 +224,87 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   }
   const float* offn = a.off + (size_t)n * a.off_bs;
   const float* mskn = a.msk + (size_t)n * a.msk_bs;
-  float offv[9][2][3];
+  // W^T: the LDS image was laid out once per call by mdcn_bwd_wt_kernel (the 24 stride-9 gathers per lane this staging used to
+  // do were the longest phase of the workgroup) -- 16-byte loads, six per lane and batch (one batch for Cout = 64)
+  const f32x4* wtp = reinterpret_cast<const f32x4*>(a.wtp + ((size_t)(a.w_gs ? n / a.wdiv : 0) * (a.C >> 3) + kc) * (size_t)(3 * KST * 64));
+  const int nv = 3 * KST * 16;   // 16-byte groups: 1536 for Cout = 64, 3072 for 128
+  f32x4 rw[6];
+  auto load_w = [&](int base) {
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+    for (int e = 0; e < 6; ++e) {
+      const int idx = base + tid + 256 * e;
+      rw[e] = idx < nv ? wtp[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_w = [&](int base) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int idx = base + tid + 256 * e;
+      if (idx < nv) *reinterpret_cast<f32x4*>(s_wt + 4 * idx) = rw[e];
+    }
+  };
+  // The lane's offsets / masks are STREAMED through the sampling phase, one tap ahead (round 6): fetched in the prologue and held
+  // across the MFMA phase -- 54 registers -- a third of them was spilled as it landed, one full vmcnt(0) wait each (the stamps
+  // had 28 k cycles before the first barrier).  ovals[nt] = {offset y, offset x, mask (logit)} of a tap.
+  const unsigned po32[2] = {(unsigned)pofs[0], (unsigned)pofs[1]};
+  auto load_tap = [&](float (&v)[2][3], int tap) {
+    const float* ph = offn + (size_t)(g * 18 + 2 * tap) * HW;
+    const float* pm = mskn + (size_t)(g * 9 + tap) * HW;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      offv[tap][nt][0] = offn[(size_t)(g * 18 + 2 * tap) * HW + pofs[nt]];
-      offv[tap][nt][1] = offn[(size_t)(g * 18 + 2 * tap + 1) * HW + pofs[nt]];
-      offv[tap][nt][2] = mskn[(size_t)(g * 9 + tap) * HW + pofs[nt]];
+      v[nt][0] = ph[po32[nt]];
+      v[nt][1] = (ph + HW)[po32[nt]];
+      v[nt][2] = pm[po32[nt]];
     }
+  };
+  if (a.vec) {
+    // 8 channels x XH rows x 12 groups of 16 bytes: 7 loads per lane
+    constexpr int NV = 8 * XH * (XWA / 4), VE = (NV + 255) / 256;
+    f32x4 rv[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int idx = tid + 256 * e;
+      const int c = idx / (XH * (XWA / 4)), r = idx - c * (XH * (XWA / 4));
+      const int ry = r / (XWA / 4), v = r - ry * (XWA / 4);
+      const int gy_ = wy0 + ry, gx_ = ox0 - 8 + 4 * v;
+      const bool ok = idx < NV && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W;
+      rv[e] = ok ? *reinterpret_cast<const f32x4*>(xg + (size_t)c * HW + (size_t)gy_ * a.W + gx_) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    load_w(0);
+    DCNB_STAMP(10);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int idx = tid + 256 * e;
+      if (idx < NV) *reinterpret_cast<f32x4*>(s_x + 4 * idx) = rv[e];
+    }
+    DCNB_STAMP(11);
+  } else {
+    constexpr int XE = (8 * XPX + 255) / 256;
+    float rx_[XE];
+#pragma unroll
+    for (int e = 0; e < XE; ++e) {
+      const int idx = tid + 256 * e;
+      const int c = idx / XPX, r = idx - c * XPX;
+      const int ry = r / XW, rx = r - ry * XW;
+      const int gy_ = wy0 + ry, gx_ = wx0 + rx;
+      const bool ok = idx < 8 * XPX && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W;
+      rx_[e] = ok ? xg[(size_t)c * HW + (size_t)gy_ * a.W + gx_] : 0.f;
+    }
+    load_w(0);
+#pragma unroll
+    for (int e = 0; e < XE; ++e) {
+      const int idx = tid + 256 * e;
+      const int c = idx / XPX, r = idx - c * XPX;
+      const int ry = r / XW, rx = r - ry * XW;
+      if (idx < 8 * XPX) s_x[c * XPXA + ry * XWA + XA0 + rx] = rx_[e];
+    }
+  }
+  store_w(0);
+  for (int base = 256 * 6; base < nv; base += 256 * 6) {   // (Cout = 128)
+    load_w(base);
+    store_w(base);
+  }
+  DCNB_STAMP(12);
   DCNB_STAMP(1);
   __syncthreads();
   DCNB_STAMP(2);
@@ -276,12 +320,13 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       for (int r = 0; r < 16; ++r) acc[i][j2][r] = 0.f;
   const float* gon = a.gout + (size_t)n * a.Cout * HW;
   float b0[8][2], b1[8][2];
+  const unsigned pb32[2] = {(unsigned)(hi * HW + pofs[0]), (unsigned)(hi * HW + pofs[1])};   // (an image's gout < 2^32 bytes)
   auto load_b = [&](float (&b)[8][2], int kbase) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const size_t ob = (size_t)(2 * (kbase + q) + hi) * HW;
-      b[q][0] = gon[ob + pofs[0]];
-      b[q][1] = gon[ob + pofs[1]];
+      const float* pl = gon + (size_t)(2 * (kbase + q)) * HW;   // wave-uniform
+      b[q][0] = pl[pb32[0]];
+      b[q][1] = pl[pb32[1]];
     }
   };
   auto mfma8 = [&](const float (&b)[8][2], int kbase) {
@@ -309,22 +354,30 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   // workgroup's largest |dcol * mask| mapped to [2^39, 2^40): at most 9216 contributions meet in a cell, so
   // the sums stay below 2^54, and every contribution keeps >= 24 significant bits down to 2^-16 of the
   // maximum (better than an fp32 running sum).  Integer adds are associative: the window is deterministic.
-  // (the mask sigmoid is taken once per (pixel row, tap), here, and kept in place of the logit)
-  float amax = 0.f;
+  // (round 6: the scale is set from max |dcol| x max |mask| -- an upper bound of the largest product, so the sums still cannot
+  // overflow; a sigmoid mask is at most 1 and costs nothing here, plain masks are read once for their maximum.  Against the
+  // exact maximum this gives away log2(max |mask| / the mask at the largest |dcol|) of the 16 spare bits.)
+  float amax = 0.f, mmax = 1.f;
+  if (!a.mask_logit) {
+    mmax = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) mmax = fmaxf(mmax, fabsf((mskn + (size_t)(g * 9 + tap) * HW)[po32[nt]]));
+  }
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const float mraw = offv[tap][nt][2];
-      const float m = a.mask_logit ? __builtin_amdgcn_rcpf(1.f + __expf(-mraw)) : mraw;
-      offv[tap][nt][2] = m;
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int cq = 0; cq < 4; ++cq) amax = fmaxf(amax, fabsf(acc[tap >> 2][nt][(tap & 3) * 4 + cq] * m));
-    }
-  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-  if (lane == 0) s_max[wave] = amax;
+      for (int cq = 0; cq < 4; ++cq) amax = fmaxf(amax, fabsf(acc[tap >> 2][nt][(tap & 3) * 4 + cq]));
+  for (int o = 32; o > 0; o >>= 1) {
+    amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    mmax = fmaxf(mmax, __shfl_xor(mmax, o, 64));
+  }
+  if (lane == 0) { s_max[wave] = amax; s_max[4 + wave] = mmax; }
   __syncthreads();  // all waves are done with s_wt
-  amax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  amax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])) * fmaxf(fmaxf(s_max[4], s_max[5]), fmaxf(s_max[6], s_max[7]));
   int aexp = 0;
   (void)frexpf(amax, &aexp);  // amax = f * 2^aexp, f in [0.5, 1)
   const float qscale = amax > 0.f ? ldexpf(1.f, 40 - aexp) : 1.f;
@@ -364,6 +417,8 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
     }
   };
   unsigned fixbits = 0;  // bit 2 tap + nt: this lane's sample left the staged window
+  float ov[2][2][3];     // [tap & 1]: the tap being sampled and the one in flight
+  load_tap(ov[0], 0);
 #pragma unroll
   for (int mt = 0; mt < 3; ++mt) {
 #pragma unroll
@@ -371,11 +426,14 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       const int tap = mt * 4 + t4;
       if (tap >= 9) continue;
       const int ki = tap / 3, kj = tap - 3 * ki;
+      if (tap + 1 < 9) load_tap(ov[(tap + 1) & 1], tap + 1);
+      __builtin_amdgcn_sched_barrier(0);   // (the next tap's six loads go out here, not eight taps early)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const float m = offv[tap][nt][2];
-        const float h_im = (float)(py[nt] - 1 + ki) + offv[tap][nt][0];
-        const float w_im = (float)(px - 1 + kj) + offv[tap][nt][1];
+        const float mraw = ov[tap & 1][nt][2];
+        const float m = a.mask_logit ? __builtin_amdgcn_rcpf(1.f + __expf(-mraw)) : mraw;
+        const float h_im = (float)(py[nt] - 1 + ki) + ov[tap & 1][nt][0];
+        const float w_im = (float)(px - 1 + kj) + ov[tap & 1][nt][1];
         const float hf = floorf(h_im), wf = floorf(w_im);
         const float lh = h_im - hf, lw = w_im - wf;
         const float hh = 1.f - lh, hw = 1.f - lw;
@@ -386,7 +444,8 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
         // gradient of the padded image is not zero while the reference's gate returns 0; the upper bounds need no test)
         const int ok = (int)pv[nt] & inwin & (h_im > -1.f) & (w_im > -1.f);
         fixbits |= (unsigned)((int)pv[nt] & (inwin ^ 1)) << (2 * tap + nt);
-        const int cell = min(max(ry, 0), XH - 2) * XW + min(max(rx, 0), XW - 2);
+        const int cry = min(max(ry, 0), XH - 2), crx = min(max(rx, 0), XW - 2);
+        const int cell = cry * XW + crx, cellx = cry * XWA + XA0 + crx;
         const float mk = ok ? m : 0.f;               // zero for samples this path does not own
         const float tsc = mk * qscale;
         float gm = 0.f, gh = 0.f, gw = 0.f;
@@ -394,8 +453,8 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
         for (int cq = 0; cq < 4; ++cq) {
           const int c = 4 * hi + cq;
           const float d = acc[mt][nt][t4 * 4 + cq];
-          const float* p1 = s_x + c * XPX + cell;
-          const float v1 = p1[0], v2 = p1[1], v3 = p1[XW], v4 = p1[XW + 1];
+          const float* p1 = s_x + c * XPXA + cellx;
+          const float v1 = p1[0], v2 = p1[1], v3 = p1[XWA], v4 = p1[XWA + 1];
           const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
           gm += d * val;                                              // kernel.cu:752
           gh += (-hw * v1 - lw * v2 + hw * v3 + lw * v4) * d;         // :541-550 (x mask below)
@@ -405,10 +464,19 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
             // measured again in round 2: this phase 47 k -> 263 k cycles, the whole call 196 -> 425 us
             unsigned long long* q1 = s_gq + c * XPX + cell;
             const float ts = d * tsc;                                 // :672, scaled
+#if defined(DCNB_NOATOM)   // (probe builds, results wrong: what the conversions + atomics / the atomics alone cost)
+            asm volatile("" :: "v"(w1 * ts), "v"(w2 * ts), "v"(w3 * ts), "v"(w4 * ts), "v"(q1));
+#elif defined(DCNB_NOCVT)
+            atomicAdd(q1, (unsigned long long)__float_as_uint(w1 * ts));
+            atomicAdd(q1 + 1, (unsigned long long)__float_as_uint(w2 * ts));
+            atomicAdd(q1 + XW, (unsigned long long)__float_as_uint(w3 * ts));
+            atomicAdd(q1 + XW + 1, (unsigned long long)__float_as_uint(w4 * ts));
+#else
             atomicAdd(q1, q64(w1 * ts));
             atomicAdd(q1 + 1, q64(w2 * ts));
             atomicAdd(q1 + XW, q64(w3 * ts));
             atomicAdd(q1 + XW + 1, q64(w4 * ts));
+#endif
           }
           // (a sample that left the window keeps d: loop 2b needs it, and stores the exact sample instead)
           COLR(tap, nt, cq) = ((int)pv[nt] & (inwin ^ 1)) ? d : val * mk;
@@ -433,19 +501,22 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       const int ki = tap / 3, kj = tap - 3 * ki;
       if ((fixbits >> b) & 1) {
         // runtime-indexed register arrays would go to scratch: select the operands with compile-time indices
-        float oh = 0.f, ow = 0.f, m = 0.f, dsel[4] = {0.f, 0.f, 0.f, 0.f};
+        float dsel[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
           for (int r = 0; r < 2; ++r)
             if (t == tap && r == nt) {
-              oh = offv[t][r][0]; ow = offv[t][r][1]; m = offv[t][r][2];
 #pragma unroll
               for (int cq = 0; cq < 4; ++cq) dsel[cq] = acc[t >> 2][r][(t & 3) * 4 + cq];
             }
         (void)mt; (void)t4;
         const int pyv = nt ? py[1] : py[0];
         const size_t pof = nt ? pofs[1] : pofs[0];
+        // (the streamed offsets of this tap are gone: read again, this path is rare)
+        const float oh = offn[(size_t)(g * 18 + 2 * tap) * HW + pof], ow = offn[(size_t)(g * 18 + 2 * tap + 1) * HW + pof];
+        const float mraw2 = mskn[(size_t)(g * 9 + tap) * HW + pof];
+        const float m = a.mask_logit ? __builtin_amdgcn_rcpf(1.f + __expf(-mraw2)) : mraw2;
         const float h_im = (float)(pyv - 1 + ki) + oh;
         const float w_im = (float)(px - 1 + kj) + ow;
         float gm = 0.f, gh = 0.f, gw = 0.f;
@@ -515,6 +586,10 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
     const int c = idx / XPX, r = idx - c * XPX;
     const int ry = r / XW, rx = r - ry * XW;
     const int gy_ = wy0 + ry, gx_ = wx0 + rx;
+#ifdef DCNB_NOFLUSH   // (probe build, results wrong: the window's global atomics as a load on the memory system)
+    asm volatile("" :: "v"(v));
+    if (false)
+#endif
     if ((unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W)
       unsafeAtomicAdd(gxg + (size_t)c * HW + (size_t)gy_ * a.W + gx_, v);
   }
@@ -548,6 +623,25 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       __syncthreads();   // the previous user of this LDS (gradient window / previous half / previous block) is done
       // gout half tile, zero outside the image: 64 channels x 4 rows x 32 pixels (two batches of 16 loads per lane:
       // 32 at once spill)
+      if (a.vec) {
+        // 64 channels x 4 rows x 8 groups of 16 bytes: 8 loads per lane in flight (round 6; the 2 x 16 scalar loads below
+        // paid two memory latencies per half)
+        f32x4 rg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int idx = tid + 256 * e;               // = o * 32 + row * 8 + v
+          const int o = ob * 64 + (idx >> 5), row = (idx >> 3) & 3, v = idx & 7;
+          const int gy_ = oy0 + 4 * half + row, gx_ = ox0 + 4 * v;
+          rg[e] = (gy_ < a.H && gx_ < a.W) ? *reinterpret_cast<const f32x4*>(gon + (size_t)o * HW + (size_t)gy_ * a.W + gx_)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int idx = tid + 256 * e;
+          float* d = s_go + (idx >> 5) * HP + ((idx >> 3) & 3) * 32 + 4 * (idx & 7);
+          d[0] = rg[e][0]; d[1] = rg[e][1]; d[2] = rg[e][2]; d[3] = rg[e][3];
+        }
+      } else
 #pragma unroll 1
       for (int eb = 0; eb < 32; eb += 16) {
         float rg[16];
@@ -607,6 +701,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       }
       __syncthreads();
     }
+    DCNB_STAMP(8);
     float* dst = a.dwp + (wg * (size_t)(a.Cout >> 6) + ob) * (size_t)(64 * 72);
     for (int idx = tid; idx < 64 * 72; idx += 256) dst[idx] = s_out[(idx / 72) * 73 + (idx % 72)];
     if (kc == 0 && tid < 64) {
@@ -616,7 +711,23 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       a.dbp[((size_t)n * gridDim.x + tile) * a.Cout + ob * 64 + tid] = sdb;
     }
   }
+  DCNB_STAMP(9);
 #undef COLR
+}
+
+// The A operands of the fused kernel's first phase in the order its LDS image has them: wtp[set][kc][(mt * KST + kk) * 64 + l]
+// = w[o = 2 kk + (l >> 5)][kc * 8 + (m & 7)][tap = m >> 3] with m = mt * 32 + (l & 31) (zero for m >= 72).  One launch per call
+// (147 k floats for 64 -> 64): every workgroup of the fused kernel then stages its 24 KB with six 16-byte loads per lane.
+__global__ void mdcn_bwd_wt_kernel(const float* __restrict__ w, long long w_gs, float* __restrict__ wtp, int C, int Cout, int nsets) {
+  const int KST = Cout >> 1, per = 3 * KST * 64, nkc = C >> 3;
+  const size_t total = (size_t)nsets * nkc * per;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int idx = (int)(i % per);
+    const int kc = (int)((i / per) % nkc), set = (int)(i / ((size_t)per * nkc));
+    const int l = idx & 63, kk = (idx >> 6) % KST, mt = idx / (64 * KST);
+    const int m = mt * 32 + (l & 31), o = 2 * kk + (l >> 5);
+    wtp[i] = m < 72 ? w[(size_t)set * w_gs + ((size_t)o * C + kc * 8 + (m & 7)) * 9 + (m >> 3)] : 0.f;
+  }
 }
 
 // dW[g][o][kc * 8 + c][tap] += sum over a chunk of the (frame, tile) rows of batch group g of
@@ -661,7 +772,8 @@ size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int s
   const int Ho = (H + 2 * pad - (dil * 2 + 1)) / stride + 1, Wo = (W + 2 * pad - (dil * 2 + 1)) / stride + 1;
   const size_t col = (size_t)N * C * 9 * Ho * Wo * sizeof(float);
   const size_t ntile = (size_t)ceil_div(Wo, 32) * ceil_div(Ho, 8);
-  const size_t fused = ((size_t)N * (C / 8) * ntile * Cout * 72 + (size_t)N * ntile * Cout) * sizeof(float);
+  const size_t fused = ((size_t)N * (C / 8) * ntile * Cout * 72 + (size_t)N * ntile * Cout +
+                        (size_t)std::max(groups, 1) * (C / 8) * 3 * (Cout / 2) * 64) * sizeof(float);   // + the W^T images
   return std::max(col + conv2d_wgrad_workspace_bytes(N, C * 9, Ho, Wo, Cout, 1, 1, -1, groups), fused);
 }
 
@@ -709,6 +821,19 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
     f.sub = a.cpg / 8;
     f.wdiv = groups > 0 ? N / groups : N; f.w_gs = w_gs;
     if (f.wdiv < 1) f.wdiv = 1;
+    {
+      // the W^T images live behind the weight / bias gradient partials (sized for them with or without a weight gradient)
+      float* wtp = (float*)ws + (size_t)N * (C / 8) * ntile * Cout * 72 + (size_t)N * ntile * Cout;
+      const int nsets = w_gs ? ceil_div(N, f.wdiv) : 1;
+      DVSR_REQUIRE(nsets <= std::max(groups, 1), DVSR_ERR_INVALID, "mdcn_backward: %d weight sets for %d groups", nsets, groups);
+      const size_t total = (size_t)nsets * (C / 8) * 3 * (Cout / 2) * 64;
+      hipLaunchKernelGGL(mdcn_bwd_wt_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1024)), dim3(256), 0, st, w, w_gs,
+                         wtp, C, Cout, nsets);
+      int rcw = check_launch("mdcn_bwd_wt_kernel");
+      if (rcw) return rcw;
+      f.wtp = wtp;
+    }
+    f.vec = (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)gout & 15) == 0) ? 1 : 0;
     if (f.sub > 1 && gmsk == goff + (size_t)dg * 18 * P && goff_bs == gmsk_bs && goff_bs == (long long)dg * 27 * P) {
       // offsets and masks are the two parts of one [N, 27 dg, H, W] tensor (the engine's layout): one memset
       DVSR_REQUIRE(hipMemsetAsync(goff, 0, (size_t)N * goff_bs * sizeof(float), st) == hipSuccess, DVSR_ERR_HIP,
@@ -721,9 +846,10 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
       }
     }
     // LDS: input window + max(gradient window, W^T operands); the weight-gradient phase re-uses it ([64 + 72][129] floats)
-    const size_t lds = (size_t)std::max(8 * XPX + std::max(16 * XPX, 3 * (Cout / 2) * 64), (64 + 72) * 129) * sizeof(float);
+    constexpr int XPXA = (8 + 2 + 2 * HALO) * 48;   // the input window's rows are 48 floats (aligned 16-byte groups)
+    const size_t lds = (size_t)std::max(8 * XPXA + std::max(16 * XPX, 3 * (Cout / 2) * 64), (64 + 72) * 129) * sizeof(float);
     static PerDeviceOnce attr_once;
-    set_dyn_lds_once(attr_once, (const void*)mdcn_bwd_fused_kernel<HALO>, (std::max(8 * XPX + std::max(16 * XPX, 3 * 64 * 64), (64 + 72) * 129) * sizeof(float)));
+    set_dyn_lds_once(attr_once, (const void*)mdcn_bwd_fused_kernel<HALO>, (std::max(8 * XPXA + std::max(16 * XPX, 3 * 64 * 64), (64 + 72) * 129) * sizeof(float)));
 #ifdef DVSR_CONV_TRACE
     f.trace = (g_dcnb_countdown == 0) ? g_dcnb_trace : nullptr;
     if (g_dcnb_countdown >= 0) --g_dcnb_countdown;

@@ -2,7 +2,8 @@
 """Cycle-stamp phases of one mdcn_bwd_fused_kernel launch (debug build: python -m dynavsr_amd.build --trace).
 usage (GPU box): python tools/dcn_bwd_trace.py [N H W]
 Stamps (thread 0 of every workgroup): 0 start, 1 staging loads issued and written, 2 barrier passed, 3 dcol MFMAs done,
-4 scale + window clear done, 5 sampling done, 6 barrier passed, 7 window flushed."""
+4 scale + window clear done, 5 sampling done, 6 barrier passed, 7 window flushed, 8 weight-gradient MFMAs + exchange done
+(last 64-cout block), 9 partials stored."""
 import ctypes
 import os
 import sys
@@ -37,7 +38,12 @@ t = t[t[:, 0] != 0]
 med = lambda v: float(np.median(v))
 print("mdcn_bwd_fused_kernel %dx64x%dx%d: %d workgroups, launch span %.0f cycles" % (n, h, w, len(t), float(t[:, 7].max() - t[:, 0].min())))
 names = ["staging (window, W^T, offsets) issued + written", "first barrier", "dcol = W^T gout (192 MFMAs per wave)",
-         "scale, barriers, window clear", "sampling (18 x (pixel row, tap))", "barrier", "window flush (global atomics)"]
+         "scale, barriers, window clear", "sampling (18 x (pixel row, tap))", "barrier", "window flush (global atomics)",
+         "weight gradient: staging + 192 MFMAs per wave + exchange", "partials stored"]
 for i, nm in enumerate(names):
     print("  %-52s %8.0f cycles (median)" % (nm, med(t[:, i + 1] - t[:, i])))
-print("  %-52s %8.0f" % ("lifetime", med(t[:, 7] - t[:, 0])))
+if t[:, 10].any():
+    for nm, i0, i1 in (("  prologue: loads issued", 0, 10), ("  prologue: window landed + written", 10, 11), ("  prologue: W^T written", 11, 12),
+                       ("  prologue: offsets landed (spills)", 12, 1)):
+        print("  %-52s %8.0f cycles (median)" % (nm, med(t[:, i1] - t[:, i0])))
+print("  %-52s %8.0f" % ("lifetime", med(t[:, 9] - t[:, 0])))
