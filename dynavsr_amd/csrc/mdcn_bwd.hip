@@ -179,13 +179,37 @@ extern "C" int dvsr_debug_dcn_bwd_trace(void* buf, int launch_index) {
   } while (0)
 #endif
 
-template <int HALO>
+typedef __bf16 dbbf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dbbf2 __attribute__((ext_vector_type(2)));
+typedef float dbf2 __attribute__((ext_vector_type(2)));
+typedef unsigned dbu4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned dcnb_cvt_pk(float x, float y) {   // {bf16(x) in bits 15:0, bf16(y) in bits 31:16}, RNE
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(dbf2{x, y}, dbbf2));
+}
+// two fp32 values -> their exact three-way bf16 split, packed pairwise: v = hi + mid + lo to 2^-24 relative (common.h)
+__device__ __forceinline__ void dcnb_split_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+  h = dcnb_cvt_pk(v0, v1);
+  const float r0 = v0 - __builtin_bit_cast(float, h << 16), r1 = v1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = dcnb_cvt_pk(r0, r1);
+  const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = dcnb_cvt_pk(q0, q1);
+}
+__device__ __forceinline__ f32x16 dcnb_mma(dbu4 a, dbu4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbbf8, a), __builtin_bit_cast(dbbf8, b), c, 0, 0, 0);
+}
+
+// SPLIT (round 6; Cout = 64, 16-byte aligned tensors with W % 4 == 0): the two contractions -- dcol = W^T gout and the tile's
+// weight gradient -- run on v_mfma_f32_32x32x16_bf16 under the exact 3-way bf16 split of both operands (six bf16 products per
+// fp32 product, fp32 accumulate: fp32 results), as the forward's contraction does since round 5.  The fp32 MFMAs they replace
+// occupied the vector datapath for 24.6 k cycles per wave with nothing running beside them; the bf16 MFMAs take 9.2 k on a
+// pipe the sampler of the co-resident workgroup issues beside.
+template <int HALO, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   constexpr int TH = 8, TW = 32, XH = TH + 2 + 2 * HALO, XW = TW + 2 + 2 * HALO, XPX = XH * XW;
   // The INPUT window's rows start at the 16-byte boundary left of the window (column ox0 - 8: XA0 columns before its first
   // one) and are XWA floats long, so that a row is twelve aligned 16-byte groups, each wholly inside or outside the image
   // when W % 4 == 0; the GRADIENT window keeps the tight pitch XW (two workgroups per CU: 27.6 + 48.4 KB each).
-  constexpr int XWA = 48, XA0 = 8 - 1 - HALO, XPXA = XH * XWA;
+  constexpr int XWA = 48, XA0 = 8 - 1 - HALO, XPXA = XH * XWA + 8;   // (+ 8: the lane halves' channels c, c + 4 sit 32 banks apart)
   static_assert(XA0 >= 0 && XA0 + XW <= XWA, "the aligned window rows must cover the sampling window");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const s_x = smem;              // [8][XH][XWA] input window
@@ -226,19 +250,24 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   const float* mskn = a.msk + (size_t)n * a.msk_bs;
   // W^T: the LDS image was laid out once per call by mdcn_bwd_wt_kernel (the 24 stride-9 gathers per lane this staging used to
   // do were the longest phase of the workgroup) -- 16-byte loads, six per lane and batch (one batch for Cout = 64)
-  const f32x4* wtp = reinterpret_cast<const f32x4*>(a.wtp + ((size_t)(a.w_gs ? n / a.wdiv : 0) * (a.C >> 3) + kc) * (size_t)(3 * KST * 64));
-  const int nv = 3 * KST * 16;   // 16-byte groups: 1536 for Cout = 64, 3072 for 128
-  f32x4 rw[6];
+  // (SPLIT: the image holds the three bf16 pieces of the A fragments, [piece][M-tile][16-cout chunk][lane][8] -- 36,864 bytes per
+  // (weight set, chunk kc), mdcn_bwd_wt3_kernel; the per-(set, kc) stride in the workspace is that of the larger image)
+  constexpr int WIMG = SPLIT ? 9216 : 0;   // floats per image (SPLIT); fp32 form: 3 * KST * 64
+  const int wimg = SPLIT ? WIMG : 3 * KST * 64;
+  const f32x4* wtp = reinterpret_cast<const f32x4*>(a.wtp + ((size_t)(a.w_gs ? n / a.wdiv : 0) * (a.C >> 3) + kc) * (size_t)wimg);
+  const int nv = wimg / 4;       // 16-byte groups: 1536 for Cout = 64 (2304 split), 3072 for 128
+  constexpr int WE = SPLIT ? 9 : 6;
+  f32x4 rw[WE];
   auto load_w = [&](int base) {
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
+    for (int e = 0; e < WE; ++e) {
       const int idx = base + tid + 256 * e;
       rw[e] = idx < nv ? wtp[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto store_w = [&](int base) {
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
+    for (int e = 0; e < WE; ++e) {
       const int idx = base + tid + 256 * e;
       if (idx < nv) *reinterpret_cast<f32x4*>(s_wt + 4 * idx) = rw[e];
     }
@@ -275,7 +304,8 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
       const int idx = tid + 256 * e;
-      if (idx < NV) *reinterpret_cast<f32x4*>(s_x + 4 * idx) = rv[e];
+      const int c = idx / (XH * (XWA / 4)), r = idx - c * (XH * (XWA / 4));
+      if (idx < NV) *reinterpret_cast<f32x4*>(s_x + c * XPXA + 4 * r) = rv[e];
     }
     DCNB_STAMP(11);
   } else {
@@ -300,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
     }
   }
   store_w(0);
-  for (int base = 256 * 6; base < nv; base += 256 * 6) {   // (Cout = 128)
+  for (int base = 256 * WE; base < nv; base += 256 * WE) {   // (Cout = 128)
     load_w(base);
     store_w(base);
   }
@@ -329,6 +359,49 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       b[q][1] = pl[pb32[1]];
     }
   };
+  if constexpr (SPLIT) {
+    // K = 64 couts in four chunks of 16: lane (lo, hi) supplies couts 16 j + 8 hi + 0..7 of its two pixels -- eight loads per
+    // pixel row and chunk, split into the three pieces pairwise --, the A fragments of a chunk are nine ds_read_b128.
+    // Products per (M-tile, pixel row, chunk): Ah Bh, Ah Bm, Am Bh, Am Bm, Ah Bl, Al Bh.
+    const dbu4* const s_w16 = reinterpret_cast<const dbu4*>(s_wt);   // [piece 3][mt 3][chunk 4][lane 64]
+    float braw[2][2][8];
+    auto load_c = [&](float (&b)[2][8], int j) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const size_t ob = (size_t)(16 * j + 8 * hi + i) * HW;
+        b[0][i] = gon[ob + pofs[0]];
+        b[1][i] = gon[ob + pofs[1]];
+      }
+    };
+    load_c(braw[0], 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j + 1 < 4) load_c(braw[(j + 1) & 1], j + 1);
+      dbu4 Bh[2], Bm[2], Bl[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v0 = pv[nt] ? braw[j & 1][nt][2 * q] : 0.f, v1 = pv[nt] ? braw[j & 1][nt][2 * q + 1] : 0.f;
+          unsigned h, m, l;
+          dcnb_split_pair(v0, v1, h, m, l);
+          Bh[nt][q] = h; Bm[nt][q] = m; Bl[nt][q] = l;
+        }
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        const dbu4 Ah = s_w16[((0 * 3 + mt) * 4 + j) * 64 + lane];
+        const dbu4 Am = s_w16[((1 * 3 + mt) * 4 + j) * 64 + lane];
+        const dbu4 Al = s_w16[((2 * 3 + mt) * 4 + j) * 64 + lane];
+        // (the two pixel rows alternate: consecutive MFMAs never wait on each other's accumulator)
+        acc[mt][0] = dcnb_mma(Ah, Bh[0], acc[mt][0]); acc[mt][1] = dcnb_mma(Ah, Bh[1], acc[mt][1]);
+        acc[mt][0] = dcnb_mma(Ah, Bm[0], acc[mt][0]); acc[mt][1] = dcnb_mma(Ah, Bm[1], acc[mt][1]);
+        acc[mt][0] = dcnb_mma(Am, Bh[0], acc[mt][0]); acc[mt][1] = dcnb_mma(Am, Bh[1], acc[mt][1]);
+        acc[mt][0] = dcnb_mma(Am, Bm[0], acc[mt][0]); acc[mt][1] = dcnb_mma(Am, Bm[1], acc[mt][1]);
+        acc[mt][0] = dcnb_mma(Ah, Bl[0], acc[mt][0]); acc[mt][1] = dcnb_mma(Ah, Bl[1], acc[mt][1]);
+        acc[mt][0] = dcnb_mma(Al, Bh[0], acc[mt][0]); acc[mt][1] = dcnb_mma(Al, Bh[1], acc[mt][1]);
+      }
+    }
+  } else {
   auto mfma8 = [&](const float (&b)[8][2], int kbase) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -347,6 +420,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
     mfma8(b0, kb);
     if (kb + 16 < KST) load_b(b0, kb + 16);
     mfma8(b1, kb + 8);
+  }
   }
 
   DCNB_STAMP(3);
@@ -620,6 +694,81 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
     float db0 = 0.f;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
+      if constexpr (SPLIT) {
+        // K = the half's 128 pixels in eight chunks of 16 (chunk c: pixel row c / 2, columns 16 (c & 1) ..+15); wave (ot, kh)
+        // takes chunks 4 kh ..+3 for its 32 couts and all three M-tiles of the samples.
+        //  * A (gout) never passes the LDS: lane (lo, hi) IS row o = 32 ot + lo, pixels 8 hi ..+7 of a chunk -- two 16-byte loads
+        //    straight from global memory, split in registers (the bias gradient sums them on the way);
+        //  * B (the modulated samples the sampler left in the accumulator registers) is transposed through the LDS as bf16
+        //    pieces, [piece][m 72][128 pixels] with rows of 272 bytes (a lane's fragment is one ds_read_b128; sixteen
+        //    consecutive rows cover the 64 banks once): 58.7 KB.
+        constexpr int SP = 136;   // halfwords per row of the sample image
+        unsigned short* const s_s16 = reinterpret_cast<unsigned short*>(smem);
+        f32x4 ga[4][2];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c = 4 * kh + cc;
+          const int gy_ = oy0 + 4 * half + (c >> 1), gx_ = ox0 + 16 * (c & 1) + 8 * hi;
+          const float* src = gon + (size_t)(ot * 32 + lo) * HW + (size_t)gy_ * a.W + gx_;
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+            ga[cc][v] = (gy_ < a.H && gx_ + 4 * v < a.W) ? *reinterpret_cast<const f32x4*>(src + 4 * v) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();   // the previous user of this LDS (gradient window / previous half) is done
+        if ((wave >> 1) == half) {
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const int p = (2 * (wave & 1) + nt) * 32 + lo;
+              unsigned h[2], m[2], l[2];
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+                dcnb_split_pair(pv[nt] ? COLR(tap, nt, 2 * q) : 0.f, pv[nt] ? COLR(tap, nt, 2 * q + 1) : 0.f, h[q], m[q], l[q]);
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                const int row = tap * 8 + 4 * hi + 2 * q;
+                s_s16[(0 * 72 + row) * SP + p] = (unsigned short)h[q]; s_s16[(0 * 72 + row + 1) * SP + p] = (unsigned short)(h[q] >> 16);
+                s_s16[(1 * 72 + row) * SP + p] = (unsigned short)m[q]; s_s16[(1 * 72 + row + 1) * SP + p] = (unsigned short)(m[q] >> 16);
+                s_s16[(2 * 72 + row) * SP + p] = (unsigned short)l[q]; s_s16[(2 * 72 + row + 1) * SP + p] = (unsigned short)(l[q] >> 16);
+              }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c = 4 * kh + cc;
+          dbu4 A[3];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float v0 = ga[cc][q >> 1][2 * (q & 1)], v1 = ga[cc][q >> 1][2 * (q & 1) + 1];
+            db0 += v0 + v1;
+            unsigned h, m, l;
+            dcnb_split_pair(v0, v1, h, m, l);
+            A[0][q] = h; A[1][q] = m; A[2][q] = l;
+          }
+          dbu4 B[3][3];   // [piece][M-tile]
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+              B[pc][mt] = (mt < 2 || lo < 8) ? *reinterpret_cast<const dbu4*>(s_s16 + (pc * 72 + mt * 32 + lo) * SP + 16 * c + 8 * hi)
+                                             : dbu4{0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) dw[mt] = dcnb_mma(A[0], B[0][mt], dw[mt]);
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) dw[mt] = dcnb_mma(A[0], B[1][mt], dw[mt]);
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) dw[mt] = dcnb_mma(A[1], B[0][mt], dw[mt]);
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) dw[mt] = dcnb_mma(A[1], B[1][mt], dw[mt]);
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) dw[mt] = dcnb_mma(A[0], B[2][mt], dw[mt]);
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) dw[mt] = dcnb_mma(A[2], B[0][mt], dw[mt]);
+        }
+        continue;
+      }
       __syncthreads();   // the previous user of this LDS (gradient window / previous half / previous block) is done
       // gout half tile, zero outside the image: 64 channels x 4 rows x 32 pixels (two batches of 16 loads per lane:
       // 32 at once spill)
@@ -730,6 +879,27 @@ __global__ void mdcn_bwd_wt_kernel(const float* __restrict__ w, long long w_gs, 
   }
 }
 
+// ... and as the three bf16 pieces of the SPLIT kernel's A fragments (Cout = 64): wtp16[set][kc][piece][mt][chunk j][lane l][i]
+// = piece of w[o = 16 j + 8 (l >> 5) + i][kc * 8 + (m & 7)][tap = m >> 3], m = mt * 32 + (l & 31) -- 18,432 bf16 per image.
+__global__ void mdcn_bwd_wt3_kernel(const float* __restrict__ w, long long w_gs, __bf16* __restrict__ wtp, int C, int nsets) {
+  constexpr int per = 3 * 4 * 64 * 8;   // values per image (each becomes three pieces)
+  const int nkc = C >> 3;
+  const size_t total = (size_t)nsets * nkc * per;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int idx = (int)(i % per);
+    const int kc = (int)((i / per) % nkc), set = (int)(i / ((size_t)per * nkc));
+    const int ii = idx & 7, l = (idx >> 3) & 63, j = (idx >> 9) & 3, mt = idx >> 11;
+    const int m = mt * 32 + (l & 31), o = 16 * j + 8 * (l >> 5) + ii;
+    const float v = m < 72 ? w[(size_t)set * w_gs + ((size_t)o * C + kc * 8 + (m & 7)) * 9 + (m >> 3)] : 0.f;
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 mm = (__bf16)r1;
+    const __bf16 ll = (__bf16)(r1 - (float)mm);
+    __bf16* d = wtp + ((size_t)set * nkc + kc) * (size_t)(3 * per) + idx;
+    d[0] = h; d[per] = mm; d[2 * per] = ll;
+  }
+}
+
 // dW[g][o][kc * 8 + c][tap] += sum over a chunk of the (frame, tile) rows of batch group g of
 // partial[n][kc][tile][ob][o][tap * 8 + c]; db[g][o] likewise.  grid (ceil(64 * 72 / 256), C / 8 * Cout / 64, groups * nsp):
 // the rows of a group are split nsp ways (one thread summing all ~1000 rows of a 180x320 call serially took 800 us for
@@ -773,7 +943,7 @@ size_t mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int s
   const size_t col = (size_t)N * C * 9 * Ho * Wo * sizeof(float);
   const size_t ntile = (size_t)ceil_div(Wo, 32) * ceil_div(Ho, 8);
   const size_t fused = ((size_t)N * (C / 8) * ntile * Cout * 72 + (size_t)N * ntile * Cout +
-                        (size_t)std::max(groups, 1) * (C / 8) * 3 * (Cout / 2) * 64) * sizeof(float);   // + the W^T images
+                        (size_t)std::max(groups, 1) * (C / 8) * 3 * (Cout / 2) * 64 * 3 / 2) * sizeof(float);   // + the W^T images (bf16 x 3)
   return std::max(col + conv2d_wgrad_workspace_bytes(N, C * 9, Ho, Wo, Cout, 1, 1, -1, groups), fused);
 }
 
@@ -821,19 +991,29 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
     f.sub = a.cpg / 8;
     f.wdiv = groups > 0 ? N / groups : N; f.w_gs = w_gs;
     if (f.wdiv < 1) f.wdiv = 1;
+    bool split = false;
     {
       // the W^T images live behind the weight / bias gradient partials (sized for them with or without a weight gradient)
       float* wtp = (float*)ws + (size_t)N * (C / 8) * ntile * Cout * 72 + (size_t)N * ntile * Cout;
       const int nsets = w_gs ? ceil_div(N, f.wdiv) : 1;
       DVSR_REQUIRE(nsets <= std::max(groups, 1), DVSR_ERR_INVALID, "mdcn_backward: %d weight sets for %d groups", nsets, groups);
-      const size_t total = (size_t)nsets * (C / 8) * 3 * (Cout / 2) * 64;
-      hipLaunchKernelGGL(mdcn_bwd_wt_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1024)), dim3(256), 0, st, w, w_gs,
-                         wtp, C, Cout, nsets);
+      f.vec = (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)gout & 15) == 0) ? 1 : 0;
+      // DVSR_DCN_BWD=fp32: the fp32-MFMA contractions for every shape (A/B aid; read once per process)
+      static const bool split_on = [] { const char* v = getenv("DVSR_DCN_BWD"); return !(v && v[0] == 'f'); }();
+      split = split_on && f.vec && Cout == 64;
+      if (split) {
+        const size_t total = (size_t)nsets * (C / 8) * (3 * 4 * 64 * 8);
+        hipLaunchKernelGGL(mdcn_bwd_wt3_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1024)), dim3(256), 0, st, w, w_gs,
+                           (__bf16*)wtp, C, nsets);
+      } else {
+        const size_t total = (size_t)nsets * (C / 8) * 3 * (Cout / 2) * 64;
+        hipLaunchKernelGGL(mdcn_bwd_wt_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1024)), dim3(256), 0, st, w, w_gs,
+                           wtp, C, Cout, nsets);
+      }
       int rcw = check_launch("mdcn_bwd_wt_kernel");
       if (rcw) return rcw;
       f.wtp = wtp;
     }
-    f.vec = (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)gout & 15) == 0) ? 1 : 0;
     if (f.sub > 1 && gmsk == goff + (size_t)dg * 18 * P && goff_bs == gmsk_bs && goff_bs == (long long)dg * 27 * P) {
       // offsets and masks are the two parts of one [N, 27 dg, H, W] tensor (the engine's layout): one memset
       DVSR_REQUIRE(hipMemsetAsync(goff, 0, (size_t)N * goff_bs * sizeof(float), st) == hipSuccess, DVSR_ERR_HIP,
@@ -846,15 +1026,18 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
       }
     }
     // LDS: input window + max(gradient window, W^T operands); the weight-gradient phase re-uses it ([64 + 72][129] floats)
-    constexpr int XPXA = (8 + 2 + 2 * HALO) * 48;   // the input window's rows are 48 floats (aligned 16-byte groups)
+    constexpr int XPXA = (8 + 2 + 2 * HALO) * 48 + 8;   // the input window's rows are 48 floats (aligned 16-byte groups)
     const size_t lds = (size_t)std::max(8 * XPXA + std::max(16 * XPX, 3 * (Cout / 2) * 64), (64 + 72) * 129) * sizeof(float);
     static PerDeviceOnce attr_once;
-    set_dyn_lds_once(attr_once, (const void*)mdcn_bwd_fused_kernel<HALO>, (std::max(8 * XPXA + std::max(16 * XPX, 3 * 64 * 64), (64 + 72) * 129) * sizeof(float)));
+    static PerDeviceOnce attr_once_s;
+    set_dyn_lds_once(attr_once, (const void*)mdcn_bwd_fused_kernel<HALO, false>, (std::max(8 * XPXA + std::max(16 * XPX, 3 * 64 * 64), (64 + 72) * 129) * sizeof(float)));
+    set_dyn_lds_once(attr_once_s, (const void*)mdcn_bwd_fused_kernel<HALO, true>, (std::max(8 * XPXA + std::max(16 * XPX, 3 * 64 * 64), (64 + 72) * 129) * sizeof(float)));
 #ifdef DVSR_CONV_TRACE
     f.trace = (g_dcnb_countdown == 0) ? g_dcnb_trace : nullptr;
     if (g_dcnb_countdown >= 0) --g_dcnb_countdown;
 #endif
-    hipLaunchKernelGGL(mdcn_bwd_fused_kernel<HALO>, dim3(f.tiles_x * f.tiles_y, C / 8, N), dim3(256), lds, st, f);
+    if (split) hipLaunchKernelGGL((mdcn_bwd_fused_kernel<HALO, true>), dim3(f.tiles_x * f.tiles_y, C / 8, N), dim3(256), lds, st, f);
+    else hipLaunchKernelGGL((mdcn_bwd_fused_kernel<HALO, false>), dim3(f.tiles_x * f.tiles_y, C / 8, N), dim3(256), lds, st, f);
     int rc = check_launch("mdcn_bwd_fused_kernel");
     if (rc || !gw) return rc;
     // dW / db: sum the per-workgroup partials (per batch group when per-group gradients are asked for) into zeroed outputs
