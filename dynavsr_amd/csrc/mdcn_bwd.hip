@@ -695,7 +695,8 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       if constexpr (SPLIT) {
-        // K = the half's 128 pixels in eight chunks of 16 (chunk c: pixel row c / 2, columns 16 (c & 1) ..+15); wave (ot, kh)
+        // K = the half's 128 pixels in eight chunks of 16 (chunk c: the half's pixel row c / 2 = tile row 2 (c / 2) + half, columns
+        // 16 (c & 1) ..+15); wave (ot, kh)
         // takes chunks 4 kh ..+3 for its 32 couts and all three M-tiles of the samples.
         //  * A (gout) never passes the LDS: lane (lo, hi) IS row o = 32 ot + lo, pixels 8 hi ..+7 of a chunk -- two 16-byte loads
         //    straight from global memory, split in registers (the bias gradient sums them on the way);
@@ -708,23 +709,27 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
           const int c = 4 * kh + cc;
-          const int gy_ = oy0 + 4 * half + (c >> 1), gx_ = ox0 + 16 * (c & 1) + 8 * hi;
+          const int gy_ = oy0 + 2 * (c >> 1) + half, gx_ = ox0 + 16 * (c & 1) + 8 * hi;
           const float* src = gon + (size_t)(ot * 32 + lo) * HW + (size_t)gy_ * a.W + gx_;
 #pragma unroll
           for (int v = 0; v < 2; ++v)
             ga[cc][v] = (gy_ < a.H && gx_ + 4 * v < a.W) ? *reinterpret_cast<const f32x4*>(src + 4 * v) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();   // the previous user of this LDS (gradient window / previous half) is done
-        if ((wave >> 1) == half) {
+        {
+          // (a half = one pixel row of every wave -- rows half, 2 + half, 4 + half, 6 + half -- so that all four waves
+          // transpose their samples at once: pixel row `wave` of the half's image)
+          const bool pvh = half ? pv[1] : pv[0];
 #pragma unroll
-          for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              const int p = (2 * (wave & 1) + nt) * 32 + lo;
+          for (int tap = 0; tap < 9; ++tap) {
+              const int p = wave * 32 + lo;
               unsigned h[2], m[2], l[2];
 #pragma unroll
-              for (int q = 0; q < 2; ++q)
-                dcnb_split_pair(pv[nt] ? COLR(tap, nt, 2 * q) : 0.f, pv[nt] ? COLR(tap, nt, 2 * q + 1) : 0.f, h[q], m[q], l[q]);
+              for (int q = 0; q < 2; ++q) {
+                const float c0 = half ? COLR(tap, 1, 2 * q) : COLR(tap, 0, 2 * q);
+                const float c1 = half ? COLR(tap, 1, 2 * q + 1) : COLR(tap, 0, 2 * q + 1);
+                dcnb_split_pair(pvh ? c0 : 0.f, pvh ? c1 : 0.f, h[q], m[q], l[q]);
+              }
 #pragma unroll
               for (int q = 0; q < 2; ++q) {
                 const int row = tap * 8 + 4 * hi + 2 * q;
