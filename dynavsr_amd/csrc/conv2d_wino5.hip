@@ -8,33 +8,39 @@
 // 4.3e-7; oracle/winograd.py restates the transforms, tests/test_gpu_ops.py holds the kernel to 4e-6).
 //
 // Shape.  A workgroup owns 32 tiles of 4x4 outputs (TC tiles per tile row: 8 x 64 or 16 x 32 pixels) x 64 couts x 36 points
-// = 1152 accumulator registers per lane -- the whole CU holds 2048, so one workgroup per CU, TWELVE waves (three per SIMD,
-// <= 168 registers each):
-//   * consumer role: wave (xi = wave % 6, mh = wave / 6) owns the six points (xi, nu = 0..5) of ONE 32-cout half: 6 x 16
-//     accumulator registers, 18 MFMAs per 8-channel chunk;
-//   * producer role: wave (pair = wave & 3, group = wave >> 2), lane (tile = lane & 31, parity = lane >> 5) transforms channel
-//     2 pair + parity of its tile for the row pair xi in {1,2} | {3,4} | {0,5} (one row pass shared by the two rows: e +- o),
-//     all six nu; v_permlane32_swap then hands lower lanes the (even, odd) channel values of the first xi and upper lanes those
-//     of the second, each lane splits six channel PAIRS into three exact bf16 pieces (v_cvt_pk_bf16_f32) and stores 18 words.
+// = 1152 accumulator registers per lane -- the whole CU holds 2048, so one workgroup per CU: SIXTEEN waves of 128 registers,
+// twelve that multiply and four that transform (the first version gave every wave both roles: its ten spilled registers were
+// reloaded behind `s_waitcnt vmcnt(0)` in the chunk loop and serialised the DMA and the weight loads -- 142 us where this
+// form takes 80):
+//   * CONSUMER waves 0..11: wave (xi = wave % 6, mh = wave / 6) owns the six points (xi, nu = 0..5) of ONE 32-cout half: 6 x 16
+//     accumulator registers, 18 MFMAs per 8-channel chunk, weight fragments from global memory (L2) through a ring of three
+//     register slots, V fragments by 16-byte LDS reads two MFMAs ahead;
+//   * PRODUCER waves 12..15: wave pw moves its quarter of the raw halo (16-byte buffer-load LDS-DMA, six instructions per
+//     chunk; lanes outside the image carry an offset the resource rejects) and transforms all 8 channels of tiles 8 pw ..+7:
+//     lane (tile, channel pair, parity) reads the six raw rows of its channel once, the row pass shares e +- o between rows
+//     (1, 2) and (3, 4); per row pair (1, 2), (3, 4), (0, 5): column pass, v_permlane32_swap pairs the even and the odd
+//     channel (lower lanes take the first row, upper lanes the second), the exact 3-way split (v_cvt_pk_bf16_f32) and 18
+//     word stores -- ~430 instructions per chunk, none of them between a consumer and its MFMAs.
 // The transformed input V goes THROUGH THE LDS as pure pieces, V[point][piece][tile][channel pair] (1536 bytes per point,
-// 54 KB per chunk, two images): with 36 points on 12 waves the register-built operand of form 4 does not fit (a wave would
-// hold 96 accumulators + two generations of three fragment sets in 168 registers), and the image decouples who transforms
-// from who multiplies -- every lane of the workgroup has exactly one transform task per chunk.
+// 54 KB per chunk, two images) + two raw buffers of 24 KB: 159,744 bytes.  With 36 points the register-built operand of form 4
+// does not fit, and the image decouples who transforms from who multiplies.
 //
 // Products.  x = hi + mid + lo for both operands, six of nine partial products (those above 2^-24), two per MFMA (K = 16 =
-// 8 channels x 2 pieces, lanes 32-63 carry K 8..15):
-//     X = (Uh | Um) . (Vh | Vh)  ->  Uh Vh + Um Vh          X . (Vm | Vm)  ->  Uh Vm + Um Vm          W = (Uh | Ul) . (Vl | Vh)  ->  Uh Vl + Ul Vh
-// so a (point, cout half, chunk) needs TWO 1 KB weight fragments (X twice, W once) instead of three, and the three V fragments
-// are 16-byte LDS reads whose lane halves simply point at different pieces.  The packed weights
-// P16[cb][k][point 36][mh 2][X | W][lane half 2][cout 32][8 ch] come straight from global memory (L2), one point ahead.
+// 8 channels x 2 pieces, lanes 32-63 carry K 8..15).  Per point PAIR (nu even, nu odd) three 1 KB weight fragments instead of
+// four: X = (Uh | Um) of the even point, X' = (Um | Uh) of the odd point, L = (Ul odd | Ul even); each X serves two MFMAs
+//     X . (Vh | Vh) -> Uh Vh + Um Vh        X . (Vm | Vm) -> Uh Vm + Um Vm
+// and is then blended with L by lane half (one v_cndmask per register) into W = (Uh | Ul) resp. W' = (Ul | Uh) for the third,
+//     W . (Vl | Vh) -> Uh Vl + Ul Vh        W' . (Vh | Vl) -> Ul Vh + Uh Vl.
+// The V fragments' lane halves simply point at different pieces.  Pack: P16[cb][k][xi][q = nu / 2][mh][X | X' | L][lane half]
+// [cout 32][8 ch] (pack_weights_wino5_kernel: G g G^T in fp64, rounded once to fp32, split).
 //
 // Pipeline.  Chunk k: consumers multiply V(k) (image k & 1) while producers build V(k + 1) from raw(k + 1) into the other
-// image and the LDS-DMA fetches raw(k + 2) into the raw buffer raw(k) has left; ONE barrier per chunk.  Raw halo: 16-byte
-// buffer-load LDS-DMA as in form 4 (unconditional; lanes outside the image carry an offset the resource rejects).
+// image and the LDS-DMA fetches raw(k + 2) into the raw buffer raw(k) has left; ONE barrier per chunk.
 //
 // Epilogue.  Y = A^T M A.  The six nu of a row are in one wave: the column transform (6 -> 4 values) is done in registers,
 // then per cout half one exchange round through the LDS ([xi][j][register quad][lane] x 16 B = 96 KB), eight reader waves
-// (tile, 2 couts) apply the row transform, bias, activation, residual and store 16-byte output rows (PixelShuffle(2): 32).
+// (tile, 2 couts) apply the row transform, bias, activation, residual and store 16-byte output rows (PixelShuffle(2): 32);
+// a ragged last tile row stores only its rows inside the image.  Used for NO-GRAD forwards only (engine.hip: Op::geo_ng).
 #include <type_traits>
 
 #include "common.h"

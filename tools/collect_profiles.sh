@@ -75,6 +75,22 @@ fi
 python tools/dcn_bwd_bench.py 20 2>&1 | grep -v amdgpu > $out/${tag}_dcn_bwd.txt
 rocprofv3 --kernel-trace --stats -d $out/db9b -o r -- python tools/dcn_bwd_bench.py 20 > /dev/null 2>&1
 python tools/rocprof_summary.py $out/db9b/r_results.db | head -8 >> $out/${tag}_dcn_bwd.txt; rm -rf $out/db9b
+# r06: the fused kernel's phases (debug build), the fp32-MFMA form beside it, and its HBM-side traffic at 5x64x180x320
+# (algorithmic: x, gout, gx 73.7 MB each + offsets / masks and their gradients 2 x 248.8 MB = 719 MB; the weight-gradient
+# partials, 170 MB per call, are the kernel's own)
+echo "== DVSR_DCN_BWD=fp32 (fp32-MFMA contractions)" >> $out/${tag}_dcn_bwd.txt
+DVSR_DCN_BWD=fp32 python tools/dcn_bwd_bench.py 20 2>&1 | grep -v amdgpu >> $out/${tag}_dcn_bwd.txt
+if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
+  python tools/dcn_bwd_trace.py 5 180 320 2>&1 | grep -v amdgpu >> $out/${tag}_dcn_bwd.txt
+  python tools/dcn_bwd_trace.py 5 44 80 2>&1 | grep -v amdgpu >> $out/${tag}_dcn_bwd.txt
+fi
+echo "== PMC, 5x64x180x320 (separate passes; mean per launch)" >> $out/${tag}_dcn_bwd.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d /tmp/dbq -o p -- python $GRAFT_REPO_ROOT/tools/dcn_bwd_bench.py 4 big > /dev/null 2>&1)
+  f=$(find /tmp/dbq -name "p_results.db" | head -1)
+  [ -n "$f" ] && python tools/pmc_dump.py $f mdcn_ >> $out/${tag}_dcn_bwd.txt
+  rm -rf /tmp/dbq
+done
 # PMC: matrix-pipe utilisation of the batched inner step's kernels
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $c --kernel-trace -d $out/dbi_$c -o p -- python tools/inner_batch_profile.py 8 3 > /dev/null 2>&1
@@ -107,10 +123,11 @@ if [ -f dynavsr_amd/libdynavsr_hip_trace.so ]; then
   DVSR_CONV_WINO5=0 python tools/wino_trace.py 2>&1 | grep -v amdgpu > $out/${tag}_wino_trace.txt
 fi
 # compile-time probe builds of the F(4x4) kernel (results WRONG: each bounds what one term of the chunk loop costs), same box
+# (no weight-fragment probe: without its global loads the compiler re-allocates the chunk loop and the build measures 2.5x SLOWER)
 if [ -x tools/wino5_variants.sh ]; then
-  tools/wino5_variants.sh NOA NOPROD NOMMA NODMA NOBR NOVW NOPROD+NOA > /dev/null 2>&1
+  tools/wino5_variants.sh NOPROD NOMMA NODMA NOBR NOVW > /dev/null 2>&1
   cp dynavsr_amd/libdynavsr_hip.so /tmp/base.so
-  for v in base NOA NOPROD NOMMA NODMA NOBR NOVW NOPROD+NOA base; do
+  for v in base NOPROD NOMMA NODMA NOBR NOVW base; do
     if [ $v = base ]; then cp /tmp/base.so dynavsr_amd/libdynavsr_hip.so; else cp dynavsr_amd/libdynavsr_hip_w5_$v.so dynavsr_amd/libdynavsr_hip.so; fi
     echo "== $v" >> $out/${tag}_wino5_ablation.txt
     DVSR_CONV_WINO=2 DVSR_CONV_WINO5=2 python tools/wino_bench.py --quick 2>&1 | grep -E "fe_rb|L1_offset|rc_rb" >> $out/${tag}_wino5_ablation.txt

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """DCN backward alone (dvsr_mdcn_backward) at the inner-step and bench sizes; kernel times come from
-rocprofv3 --kernel-trace --stats around this script.  usage (GPU box): python tools/dcn_bwd_bench.py [reps]"""
+rocprofv3 --kernel-trace --stats around this script.  usage (GPU box): python tools/dcn_bwd_bench.py [reps [big|small]]"""
 import os
 import sys
 
@@ -13,7 +13,8 @@ from dynavsr_amd import hipops  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 torch.manual_seed(0)
-for (n, h, w) in [(5, 44, 80), (5, 180, 320)]:
+which = sys.argv[2] if len(sys.argv) > 2 else "both"
+for (n, h, w) in [s_ for s_ in [(5, 44, 80), (5, 180, 320)] if which == "both" or (which == "big") == (s_[1] == 180)]:
     x = torch.randn(n, 64, h, w, device="cuda")
     off = torch.randn(n, 144, h, w, device="cuda") * 1.3
     msk = torch.sigmoid(torch.randn(n, 72, h, w, device="cuda"))
