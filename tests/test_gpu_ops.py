@@ -248,6 +248,22 @@ def test_mdcn_backward_vs_oracle(ops, std, h, w):
         assert relerr(a, b_) < TOL, name
 
 
+def test_mdcn_backward_fp32_contractions_switch():
+    """Since round 6 the fused backward runs its two contractions (dcol = W^T gout, the tile's weight gradient) on the bf16
+    pipe under the exact 3-way split where Cout = 64, W % 4 == 0 and the tensors are 16-byte aligned (the 20x40 case of
+    test_mdcn_backward_vs_oracle and the goldens; 14x34 / 9x33 and EDVR-L's 128-cout layers keep the fp32 MFMAs).
+    DVSR_DCN_BWD=fp32 puts every shape on the fp32 MFMAs again: the same cases, same bars, in a child (the switch is read
+    once per process)."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "test_mdcn_backward_vs_oracle or test_mdcn_backward_golden"],
+                       env=dict(os.environ, DVSR_DCN_BWD="fp32"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("std", [1.5, 8.0])
 def test_mdcn_16_channels_per_group_vs_oracle(ops, std):
     """EDVR-L's DCN: C = 128, dg = 8 -> 16 channels per deformable group.  The LDS-sampler forward and the fused
