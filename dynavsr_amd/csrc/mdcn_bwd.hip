@@ -152,7 +152,7 @@ struct DcnF {
   float* dbp;  // [N][tiles][Cout] bias-gradient partials
   long long off_bs, msk_bs, goff_bs, gmsk_bs;
   int mask_logit, N, C, H, W, Cout, dg, tiles_x, tiles_y;
-  int sub;  // 8-channel chunks per deformable group (1: EDVR-M, 2: EDVR-L); blockIdx.y walks the C/8 chunks
+  int sub;  // 8-channel chunks per deformable group (1: EDVR-M, 2: EDVR-L); a workgroup takes one of the C/8 chunks
   int wdiv = 1; long long w_gs = 0;  // per-sample weight sets: frame n convolves with w + (n / wdiv) * w_gs
   const float* wtp = nullptr;        // [weight set][C / 8][3][Cout / 2][64]: the A operands of phase 1 in LDS order (mdcn_bwd_wt_kernel)
   int vec = 0;                       // W % 4 == 0 and x / gout 16-byte aligned: the window and the gout tiles are staged with 16-byte loads
@@ -164,7 +164,7 @@ struct DcnF {
 #define DCNB_STAMP(i)                                                                                              \
   do {                                                                                                             \
     if (a.trace && threadIdx.x == 0)                                                                               \
-      a.trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); \
+      a.trace[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
 static long long* g_dcnb_trace = nullptr;
 static int g_dcnb_countdown = -1;
@@ -218,10 +218,18 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   __shared__ float s_max[8];
   const int KST = a.Cout >> 1;
 
-  // blockIdx.y = 8-channel chunk kc of the input; its deformable group g supplies offsets / masks.  With more
+  // kc = 8-channel chunk of the input; its deformable group g supplies offsets / masks.  With more
   // than one chunk per group the offset / mask gradients of the chunks are summed with atomics into buffers the
   // host zeroed (two commutative adds per element: still deterministic).
-  const int tile = blockIdx.x, kc = blockIdx.y, n = blockIdx.z;
+  // Workgroup -> (frame, tile, chunk): the C / 8 chunk workgroups of one (frame, tile) all read the same gout tile (twice each:
+  // phase 1 and the weight gradient), so they sit on ONE XCD in consecutive dispatch slots -- workgroups are dealt to the eight
+  // XCDs round-robin (blockIdx.x & 7) and an XCD has its own L2 (round 6; as a (tile, chunk, frame) grid the eight of a tile
+  // were 230 dispatches apart and on eight different XCDs).
+  const int nkc = a.C >> 3, ntile = a.tiles_x * a.tiles_y;
+  const int slot = blockIdx.x >> 3;
+  const int pair = (int)(blockIdx.x & 7) + 8 * (slot / nkc);   // (frame, tile) index
+  if (pair >= a.N * ntile) return;
+  const int kc = slot - (slot / nkc) * nkc, n = pair / ntile, tile = pair - n * ntile;
   const int g = kc / a.sub;
   const int tx_ = tile % a.tiles_x, ty_ = tile / a.tiles_x;
   const int oy0 = ty_ * TH, ox0 = tx_ * TW;
@@ -681,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
   float* const s_ct = smem + 64 * HP;       // [72][HP]  (70 KB together: within the 72.6 KB of phases 0-3, two workgroups per CU)
   float* const s_out = smem;                // [64][73] (after the MFMAs)
   float* const s_db = smem + 64 * 73;       // [4][64]
-  const size_t wg = ((size_t)n * gridDim.y + kc) * gridDim.x + tile;
+  const size_t wg = ((size_t)n * nkc + kc) * ntile + tile;
 #pragma unroll 1
   for (int ob = 0; ob < (a.Cout >> 6); ++ob) {
     // wave -> (32-cout half ot, half kh of a step's pixels): 3 tiles per wave, ONE exchange between the two k halves
@@ -862,7 +870,7 @@ __global__ __launch_bounds__(256, 2) void mdcn_bwd_fused_kernel(DcnF a) {
       float sdb = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) sdb += s_db[q * 64 + tid];
-      a.dbp[((size_t)n * gridDim.x + tile) * a.Cout + ob * 64 + tid] = sdb;
+      a.dbp[((size_t)n * ntile + tile) * a.Cout + ob * 64 + tid] = sdb;
     }
   }
   DCNB_STAMP(9);
@@ -1041,8 +1049,9 @@ int mdcn_backward_run(const float* x, const float* off, long long off_bs, const 
     f.trace = (g_dcnb_countdown == 0) ? g_dcnb_trace : nullptr;
     if (g_dcnb_countdown >= 0) --g_dcnb_countdown;
 #endif
-    if (split) hipLaunchKernelGGL((mdcn_bwd_fused_kernel<HALO, true>), dim3(f.tiles_x * f.tiles_y, C / 8, N), dim3(256), lds, st, f);
-    else hipLaunchKernelGGL((mdcn_bwd_fused_kernel<HALO, false>), dim3(f.tiles_x * f.tiles_y, C / 8, N), dim3(256), lds, st, f);
+    const dim3 grid((unsigned)(8 * (C / 8) * ceil_div(N * f.tiles_x * f.tiles_y, 8)));
+    if (split) hipLaunchKernelGGL((mdcn_bwd_fused_kernel<HALO, true>), grid, dim3(256), lds, st, f);
+    else hipLaunchKernelGGL((mdcn_bwd_fused_kernel<HALO, false>), grid, dim3(256), lds, st, f);
     int rc = check_launch("mdcn_bwd_fused_kernel");
     if (rc || !gw) return rc;
     // dW / db: sum the per-workgroup partials (per batch group when per-group gradients are asked for) into zeroed outputs
