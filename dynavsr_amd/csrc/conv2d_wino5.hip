@@ -538,6 +538,7 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
   if (a.trace && threadIdx.x == 0) {
     a.trace[(size_t)blockIdx.x * 64 + 61] = __builtin_amdgcn_s_memrealtime();
     a.trace[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_ID
+    a.trace[(size_t)blockIdx.x * 64 + 62] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // XCC_ID
   }
 #endif
   }

@@ -73,3 +73,20 @@ for nm, i0, i1 in (("epilogue: column transform", 40, 50), ("first barrier", 50,
                    ("round 0: reads + row transform + stores", 53, 54), ("barrier (reads done)", 54, 55), ("round 1: LDS writes", 55, 56),
                    ("round 1: barrier", 56, 57), ("round 1: reads + row transform + stores", 57, 58), ("stores acknowledged", 41, 42)):
     stat(nm, t[:, i1] - t[:, i0])
+
+# workgroups that followed each other on one CU (XCC_ID, HW_ID's se / sh / cu): idle time between the end of one and the start
+# of the next (s_memrealtime, 100 MHz)
+import collections  # noqa: E402
+by_cu = collections.defaultdict(list)
+for r in t:
+    hw = int(r[63])
+    by_cu[(int(r[62]) & 0xf, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf)].append((int(r[60]), int(r[61])))
+gaps = []
+for v in by_cu.values():
+    v.sort()
+    gaps += [b[0] - a_[1] for a_, b in zip(v, v[1:])]
+if gaps:
+    print("CUs seen: %d; workgroups per CU: %s" % (len(by_cu), dict(collections.Counter(len(v) for v in by_cu.values()))))
+    stat("idle between two workgroups of a CU (x 10 ns)", gaps)
+    first = min(r[60] for r in t)
+    stat("a CU's first workgroup starts after the kernel's first (x 10 ns)", [v[0][0] - first for v in by_cu.values()])
