@@ -126,6 +126,48 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __rest
   }
 }
 
+// The same arithmetic with one thread = TWO input columns of one input row -> a 2 x 4 output block: the lanes of a wave store
+// 64 consecutive 16-byte groups of an output row (one whole 1 KB segment per store instruction).  With four input columns per
+// thread every store instruction wrote alternate 16-byte halves of its 32-byte lane stride: two instructions to complete
+// each 64-byte line, 3.2 TB/s on the 92 MB launches of the PCD pyramid (round 6).
+__global__ void upsample2x_fwd2_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned planes, int H,
+                                       int W, float mul) {
+  const int Wh = W >> 1, Wo = 2 * W;
+  const unsigned total = planes * (unsigned)H * (unsigned)Wh;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int xh = (int)(i % (unsigned)Wh);
+    const unsigned t = i / (unsigned)Wh;
+    const int iy = (int)(t % (unsigned)H);
+    const unsigned p = t / (unsigned)H;
+    const float* pl = x + (size_t)p * H * W;
+    const int x0 = 2 * xh;
+    const int rows[3] = {iy > 0 ? iy - 1 : 0, iy, iy < H - 1 ? iy + 1 : H - 1};
+    float h[3][4];  // horizontally interpolated rows: output columns 2*x0 .. 2*x0 + 3
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float* row = pl + (size_t)rows[r] * W;
+      typedef float f32x2_ __attribute__((ext_vector_type(2)));
+      const f32x2_ c = *reinterpret_cast<const f32x2_*>(row + x0);
+      const float in[4] = {row[x0 > 0 ? x0 - 1 : 0], c[0], c[1], row[x0 + 2 < W ? x0 + 2 : W - 1]};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        h[r][2 * j] = (x0 + j > 0) ? 0.25f * in[j] + 0.75f * in[j + 1] : in[j + 1];
+        h[r][2 * j + 1] = 0.75f * in[j + 1] + 0.25f * in[j + 2];
+      }
+    }
+    float* o0 = y + ((size_t)p * 2 * H + 2 * iy) * Wo + 2 * x0;
+    f32x4 a0, b0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ev = iy > 0 ? 0.25f * h[0][j] + 0.75f * h[1][j] : h[1][j];
+      const float od = 0.75f * h[1][j] + 0.25f * h[2][j];
+      a0[j] = ev * mul; b0[j] = od * mul;
+    }
+    *reinterpret_cast<f32x4*>(o0) = a0;
+    *reinterpret_cast<f32x4*>(o0 + Wo) = b0;
+  }
+}
+
 // Backward of the above: each input pixel gathers from the <= (S+1)^2 outputs that read it
 // (deterministic, no atomics).  gx = sum_o w(o -> i) * gy[o] * mul.
 __global__ void upsample_bilinear_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
@@ -554,6 +596,12 @@ int upsample_bilinear_fwd(const float* x, float* y, size_t planes, int H, int W,
                "upsample_bilinear_fwd: bad argument");
   const size_t nout = planes * H * W * S * S;
   if (S == 2 && W % 4 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)x & 15) == 0 && nout < (1ull << 32)) {
+    // DVSR_UP2=4: four input columns per thread (the round-1 kernel; A/B aid, read once per process)
+    static const bool four = [] { const char* v = getenv("DVSR_UP2"); return v && v[0] == '4'; }();
+    if (!four) {
+      LAUNCH(upsample2x_fwd2_kernel, planes * H * (W / 2), st, x, y, (unsigned)planes, H, W, mul);
+      return check_launch("upsample2x_fwd2_kernel");
+    }
     LAUNCH(upsample2x_fwd_kernel, planes * H * (W / 4), st, x, y, (unsigned)planes, H, W, mul);
     return check_launch("upsample2x_fwd_kernel");
   }

@@ -145,7 +145,7 @@ def test_mdcn_rejects_unsupported(ops):
                          1, 1, 1, 4)
 
 
-@pytest.mark.parametrize("scale,mul,h,w", [(2, 1.0, 9, 13), (2, 2.0, 4, 4), (4, 1.0, 16, 16), (4, 1.0, 7, 5)])
+@pytest.mark.parametrize("scale,mul,h,w", [(2, 1.0, 9, 13), (2, 2.0, 4, 4), (2, 2.0, 45, 80), (2, 1.0, 11, 20), (4, 1.0, 16, 16), (4, 1.0, 7, 5)])
 def test_upsample_bilinear(ops, scale, mul, h, w):
     x = rnd(2, 3, h, w, seed=1).requires_grad_()
     ref = F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=False) * mul
