@@ -14,6 +14,11 @@
 //    [Cout][72] partial per workgroup (plain stores) that a small kernel sums -- NO column buffer anywhere (the
 //    reference, and this file until r02, wrote [N, C*9, H*W] floats and ran a 1x1 weight-gradient GEMM over them:
 //    663 MB written + read per L1 call at 5x64x180x320).  Groups of 16 channels are walked as two 8-channel chunks.
+//    Round 6: where Cout = 64, W % 4 == 0 and the tensors are 16-byte aligned both contractions run on the bf16 pipe under
+//    the exact 3-way operand split (template parameter SPLIT; DVSR_DCN_BWD=fp32 keeps the fp32 MFMAs); the A operands of
+//    the first phase are laid out once per call (mdcn_bwd_wt_kernel / mdcn_bwd_wt3_kernel), the window is staged with
+//    16-byte loads, the lane's offsets / masks are streamed through the sampling phase one tap ahead, and the C / 8 chunk
+//    workgroups of a tile share one XCD's L2.  1.58 -> 1.02-1.06 ms at 5x64x180x320.
 //  * every other configuration (C/dg = 4, other strides / dilations; DVSR_DCN_BWD=unfused forces it): the
 //    three-kernel form of the reference -- the two contractions on the MFMA conv kernels (dcol = 1x1 "dgrad"
 //    over the flattened [Cout][C*9] weight, dW/db = 1x1 wgrad over the column buffer) around the fused
