@@ -118,10 +118,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dual_kernel(Dual1x1K a) {
   const int px = p0 + 4 * nn;
   if (px >= a.HW) return;
   float* yb = (conv ? a.y1 : a.y0) + (size_t)n * 64 * a.HW + px;
+  // (the sixteen bias values first: read inside the store loop each load waited behind the previous store, which the
+  // compiler may not reorder it with -- sixteen dependent round trips per thread)
+  float bvs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bvs[r] = bsel ? bsel[cw + (r & 3) + 8 * (r >> 2) + 4 * k] : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co = cw + (r & 3) + 8 * (r >> 2) + 4 * k;
-    const float bv = bsel ? bsel[co] : 0.f;
+    const float bv = bvs[r];
     f32x4 v = {apply_act(acc[0][r] + bv, a.act), apply_act(acc[1][r] + bv, a.act), apply_act(acc[2][r] + bv, a.act),
                apply_act(acc[3][r] + bv, a.act)};
     *reinterpret_cast<f32x4*>(yb + (size_t)co * a.HW) = v;

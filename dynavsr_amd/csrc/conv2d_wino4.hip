@@ -511,6 +511,19 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
           y[i][j][k] = fmaxf(v, v * slope);
         }
     if (a.ps == 0) {
+      // (data-gradient launches: the activation mask of the producer.  Its eight loads go out TOGETHER, ahead of the round's
+      // stores: read inside the store loop -- as rounds 4-5 had it, to save registers -- every load waited behind the previous
+      // row's store, which the compiler may not reorder it with: eight dependent round trips per thread and round.)
+      w4f2 gmv[4][2];
+      if (full && a.gmask) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const size_t sb = (((size_t)n * a.Cout + cob + k) * HWo + (size_t)i * a.Wo) * 4;   // scalar
+            gmv[k][i] = *reinterpret_cast<const w4f2*>(reinterpret_cast<const char*>(a.gmask) + sb + lane_off);
+          }
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -520,8 +533,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
             const size_t sb = (((size_t)n * a.Cout + cob + k) * HWo + (size_t)i * a.Wo) * 4;   // scalar
             if (!plain) {
               v += ex[k][i];
-              if (a.gmask) {   // (data-gradient launches: the activation mask of the producer)
-                const w4f2 m = *reinterpret_cast<const w4f2*>(reinterpret_cast<const char*>(a.gmask) + sb + lane_off);
+              if (a.gmask) {
+                const w4f2 m = gmv[k][i];
                 v = w4f2{v[0] * (m[0] > 0.f ? 1.f : neg), v[1] * (m[1] > 0.f ? 1.f : neg)};
               }
             }

@@ -143,7 +143,7 @@ int pack_weights_wino5_run(const PackTable& t, hipStream_t st) {
   return check_launch("pack_weights_wino5_kernel");
 }
 
-template <int TC>
+template <int TC, bool RES>   // RES: the epilogue adds a residual tensor (a.res != nullptr; plain stores only)
 __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
   using Sh = Wino5Shape<TC>;
   constexpr int IH = Sh::IH, RP = Sh::RP, GR = Sh::GR;
@@ -505,12 +505,29 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
           for (int c = 0; c < 2; ++c) {
             if (c == 1 && !two) break;
             const size_t base = ((size_t)n * a.Cout + co0 + c) * HWo + (size_t)oy * a.Wo + ox;
+            // (the residual rows of a cout are fetched TOGETHER, ahead of its stores: res may be the output buffer itself, so
+            // the compiler keeps every load behind the previous row's store -- eight dependent round trips per thread and
+            // round, 15-20 us of the 5 x 64 x 180 x 320 layers with a residual.  Every element is read and written by this
+            // thread only, so reading a cout's four rows before writing them is the same computation.  A separate
+            // instantiation: in one kernel with the plain form the allocator spilled three more registers and every layer
+            // WITHOUT a residual lost 4 %.)
+            if constexpr (RES) {
+              f32x4 rr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              if (i >= nrow) break;
-              f32x4 v = {y[c][i][0], y[c][i][1], y[c][i][2], y[c][i][3]};
-              if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + base + (size_t)i * a.Wo);
-              *reinterpret_cast<f32x4*>(a.y + base + (size_t)i * a.Wo) = v;
+              for (int i = 0; i < 4; ++i)
+                rr[i] = i < nrow ? *reinterpret_cast<const f32x4*>(a.res + base + (size_t)i * a.Wo) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (i >= nrow) break;
+                const f32x4 v = f32x4{y[c][i][0], y[c][i][1], y[c][i][2], y[c][i][3]} + rr[i];
+                *reinterpret_cast<f32x4*>(a.y + base + (size_t)i * a.Wo) = v;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (i >= nrow) break;
+                *reinterpret_cast<f32x4*>(a.y + base + (size_t)i * a.Wo) = f32x4{y[c][i][0], y[c][i][1], y[c][i][2], y[c][i][3]};
+              }
             }
           }
         } else {
@@ -547,9 +564,10 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
 template <int TC>
 static int launch_wino5(ConvK2 k, hipStream_t st) {
   using Sh = Wino5Shape<TC>;
-  auto kern = conv2d_wino5_kernel<TC>;
-  static PerDeviceOnce attr_once;
-  set_dyn_lds_once(attr_once, (const void*)kern, Sh::LDS_BYTES);
+  auto kern = k.res ? conv2d_wino5_kernel<TC, true> : conv2d_wino5_kernel<TC, false>;
+  static PerDeviceOnce attr_once, attr_once_r;
+  set_dyn_lds_once(attr_once, (const void*)conv2d_wino5_kernel<TC, false>, Sh::LDS_BYTES);
+  set_dyn_lds_once(attr_once_r, (const void*)conv2d_wino5_kernel<TC, true>, Sh::LDS_BYTES);
   k.tiles_x = ceil_div(k.Wo, Sh::OW); k.tiles_y = ceil_div(k.Ho, Sh::OH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 64);
   k.tiles_per_xcd = ceil_div(k.ntiles, 8);

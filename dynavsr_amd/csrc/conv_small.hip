@@ -114,13 +114,22 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(SmallK a) {
   const int oy = oy0 + py, ox = ox0 + px2;
   if (oy >= a.H || ox >= a.W) return;
   const bool two = ox + 1 < a.W;
+  // (bias and residual of all COUT channels first: read inside the store loop every load waited behind the previous store)
+  float bvs[COUT];
+  f32x2 rvs[COUT];
 #pragma unroll
   for (int o = 0; o < COUT; ++o) {
-    const float bv = bn ? bn[o] : 0.f;
+    bvs[o] = bn ? bn[o] : 0.f;
+    const size_t idx = ((size_t)n * a.Cout + o) * HW + (size_t)oy * a.W + ox;
+    rvs[o] = (a.res && two && (idx & 1) == 0) ? *reinterpret_cast<const f32x2*>(a.res + idx) : f32x2{0.f, 0.f};
+  }
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    const float bv = bvs[o];
     f32x2 v = {apply_act(acc[o][0] + bv, a.act), apply_act(acc[o][1] + bv, a.act)};
     const size_t idx = ((size_t)n * a.Cout + o) * HW + (size_t)oy * a.W + ox;
     if (two && (idx & 1) == 0) {  // whole, 8-byte aligned pair
-      if (a.res) v += *reinterpret_cast<const f32x2*>(a.res + idx);
+      v += rvs[o];
       *reinterpret_cast<f32x2*>(a.y + idx) = v;
     } else {
       a.y[idx] = v[0] + (a.res ? a.res[idx] : 0.f);
