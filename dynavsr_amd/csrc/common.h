@@ -209,9 +209,12 @@ __device__ __forceinline__ void store_mfma_tile_impl(const f32x16 (&acc)[MT][NT]
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         extra[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, off[r], 0, 0));
+      // (all sixteen mask loads first, unconditionally -- without a mask the resource is empty and they return 0 --: written as
+      // `t.gmask && load(...) <= 0` every load sat in its own branch with a full wait: sixteen dependent round trips per tile row)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        gm[r] = (t.gmask && __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, off[r], 0, 0)) <= 0.f) ? neg : 1.f;
+      for (int r = 0; r < 16; ++r) gm[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, off[r], 0, 0));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gm[r] = (t.gmask && gm[r] <= 0.f) ? neg : 1.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[mt][nt][r] + bv[mt][r];
@@ -303,6 +306,16 @@ __device__ __forceinline__ void store_mfma_tile_padded(const f32x16 (&acc)[MT][N
   const int pxm[2] = {ox == 1 ? 0 : -1, ox == t.Wo - 2 ? Wp - 1 : -1};
   const bool col_ring[2] = {__builtin_amdgcn_ballot_w64(pxm[0] >= 0 && col_ok) != 0,
                             __builtin_amdgcn_ballot_w64(pxm[1] >= 0 && col_ok) != 0};
+  // (the bias values of all registers first, with a clamped index: fetched one per value inside the loop below each load sat in
+  // its own branch with a full wait -- sixteen dependent round trips per M-tile and thread)
+  float bvp[MT][16];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+      bvp[mt][r] = t.bias ? t.bias[co < t.Cout ? co : t.Cout - 1] : 0.f;
+    }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     float v[NT][16];
@@ -310,8 +323,7 @@ __device__ __forceinline__ void store_mfma_tile_padded(const f32x16 (&acc)[MT][N
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co_base + mt * 32 + (r & 3) + 8 * (r >> 2);
-        const float x = acc[mt][nt][r] + (t.bias ? t.bias[co < t.Cout ? co : t.Cout - 1] : 0.f);
+        const float x = acc[mt][nt][r] + bvp[mt][r];
         v[nt][r] = fmaxf(x, slope * x);
       }
 #pragma unroll
