@@ -524,6 +524,50 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4_kernel(ConvK2 a) {
             gmv[k][i] = *reinterpret_cast<const w4f2*>(reinterpret_cast<const char*>(a.gmask) + sb + lane_off);
           }
       }
+      if (!full) {
+        // Edge tiles (44 x 80 is 5.5 x 2.5 tiles of 8 x 32: 44 % of the inner step's workgroups): every access goes through a
+        // bounds-checked raw buffer of this image with the byte offset forced out of range for invalid (row, column, channel)
+        // combinations, as in store_mfma_tile's edge path -- ALL loads of the round first, then the stores.  (Round 6: the
+        // per-element `if (ok) { w += res[..]; w += y[..]; w *= mask[..]; y[..] = w; }` form was up to 48 dependent round
+        // trips per thread and round.)
+        const size_t img = (size_t)a.Cout * HWo;
+        const __amdgpu_buffer_rsrc_t ry = image_rsrc(a.y + (size_t)n * img, img);
+        const __amdgpu_buffer_rsrc_t rr = image_rsrc(a.res ? a.res + (size_t)n * img : a.y, a.res ? img : 0);
+        const __amdgpu_buffer_rsrc_t rg = image_rsrc(a.gmask ? a.gmask + (size_t)n * img : a.y, a.gmask ? img : 0);
+        const __amdgpu_buffer_rsrc_t ra = image_rsrc(a.y + (size_t)n * img, a.accum ? img : 0);
+        unsigned off[4][2][2];
+        float e[4][2][2], g[4][2][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int co = cob + 4 * hi_e + k, oy = orow + i;
+            const bool ok0 = co < a.Cout && oy < a.Ho && ocol < a.Wo;
+            const unsigned o0 = (unsigned)(((size_t)co * HWo + (size_t)oy * a.Wo + ocol) * 4);
+            off[k][i][0] = ok0 ? o0 : 0xFFFFFFFFu;
+            off[k][i][1] = (ok0 && ocol + 1 < a.Wo) ? o0 + 4u : 0xFFFFFFFFu;
+          }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              e[k][i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off[k][i][j], 0, 0)) +
+                           __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, off[k][i][j], 0, 0));
+              g[k][i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, off[k][i][j], 0, 0));
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              float w = y[i][j][k] + e[k][i][j];
+              w *= (a.gmask && g[k][i][j] <= 0.f) ? neg : 1.f;
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, w), ry, off[k][i][j], 0, 0);
+            }
+      } else
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
 #pragma unroll
