@@ -73,9 +73,11 @@ int dvsr_mdcn_forward_fast(const float* x, const float* offset, const float* mas
  * w.r.t. the op's output (act = NONE).  gx is ACCUMULATED into with fp32 atomics (zero it first, the
  * reference's caller does: deform_conv.py:128); goffset/gmask/gw/gb are overwritten; gx/gw/gb may
  * be NULL.  Workspace: the EDVR configuration (3x3, stride / pad / dilation 1, 8 channels per group) runs the fused
- * kernel, whose only scratch is the per-workgroup [Cout][72] weight-gradient partials (no column buffer: dcol and the
- * sampled columns stay on chip); other configurations take the three-kernel path, which also needs the [C*9, Ho*Wo]
- * column buffer.  dvsr_mdcn_backward_workspace_bytes() returns the larger of the two. */
+ * kernel, whose scratch is the per-workgroup [Cout][72] weight-gradient partials and (r06) the weights re-laid-out as the
+ * kernel's first-phase operands, once per call (no column buffer: dcol and the sampled columns stay on chip; with Cout = 64,
+ * W % 4 == 0 and 16-byte aligned x / grad_out both contractions run on the bf16 MFMA under the exact 3-way operand split:
+ * fp32 results); other configurations take the three-kernel path, which also needs the [C*9, Ho*Wo] column buffer.
+ * dvsr_mdcn_backward_workspace_bytes() returns the larger of the two. */
 size_t dvsr_mdcn_backward_workspace_bytes(int N, int C, int H, int W, int Cout, int kh, int kw, int stride,
                                           int pad, int dil);
 int dvsr_mdcn_backward(const float* x, const float* offset, const float* mask, const float* w,
