@@ -25,7 +25,7 @@ _PROCESS_ENV = ("DVSR_CONV_WINO_T16", "DVSR_CONV_DMA", "DVSR_CONV_DMAROW", "DVSR
                 "DVSR_WGRAD_SPLITS", "DVSR_WGRAD_SIMPLE", "DVSR_WGRAD_WIDE", "DVSR_WGRAD_S3V", "DVSR_WGRAD_S3_KYS_BELOW", "DVSR_WGRAD_S3_WGS",
                 "DVSR_WGRAD_S3W", "DVSR_WGRAD_KYS_BELOW", "DVSR_WGRAD_KYS_WGS", "DVSR_WGRAD_BF_WGS", "DVSR_DCN_FWD", "DVSR_DCN_BWD",
                 "DVSR_EST_FUSE_PAD", "DVSR_FUSE_RES_BWD", "DVSR_BWD_FORK_EVERY", "DVSR_BWD_PROBE", "DVSR_TSA_DUAL", "DVSR_TSA_V",
-                "DVSR_DEGRADE_GENERIC")
+                "DVSR_DEGRADE_GENERIC", "DVSR_UP2")
 _process_env_seen = None   # their values when the first plan of the process was built
 
 
