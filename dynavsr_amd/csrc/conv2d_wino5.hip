@@ -143,7 +143,11 @@ int pack_weights_wino5_run(const PackTable& t, hipStream_t st) {
   return check_launch("pack_weights_wino5_kernel");
 }
 
-template <int TC, bool RES>   // RES: the epilogue adds a residual tensor (a.res != nullptr; plain stores only)
+// RES: the epilogue adds a residual tensor (a.res != nullptr; plain stores only).  R16 (instantiated with RES): all sixteen
+// waves read the exchange image, one cout each; otherwise eight consumer waves read a cout PAIR each -- what PixelShuffle(2)
+// needs for 16-byte rows of the shuffled image, and what measures faster without a residual -- and the producers leave after
+// the loop.
+template <int TC, bool RES, bool R16>
 __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
   using Sh = Wino5Shape<TC>;
   constexpr int IH = Sh::IH, RP = Sh::RP, GR = Sh::GR;
@@ -179,6 +183,61 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
 #ifdef DVSR_CONV_TRACE
   if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 64 + 60] = __builtin_amdgcn_s_memrealtime();
 #endif
+
+  // R16 epilogue, one round: every wave reads the exchange image [xi 6][j 4][rq 4][lane 64] x 16 B -- lane' = the writer's lane
+  // (tile, hi), register quad rq' = wave & 3, cout wave >> 2 of the quad --, applies the row transform, bias, activation and
+  // residual and stores four 16-byte output rows.  (Eight readers with a cout pair each took 3.1-3.7 k cycles per round,
+  // sixteen take 1.8 k.)
+  auto read16 = [&](int m) __attribute__((always_inline)) {
+    int le = lane;
+    asm volatile("" : "+v"(le));   // (nothing of this addressing may be hoisted above the chunk loop)
+    const int rq_r = wave & 3, cp_r = wave >> 2;
+    const float* const xr = smem + (rq_r * 64 + le) * 4 + cp_r;
+    const int lo_e = le & 31, hi_e = le >> 5;
+    const int trow_e = lo_e / TC, tcol_e = lo_e - trow_e * TC;
+    const int oy = oy0 + 4 * trow_e, ox = ox0 + 4 * tcol_e;
+    const size_t HWo = (size_t)a.Ho * a.Wo;
+    const float slope = a.act == ACT_LRELU ? 0.1f : (a.act == ACT_RELU ? 0.f : 1.f);
+    const float* bias = wset_ptr(a.bias, a.b_gs, n, a.wdiv);
+    const int co0 = cbi * 64 + m * 32 + 8 * rq_r + 4 * hi_e + cp_r;   // this thread's cout
+    float y[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float z[6];
+#pragma unroll
+      for (int x = 0; x < 6; ++x) z[x] = xr[(x * 16 + j * 4) * 256];
+      const float sa = z[1] + z[2], da = z[1] - z[2];
+      const float sb = z[3] + z[4], db = z[3] - z[4];
+      y[0][j] = z[0] + sa + sb;
+      y[1][j] = __builtin_fmaf(2.f, db, da);
+      y[2][j] = __builtin_fmaf(4.f, sb, sa);
+      y[3][j] = __builtin_fmaf(8.f, db, da) + z[5];
+    }
+    const bool px_ok = oy < a.Ho && ox < a.Wo;   // (Wo is a multiple of 4: whole tile columns; the last tile row may be cut)
+    const int nrow = a.Ho - oy < 4 ? a.Ho - oy : 4;
+    if (px_ok && co0 < a.Cout) {
+      const float b0 = bias ? bias[co0] : 0.f;
+      const size_t base = ((size_t)n * a.Cout + co0) * HWo + (size_t)oy * a.Wo + ox;
+      f32x4 rr[4];
+      if constexpr (RES) {   // (the four residual rows together, ahead of the stores: see the pair reader below)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          rr[i] = i < nrow ? *reinterpret_cast<const f32x4*>(a.res + base + (size_t)i * a.Wo) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i >= nrow) break;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v0 = y[i][j] + b0;
+          v[j] = fmaxf(v0, v0 * slope);
+        }
+        if constexpr (RES) v += rr[i];
+        *reinterpret_cast<f32x4*>(a.y + base + (size_t)i * a.Wo) = v;
+      }
+    }
+  };
 
   if (wave >= 12) {
     // =================================================================================================================
@@ -329,8 +388,17 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
       vw12 -= vstep; vw34 -= vstep; vw05 -= vstep; prd -= rstep;
       vstep = -vstep; rstep = -rstep;
     }
-    // (the epilogue's four barriers; the producers hold no results)
-    lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier();
+    if constexpr (R16) {
+      // (the producers hold no results: they are four of the epilogue's sixteen reader waves)
+      __builtin_amdgcn_s_setprio(0);
+      lds_barrier();                 // every wave is past its last V read
+      lds_barrier(); read16(0);      // round 0 written / read
+      lds_barrier();                 // ... its reads done
+      lds_barrier(); read16(1);      // round 1
+    } else {
+      // (the epilogue's four barriers; the producers hold no results)
+      lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier();
+    }
     return;
   }
   {
@@ -469,7 +537,8 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
     W5_STAMP(52 + 4 * m);
     lds_barrier();
     W5_STAMP(53 + 4 * m);
-    if (wave < 8) {
+    if constexpr (R16) read16(m);
+    else if (wave < 8) {
       const int co0 = cbi * 64 + m * 32 + 8 * rq_r + 4 * hi_e + 2 * cp_r;   // this thread's two couts: co0, co0 + 1
       float y[2][4][4];
 #pragma unroll
@@ -564,10 +633,13 @@ __global__ __launch_bounds__(1024) void conv2d_wino5_kernel(ConvK2 a) {
 template <int TC>
 static int launch_wino5(ConvK2 k, hipStream_t st) {
   using Sh = Wino5Shape<TC>;
-  auto kern = k.res ? conv2d_wino5_kernel<TC, true> : conv2d_wino5_kernel<TC, false>;
+  // Sixteen readers only where the epilogue also fetches a residual (fe_rb_b 96-99 -> 91-92 us on one box); without one the
+  // eight pair readers measure 2-3 % FASTER per launch (L1_om 238 against 243 us, HRconv 222-226 against 229-233), and a
+  // PixelShuffle(2) launch (never with a residual: conv2_prepare) needs the pairs for its 16-byte rows.
+  auto kern = k.res ? conv2d_wino5_kernel<TC, true, true> : conv2d_wino5_kernel<TC, false, false>;
   static PerDeviceOnce attr_once, attr_once_r;
-  set_dyn_lds_once(attr_once, (const void*)conv2d_wino5_kernel<TC, false>, Sh::LDS_BYTES);
-  set_dyn_lds_once(attr_once_r, (const void*)conv2d_wino5_kernel<TC, true>, Sh::LDS_BYTES);
+  set_dyn_lds_once(attr_once, (const void*)conv2d_wino5_kernel<TC, false, false>, Sh::LDS_BYTES);
+  set_dyn_lds_once(attr_once_r, (const void*)conv2d_wino5_kernel<TC, true, true>, Sh::LDS_BYTES);
   k.tiles_x = ceil_div(k.Wo, Sh::OW); k.tiles_y = ceil_div(k.Ho, Sh::OH); k.ntiles = k.tiles_x * k.tiles_y * k.N;
   k.ncb = ceil_div(k.Cout, 64);
   k.tiles_per_xcd = ceil_div(k.ntiles, 8);
