@@ -463,3 +463,39 @@ def test_process_env_switches_are_snapshot_and_a_change_warns(monkeypatch):
         monkeypatch.setenv("DVSR_DCN_FWD", "dma")
         engine._check_process_env()
         assert len(w) == 1 and "DVSR_DCN_FWD" in str(w[0].message)
+
+
+def test_tape_functions_read_the_callers_grad_mode():
+    """engine._TapeFunction: inside autograd.Function.forward grad mode is always off and ctx.needs_input_grad reports
+    requires_grad of the inputs even under torch.no_grad() -- so the wrapper captures the CALLER's grad mode in apply().
+    (Round 6: without it every no-grad forward of a trainable network sized the gradient workspace and missed the engine's
+    no-grad launch geometries; the GPU suite holds the workspace size, this holds the decision.)"""
+    import torch
+    from dynavsr_amd import engine
+    seen = []
+
+    class Probe(engine._TapeFunction):
+        @staticmethod
+        def forward(ctx, x, w):
+            seen.append((engine._need_grad(ctx), tuple(ctx.needs_input_grad), torch.is_grad_enabled()))
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            return g, g
+
+    w = torch.nn.Parameter(torch.ones(3))
+    x = torch.ones(3)
+    y = Probe.apply(x, w)
+    assert seen[-1] == (True, (False, True), False) and y.requires_grad
+    with torch.no_grad():
+        y = Probe.apply(x, w)
+    assert seen[-1] == (False, (False, True), False) and not y.requires_grad     # needs_input_grad alone would have said True
+    y = Probe.apply(x, w.detach())
+    assert seen[-1][0] is False                                                   # nothing requires grad: no tape either
+    with torch.no_grad():
+        with torch.enable_grad():
+            y = Probe.apply(x, w)
+    assert seen[-1][0] is True
+    y.sum().backward()
+    assert torch.equal(w.grad, torch.ones(3))
